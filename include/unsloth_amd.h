@@ -1,0 +1,183 @@
+/*
+ * unsloth_amd.h -- C ABI of libunsloth_amd.so (MI355X / gfx950 hot-path kernels).
+ *
+ * This is the drop-in boundary of the project. The reference
+ * (unslothai/unsloth) has no C FFI of its own: its hot path is Triton kernels launched from
+ * Python plus ONE ctypes binding, to bitsandbytes' C library (unsloth/kernels/utils.py:266-284).
+ * This header therefore declares
+ *   (1) the bitsandbytes symbols that binding uses, with bitsandbytes' exact C signatures, and
+ *   (2) one `uamd_*` entry point per Triton kernel launch of unsloth/kernels/*.py, following the
+ *       calling convention the reference already uses for native code (utils.py:198-202,242-253):
+ *       raw device pointers, C int / int64 scalars, the CURRENT stream of the tensor's device
+ *       passed as an opaque pointer, no allocation, no synchronisation.
+ *
+ * Conventions
+ *   - every `uamd_*` function returns 0 on success, a negative UAMD_ERR_* code for rejected
+ *     arguments, or a positive hipError_t from the launch. Nothing is launched on error.
+ *   - `dtype` arguments: UAMD_F32 / UAMD_F16 / UAMD_BF16.
+ *   - strides are in ELEMENTS, sizes in elements unless stated.
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); kernels are enqueued,
+ *     never synchronised. All pointers are device pointers.
+ *   - in-place contracts of the reference are part of the ABI and are stated per function.
+ */
+#ifndef UNSLOTH_AMD_H
+#define UNSLOTH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAMD_OK 0
+#define UAMD_ERR_DTYPE (-1)
+#define UAMD_ERR_ARG (-2)
+#define UAMD_ERR_ALIGN (-3)
+
+#define UAMD_F32 0
+#define UAMD_F16 1
+#define UAMD_BF16 2
+
+/* library / ABI version: (major << 16) | minor */
+int uamd_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * RMSNorm.  Replaces unsloth/kernels/rms_layernorm.py:21-59 (_rms_layernorm_forward),
+ * :123-159 (_gemma_rms_layernorm_forward), :62-120 (_rms_layernorm_backward), as launched by
+ * Fast_RMS_Layernorm.forward/backward (:162-240).
+ *   fwd: r[row] = rsqrt(mean(x^2) + eps) (fp32);  y = (x*r).to(W.dtype) * W   (gemma: x*r*(W+1) in fp32)
+ *   bwd: dX = r/n * (n*dY*W - xhat * sum(dY*W*xhat));  dX MAY ALIAS dY (the reference writes in
+ *        place for the non-gemma case, :92-95,218).
+ */
+int uamd_rms_layernorm_fwd(const void* X, const void* W, void* Y, float* r, int64_t n_rows,
+                           int n_cols, int64_t x_row_stride, int64_t y_row_stride, float eps,
+                           int gemma, int x_dtype, int w_dtype, void* stream);
+int uamd_rms_layernorm_bwd(const void* dY, void* dX, const void* X, const void* W, const float* r,
+                           int64_t n_rows, int n_cols, int64_t dy_row_stride,
+                           int64_t dx_row_stride, int64_t x_row_stride, int gemma, int x_dtype,
+                           int w_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RoPE (rotate-half), IN PLACE.  backward != 0 negates sin (rope_embedding.py:140-142).
+ * uamd_rope_embedding    replaces _rope_embedding    (rope_embedding.py:104-166) as launched by
+ *                        Fast_RoPE_Embedding (:169-261): Q is [n_rows, n_heads*head_dim],
+ *                        position = row % seqlen.
+ * uamd_rope_embedding_qk replaces _rope_embedding_QK (rope_embedding.py:23-98) as launched by
+ *                        Fast_RoPE_Embedding_QK (:283-399): Q [B,Hq,T,D] and K [B,Hk,T,D] given by
+ *                        element strides; rope_indices (int32 [B*T]) may be NULL (-> row % seqlen).
+ * cos/sin: [>=max_pos, >=head_dim/2] tables, only the first head_dim/2 columns are read.
+ */
+int uamd_rope_embedding(void* Q, int64_t q_row_stride, const void* cos, int64_t cos_row_stride,
+                        const void* sin, int64_t sin_row_stride, int64_t n_rows, int seqlen,
+                        int n_heads, int head_dim, int backward, int q_dtype, int table_dtype,
+                        void* stream);
+int uamd_rope_embedding_qk(void* Q, int64_t q_batch_stride, int64_t q_head_stride,
+                           int64_t q_seq_stride, void* K, int64_t k_batch_stride,
+                           int64_t k_head_stride, int64_t k_seq_stride, const void* cos,
+                           int64_t cos_row_stride, const void* sin, int64_t sin_row_stride,
+                           const int32_t* rope_indices, int batch, int seqlen, int n_heads_q,
+                           int n_heads_k, int head_dim, int backward, int q_dtype,
+                           int table_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Gated MLP activations over n contiguous elements.
+ * forward : h = f(e).to(dtype) * g            swiglu.py:27-47, geglu.py:31-53, :142-167
+ * backward: IN PLACE  DW <- h = f*g,  e <- df = DW*f,  g <- de = DW*g*f'(e)
+ *                                            swiglu.py:67-109, geglu.py:74-123, :188-244
+ */
+int uamd_swiglu_fg(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream);
+int uamd_swiglu_DWf_DW_dfg(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
+int uamd_geglu_exact_forward(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream);
+int uamd_geglu_exact_backward(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
+int uamd_geglu_approx_forward(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream);
+int uamd_geglu_approx_backward(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross entropy.  Replaces cross_entropy_loss.py:35-111 / :114-199 (+ host logsumexp :366-370) and
+ * :202-285, as launched by Fast_CrossEntropyLoss (:288-418).  No vocabulary-size limit.
+ *   forward : logsumexp[row], loss[row] = logsumexp - x[label]  (0 when label == -100)
+ *   backward: logits <- dloss[row] * (softmax - onehot) (x scale, x (1 - tanh^2) for softcap),
+ *             IN PLACE over logits (:276, :413-418); rows with label == -100 become zeros.
+ * logit_softcapping / logit_scaling == 0 disable the transform. labels are int64.
+ */
+int uamd_cross_entropy_forward(const void* logits, int64_t logits_row_stride, float* loss,
+                               float* logsumexp, const int64_t* labels, int64_t n_rows,
+                               int vocab_size, float logit_softcapping, float logit_scaling,
+                               int dtype, void* stream);
+int uamd_cross_entropy_backward(void* logits, int64_t logits_row_stride, const float* dloss,
+                                int64_t dloss_stride, const float* logsumexp,
+                                const int64_t* labels, int64_t n_rows, int vocab_size,
+                                float logit_softcapping, float logit_scaling, int dtype,
+                                void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bitsandbytes-compatible symbols (exact bitsandbytes signatures; bound by the reference at
+ * unsloth/kernels/utils.py:272-275 and called at :650-675).  `code` may be NULL for the *_nf4
+ * functions (built-in NF4 table), as the reference passes NULL (:663-664).
+ */
+void cdequantize_blockwise_fp32(float* code, unsigned char* A, float* absmax, float* out,
+                                int blocksize, const int n, void* stream);
+void cdequantize_blockwise_bf16_nf4(float* code, unsigned char* A, float* absmax, void* out,
+                                    int blocksize, const int n, void* stream);
+void cdequantize_blockwise_fp16_nf4(float* code, unsigned char* A, float* absmax, void* out,
+                                    int blocksize, const int n, void* stream);
+void cdequantize_blockwise_fp32_nf4(float* code, unsigned char* A, float* absmax, void* out,
+                                    int blocksize, const int n, void* stream);
+
+/* Native NF4 entry points: the whole of fast_dequantize (utils.py:567-679) in one launch.
+ *   absmax_f32[k] = code2[absmax_u8[k]] * absmax2[k / blocksize2] + offset        (:650-659)
+ *   W[j]          = NF4[nibble_j] * absmax_f32[j / blocksize]                     (:662-675)
+ * Give EITHER absmax_f32 (not nested / pre-dequantised) OR the nested triple.
+ * transpose_out != 0 writes out[c * ld_out + r] (W^T, for the contraction over `out` in dX = dY @ W).
+ */
+int uamd_dequantize_absmax(const float* code2, const uint8_t* absmax_u8, const float* absmax2,
+                           float offset, float* out, int blocksize2, int64_t n, void* stream);
+int uamd_nf4_dequantize(const uint8_t* packed, const float* absmax_f32, const uint8_t* absmax_u8,
+                        const float* code2, const float* absmax2, float offset, int blocksize2,
+                        const float* nf4_lut, void* out, int64_t rows, int64_t cols, int blocksize,
+                        int out_dtype, int transpose_out, int64_t ld_out, void* stream);
+/* First-level NF4 quantiser (absmax + 4-bit codes); replaces bitsandbytes quantize_4bit for
+ * building checkpoints without bitsandbytes. blocksize: power of two in [8,512]. */
+int uamd_nf4_quantize(const void* in, uint8_t* packed, float* absmax, int64_t n, int blocksize,
+                      int in_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LoRA / QLoRA linear GEMMs.  Replace matmul_lora (utils.py:1128-1170) and the dX products of
+ * LoRA_MLP / LoRA_QKV / LoRA_W .backward (fast_lora.py:156,193-204,497-517,639-647).
+ *
+ *   C_g[M,N_g] (+)= A[M,K] @ B_g[N_g,K]^T  +  lora_scale_g * T(XA_g[M,R_g]) @ LB_g[N_g,R_g]^T
+ *
+ * for up to 3 groups g sharing the activation A (q/k/v, gate/up). fp32 MFMA accumulation, one
+ * rounding to the activation dtype. `accumulate` != 0 adds into the existing C (dX += ...).
+ * uamd_gemm_nt     : B_g dense [N_g,K] (activation dtype).
+ * uamd_gemm_nt_nf4 : B_g = bitsandbytes NF4 packed bytes of the [N_g,K] weight, blocksize 64,
+ *                    `absmax` = fp32 statistics (uamd_dequantize_absmax); K % 64 == 0.
+ * uamd_lora_xa     : XA[M,out_cols] = X[M,K] @ A[R,K]^T in fp32 (columns >= R zero-filled).
+ */
+typedef struct {
+    const void* B;
+    void* C;
+    const float* absmax;
+    const float* lora_xa;
+    const void* lora_b;
+    int64_t ldb, ldc, ld_xa, ld_lb;
+    int N;
+    int R;
+    float lora_scale;
+    int _pad;
+} uamd_gemm_group;
+
+int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                 int n_groups, int accumulate, int dtype, void* stream);
+int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                     int n_groups, int accumulate, int dtype, void* stream);
+int uamd_lora_xa(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,
+                 int64_t ld_out, int M, int K, int R, int out_cols, int dtype, void* stream);
+
+/* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
+int uamd_debug_mfma_probe(float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNSLOTH_AMD_H */

@@ -1,0 +1,210 @@
+"""-m gpu: NF4 quantise/dequantise (bit-exact vs the oracle's restatement of the bitsandbytes
+format), the MFMA GEMMs (dense, fused-NF4, grouped, LoRA-fused, accumulate) and the skinny XA
+kernel against fp32 references of the same bf16/fp16 inputs."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+from tests._util import assert_ulp, rel_fro
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_mfma_probe_layout():
+    """the (lane,reg)->(row,col) map the GEMM epilogue relies on (cdna guide section 3)."""
+    from unsloth_amd import _lib
+    out = torch.zeros(2, 64, 4, device=DEV)
+    _lib.check(_lib.lib().uamd_debug_mfma_probe(_lib.ptr(out), _lib.stream_of(out)), "probe")
+    out = out.cpu()
+    lanes = torch.arange(64)
+    want_row = ((lanes >> 4) * 4)[:, None] + torch.arange(4)[None, :] + 1     # row = 4*(lane>>4)+reg
+    want_col = (lanes & 15)[:, None].expand(64, 4) + 1                          # col = lane&15
+    assert torch.equal(out[0].round().long(), want_row), out[0]
+    assert torch.equal(out[1].round().long(), want_col), out[1]
+
+
+# ---------------------------------------------------------------- NF4
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_nf4_quantize_matches_oracle_bit_exact(dtype):
+    from unsloth_amd.nf4 import quantize_nf4
+    W = (torch.randn(96, 256, generator=g(1)) * 0.02).to(dtype)
+    W[5, :64] = 0                                   # an all-zero block
+    packed, qs = quantize_nf4(W.to(DEV), compress_statistics=False)
+    p_ref, a_ref = R.nf4_quantize_np(W.float().numpy().reshape(-1), 64)
+    assert np.array_equal(packed.cpu().numpy().reshape(-1), p_ref)
+    assert np.array_equal(qs.absmax.cpu().numpy(), a_ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("nested", [False, True])
+def test_nf4_dequantize_bit_exact(dtype, nested):
+    from unsloth_amd.nf4 import quantize_nf4, dequantize_nf4
+    from unsloth_amd.kernels import fast_dequantize
+    W = (torch.randn(192, 320, generator=g(2)) * 0.02).to(dtype)
+    packed, qs = quantize_nf4(W.to(DEV), compress_statistics=nested)
+    want = R.nf4_dequantize_state(packed, qs)                     # CPU restatement, same bytes
+    for cache in (False, True):
+        got = dequantize_nf4(packed, qs, cache_absmax=cache)
+        assert torch.equal(got.cpu(), want), f"dequant mismatch (cache_absmax={cache})"
+    if dtype != torch.float32:
+        got_t = dequantize_nf4(packed, qs, transpose=True)
+        assert torch.equal(got_t.cpu(), want.t())
+    # reference call conventions: passthrough, and W.t() -> transposed result (utils.py:578, 678)
+    assert fast_dequantize(W, None) is W
+    assert torch.equal(fast_dequantize(packed.t(), qs).cpu(), want.t())
+    # quantisation error sanity: NF4 with absmax scaling keeps |err| <= absmax * max half-gap
+    err = (want.float() - W.float()).abs().max()
+    assert err < 0.16 * W.float().abs().max()
+
+
+def test_bnb_compat_entry_points():
+    """The symbols the reference binds (unsloth/kernels/utils.py:272-275), called the way
+    fast_dequantize calls them (:650-675): nested absmax -> += offset -> NF4."""
+    from unsloth_amd import _lib
+    from unsloth_amd.nf4 import quantize_nf4
+    W = (torch.randn(64, 512, generator=g(3)) * 0.02).to(torch.bfloat16)
+    packed, qs = quantize_nf4(W.to(DEV), compress_statistics=True)
+    n_abs = qs.absmax.numel()
+    out_absmax = torch.empty(n_abs, dtype=torch.float32, device=DEV)
+    L = _lib.lib()
+    st = _lib.stream_of(out_absmax)
+    L.cdequantize_blockwise_fp32(_lib.ptr(qs.state2.code), _lib.ptr(qs.absmax), _lib.ptr(qs.state2.absmax),
+                                 _lib.ptr(out_absmax), ctypes.c_int(qs.state2.blocksize), ctypes.c_int(n_abs), st)
+    out_absmax += qs.offset
+    out = torch.empty(64, 512, dtype=torch.bfloat16, device=DEV)
+    L.cdequantize_blockwise_bf16_nf4(None, _lib.ptr(packed), _lib.ptr(out_absmax), _lib.ptr(out),
+                                     ctypes.c_int(qs.blocksize), ctypes.c_int(out.numel()), st)
+    want = R.nf4_dequantize_state(packed, qs)
+    # `+= offset` on the GPU is one fp32 add, the oracle does code*absmax2 + offset the same way
+    assert torch.equal(out.cpu(), want)
+
+
+# ---------------------------------------------------------------- GEMM
+def _ref_mm(X, W):
+    return X.float() @ W.float().t()
+
+
+def _check_gemm(got, want_f32, dtype, K, what):
+    """fp32-accumulated result rounded once: within 1 ulp of the fp32 reference + accumulation noise."""
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    scale = float(want_f32.abs().mean())
+    assert_ulp(got, want_f32, dtype, ulps=1, atol=eps * scale * 0.5 + 1e-6 * scale * K ** 0.5, what=what,
+               allow_frac=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (200, 130, 136), (1, 128, 4096),
+                                   (2048, 1024, 4096), (333, 4096, 1088)])
+def test_gemm_nt_dense(dtype, M, N, K):
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    X = torch.randn(M, K, generator=g(5)).to(dtype)
+    W = (torch.randn(N, K, generator=g(6)) * 0.05).to(dtype)
+    (Y,) = lora_linear_forward(X.to(DEV), [(W.to(DEV), None, None, None, None)])
+    _check_gemm(Y, _ref_mm(X, W), dtype, K, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_transpose_detecting():
+    """asymmetric operands: catches an output written as C^T or a swapped fragment map."""
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    M, N, K = 128, 256, 64
+    X = torch.zeros(M, K)
+    W = torch.zeros(N, K)
+    X[:, 0] = torch.arange(M).float() % 7 + 1
+    W[:, 0] = torch.arange(N).float() % 5 + 1
+    X[:, 1] = 1
+    W[:, 1] = (torch.arange(N) % 3).float()
+    (Y,) = lora_linear_forward(X.to(torch.bfloat16).to(DEV), [(W.to(torch.bfloat16).to(DEV), None, None, None, None)])
+    assert torch.equal(Y.float().cpu(), X @ W.t())
+
+
+@pytest.mark.parametrize("r", [8, 16, 64])
+def test_gemm_with_lora_and_groups(r):
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    dtype = torch.bfloat16
+    M, K = 300, 512
+    Ns = [512, 128, 128]
+    X = torch.randn(M, K, generator=g(7)).to(dtype)
+    projs, refs = [], []
+    for i, N in enumerate(Ns):
+        W = (torch.randn(N, K, generator=g(10 + i)) * 0.05).to(dtype)
+        A = torch.randn(r, K, generator=g(20 + i)) * 0.05
+        B = torch.randn(N, r, generator=g(30 + i)) * 0.05
+        s = 2.0
+        projs.append((W.to(DEV), None, A.to(DEV), B.to(DEV), s))
+        xa = (X.float() @ A.to(dtype).float().t()).to(dtype).float()
+        refs.append(_ref_mm(X, W) + s * xa @ B.to(dtype).float().t())
+    outs = lora_linear_forward(X.to(DEV), projs)
+    for o, ref, N in zip(outs, refs, Ns):
+        _check_gemm(o, ref, dtype, K, f"grouped lora N={N} r={r}")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (2048, 4096, 4096), (77, 1024, 256), (512, 14336, 4096)])
+def test_gemm_nf4_fused_matches_dequant_then_gemm(M, N, K):
+    from unsloth_amd.nf4 import quantize_nf4
+    from unsloth_amd.kernels import utils as U
+    dtype = torch.bfloat16
+    X = torch.randn(M, K, generator=g(40)).to(dtype).to(DEV)
+    W = (torch.randn(N, K, generator=g(41)) * 0.02).to(dtype).to(DEV)
+    packed, qs = quantize_nf4(W, compress_statistics=True)
+    Wd = R.nf4_dequantize_state(packed, qs)                       # oracle-decoded weight
+    want = _ref_mm(X.cpu(), Wd)
+    old = U.FUSED_NF4
+    try:
+        for fused in (True, False):
+            U.FUSED_NF4 = fused
+            (Y,) = U.lora_linear_forward(X, [(packed, qs, None, None, None)])
+            _check_gemm(Y, want, dtype, K, f"nf4 gemm fused={fused} {M}x{N}x{K}")
+    finally:
+        U.FUSED_NF4 = old
+
+
+def test_lora_linear_dx_accumulates_groups():
+    from unsloth_amd.nf4 import quantize_nf4
+    from unsloth_amd.kernels.utils import lora_linear_dx
+    dtype = torch.bfloat16
+    M, Kin, r = 260, 512, 16
+    Ns = [512, 128]
+    want = torch.zeros(M, Kin)
+    dYs, projs = [], []
+    for i, N in enumerate(Ns):
+        W = (torch.randn(N, Kin, generator=g(50 + i)) * 0.02).to(dtype).to(DEV)
+        packed, qs = quantize_nf4(W, compress_statistics=True)
+        Wd = R.nf4_dequantize_state(packed, qs).float()
+        A = torch.randn(r, Kin, generator=g(60 + i)) * 0.05
+        B = torch.randn(N, r, generator=g(70 + i)) * 0.05
+        dY = torch.randn(M, N, generator=g(80 + i)).to(dtype)
+        s = 0.5
+        dyb = (dY.float() @ B.to(dtype).float()).to(dtype).float()
+        want = want + dY.float() @ Wd + s * dyb @ A.to(dtype).float()
+        dYs.append(dY.to(DEV))
+        projs.append((packed, qs, A.to(DEV), B.to(DEV), s))
+    out = torch.full((M, Kin), 7.0, dtype=dtype, device=DEV)      # must be overwritten, not added to
+    got = lora_linear_dx(dYs, projs, out=out)
+    assert got.data_ptr() == out.data_ptr()
+    # two sequential roundings (per group) -> 2 ulp
+    assert_ulp(got, want, dtype, ulps=2, atol=2.0 ** -7 * float(want.abs().mean()), what="dX", allow_frac=1e-3)
+
+
+@pytest.mark.parametrize("M,K,Rs", [(2048, 4096, [16, 16, 16]), (100, 512, [8]), (64, 14336, [64, 64])])
+def test_lora_xa(M, K, Rs):
+    from unsloth_amd.kernels.utils import lora_xa
+    dtype = torch.bfloat16
+    X = torch.randn(M, K, generator=g(90)).to(dtype)
+    As = [torch.randn(r, K, generator=g(91 + i)) * 0.05 for i, r in enumerate(Rs)]
+    out, offs = lora_xa(X.to(DEV), [a.to(DEV) for a in As])
+    for a, (o, rp) in zip(As, offs):
+        want = X.float() @ a.to(dtype).float().t()
+        got = out[:, o:o + a.shape[0]].cpu()
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-4 * float(want.abs().mean()) + 1e-5)
+        assert torch.all(out[:, o + a.shape[0]:o + rp] == 0)
+    # deterministic split-K: two runs are bitwise identical
+    out2, _ = lora_xa(X.to(DEV), [a.to(DEV) for a in As])
+    assert torch.equal(out, out2)

@@ -1,0 +1,80 @@
+"""Builds libunsloth_amd.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+`python -m unsloth_amd._build` or `unsloth_amd._build.build()`; __graft_entry__.build() calls it.
+The .so is git-ignored but travels with the repo snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB = os.path.join(LIBDIR, "libunsloth_amd.so")
+ARCH = "gfx950"
+
+SOURCES = [
+    "abi.hip",
+    "rms_layernorm.hip",
+    "rope_embedding.hip",
+    "glu.hip",
+    "cross_entropy_loss.hip",
+    "nf4.hip",
+    "gemm.hip",
+]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; cannot build libunsloth_amd.so")
+
+
+def _flags():
+    return [
+        f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+        "-mcode-object-version=5",   # loadable by the ROCm 7.0 runtime bundled with the torch wheel
+        "-ffp-contract=off",         # keep the reference's rounding points; no silent fma fusion
+        f"-I{INCLUDE}", f"-I{CSRC}",
+    ]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "unsloth_amd.h")]
+    objs, jobs = [], []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([hipcc] + _flags() + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC"] + objs + ["-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,137 @@
+"""ctypes binding of libunsloth_amd.so (the C ABI declared in include/unsloth_amd.h).
+
+Mirrors how the reference binds its only native dependency (bitsandbytes) at
+unsloth/kernels/utils.py:198-202,242-284: function pointers off a shared library, raw device
+pointers, C scalars, and the current stream of the tensor's device as an opaque pointer.
+
+There is NO fallback: if the library is missing or a kernel rejects its arguments, the call
+raises. A product path that silently ran PyTorch ops instead would void every parity claim.
+"""
+import ctypes
+import os
+from contextlib import nullcontext
+
+import torch
+
+c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libunsloth_amd.so")
+
+UAMD_F32, UAMD_F16, UAMD_BF16 = 0, 1, 2
+_DTYPE_CODE = {torch.float32: UAMD_F32, torch.float16: UAMD_F16, torch.bfloat16: UAMD_BF16}
+_ERR = {-1: "unsupported dtype", -2: "invalid argument", -3: "pointer/stride not 16-byte aligned"}
+
+
+class GemmGroup(ctypes.Structure):
+    """uamd_gemm_group (include/unsloth_amd.h)."""
+
+    _fields_ = [
+        ("B", c_void_p), ("C", c_void_p), ("absmax", c_void_p), ("lora_xa", c_void_p),
+        ("lora_b", c_void_p), ("ldb", c_int64), ("ldc", c_int64), ("ld_xa", c_int64),
+        ("ld_lb", c_int64), ("N", c_int), ("R", c_int), ("lora_scale", c_float), ("_pad", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/unsloth_amd.h declares
+SIGNATURES = {
+    "uamd_version": (c_int, []),
+    "uamd_rms_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64,
+                                       c_int64, c_float, c_int, c_int, c_int, c_void_p]),
+    "uamd_rms_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                                       c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "uamd_rope_embedding": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "uamd_rope_embedding_qk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                       c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "uamd_swiglu_fg": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_swiglu_DWf_DW_dfg": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_geglu_exact_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_geglu_exact_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_geglu_approx_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_geglu_approx_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_cross_entropy_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_int, c_float, c_float, c_int, c_void_p]),
+    "uamd_cross_entropy_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
+                                            c_int64, c_int, c_float, c_float, c_int, c_void_p]),
+    "cdequantize_blockwise_fp32": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "cdequantize_blockwise_bf16_nf4": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "cdequantize_blockwise_fp16_nf4": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "cdequantize_blockwise_fp32_nf4": (None, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "uamd_dequantize_absmax": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int64,
+                                       c_void_p]),
+    "uamd_nf4_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
+                                    c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int64,
+                                    c_void_p]),
+    "uamd_nf4_quantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "uamd_gemm_nt": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
+                             c_int, c_void_p]),
+    "uamd_gemm_nt_nf4": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int,
+                                 c_int, c_int, c_void_p]),
+    "uamd_lora_xa": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                             c_int, c_int, c_int, c_void_p]),
+    "uamd_debug_mfma_probe": (c_int, [c_void_p, c_void_p]),
+}
+
+_LIB = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle. Raises if the HIP library is absent."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"unsloth_amd: {LIB_PATH} is missing. Build it with `python -m unsloth_amd._build` "
+                "(hipcc, gfx950). There is no CPU / PyTorch fallback for the fused kernels."
+            )
+        # torch is already imported, so libamdhip64.so.7 resolves to the runtime torch uses.
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def dtype_code(dtype):
+    try:
+        return _DTYPE_CODE[dtype]
+    except KeyError:
+        raise TypeError(f"unsloth_amd kernels support fp32/fp16/bf16, got {dtype}") from None
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "unsloth_amd kernels run on MI355X (torch device 'cuda' under ROCm); got a "
+                f"{t.device} tensor. The CPU oracle lives under oracle/ and is test-only."
+            )
+
+
+def stream_of(t):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+_MULTI = None
+
+
+def device_ctx(t):
+    """`with torch.cuda.device(...)` only when several GPUs are visible (utils.py:170-178)."""
+    global _MULTI
+    if _MULTI is None:
+        _MULTI = torch.cuda.device_count() > 1
+    return torch.cuda.device(t.device) if _MULTI else nullcontext()
+
+
+def check(rc, name):
+    if rc != 0:
+        why = _ERR.get(rc, f"hipError {rc}")
+        raise RuntimeError(f"unsloth_amd: {name} failed: {why} (code {rc})")

@@ -1,0 +1,115 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// Wave size is 64 on CDNA; every reduction below is written for 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "unsloth_amd.h"   // C ABI: error codes, dtype codes, entry-point prototypes
+
+typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+
+#define UAMD_WAVE 64
+
+// 16-byte vector of T (8 x 16-bit or 4 x 32-bit)
+template <typename T> struct Vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    union {
+        uint4 raw;
+        T e[16 / sizeof(T)];
+    };
+    __device__ __forceinline__ Vec16() {}
+};
+
+template <typename T>
+__device__ __forceinline__ Vec16<T> ld16(const T* p) {
+    Vec16<T> v;
+    v.raw = *reinterpret_cast<const uint4*>(p);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void st16(T* p, const Vec16<T>& v) {
+    *reinterpret_cast<uint4*>(p) = v.raw;
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
+
+// round a float through T (the "rounding point" of the reference kernels)
+template <typename T> __device__ __forceinline__ float round_to(float x) { return (float)((T)x); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blocks of NW waves; `red` is NW floats of LDS. Result is broadcast.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if (NW == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    if (NW == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+// load VEC consecutive elements of WT (vector loads of 8/16/32 bytes) as floats
+template <typename WT, int VEC>
+__device__ __forceinline__ void load_w(const WT* __restrict__ w, float* out) {
+    constexpr int BYTES = VEC * (int)sizeof(WT);
+    static_assert(BYTES == 8 || BYTES == 16 || BYTES == 32, "unsupported vector width");
+    if constexpr (BYTES == 8) {
+        union { uint2 raw; WT e[VEC]; } v;
+        v.raw = *reinterpret_cast<const uint2*>(w);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) out[j] = to_f32(v.e[j]);
+    } else {
+        constexpr int WN = Vec16<WT>::N;
+#pragma unroll
+        for (int k = 0; k < VEC / WN; ++k) {
+            Vec16<WT> v = ld16(w + k * WN);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) out[k * WN + j] = to_f32(v.e[j]);
+        }
+    }
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static inline int uamd_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? UAMD_OK : (int)e;
+}
+
+// dispatch helper over the three activation dtypes
+#define UAMD_DISPATCH_FLOAT(dtype, ...)                       \
+    switch (dtype) {                                          \
+        case UAMD_F32: { using T = float; __VA_ARGS__; break; }  \
+        case UAMD_F16: { using T = f16_t; __VA_ARGS__; break; }  \
+        case UAMD_BF16: { using T = bf16_t; __VA_ARGS__; break; } \
+        default: return UAMD_ERR_DTYPE;                       \
+    }

@@ -1,0 +1,249 @@
+// RMSNorm forward / backward for gfx950.
+//
+// Replaces the Triton kernels of the reference:
+//   unsloth/kernels/rms_layernorm.py:21-59   _rms_layernorm_forward
+//   unsloth/kernels/rms_layernorm.py:62-120  _rms_layernorm_backward
+//   unsloth/kernels/rms_layernorm.py:123-159 _gemma_rms_layernorm_forward
+//
+// HBM-bound. Design for CDNA4: ONE WAVE (64 lanes) owns one row, the whole row lives in
+// registers as 16-byte vectors (single HBM read, all loads issued before the first use),
+// the reduction is a 6-step wave64 xor-shuffle: no LDS, no barrier. A 256-thread block
+// carries 4 rows. Rows that do not fit the register budget (or are not 16-byte aligned)
+// take the generic block-per-row two-pass kernel.
+#include "common.h"
+
+namespace {
+
+template <typename T, typename WT, int ITERS, bool GEMMA>
+__global__ void __launch_bounds__(256)
+rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ Y,
+             float* __restrict__ R, int64_t n_rows, int n_cols, int64_t xs, int64_t ys, float eps) {
+    constexpr int VEC = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const T* x = X + row * xs;
+    Vec16<T> xv[ITERS];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (c < n_cols) xv[i] = ld16(x + c);
+        else xv[i].raw = make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { float f = to_f32(xv[i].e[j]); ss += f * f; }
+    ss = wave_sum(ss);
+    const float inv = rsqrtf(ss / (float)n_cols + eps);
+    if (lane == 0) R[row] = inv;
+    T* y = Y + row * ys;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (c < n_cols) {
+            Vec16<T> o;
+            float wf[VEC];
+            load_w<WT, VEC>(W + c, wf);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float normed = to_f32(xv[i].e[j]) * inv;
+                if (GEMMA) {
+                    o.e[j] = from_f32<T>(normed * (wf[j] + 1.0f));
+                } else {
+                    // rms_layernorm.py:56-58: normed.to(W.dtype) * W, product in W's dtype
+                    o.e[j] = from_f32<T>(round_to<WT>(round_to<WT>(normed) * wf[j]));
+                }
+            }
+            st16(y + c, o);
+        }
+    }
+}
+
+template <typename T, typename WT, int ITERS, bool GEMMA>
+__global__ void __launch_bounds__(256)
+rms_bwd_wave(const T* dY, T* dX, const T* __restrict__ X,
+             const WT* __restrict__ W, const float* __restrict__ R, int64_t n_rows, int n_cols,
+             int64_t dys, int64_t dxs, int64_t xs) {
+    constexpr int VEC = Vec16<T>::N;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const T* dy = dY + row * dys;
+    const T* x = X + row * xs;
+    Vec16<T> dv[ITERS], xv[ITERS];
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (c < n_cols) { dv[i] = ld16(dy + c); xv[i] = ld16(x + c); }
+        else { dv[i].raw = make_uint4(0, 0, 0, 0); xv[i].raw = make_uint4(0, 0, 0, 0); }
+    }
+    const float inv = R[row];
+    float rs = 0.f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (c < n_cols) {
+            float wf[VEC];
+            load_w<WT, VEC>(W + c, wf);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float w = wf[j];
+                if (GEMMA) w += 1.0f;
+                rs += to_f32(dv[i].e[j]) * w * (to_f32(xv[i].e[j]) * inv);
+            }
+        }
+    }
+    rs = wave_sum(rs);
+    const float n = (float)n_cols;
+    T* dx = dX + row * dxs;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = (lane + 64 * i) * VEC;
+        if (c < n_cols) {
+            Vec16<T> o;
+            float wf[VEC];
+            load_w<WT, VEC>(W + c, wf);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float w = wf[j];
+                if (GEMMA) w += 1.0f;
+                const float dyw = to_f32(dv[i].e[j]) * w;
+                const float normed = to_f32(xv[i].e[j]) * inv;
+                // rms_layernorm.py:112
+                o.e[j] = from_f32<T>(inv / n * (n * dyw - normed * rs));
+            }
+            st16(dx + c, o);
+        }
+    }
+}
+
+// Generic fallback: one 256-thread block per row, two passes (second pass hits L2).
+template <typename T, typename WT, bool GEMMA>
+__global__ void __launch_bounds__(256)
+rms_fwd_block(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ Y,
+              float* __restrict__ R, int n_cols, int64_t xs, int64_t ys, float eps) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const T* x = X + row * xs;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < n_cols; c += 256) { float f = to_f32(x[c]); ss += f * f; }
+    ss = block_sum<4>(ss, red);
+    const float inv = rsqrtf(ss / (float)n_cols + eps);
+    if (threadIdx.x == 0) R[row] = inv;
+    T* y = Y + row * ys;
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        const float normed = to_f32(x[c]) * inv;
+        if (GEMMA) y[c] = from_f32<T>(normed * (to_f32(W[c]) + 1.0f));
+        else y[c] = from_f32<T>(round_to<WT>(round_to<WT>(normed) * to_f32(W[c])));
+    }
+}
+
+template <typename T, typename WT, bool GEMMA>
+__global__ void __launch_bounds__(256)
+rms_bwd_block(const T* dY, T* dX, const T* __restrict__ X,
+              const WT* __restrict__ W, const float* __restrict__ R, int n_cols, int64_t dys,
+              int64_t dxs, int64_t xs) {
+    __shared__ float red[4];
+    const int64_t row = blockIdx.x;
+    const T* dy = dY + row * dys;
+    const T* x = X + row * xs;
+    const float inv = R[row];
+    float rs = 0.f;
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        float w = to_f32(W[c]);
+        if (GEMMA) w += 1.0f;
+        rs += to_f32(dy[c]) * w * (to_f32(x[c]) * inv);
+    }
+    rs = block_sum<4>(rs, red);
+    const float n = (float)n_cols;
+    T* dx = dX + row * dxs;
+    for (int c = threadIdx.x; c < n_cols; c += 256) {
+        float w = to_f32(W[c]);
+        if (GEMMA) w += 1.0f;
+        const float dyw = to_f32(dy[c]) * w;  // same thread reads before it writes: alias-safe
+        const float normed = to_f32(x[c]) * inv;
+        dx[c] = from_f32<T>(inv / n * (n * dyw - normed * rs));
+    }
+}
+
+template <typename T, typename WT, bool GEMMA>
+int launch_fwd(const void* X, const void* W, void* Y, float* R, int64_t n_rows, int n_cols,
+               int64_t xs, int64_t ys, float eps, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool vec_ok = (n_cols % VEC == 0) && (xs % VEC == 0) && (ys % VEC == 0) &&
+                        aligned16(X) && aligned16(Y) && aligned16(W) && n_cols <= 64 * VEC * 16;
+    const T* x = (const T*)X; const WT* w = (const WT*)W; T* y = (T*)Y;
+    if (vec_ok) {
+        const int iters = (n_cols + 64 * VEC - 1) / (64 * VEC);
+        dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+#define L(I) hipLaunchKernelGGL((rms_fwd_wave<T, WT, I, GEMMA>), grid, block, 0, st, x, w, y, R, n_rows, n_cols, xs, ys, eps)
+        if (iters <= 1) L(1); else if (iters <= 2) L(2); else if (iters <= 4) L(4);
+        else if (iters <= 8) L(8); else L(16);
+#undef L
+    } else {
+        hipLaunchKernelGGL((rms_fwd_block<T, WT, GEMMA>), dim3((unsigned)n_rows), dim3(256), 0, st,
+                           x, w, y, R, n_cols, xs, ys, eps);
+    }
+    return uamd_launch_status();
+}
+
+template <typename T, typename WT, bool GEMMA>
+int launch_bwd(const void* dY, void* dX, const void* X, const void* W, const float* R,
+               int64_t n_rows, int n_cols, int64_t dys, int64_t dxs, int64_t xs, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool vec_ok = (n_cols % VEC == 0) && (xs % VEC == 0) && (dys % VEC == 0) &&
+                        (dxs % VEC == 0) && aligned16(X) && aligned16(dY) && aligned16(dX) && aligned16(W) &&
+                        n_cols <= 64 * VEC * 8;
+    const T* dy = (const T*)dY; T* dx = (T*)dX; const T* x = (const T*)X; const WT* w = (const WT*)W;
+    if (vec_ok) {
+        const int iters = (n_cols + 64 * VEC - 1) / (64 * VEC);
+        dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+#define L(I) hipLaunchKernelGGL((rms_bwd_wave<T, WT, I, GEMMA>), grid, block, 0, st, dy, dx, x, w, R, n_rows, n_cols, dys, dxs, xs)
+        if (iters <= 1) L(1); else if (iters <= 2) L(2); else if (iters <= 4) L(4); else L(8);
+#undef L
+    } else {
+        hipLaunchKernelGGL((rms_bwd_block<T, WT, GEMMA>), dim3((unsigned)n_rows), dim3(256), 0, st,
+                           dy, dx, x, w, R, n_cols, dys, dxs, xs);
+    }
+    return uamd_launch_status();
+}
+
+}  // namespace
+
+#define RMS_DISPATCH(FN, ...)                                                        \
+    if (x_dtype == UAMD_BF16 && w_dtype == UAMD_BF16) {                               \
+        return gemma ? FN<bf16_t, bf16_t, true>(__VA_ARGS__) : FN<bf16_t, bf16_t, false>(__VA_ARGS__); \
+    } else if (x_dtype == UAMD_BF16 && w_dtype == UAMD_F32) {                         \
+        return gemma ? FN<bf16_t, float, true>(__VA_ARGS__) : FN<bf16_t, float, false>(__VA_ARGS__);   \
+    } else if (x_dtype == UAMD_F16 && w_dtype == UAMD_F16) {                          \
+        return gemma ? FN<f16_t, f16_t, true>(__VA_ARGS__) : FN<f16_t, f16_t, false>(__VA_ARGS__);     \
+    } else if (x_dtype == UAMD_F16 && w_dtype == UAMD_F32) {                          \
+        return gemma ? FN<f16_t, float, true>(__VA_ARGS__) : FN<f16_t, float, false>(__VA_ARGS__);     \
+    } else if (x_dtype == UAMD_F32 && w_dtype == UAMD_F32) {                          \
+        return gemma ? FN<float, float, true>(__VA_ARGS__) : FN<float, float, false>(__VA_ARGS__);     \
+    }                                                                                \
+    return UAMD_ERR_DTYPE;
+
+extern "C" int uamd_rms_layernorm_fwd(const void* X, const void* W, void* Y, float* r,
+                                      int64_t n_rows, int n_cols, int64_t x_row_stride,
+                                      int64_t y_row_stride, float eps, int gemma, int x_dtype,
+                                      int w_dtype, void* stream) {
+    if (n_rows < 0 || n_cols <= 0) return UAMD_ERR_ARG;
+    if (n_rows == 0) return UAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    RMS_DISPATCH(launch_fwd, X, W, Y, r, n_rows, n_cols, x_row_stride, y_row_stride, eps, st)
+}
+
+extern "C" int uamd_rms_layernorm_bwd(const void* dY, void* dX, const void* X, const void* W,
+                                      const float* r, int64_t n_rows, int n_cols,
+                                      int64_t dy_row_stride, int64_t dx_row_stride,
+                                      int64_t x_row_stride, int gemma, int x_dtype, int w_dtype,
+                                      void* stream) {
+    if (n_rows < 0 || n_cols <= 0) return UAMD_ERR_ARG;
+    if (n_rows == 0) return UAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    RMS_DISPATCH(launch_bwd, dY, dX, X, W, r, n_rows, n_cols, dy_row_stride, dx_row_stride,
+                 x_row_stride, st)
+}

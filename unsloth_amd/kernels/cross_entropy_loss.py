@@ -1,0 +1,202 @@
+"""Cross-entropy through the HIP kernels; mirror of unsloth/kernels/cross_entropy_loss.py, plus
+the fused linear + cross-entropy entry point the reference imports from unsloth_zoo
+(`unsloth_fused_ce_loss`, call site unsloth/models/llama.py:1497-1509).
+
+  Fast_CrossEntropyLoss     (:288-418)  per-row loss, saves (logits, logsumexp, labels), backward
+                                        overwrites logits with the gradient and returns that buffer
+  fast_cross_entropy_loss   (:421-449)  sum / n_items
+  patch_loss_functions      (:459-473)  installs the fast loss into transformers' LOSS_MAPPING
+
+Vocabulary size is unlimited here (one streaming launch), so the reference's split into a
+<=65536 kernel and a chunked kernel + host torch.logsumexp (:303-370) disappears; results are
+the same quantity (logsumexp over the whole row).
+"""
+import torch
+
+from .. import _lib
+from . import utils as _u
+
+
+def _ce_forward(logits2d, labels, softcap, scale):
+    n_rows, vocab = logits2d.shape
+    losses = torch.empty(n_rows, dtype=torch.float32, device=logits2d.device)
+    lse = torch.empty(n_rows, dtype=torch.float32, device=logits2d.device)
+    with _lib.device_ctx(logits2d):
+        rc = _lib.lib().uamd_cross_entropy_forward(
+            _lib.ptr(logits2d), logits2d.stride(0), _lib.ptr(losses), _lib.ptr(lse), _lib.ptr(labels),
+            n_rows, vocab, float(softcap), float(scale), _lib.dtype_code(logits2d.dtype),
+            _lib.stream_of(logits2d))
+    _lib.check(rc, "uamd_cross_entropy_forward")
+    return losses, lse
+
+
+def _ce_backward_(logits2d, dlosses, lse, labels, softcap, scale):
+    n_rows, vocab = logits2d.shape
+    with _lib.device_ctx(logits2d):
+        rc = _lib.lib().uamd_cross_entropy_backward(
+            _lib.ptr(logits2d), logits2d.stride(0), _lib.ptr(dlosses), dlosses.stride(0), _lib.ptr(lse),
+            _lib.ptr(labels), n_rows, vocab, float(softcap), float(scale),
+            _lib.dtype_code(logits2d.dtype), _lib.stream_of(logits2d))
+    _lib.check(rc, "uamd_cross_entropy_backward")
+    return logits2d
+
+
+class Fast_CrossEntropyLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, logit_softcapping=0, logit_scaling=0):
+        _lib.require_gpu(logits)
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        labels = labels.to(device=logits.device, dtype=torch.int64).contiguous()
+        losses, lse = _ce_forward(logits, labels, logit_softcapping or 0, logit_scaling or 0)
+        ctx.save_for_backward(logits, lse, labels)
+        ctx.logit_softcapping = logit_softcapping or 0
+        ctx.logit_scaling = logit_scaling or 0
+        return losses
+
+    @staticmethod
+    def backward(ctx, dlosses):
+        logits, lse, labels = ctx.saved_tensors
+        dlosses = dlosses.to(torch.float32)
+        if dlosses.dim() == 0 or dlosses.stride(0) == 0:
+            dlosses = dlosses.expand(logits.shape[0]).contiguous()
+        # in place over the saved logits, returned as the gradient (:413-418)
+        _ce_backward_(logits, dlosses, lse, labels, ctx.logit_softcapping, ctx.logit_scaling)
+        return logits, None, None, None
+
+
+def fast_cross_entropy_loss(logits, labels, logit_softcapping=0, logit_scaling=0, n_items=None):
+    """logits (batch, seq_len, vocab), labels (batch, seq_len) -> scalar; :421-449."""
+    batch, seq_len, d = logits.shape
+    assert labels.shape == (batch, seq_len)
+    loss = Fast_CrossEntropyLoss.apply(
+        logits.view(batch * seq_len, d), labels.view(-1), logit_softcapping, logit_scaling)
+    if n_items is None:
+        n_items = torch.count_nonzero(labels != -100)
+    if torch.is_tensor(n_items):
+        n_items = n_items.to(logits.device)
+    return loss.sum() / n_items
+
+
+def _unsloth_causal_lm_loss(logits, labels, vocab_size=None, num_items_in_batch=None,
+                            ignore_index=-100, **kwargs):
+    """ForCausalLM loss with the fast kernel: shift labels (llama.py:1545-1551) then CE."""
+    shift_labels = kwargs.get("shift_labels")
+    if shift_labels is None:
+        shift_labels = torch.empty_like(labels)
+        shift_labels[..., :-1] = labels[..., 1:]
+        shift_labels[..., -1] = -100
+    if logits.dim() == 2:
+        logits = logits.unsqueeze(0)
+    return fast_cross_entropy_loss(logits, shift_labels.view(logits.shape[0], -1), n_items=num_items_in_batch)
+
+
+def post_patch_loss_function(model):
+    """unsloth_zoo.loss_utils.post_patch_loss_function: point the instance at the patched loss."""
+    try:
+        model.loss_function = _unsloth_causal_lm_loss
+    except Exception:
+        pass
+    return model
+
+
+def patch_loss_functions(torch_compile=True):
+    """:459-473: route transformers' ForCausalLM loss (and aliases of it) to the fast kernel."""
+    try:
+        import transformers.loss.loss_utils as _lu
+        for key, fn in list(_lu.LOSS_MAPPING.items()):
+            if key == "ForCausalLM" or getattr(fn, "__name__", "") == "ForCausalLMLoss":
+                _lu.LOSS_MAPPING[key] = _unsloth_causal_lm_loss
+    except (ImportError, AttributeError):
+        pass
+
+
+# ------------------------------------------------------------------------------------------------
+class _FusedLinearCE(torch.autograd.Function):
+    """loss = sum_rows CE(hidden @ W^T) / n_items without ever holding [T, V] logits.
+
+    Semantics of unsloth_zoo's unsloth_fused_ce_loss (third party, parity unpinned):
+    labels are already shifted by the caller of this Function; rows are processed in chunks; per
+    chunk: logits = h @ W^T in the activation dtype (MFMA GEMM), CE in fp32 inside the kernel,
+    d(hidden) computed in the forward (W is frozen) and scaled by the upstream scalar in backward.
+    """
+
+    @staticmethod
+    def forward(ctx, hidden2d, weight, weight_t, labels, n_items, softcap, scale, chunk_rows):
+        T, H = hidden2d.shape
+        V = weight.shape[0]
+        dev = hidden2d.device
+        loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        need_grad = hidden2d.requires_grad
+        dh = torch.empty_like(hidden2d) if need_grad else None
+        inv_n = (1.0 / n_items) if not torch.is_tensor(n_items) else (1.0 / n_items.to(torch.float32))
+        for r0 in range(0, T, chunk_rows):
+            r1 = min(T, r0 + chunk_rows)
+            h = hidden2d[r0:r1]
+            logits = torch.empty((r1 - r0, V), dtype=hidden2d.dtype, device=dev)
+            _u._launch_gemm(h, [_u._group(weight, logits, V, weight.stride(0))], nf4=False)
+            lab = labels[r0:r1]
+            losses, lse = _ce_forward(logits, lab, softcap, scale)
+            loss_sum += losses.sum()
+            if need_grad:
+                dl = torch.ones(r1 - r0, dtype=torch.float32, device=dev) * inv_n
+                _ce_backward_(logits, dl, lse, lab, softcap, scale)        # logits <- dlogits
+                # dh = dlogits @ W : contraction over V -> NT GEMM against W^T [H, V]
+                _u._launch_gemm(logits, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
+        ctx.save_for_backward(dh)
+        return loss_sum * inv_n
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dh,) = ctx.saved_tensors
+        if dh is not None:
+            dh = dh * dloss.to(dh.dtype)
+        return dh, None, None, None, None, None, None, None
+
+
+_WT_CACHE = {}
+
+
+def _transposed_weight(weight):
+    """W^T [H, V] of the frozen lm_head, built once per weight version (288 GB HBM: 1 GB is cheap,
+    and it turns the d(hidden) product into the same K-contiguous NT GEMM as everything else)."""
+    key = weight.data_ptr()
+    ent = _WT_CACHE.get(key)
+    if ent is None or ent[0] != weight._version or ent[1].shape != (weight.shape[1], weight.shape[0]):
+        _WT_CACHE.clear()
+        ent = (weight._version, weight.detach().t().contiguous())
+        _WT_CACHE[key] = ent
+    return ent[1]
+
+
+def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, labels, mask=None,
+                          n_items=None, scaling=None, target_gb=None, torch_compile=True,
+                          logit_softcapping=0, logit_scaling=0, chunk_rows=None, **kwargs):
+    """Same call signature as the reference's import (llama.py:1497-1509): shifts labels
+    internally, never materialises [T, V], returns the scalar mean loss over n_items."""
+    if lm_head_bias is not None or lm_head_weight.requires_grad:
+        raise NotImplementedError("fused linear-CE: frozen, bias-free lm_head only")
+    _lib.require_gpu(hidden_states)
+    H = hidden_states.shape[-1]
+    shift = torch.empty_like(labels)
+    shift[..., :-1] = labels[..., 1:]
+    shift[..., -1] = -100
+    if mask is not None:
+        shift = torch.where(mask.bool(), shift, torch.full_like(shift, -100))
+    shift = shift.reshape(-1).to(torch.int64).contiguous()
+    if n_items is None:
+        n_items = torch.count_nonzero(shift != -100)
+    h2d = hidden_states.reshape(-1, H)
+    if h2d.stride(1) != 1 or h2d.stride(0) % 8:
+        h2d = h2d.contiguous()
+    W = lm_head_weight.detach()
+    if W.dtype != h2d.dtype:
+        W = W.to(h2d.dtype)
+    Wt = _transposed_weight(W)
+    if chunk_rows is None:
+        chunk_rows = 4096           # 4096 x 128256 bf16 = 1.05 GB transient per chunk
+    loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
+                                int(chunk_rows))
+    if scaling is not None:
+        loss = loss * scaling
+    return loss

@@ -1,0 +1,191 @@
+"""Manual-autograd LoRA blocks; mirror of unsloth/kernels/fast_lora.py.
+
+  LoRA_MLP  (:28-229)   e = X Wg^T(+LoRA), g = X Wu^T(+LoRA), h = act(e,g), i = h Wd^T(+LoRA)
+  LoRA_QKV  (:335-540)  Q,K,V = X W{q,k,v}^T (+LoRA)
+  LoRA_W    (:574-650)  single projection (o_proj)
+  apply_lora_mlp_swiglu / _geglu_exact / _geglu_approx (:235-332), apply_lora_qkv (:543-571),
+  apply_lora_o (:653-657), fast_lora_forward (:662-665, raises NotImplementedError like the reference)
+
+Same saved tensors, same in-place contracts (the activation backward overwrites DW/e/g; dX is
+written into the saved X buffer when inplace=True, :193-204, :497-517), same gradient formulas:
+    dA = s * (dY B)^T X      dB = s * dY^T (X A^T)      dX = dY W + s (dY B) A
+What changes is the launch structure (kernels/utils.py): gate+up and q+k+v are one grouped MFMA
+GEMM with NF4 decode + LoRA term fused; each dX contribution is one transposing-dequant launch +
+one GEMM with the LoRA term fused. The six rank-r gradient products per block stay on the library
+GEMM (torch.matmul/addmm_), as in the reference (:172-189): they are tiny and latency-bound.
+"""
+import torch
+
+from .utils import (
+    get_lora_parameters,
+    lora_linear_dx,
+    lora_linear_forward,
+)
+from .swiglu import swiglu_fg_kernel, swiglu_DWf_DW_dfg_kernel
+from .geglu import (
+    geglu_exact_forward_kernel,
+    geglu_exact_backward_kernel,
+    geglu_approx_forward_kernel,
+    geglu_approx_backward_kernel,
+)
+
+try:  # amp decorators as unsloth/kernels/utils.py:45-54
+    _custom_fwd = torch.amp.custom_fwd(device_type="cuda")
+    _custom_bwd = torch.amp.custom_bwd(device_type="cuda")
+except Exception:  # pragma: no cover
+    _custom_fwd = lambda f: f
+    _custom_bwd = lambda f: f
+
+
+def _lora_grads(X2d, dY2d, A, B, s, dtype):
+    """(dA [r,in], dB [out,r]) for Y = X W^T + s (X A^T) B^T; fast_lora.py:172-189 in the
+    un-transposed layout. Returns (None, None) when the adapter is absent."""
+    if A is None:
+        return None, None
+    At, Bt = A.to(dtype).t(), B.to(dtype).t()          # [in,r], [r,out]
+    dA_t = torch.empty_like(At)                          # [in, r]
+    dB_t = torch.empty_like(Bt)                          # [r, out]
+    # d_A = X^T @ (dY @ B^T-as-stored) ; d_B = (A^T-as-stored @ X^T) @ dY     (:172-173)
+    dA_t.addmm_(X2d.t(), dY2d @ Bt.t(), alpha=s, beta=0)
+    dB_t.addmm_(At.t() @ X2d.t(), dY2d, alpha=s, beta=0)
+    return dA_t.t(), dB_t.t()
+
+
+class LoRA_MLP(torch.autograd.Function):
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, X, gateW, gateW_quant, gateA, gateB, gateS, upW, upW_quant, upA, upB, upS,
+                downW, downW_quant, downA, downB, downS, _forward_function, _backward_function,
+                inplace=True):
+        e, g = lora_linear_forward(X, [(gateW, gateW_quant, gateA, gateB, gateS),
+                                       (upW, upW_quant, upA, upB, upS)])
+        h = _forward_function(e, g)
+        (i,) = lora_linear_forward(h, [(downW, downW_quant, downA, downB, downS)])
+        ctx.custom_saved_tensors = (gateW, gateW_quant, gateS, upW, upW_quant, upS, downW,
+                                    downW_quant, downS, _backward_function)
+        ctx.save_for_backward(gateA, gateB, upA, upB, downA, downB, X, e, g)
+        ctx.inplace = inplace
+        return i
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dY):
+        (gateW, gateW_quant, gateS, upW, upW_quant, upS, downW, downW_quant, downS,
+         _backward_function) = ctx.custom_saved_tensors
+        gateA, gateB, upA, upB, downA, downB, X, e, g = ctx.saved_tensors
+        shape = X.shape
+        dY = dY.reshape(-1, dY.shape[-1])
+        X2 = X.reshape(-1, X.shape[-1])
+        e = e.view(-1, e.shape[-1])
+        g = g.view(-1, g.shape[-1])
+        dtype = X2.dtype
+
+        # DW = dY @ W_down (+ LoRA)                                     fast_lora.py:156
+        DW = lora_linear_dx([dY], [(downW, downW_quant, downA, downB, downS)])
+        DW, e, g = _backward_function(DW, e, g)                        # in place (:157)
+        h, df, de = DW, e, g
+
+        d_downA, d_downB = _lora_grads(h, dY, downA, downB, downS, dtype)
+        d_upA, d_upB = _lora_grads(X2, df, upA, upB, upS, dtype)
+        d_gateA, d_gateB = _lora_grads(X2, de, gateA, gateB, gateS, dtype)
+
+        # dX = df @ W_up + de @ W_gate (+ LoRA terms), into X's buffer when inplace (:193-204)
+        dX = lora_linear_dx([df, de], [(upW, upW_quant, upA, upB, upS),
+                                       (gateW, gateW_quant, gateA, gateB, gateS)],
+                            out=X2 if (ctx.inplace and X2.is_contiguous()) else None)
+        return (dX.view(shape), None, None, d_gateA, d_gateB, None, None, None, d_upA, d_upB, None,
+                None, None, d_downA, d_downB, None, None, None, None)
+
+
+def _apply_mlp(self, X, fwd, bwd, inplace=True):
+    gateW, gateW_quant, gateA, gateB, gateS = get_lora_parameters(self.gate_proj)
+    upW, upW_quant, upA, upB, upS = get_lora_parameters(self.up_proj)
+    downW, downW_quant, downA, downB, downS = get_lora_parameters(self.down_proj)
+    return LoRA_MLP.apply(X, gateW, gateW_quant, gateA, gateB, gateS, upW, upW_quant, upA, upB, upS,
+                          downW, downW_quant, downA, downB, downS, fwd, bwd, inplace)
+
+
+def apply_lora_mlp_swiglu(self, X, inplace=True):
+    return _apply_mlp(self, X, swiglu_fg_kernel, swiglu_DWf_DW_dfg_kernel, inplace)
+
+
+def apply_lora_mlp_geglu_exact(self, X, inplace=True):
+    return _apply_mlp(self, X, geglu_exact_forward_kernel, geglu_exact_backward_kernel, inplace)
+
+
+def apply_lora_mlp_geglu_approx(self, X):
+    return _apply_mlp(self, X, geglu_approx_forward_kernel, geglu_approx_backward_kernel)
+
+
+class LoRA_QKV(torch.autograd.Function):
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB, VS,
+                inplace=True):
+        Q, K, V = lora_linear_forward(X, [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS),
+                                          (VW, VW_quant, VA, VB, VS)])
+        ctx.custom_saved_tensors = (QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS)
+        ctx.save_for_backward(X, QA, QB, KA, KB, VA, VB)
+        ctx.inplace = inplace
+        return Q, K, V
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dQ, dK, dV):
+        QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS = ctx.custom_saved_tensors
+        X, QA, QB, KA, KB, VA, VB = ctx.saved_tensors
+        shape = X.shape
+        dQ = dQ.reshape(-1, dQ.shape[-1])
+        dK = dK.reshape(-1, dK.shape[-1])
+        dV = dV.reshape(-1, dV.shape[-1])
+        X2 = X.reshape(-1, X.shape[-1])
+        dtype = X2.dtype
+        d_QA, d_QB = _lora_grads(X2, dQ, QA, QB, QS, dtype)
+        d_KA, d_KB = _lora_grads(X2, dK, KA, KB, KS, dtype)
+        d_VA, d_VB = _lora_grads(X2, dV, VA, VB, VS, dtype)
+        # dX accumulated over q, k, v; overwrites X when inplace (fast_lora.py:497-517)
+        dX = lora_linear_dx([dQ, dK, dV], [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS),
+                                           (VW, VW_quant, VA, VB, VS)],
+                            out=X2 if (ctx.inplace and X2.is_contiguous()) else None)
+        return (dX.view(shape), None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None,
+                d_VA, d_VB, None, None)
+
+
+def apply_lora_qkv(self, X, inplace=True):
+    QW, QW_quant, QA, QB, QS = get_lora_parameters(self.q_proj)
+    KW, KW_quant, KA, KB, KS = get_lora_parameters(self.k_proj)
+    VW, VW_quant, VA, VB, VS = get_lora_parameters(self.v_proj)
+    return LoRA_QKV.apply(X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB,
+                          VS, inplace)
+
+
+class LoRA_W(torch.autograd.Function):
+    @staticmethod
+    @_custom_fwd
+    def forward(ctx, X, W, W_quant, A, B, S):
+        (XW,) = lora_linear_forward(X, [(W, W_quant, A, B, S)])
+        ctx.custom_saved_tensors = (W, W_quant, S)
+        ctx.save_for_backward(A, B, X)
+        return XW
+
+    @staticmethod
+    @_custom_bwd
+    def backward(ctx, dY):
+        W, W_quant, S = ctx.custom_saved_tensors
+        A, B, X = ctx.saved_tensors
+        shape = X.shape
+        dY = dY.reshape(-1, dY.shape[-1])
+        X2 = X.reshape(-1, X.shape[-1])
+        d_A, d_B = _lora_grads(X2, dY, A, B, S, X2.dtype)
+        dX = lora_linear_dx([dY], [(W, W_quant, A, B, S)])
+        return dX.view(shape), None, None, d_A, d_B, None
+
+
+def apply_lora_o(self, X):
+    OW, OW_quant, OA, OB, OS = get_lora_parameters(self.o_proj)
+    return LoRA_W.apply(X, OW, OW_quant, OA, OB, OS)
+
+
+@torch._disable_dynamo
+def fast_lora_forward(self, x, *args, **kwargs):
+    raise NotImplementedError("Unsloth: Currently not supported yet - reshaping done incorrectly")

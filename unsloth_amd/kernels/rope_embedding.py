@@ -1,0 +1,142 @@
+"""RoPE through the HIP kernel; mirror of unsloth/kernels/rope_embedding.py.
+
+  Fast_RoPE_Embedding     (:169-261)  dense [B,T,H,D] rows, position = row % seqlen, in place
+  Fast_RoPE_Embedding_QK  (:283-399)  Q,K as [B,H,T,D] (possibly strided views), optional int32
+                                      per-token gather indices, one launch for Q and K
+  fast_rope_embedding     (:265-280)  dispatch on rope_embedding_indices
+  Slow_RoPE_Embedding / inplace_rope_embedding (:402-439) torch formulation, kept as the reference has it
+
+MI355X difference: the kernel takes element strides, so `fast_rope_embedding` without indices
+does NOT pay the reference's `Q.transpose(1,2).contiguous()` copies (:276-277): it rotates the
+[B,H,T,D] views in place through the strided entry point. Backward = same kernel with sin -> -sin.
+"""
+import torch
+
+from .. import _lib
+
+
+def _tables(cos, sin):
+    cos, sin = cos.squeeze(), sin.squeeze()
+    if cos.dim() != 2 or cos.stride(1) != 1 or sin.stride(1) != 1:
+        cos, sin = cos.reshape(-1, cos.shape[-1]).contiguous(), sin.reshape(-1, sin.shape[-1]).contiguous()
+    return cos, sin
+
+
+def _launch_qk(Q, K, cos, sin, idx, backward):
+    batch, n_heads_Q, seq_len, head_dim = Q.shape
+    n_heads_K = K.shape[1] if K is not None else 0
+    if Q.stride(3) != 1 or (K is not None and K.stride(3) != 1):
+        raise ValueError("head_dim must be the contiguous dimension")
+    with _lib.device_ctx(Q):
+        rc = _lib.lib().uamd_rope_embedding_qk(
+            _lib.ptr(Q), Q.stride(0), Q.stride(1), Q.stride(2),
+            _lib.ptr(K), *( (K.stride(0), K.stride(1), K.stride(2)) if K is not None else (0, 0, 0) ),
+            _lib.ptr(cos), cos.stride(0), _lib.ptr(sin), sin.stride(0), _lib.ptr(idx),
+            batch, seq_len, n_heads_Q, n_heads_K, head_dim, int(backward),
+            _lib.dtype_code(Q.dtype), _lib.dtype_code(cos.dtype), _lib.stream_of(Q))
+    _lib.check(rc, "uamd_rope_embedding_qk")
+
+
+class Fast_RoPE_Embedding(torch.autograd.Function):
+    """Q: [batch, seq_len, n_heads, head_dim] contiguous; rotated in place (:169-261)."""
+
+    @staticmethod
+    def forward(ctx, Q, cos, sin):
+        _lib.require_gpu(Q, cos, sin)
+        cos, sin = _tables(cos, sin)
+        batch, seq_len, n_heads, head_dim = Q.shape
+        assert seq_len <= cos.shape[0]
+        Q = Q.reshape(batch * seq_len, n_heads * head_dim)
+        if Q.stride(1) != 1:
+            Q = Q.contiguous()
+        Fast_RoPE_Embedding._run(Q, cos, sin, seq_len, n_heads, head_dim, False)
+        ctx.cos, ctx.sin = cos, sin
+        return Q.reshape(batch, seq_len, n_heads, head_dim)
+
+    @staticmethod
+    def _run(Q2d, cos, sin, seq_len, n_heads, head_dim, backward):
+        with _lib.device_ctx(Q2d):
+            rc = _lib.lib().uamd_rope_embedding(
+                _lib.ptr(Q2d), Q2d.stride(0), _lib.ptr(cos), cos.stride(0), _lib.ptr(sin), sin.stride(0),
+                Q2d.shape[0], seq_len, n_heads, head_dim, int(backward), _lib.dtype_code(Q2d.dtype),
+                _lib.dtype_code(cos.dtype), _lib.stream_of(Q2d))
+        _lib.check(rc, "uamd_rope_embedding")
+
+    @staticmethod
+    def backward(ctx, dY):
+        batch, seq_len, n_heads, head_dim = dY.shape
+        dY = dY.reshape(batch * seq_len, n_heads * head_dim)
+        if dY.stride(1) != 1:
+            dY = dY.contiguous()
+        Fast_RoPE_Embedding._run(dY, ctx.cos, ctx.sin, seq_len, n_heads, head_dim, True)
+        return dY.reshape(batch, seq_len, n_heads, head_dim), None, None
+
+
+class Fast_RoPE_Embedding_QK(torch.autograd.Function):
+    """Q [B,Hq,T,D], K [B,Hk,T,D]; rope_indices int32 [B*T] or None (:283-399). In place; strided
+    views (e.g. the transposed halves of a fused QKV GEMM output) are rotated where they live."""
+
+    @staticmethod
+    def forward(ctx, Q, K, cos, sin, rope_indices):
+        _lib.require_gpu(Q, K, cos, sin)
+        has_indices = rope_indices is not None
+        cos, sin = _tables(cos, sin)
+        Q_out = Q if Q.stride(-1) == 1 else Q.contiguous()
+        K_out = K if K.stride(-1) == 1 else K.contiguous()
+        idx = None
+        if has_indices:
+            # rope_embedding.py:295-297: int32 on the device
+            idx = rope_indices.reshape(-1).to(dtype=torch.int32, device=Q.device).contiguous()
+            assert idx.numel() == Q.shape[0] * Q.shape[2]
+        _launch_qk(Q_out, K_out, cos, sin, idx, False)
+        ctx.cos, ctx.sin, ctx.idx = cos, sin, idx
+        # Like the reference (:290-294 "Inplace rotary embedding is generally fine") the rotation is
+        # written through the raw pointer and the input object is returned; nothing upstream needs
+        # the un-rotated projections (LoRA_QKV saves X, not Q/K).
+        return Q_out, K_out
+
+    @staticmethod
+    def backward(ctx, dQ, dK):
+        dQ_out = dQ if dQ.stride(-1) == 1 else dQ.contiguous()
+        dK_out = dK if dK.stride(-1) == 1 else dK.contiguous()
+        _launch_qk(dQ_out, dK_out, ctx.cos, ctx.sin, ctx.idx, True)
+        return dQ_out, dK_out, None, None, None
+
+
+@torch.compiler.disable
+def fast_rope_embedding(Q, K, cos, sin, rope_embedding_indices=None):
+    """rope_embedding.py:265-280. Q [B,Hq,T,D], K [B,Hk,T,D] -> (Q, K) rotated."""
+    return Fast_RoPE_Embedding_QK.apply(Q, K, cos, sin, rope_embedding_indices)
+
+
+class Slow_RoPE_Embedding(torch.autograd.Function):
+    """Torch formulation, verbatim semantics of rope_embedding.py:402-432 (in place on Q)."""
+
+    @staticmethod
+    def forward(ctx, Q, cos, sin, position_ids):
+        if position_ids is not None:
+            cos = cos.squeeze(1).squeeze(0)
+            sin = sin.squeeze(1).squeeze(0)
+            cos = cos[position_ids].unsqueeze(2)
+            sin = sin[position_ids].unsqueeze(2)
+        half = Q.shape[-1] // 2
+        RH_Q = torch.cat((-Q[..., half:], Q[..., :half]), dim=-1)
+        Q *= cos
+        Q.addcmul_(RH_Q, sin)
+        ctx.save_for_backward(cos, sin)
+        return Q
+
+    @staticmethod
+    def backward(ctx, dY):
+        cos, sin = ctx.saved_tensors
+        half = dY.shape[-1] // 2
+        RH_dY = torch.cat((dY[..., half:], -dY[..., :half]), dim=-1)
+        dY *= cos
+        dY.addcmul_(RH_dY, sin)
+        return dY, None, None, None
+
+
+def inplace_rope_embedding(Q, K, cos, sin, position_ids):
+    Q = Slow_RoPE_Embedding.apply(Q, cos, sin, position_ids)
+    K = Slow_RoPE_Embedding.apply(K, cos, sin, position_ids)
+    return Q, K

@@ -1,0 +1,280 @@
+"""Host-side mirror of unsloth/kernels/utils.py for the MI355X path.
+
+Same names and argument meaning as the reference:
+  QUANT_STATE                utils.py:319-320
+  get_lora_parameters(_bias) utils.py:335-440   (the plug-in contract with PEFT)
+  fast_dequantize            utils.py:567-679
+  matmul_lora                utils.py:1128-1170
+  calculate_settings         utils.py:114-133   (kept for API compatibility; the HIP kernels have no
+                                                 65536-column limit, so nothing here raises on size)
+plus the grouped entry points the manual-autograd Functions in fast_lora.py use
+(`lora_linear_forward`, `lora_linear_dx`), which is where the MI355X design differs: projections
+that share their input (q/k/v, gate/up) are ONE uamd_lora_xa launch and ONE grouped MFMA GEMM
+launch, with NF4 decode and the LoRA term fused into the GEMM (csrc/gemm.hip).
+"""
+import ctypes
+import os
+
+import torch
+
+from .. import _lib
+from .. import nf4 as _nf4
+from .._lib import GemmGroup
+
+MAX_FUSED_SIZE = 65536
+next_power_of_2 = lambda n: 1 << (max(int(n), 1) - 1).bit_length()
+
+# fused NF4-decode-in-GEMM forward (no bf16 copy of W in HBM) vs dequant-to-scratch + dense GEMM
+FUSED_NF4 = os.environ.get("UNSLOTH_AMD_FUSED_NF4", "1") == "1"
+
+
+def calculate_settings(n):
+    """(BLOCK_SIZE, num_warps) as utils.py:114-133. Informational only on this backend."""
+    BLOCK_SIZE = next_power_of_2(n)
+    num_warps = 4
+    if BLOCK_SIZE >= 32768:
+        num_warps = 32
+    elif BLOCK_SIZE >= 8192:
+        num_warps = 16
+    elif BLOCK_SIZE >= 2048:
+        num_warps = 8
+    return BLOCK_SIZE, num_warps
+
+
+def QUANT_STATE(W):
+    return getattr(W, "quant_state", None)
+
+
+def get_lora_parameters(proj):
+    """(W, quant_state, A, B, scaling) of a PEFT-style LoRA layer; utils.py:335-397.
+    Disabled / merged adapters -> (W, quant_state, None, None, None) (:369-370)."""
+    base_layer = getattr(proj, "base_layer", proj)
+    W = base_layer.weight
+    if hasattr(base_layer, "weight_fake_quantizer"):
+        fq = getattr(base_layer, "weight_fake_quantizer", None)
+        if fq is not None:
+            W = fq(W)
+    W_quant = getattr(W, "quant_state", None)
+    if getattr(proj, "disable_adapters", True) or proj.merged:
+        return W, W_quant, None, None, None
+    adapter = getattr(proj, "active_adapters", None)
+    if adapter is None:
+        adapter = getattr(proj, "active_adapter", ("default"))
+    adapter = adapter[0]
+    A = proj.lora_A[adapter].weight
+    B = proj.lora_B[adapter].weight
+    fq = getattr(proj.lora_A[adapter], "weight_fake_quantizer", None)
+    if fq is not None:
+        A = fq(A)
+    fq = getattr(proj.lora_B[adapter], "weight_fake_quantizer", None)
+    if fq is not None:
+        B = fq(B)
+    return W, W_quant, A, B, proj.scaling[adapter]
+
+
+def get_lora_parameters_bias(proj):
+    """utils.py:400-440: same plus the base layer's bias."""
+    base_layer = getattr(proj, "base_layer", proj)
+    W = base_layer.weight
+    W_quant = getattr(W, "quant_state", None)
+    if getattr(proj, "disable_adapters", True) or proj.merged:
+        return W, W_quant, None, None, None, base_layer.bias
+    adapter = getattr(proj, "active_adapters", None)
+    if adapter is None:
+        adapter = getattr(proj, "active_adapter", ("default"))
+    adapter = adapter[0]
+    return (W, W_quant, proj.lora_A[adapter].weight, proj.lora_B[adapter].weight,
+            proj.scaling[adapter], base_layer.bias)
+
+
+@torch.inference_mode()
+def fast_dequantize(W, quant_state=None, out=None, use_global_buffer=False):
+    """utils.py:567-679. Dense [out,in] weight in quant_state.dtype; passthrough when
+    quant_state is None (:578-579); returns the TRANSPOSE when handed `W.t()` of the packed
+    storage, i.e. W.shape[0] == 1 (:678-679). With use_global_buffer the result is a view of a
+    per-device scratch buffer that the next call overwrites (:608-632)."""
+    if quant_state is None:
+        return W
+    is_transposed = W.shape[0] == 1
+    packed = W.t() if is_transposed else W
+    out = _nf4.dequantize_nf4(packed, quant_state, out=out, use_global_buffer=use_global_buffer)
+    return out.t() if is_transposed else out
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM plumbing
+def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0):
+    return GemmGroup(
+        B=B.data_ptr(), C=C.data_ptr(), absmax=absmax.data_ptr() if absmax is not None else None,
+        lora_xa=xa.data_ptr() if xa is not None else None, lora_b=lb.data_ptr() if lb is not None else None,
+        ldb=ldb, ldc=C.stride(0), ld_xa=ld_xa, ld_lb=lb.stride(0) if lb is not None else 0,
+        N=N, R=R, lora_scale=float(scale), _pad=0)
+
+
+def _launch_gemm(X2d, groups, nf4, accumulate=False):
+    arr = (GemmGroup * len(groups))(*groups)
+    fn = _lib.lib().uamd_gemm_nt_nf4 if nf4 else _lib.lib().uamd_gemm_nt
+    with _lib.device_ctx(X2d):
+        rc = fn(_lib.ptr(X2d), X2d.stride(0), X2d.shape[0], X2d.shape[1], arr, len(groups),
+                int(accumulate), _lib.dtype_code(X2d.dtype), _lib.stream_of(X2d))
+    _lib.check(rc, "uamd_gemm_nt_nf4" if nf4 else "uamd_gemm_nt")
+
+
+def _rows2d(X):
+    X2d = X.reshape(-1, X.shape[-1])
+    if X2d.stride(1) != 1 or (X2d.stride(0) % 8) or (X2d.data_ptr() % 16):
+        X2d = X2d.contiguous()
+    return X2d
+
+
+def lora_xa(X2d, A_list):
+    """XA_g = X @ A_g^T for every projection sharing X, ONE launch. fp32, each block of columns
+    padded to a multiple of 8. Returns (buffer, [(col_offset, R_padded)])."""
+    dtype = X2d.dtype
+    Rs = [A.shape[0] for A in A_list]
+    Rp = [(r + 7) // 8 * 8 for r in Rs]
+    K = X2d.shape[1]
+    if len(A_list) == 1 and Rs[0] == Rp[0]:
+        Acat = A_list[0].to(dtype).contiguous()                       # A.to(dtype), utils.py:1166
+    else:
+        Acat = torch.zeros((sum(Rp), K), dtype=dtype, device=X2d.device)
+        o = 0
+        for A, r, rp in zip(A_list, Rs, Rp):
+            Acat[o:o + r] = A
+            o += rp
+    Rt = Acat.shape[0]
+    if Rt > 192:
+        raise NotImplementedError(f"sum of LoRA ranks sharing one input = {Rt} > 192")
+    out = torch.empty((X2d.shape[0], Rt), dtype=torch.float32, device=X2d.device)
+    with _lib.device_ctx(X2d):
+        rc = _lib.lib().uamd_lora_xa(_lib.ptr(X2d), X2d.stride(0), _lib.ptr(Acat), Acat.stride(0),
+                                     _lib.ptr(out), out.stride(0), X2d.shape[0], K, Rt, Rt,
+                                     _lib.dtype_code(dtype), _lib.stream_of(X2d))
+    _lib.check(rc, "uamd_lora_xa")
+    offs, o = [], 0
+    for rp in Rp:
+        offs.append((o, rp))
+        o += rp
+    return out, offs
+
+
+def _pad_rank(B, Rp, dtype):
+    """LoRA B [N, r] -> contiguous [N, Rp] in the activation dtype (B.to(dtype), utils.py:1167)."""
+    N, r = B.shape
+    if r == Rp:
+        return B.to(dtype).contiguous()
+    out = torch.zeros((N, Rp), dtype=dtype, device=B.device)
+    out[:, :r] = B
+    return out
+
+
+def lora_linear_forward(X, projs, outs=None):
+    """Y_g = X @ W_g^T + s_g * (X @ A_g^T) @ B_g^T for projections `projs` = [(W, W_quant, A, B, s)]
+    that share X. Returns a list of [.., N_g] tensors. This is matmul_lora (utils.py:1128-1170)
+    for q/k/v or gate/up at once."""
+    _lib.require_gpu(X)
+    dtype = X.dtype
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError("the MFMA GEMM path takes bf16/fp16 activations")
+    X2d = _rows2d(X)
+    M, K = X2d.shape
+    lead = X.shape[:-1]
+    with_lora = [p for p in projs if p[2] is not None]
+    xa, offs = (None, [])
+    if with_lora:
+        xa, offs = lora_xa(X2d, [p[2] for p in with_lora])
+    results, dense_groups, nf4_groups, keep = [], [], [], []
+    li = 0
+    for gi, (W, W_quant, A, B, s) in enumerate(projs):
+        if W_quant is not None:
+            N = W_quant.shape[0]
+            assert W_quant.shape[1] == K, "weight/in_features mismatch"
+        else:
+            N = W.shape[0]
+        C = outs[gi] if outs is not None else torch.empty((M, N), dtype=dtype, device=X.device)
+        kw = {}
+        if A is not None:
+            o, rp = offs[li]
+            li += 1
+            lb = _pad_rank(B, rp, dtype)
+            keep.append(lb)
+            kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
+        if W_quant is not None and FUSED_NF4 and W_quant.blocksize == 64 and K % 64 == 0:
+            nf4_groups.append(_group(W, C, N, 0, absmax=_nf4.absmax_f32(W_quant), **kw))
+        else:
+            Wd = W
+            if W_quant is not None:
+                Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=(len(projs) == 1))
+            elif Wd.dtype != dtype or Wd.stride(1) != 1 or Wd.stride(0) % 8:
+                Wd = Wd.to(dtype).contiguous()
+            keep.append(Wd)
+            dense_groups.append(_group(Wd, C, N, Wd.stride(0), **kw))
+        results.append(C)
+    if nf4_groups:
+        _launch_gemm(X2d, nf4_groups, nf4=True)
+    if dense_groups:
+        _launch_gemm(X2d, dense_groups, nf4=False)
+    return [r.view(*lead, r.shape[-1]) for r in results]
+
+
+def lora_linear_dx(dYs, projs, out=None):
+    """dX = sum_g dY_g @ W_g + s_g * (dY_g @ B_g) @ A_g   (fast_lora.py:193-204, 497-517, 639-647).
+    The contraction runs over `out`, so the NF4 weight is decoded TRANSPOSED into the per-device
+    scratch (one launch) and fed to the same NT GEMM. `out` (e.g. the saved X, reference's
+    inplace=True) receives the result."""
+    dtype = dYs[0].dtype
+    first = True
+    for dY, (W, W_quant, A, B, s) in zip(dYs, projs):
+        dY2d = _rows2d(dY)
+        M, N = dY2d.shape
+        if W_quant is not None:
+            Kin = W_quant.shape[1]
+            Wt = _nf4.dequantize_nf4(W, W_quant, transpose=True, use_global_buffer=True)   # [Kin, N]
+        else:
+            Kin = W.shape[1]
+            Wt = W.to(dtype).t().contiguous()
+        if out is None:
+            out = torch.empty((M, Kin), dtype=dtype, device=dY.device)
+        kw = {}
+        if A is not None:
+            Bt = B.to(dtype).t().contiguous()                       # [r, N]
+            xa, offs = lora_xa(dY2d, [Bt])                          # dY @ B
+            rp = offs[0][1]
+            lb = _pad_rank(A.to(dtype).t(), rp, dtype)              # A^T [Kin, r]
+            kw = dict(xa=xa, ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
+        g = _group(Wt, out, Kin, Wt.stride(0), **kw)
+        _launch_gemm(dY2d, [g], nf4=False, accumulate=not first)
+        first = False
+    return out
+
+
+def matmul_lora(X, W, W_quant, A, B, s, out=None):
+    """utils.py:1128-1170: out = X @ dequant(W).T (+ s * (X @ A.T) @ B.T).
+    `W` may be the transposed packed storage (`W.t()`, shape [1, n/2]) or a transposed dense view,
+    as LoRA_MLP.backward passes it (fast_lora.py:156); then the product is X @ W and A/B arrive
+    already swapped and transposed ([in? r] layout), exactly like the reference."""
+    reshape = X.dim() == 3
+    if reshape:
+        batch, seq_len, _ = X.shape
+    transposed = (W_quant is not None and W.shape[0] == 1) or (
+        W_quant is None and W.dim() == 2 and W.stride(0) == 1 and W.stride(1) != 1)
+    if not transposed:
+        res = lora_linear_forward(X, [(W, W_quant, A, B, s)], outs=None if out is None else [out])[0]
+    else:
+        Wn = W.t()
+        # reference call: matmul_lora(dY, W.t(), q, B.t(), A.t(), s) -> our (A, B) are (B_lora^T, A_lora^T)
+        proj = (Wn, W_quant, None if B is None else B.t(), None if A is None else A.t(), s)
+        res = lora_linear_dx([X], [proj], out=out)
+    return res.view(batch, seq_len, -1) if reshape else res
+
+
+def fast_linear_forward(proj, X, temp_lora=None, out=None):
+    """utils.py:1082-1125 (decode-time linear). Inference is out of scope; this keeps
+    the entry point working through the training GEMM."""
+    W, W_quant, A, B, s = get_lora_parameters(proj)
+    return matmul_lora(X, W, W_quant, A, B, s, out=out)
+
+
+def fast_gemv(X, W, quant_state, out=None):
+    """utils.py:872-977 (NF4 GEMV for single-token decode): out of scope, routed to the GEMM."""
+    return matmul_lora(X, W, quant_state, None, None, None, out=out)

@@ -1,0 +1,277 @@
+"""NF4 (bitsandbytes 4-bit NormalFloat) quantisation state, quantiser and 4-bit Linear, without
+bitsandbytes.
+
+The reference never touches these bytes itself: it builds a `BitsAndBytesConfig(nf4,
+double_quant)` (unsloth/models/llama.py:2615-2626) and reads `W.quant_state` fields in
+`fast_dequantize` (unsloth/kernels/utils.py:582-606): `absmax, shape, dtype, blocksize, offset,
+state2.{absmax, code, blocksize}`. This module provides objects with exactly those attribute
+names so `get_lora_parameters` / `fast_dequantize` read them the same way, plus the serialised
+key layout of bitsandbytes checkpoints:
+    weight, weight.absmax, weight.quant_map, weight.nested_absmax, weight.nested_quant_map,
+    weight.quant_state.bitsandbytes__nf4
+Format restated from the published bitsandbytes algorithm (pinned >=0.45.5 by the reference,
+pyproject.toml:473); parity against bitsandbytes itself is UNPINNED (not installed here).
+"""
+import json
+
+import torch
+
+from . import _lib
+
+NF4_CODE = [
+    -1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453,
+    -0.28444138169288635, -0.18477343022823334, -0.09105003625154495, 0.0,
+    0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+    0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0,
+]
+
+
+def create_dynamic_map(signed=True, max_exponent_bits=7, total_bits=8):
+    """bitsandbytes' 8-bit "dynamic" quantisation map (functional.create_dynamic_map), used for
+    the nested quantisation of absmax. Restated; the map also travels inside the quant state, so
+    kernels read it from there and never depend on this function."""
+    data = []
+    non_sign_bits = total_bits - 1
+    additional_items = 2 ** (non_sign_bits - max_exponent_bits) - 1
+    for i in range(max_exponent_bits):
+        fraction_items = int(
+            2 ** (i + non_sign_bits - max_exponent_bits) + 1
+            if signed
+            else 2 ** (i + non_sign_bits - max_exponent_bits + 1) + 1
+        )
+        boundaries = torch.linspace(0.1, 1, fraction_items)
+        means = (boundaries[:-1] + boundaries[1:]) / 2.0
+        data += ((10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+        if signed:
+            data += (-(10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+    if additional_items > 0:
+        boundaries = torch.linspace(0.1, 1, additional_items + 1)
+        means = (boundaries[:-1] + boundaries[1:]) / 2.0
+        data += ((10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+        if signed:
+            data += (-(10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+    data.append(0)
+    data.append(1.0)
+    assert len(data) == 2**total_bits
+    data.sort()
+    return torch.tensor(data, dtype=torch.float32)
+
+
+class QuantState:
+    """Attribute-compatible with bitsandbytes.functional.QuantState."""
+
+    def __init__(self, absmax, shape=None, code=None, blocksize=64, quant_type="nf4", dtype=None,
+                 offset=None, state2=None):
+        self.absmax = absmax
+        self.shape = torch.Size(shape) if shape is not None else None
+        self.code = code
+        self.blocksize = blocksize
+        self.quant_type = quant_type
+        self.dtype = dtype
+        self.offset = offset
+        self.state2 = state2
+        self.nested = state2 is not None
+        self._absmax_f32 = None  # lazily de-nested statistics (288 GB HBM: keep, do not recompute)
+
+    def to(self, device):
+        self.absmax = self.absmax.to(device)
+        if self.code is not None:
+            self.code = self.code.to(device)
+        if self.nested:
+            self.offset = self.offset.to(device)
+            self.state2.absmax = self.state2.absmax.to(device)
+            self.state2.code = self.state2.code.to(device)
+        self._absmax_f32 = None
+        return self
+
+    # ---- bitsandbytes checkpoint (safetensors) layout ---------------------------------------
+    def as_dict(self, packed=True):
+        qs = {
+            "quant_type": self.quant_type, "blocksize": self.blocksize,
+            "dtype": str(self.dtype).replace("torch.", ""), "shape": tuple(self.shape),
+        }
+        out = {"absmax": self.absmax, "quant_map": self.code}
+        if self.nested:
+            qs.update(nested_blocksize=self.state2.blocksize, nested_dtype="float32",
+                      nested_offset=float(self.offset))
+            out.update(nested_absmax=self.state2.absmax, nested_quant_map=self.state2.code)
+        if packed:
+            blob = torch.tensor(list(json.dumps(qs).encode("utf-8")), dtype=torch.uint8)
+            out["quant_state.bitsandbytes__" + self.quant_type] = blob
+        else:
+            out.update(qs)
+        return out
+
+    @classmethod
+    def from_dict(cls, qs_dict, device):
+        qs_dict = dict(qs_dict)
+        key = [k for k in qs_dict if "quant_state.bitsandbytes__" in k]
+        if key:
+            blob = qs_dict.pop(key[0])
+            qs_dict.update(json.loads(bytes(blob.cpu().tolist()).decode("utf-8")))
+        qs_dict = {k.split(".")[-1]: v for k, v in qs_dict.items()}
+        state2, offset = None, None
+        if "nested_absmax" in qs_dict:
+            offset = torch.tensor(float(qs_dict["nested_offset"]), dtype=torch.float32, device=device)
+            state2 = cls(absmax=qs_dict["nested_absmax"].to(device), blocksize=qs_dict["nested_blocksize"],
+                         code=qs_dict["nested_quant_map"].to(device), dtype=torch.float32,
+                         quant_type=None)
+        return cls(absmax=qs_dict["absmax"].to(device), shape=qs_dict["shape"],
+                   code=qs_dict["quant_map"].to(device), blocksize=qs_dict["blocksize"],
+                   quant_type=qs_dict["quant_type"], dtype=getattr(torch, qs_dict["dtype"]),
+                   offset=offset, state2=state2)
+
+
+def absmax_f32(quant_state):
+    """fp32 absmax per block, de-nesting once: code2[absmax_u8]*absmax2 + offset
+    (the arithmetic of utils.py:650-659). Cached on the state: statistics are frozen."""
+    qs = quant_state
+    if not qs.nested:
+        return qs.absmax
+    if qs._absmax_f32 is None or qs._absmax_f32.device != qs.absmax.device:
+        _lib.require_gpu(qs.absmax)
+        n = qs.absmax.numel()
+        out = torch.empty(n, dtype=torch.float32, device=qs.absmax.device)
+        offset = float(qs.offset)  # one-time sync per weight (cached afterwards)
+        with _lib.device_ctx(out):
+            rc = _lib.lib().uamd_dequantize_absmax(
+                _lib.ptr(qs.state2.code), _lib.ptr(qs.absmax), _lib.ptr(qs.state2.absmax), offset,
+                _lib.ptr(out), qs.state2.blocksize, n, _lib.stream_of(out))
+        _lib.check(rc, "uamd_dequantize_absmax")
+        qs._absmax_f32 = out
+    return qs._absmax_f32
+
+
+def _quantize_blockwise_8bit(x, code, blocksize):
+    """Nested statistics quantiser: nearest entry of `code` after per-block absmax scaling
+    (bitsandbytes quantize_blockwise). Host logic on tiny tensors -> plain torch ops."""
+    n = x.numel()
+    pad = (-n) % blocksize
+    xp = torch.nn.functional.pad(x.float(), (0, pad)).view(-1, blocksize)
+    absmax2 = xp.abs().amax(dim=1)
+    scaled = xp / absmax2.clamp_min(1e-30).unsqueeze(1)
+    code = code.to(x.device)
+    mids = (code[:-1] + code[1:]) / 2
+    idx = torch.bucketize(scaled.reshape(-1)[:n].contiguous(), mids)
+    return idx.to(torch.uint8), absmax2
+
+
+def quantize_nf4(W, blocksize=64, compress_statistics=True):
+    """W [out,in] (fp32/fp16/bf16, on the GPU) -> (packed uint8 [out*in/2, 1], QuantState).
+    First level through the HIP kernel (uamd_nf4_quantize); double quantisation of absmax with
+    blocksize 256 and the fp32 mean offset as bitsandbytes quantize_4bit does."""
+    _lib.require_gpu(W)
+    W = W.contiguous()
+    n = W.numel()
+    if n % blocksize:
+        raise ValueError(f"numel {n} is not a multiple of blocksize {blocksize}")
+    packed = torch.empty((n // 2, 1), dtype=torch.uint8, device=W.device)
+    absmax = torch.empty(n // blocksize, dtype=torch.float32, device=W.device)
+    with _lib.device_ctx(W):
+        rc = _lib.lib().uamd_nf4_quantize(_lib.ptr(W), _lib.ptr(packed), _lib.ptr(absmax), n, blocksize,
+                                          _lib.dtype_code(W.dtype), _lib.stream_of(W))
+    _lib.check(rc, "uamd_nf4_quantize")
+    code = torch.tensor(NF4_CODE, dtype=torch.float32, device=W.device)
+    if compress_statistics:
+        offset = absmax.mean()
+        code2 = create_dynamic_map().to(W.device)
+        q, absmax2 = _quantize_blockwise_8bit(absmax - offset, code2, 256)
+        state2 = QuantState(absmax=absmax2, code=code2, blocksize=256, dtype=torch.float32, quant_type=None)
+        qs = QuantState(absmax=q, shape=W.shape, dtype=W.dtype, blocksize=blocksize, code=code,
+                        quant_type="nf4", offset=offset, state2=state2)
+    else:
+        qs = QuantState(absmax=absmax, shape=W.shape, dtype=W.dtype, blocksize=blocksize, code=code,
+                        quant_type="nf4")
+    return packed, qs
+
+
+_SCRATCH = {}
+
+
+def scratch(device, numel, dtype, slot=0):
+    """Per-device reusable buffer, the analogue of WEIGHT_BUFFERS (utils.py:608-632). The view it
+    returns is overwritten by the next call with the same slot on that device (stream ordered)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), dtype, slot)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = torch.empty(numel, dtype=dtype, device=device)
+        _SCRATCH[key] = buf
+    return buf[:numel]
+
+
+def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_buffer=False,
+                   cache_absmax=True):
+    """Dense [out,in] (or [in,out] when transpose) matrix in quant_state.dtype: ONE launch for the
+    nested-absmax + NF4 decode that the reference does in three (utils.py:650-675)."""
+    qs = quant_state
+    _lib.require_gpu(packed)
+    if qs.quant_type != "nf4":
+        raise NotImplementedError(f"quant_type {qs.quant_type!r}: only nf4 is implemented")
+    rows, cols = qs.shape
+    dtype = qs.dtype
+    shape = (cols, rows) if transpose else (rows, cols)
+    if out is None:
+        if use_global_buffer:
+            out = scratch(packed.device, rows * cols, dtype, slot=1 if transpose else 0).view(shape)
+        else:
+            out = torch.empty(shape, dtype=dtype, device=packed.device)
+    else:
+        assert tuple(out.shape) == tuple(shape) and out.dtype == dtype and out.is_contiguous()
+    lut = qs.code
+    with _lib.device_ctx(packed):
+        if qs.nested and not cache_absmax:
+            if getattr(qs, "_offset_f", None) is None:
+                qs._offset_f = float(qs.offset)   # one device sync per weight, then cached
+            rc = _lib.lib().uamd_nf4_dequantize(
+                _lib.ptr(packed), None, _lib.ptr(qs.absmax), _lib.ptr(qs.state2.code),
+                _lib.ptr(qs.state2.absmax), qs._offset_f, qs.state2.blocksize, _lib.ptr(lut),
+                _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), rows,
+                _lib.stream_of(packed))
+        else:
+            rc = _lib.lib().uamd_nf4_dequantize(
+                _lib.ptr(packed), _lib.ptr(absmax_f32(qs)), None, None, None, 0.0, 0, _lib.ptr(lut),
+                _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), rows,
+                _lib.stream_of(packed))
+    _lib.check(rc, "uamd_nf4_dequantize")
+    return out
+
+
+class Params4bit(torch.nn.Parameter):
+    """uint8 storage + `.quant_state`, what get_lora_parameters reads (utils.py:352)."""
+
+    def __new__(cls, data, quant_state=None):
+        self = torch.Tensor._make_subclass(cls, data, False)
+        self.quant_state = quant_state
+        return self
+
+    def __deepcopy__(self, memo):
+        return type(self)(self.data.clone(), self.quant_state)
+
+
+class Linear4bit(torch.nn.Module):
+    """Frozen NF4 linear layer (bias-free or with a dense bias), bitsandbytes.nn.Linear4bit's role."""
+
+    def __init__(self, in_features, out_features, packed, quant_state, bias=None):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = Params4bit(packed, quant_state)
+        self.bias = bias
+        self.compute_dtype = quant_state.dtype
+
+    @classmethod
+    def from_linear(cls, linear, blocksize=64, compress_statistics=True):
+        packed, qs = quantize_nf4(linear.weight.data, blocksize, compress_statistics)
+        return cls(linear.in_features, linear.out_features, packed, qs, linear.bias)
+
+    def forward(self, x):
+        from .kernels.utils import matmul_lora
+        out = matmul_lora(x, self.weight, self.weight.quant_state, None, None, None)
+        return out if self.bias is None else out + self.bias
+
+    def extra_repr(self):
+        return f"in_features={self.in_features}, out_features={self.out_features}, nf4"
+
+
+def nf4_bytes_per_param(blocksize=64, blocksize2=256):
+    """0.5 + 1/64 + 4/16384 = 0.515869 B/param."""
+    return 0.5 + 1.0 / blocksize + 4.0 / (blocksize * blocksize2)
