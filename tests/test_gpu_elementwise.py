@@ -15,6 +15,12 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+def U(dtype, ulps):
+    """fp32 comparisons allow 32 ulp (4e-6 relative): rsqrt/exp/erf/tanh implementations differ by a
+    few fp32 ulps between the GPU and the CPU oracle; 16-bit results must match to `ulps`."""
+    return 32 if dtype == torch.float32 else ulps
+
+
 # ---------------------------------------------------------------- RMSNorm
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("dim", [512, 1024, 2048, 4096, 8192, 100, 16384])
@@ -29,11 +35,11 @@ def test_rms_layernorm(dtype, dim, gemma):
     dXo = R.rms_layernorm_backward(dY, X, W, r, gemma)
     Xg = X.to(DEV).requires_grad_(True)
     Y = Fast_RMS_Layernorm.apply(Xg, W.to(DEV), 1e-5, gemma)
-    assert_ulp(Y, Yo, dtype, ulps=1, what="rms fwd", allow_frac=2e-3)
+    assert_ulp(Y, Yo, dtype, ulps=U(dtype, 1), what="rms fwd", allow_frac=2e-3)
     dYg = dY.to(DEV)
     ptr = dYg.data_ptr()
     Y.backward(dYg)
-    assert_ulp(Xg.grad, dXo, dtype, ulps=2, what="rms bwd", allow_frac=2e-3)
+    assert_ulp(Xg.grad, dXo, dtype, ulps=U(dtype, 2), what="rms bwd", allow_frac=2e-3)
     if not gemma:
         assert Xg.grad.data_ptr() == ptr, "non-gemma backward must write dX in place over dY"
 
@@ -146,15 +152,15 @@ def test_glu(dtype, kind, shape):
     gg = torch.randn(*shape, generator=g(12)).to(dtype)
     DW = torch.randn(shape[0] * shape[1], shape[2], generator=g(13)).to(dtype)
     h = fwd(e.to(DEV), gg.to(DEV))
-    assert_ulp(h, R.glu_forward(e, gg, kind), dtype, ulps=1, what=f"{kind} fwd", allow_frac=5e-3)
+    assert_ulp(h, R.glu_forward(e, gg, kind), dtype, ulps=U(dtype, 1), what=f"{kind} fwd", allow_frac=5e-3)
     e2, g2, d2 = e.view(-1, shape[2]).to(DEV), gg.view(-1, shape[2]).to(DEV), DW.to(DEV)
     ptrs = (d2.data_ptr(), e2.data_ptr(), g2.data_ptr())
     ho, dfo, deo = R.glu_backward(DW, e.view(-1, shape[2]), gg.view(-1, shape[2]), kind)
     hh, df, de = bwd(d2, e2, g2)
     assert (hh.data_ptr(), df.data_ptr(), de.data_ptr()) == ptrs, "backward must overwrite DW, e, g"
-    assert_ulp(hh, ho, dtype, ulps=1, what=f"{kind} bwd h", allow_frac=5e-3)
-    assert_ulp(df, dfo, dtype, ulps=1, what=f"{kind} bwd df", allow_frac=5e-3)
-    assert_ulp(de, deo, dtype, ulps=2, what=f"{kind} bwd de", allow_frac=5e-3)
+    assert_ulp(hh, ho, dtype, ulps=U(dtype, 1), what=f"{kind} bwd h", allow_frac=5e-3)
+    assert_ulp(df, dfo, dtype, ulps=U(dtype, 1), what=f"{kind} bwd df", allow_frac=5e-3)
+    assert_ulp(de, deo, dtype, ulps=U(dtype, 2), what=f"{kind} bwd de", allow_frac=5e-3)
 
 
 def test_glu_golden(golden):
@@ -192,7 +198,7 @@ def test_cross_entropy(dtype, V, softcap, scale):
     dl = torch.rand(rows, generator=g(23))
     loss.backward(dl.to(DEV))
     want = R.cross_entropy_backward(logits, dl, lse, labels, softcap, scale)
-    assert_ulp(lg.grad, want, dtype, ulps=2, atol=1e-6 if dtype != torch.float32 else 1e-9, what="ce bwd",
+    assert_ulp(lg.grad, want, dtype, ulps=U(dtype, 2), atol=1e-6 if dtype != torch.float32 else 1e-8, what="ce bwd",
                allow_frac=5e-3)
     assert torch.all(lg.grad[3] == 0), "ignored row must have an exactly zero gradient"
     # exactly one column per valid row carries the -1: gradient rows sum to ~0

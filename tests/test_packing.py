@@ -1,0 +1,102 @@
+"""CPU, bit-exact: the token-index functions against the reference's own vectors
+(/root/reference/tests/utils/test_packing.py:135-157, 1375-1439, 1488-1524, 1575-1582; restated here
+because the reference tree does not travel)."""
+import torch
+
+from unsloth_amd.utils.packing import (
+    build_sdpa_packed_attention_mask,
+    enable_padding_free_metadata,
+    get_packed_info_from_kwargs,
+    mask_packed_boundary_labels,
+    mask_packed_sequence_boundaries,
+    packed_position_ids,
+)
+from oracle.ref_ops import shift_labels
+
+
+def test_mask_packed_sequence_boundaries_marks_single_row():          # ref :135-147
+    s = torch.arange(6, dtype=torch.long).view(1, 6)
+    assert mask_packed_sequence_boundaries(s, torch.tensor([2, 1, 3], dtype=torch.int32)) is True
+    assert s.view(-1).tolist() == [0, -100, -100, 3, 4, -100]
+
+
+def test_mask_packed_sequence_boundaries_across_multiple_rows():      # ref :149-157
+    s = torch.arange(10, dtype=torch.long).view(2, 5)
+    assert mask_packed_sequence_boundaries(s, torch.tensor([3, 2, 4, 1], dtype=torch.int32)) is True
+    assert [i for i, v in enumerate(s.view(-1).tolist()) if v == -100] == [2, 4, 8, 9]
+
+
+def test_mask_packed_boundary_labels_vectors():                       # ref :1375-1439
+    labels = torch.arange(6, dtype=torch.long).view(1, 6)
+    out = mask_packed_boundary_labels(labels, torch.tensor([2, 1, 3], dtype=torch.int32))
+    assert out.reshape(-1).tolist() == [-100, 1, -100, -100, 4, 5]
+    assert labels.reshape(-1).tolist() == [0, 1, 2, 3, 4, 5]          # out of place
+    assert out.shape == labels.shape and out.dtype == labels.dtype
+    assert mask_packed_boundary_labels(labels, None) is labels
+    assert mask_packed_boundary_labels(labels, torch.tensor([], dtype=torch.int32)) is labels
+    assert mask_packed_boundary_labels(None, torch.tensor([2, 4])) is None
+    padded = torch.tensor([[10, 11, 12, 13, -100, -100]], dtype=torch.long)
+    assert mask_packed_boundary_labels(padded, torch.tensor([2, 2], dtype=torch.int32)).reshape(-1).tolist() == \
+        [10, 11, -100, 13, -100, -100]
+    whole = torch.arange(4, dtype=torch.long).view(1, 4)
+    assert mask_packed_boundary_labels(whole, [2, 2]).reshape(-1).tolist() == [-100, 1, -100, 3]
+
+
+def test_raw_guard_equals_shifted_guard():                            # ref :1389-1407
+    labels = torch.arange(100, 112, dtype=torch.long).view(1, 12)
+    lengths = torch.tensor([5, 4, 3], dtype=torch.int32)
+    a = shift_labels(labels)
+    mask_packed_sequence_boundaries(a, lengths)
+    b = shift_labels(mask_packed_boundary_labels(labels, lengths))
+    assert torch.equal(a, b)
+
+
+def test_guard_idempotent_on_trl_labels():                            # ref :1410-1422, :1575-1582
+    lengths = torch.tensor([2, 1, 3], dtype=torch.int32)
+    labels = torch.arange(6, dtype=torch.long).view(1, 6)
+    pos = torch.tensor([[0, 1, 0, 0, 1, 2]])
+    trl = labels.clone()
+    trl[pos == 0] = -100
+    once = mask_packed_boundary_labels(trl, lengths)
+    assert torch.equal(once, trl) and torch.equal(mask_packed_boundary_labels(once, lengths), once)
+
+
+def test_fused_ce_label_vector():                                     # ref :1488-1524
+    labels = torch.arange(8, dtype=torch.long).view(1, 8)
+    got = mask_packed_boundary_labels(labels, torch.tensor([3, 5], dtype=torch.int32))
+    assert got.reshape(-1).tolist() == [-100, 1, 2, -100, 4, 5, 6, 7]
+    assert labels.reshape(-1).tolist() == list(range(8))
+
+
+def test_packed_info_and_positions():                                 # ref :1095-1117, packing.py:586-606
+    lengths = torch.tensor([3, 5, 2], dtype=torch.int64)
+    info = get_packed_info_from_kwargs({"packed_seq_lengths": lengths}, torch.device("cpu"))
+    l32, cu, mx = info
+    assert l32.dtype == torch.int32 and cu.dtype == torch.int32
+    assert cu.tolist() == [0, 3, 8, 10] and mx == 5
+    assert get_packed_info_from_kwargs({}, torch.device("cpu")) is None
+    pos = packed_position_ids(lengths)
+    assert pos.dtype == torch.int32 and pos.tolist() == [0, 1, 2, 0, 1, 2, 3, 4, 0, 1]
+
+
+def test_padding_free_collation_and_num_items():                      # ref :1545-1571
+    b = enable_padding_free_metadata([[10, 11], [12], [13, 14, 15]])
+    assert b["input_ids"].tolist() == [[10, 11, 12, 13, 14, 15]]
+    assert b["position_ids"].tolist() == [[0, 1, 0, 0, 1, 2]] and b["position_ids"].dtype == torch.int32
+    assert b["packed_seq_lengths"].tolist() == [2, 1, 3] and b["packed_seq_lengths"].dtype == torch.int32
+    assert int(b["packed_seq_lengths"].sum()) == b["input_ids"].numel()
+    # docs [10,11] [12] [13,14,15] -> 1 + 0 + 2 real CE targets after shift + boundary mask
+    tgt = shift_labels(mask_packed_boundary_labels(b["labels"], b["packed_seq_lengths"]))
+    assert int((tgt != -100).sum()) == 3
+
+
+def test_sdpa_packed_mask_is_block_causal():                          # packing.py:650-693
+    lengths = torch.tensor([2, 3], dtype=torch.int32)
+    info = (lengths, None, 3)
+    m = build_sdpa_packed_attention_mask(info, dtype=torch.float32, device=torch.device("cpu"))
+    assert m.shape == (1, 1, 5, 5)
+    allowed = (m[0, 0] == 0).int().tolist()
+    assert allowed == [[1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [0, 0, 1, 0, 0], [0, 0, 1, 1, 0], [0, 0, 1, 1, 1]]
+    w = build_sdpa_packed_attention_mask((torch.tensor([4]), None, 4), dtype=torch.float32,
+                                         device=torch.device("cpu"), sliding_window=2)
+    assert (w[0, 0] == 0).int().tolist() == [[1, 0, 0, 0], [1, 1, 0, 0], [0, 1, 1, 0], [0, 0, 1, 1]]

@@ -1,0 +1,468 @@
+"""Llama-family fast path over HuggingFace transformers modules; mirror of the training half of
+unsloth/models/llama.py.
+
+  RopeTables                         LlamaRotaryEmbedding cache (llama.py:1775-1914), llama3 band scaling
+                                     (:1688-1717), linear scaling (:1917-1945); rebuilt by us after load
+                                     (never trust the loaded buffer), grows in 8192 steps
+  LlamaAttention_fast_forward        llama.py:671-770
+  LlamaDecoderLayer_fast_forward     llama.py:774-851 (training branch :823-844)
+  LlamaModel_fast_forward            llama.py:866-1245 (embed -> layers (checkpointed) -> final norm)
+  CausalLM_fast_forward              llama.py:1370-1590 (fused linear-CE branch :1466-1523, logits branch :1525-1562)
+  FastLlamaModel                     pre_patch (:2288-2320), from_pretrained (:2323-3058),
+                                     get_peft_model (:3061-3597), patch_peft_model (:3599-3821),
+                                     for_training / for_inference (:3824-3929)
+
+The composition reads HF module ATTRIBUTES (q_proj, input_layernorm.weight, ...) and never calls HF's
+own layer forwards on the training path, so it is insensitive to transformers' internal attention /
+cache / mask API (the installed 5.15 is above the reference's ceiling).
+Attention itself is torch SDPA (flash via AOTriton/CK on ROCm): adjacent component, SURVEY 8(f1).
+"""
+import math
+import os
+from types import MethodType
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from transformers.modeling_outputs import CausalLMOutputWithPast
+
+from ..kernels import (
+    apply_lora_mlp_swiglu,
+    apply_lora_o,
+    apply_lora_qkv,
+    fast_cross_entropy_loss,
+    fast_rms_layernorm,
+    fast_rope_embedding,
+    unsloth_fused_ce_loss,
+)
+from ..kernels.utils import lora_linear_forward
+from ..utils.packing import (
+    build_sdpa_packed_attention_mask,
+    get_packed_info_from_kwargs,
+    mask_packed_boundary_labels,
+    mask_packed_sequence_boundaries,
+)
+from .. import lora as _lora
+from .. import nf4 as _nf4
+
+__version__ = "0.1.0"
+
+
+# ------------------------------------------------------------------------------------------------
+# Rotary tables (a5)
+def _rope_params(config):
+    rp = getattr(config, "rope_parameters", None) or {}
+    rs = getattr(config, "rope_scaling", None) or {}
+    theta = rp.get("rope_theta", None) or getattr(config, "rope_theta", None) or 10000.0
+    kind = rp.get("rope_type", None) or rs.get("rope_type", None) or rs.get("type", None) or "default"
+    merged = dict(rs)
+    merged.update(rp)
+    return float(theta), kind, merged
+
+
+def compute_inv_freq(config):
+    """fp32 inv_freq as llama.py:1851-1855 (int64 arange -> float), then the config's scaling."""
+    theta, kind, p = _rope_params(config)
+    dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+    dim = int(dim * getattr(config, "partial_rotary_factor", 1.0))
+    inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+    attention_scaling, time_scale = 1.0, 1.0
+    if kind == "llama3":                                            # llama.py:1688-1717
+        factor = p.get("factor", 8.0)
+        low, high = p.get("low_freq_factor", 1.0), p.get("high_freq_factor", 4.0)
+        old = p.get("original_max_position_embeddings", 8192)
+        low_wl, high_wl = old / low, old / high
+        wavelen = 2 * math.pi / inv_freq
+        scaled = torch.where(wavelen > low_wl, inv_freq / factor, inv_freq)
+        smooth = (old / wavelen - low) / (high - low)
+        smoothed = (1 - smooth) * inv_freq / factor + smooth * inv_freq
+        is_medium = (wavelen >= high_wl) & (wavelen <= low_wl)
+        inv_freq = torch.where(is_medium, smoothed, scaled)
+    elif kind == "linear":                                          # llama.py:1917-1945
+        time_scale = 1.0 / p.get("factor", 1.0)
+    elif kind not in ("default", None):
+        raise NotImplementedError(f"rope_type {kind!r} (yarn/longrope/dynamic) is outside the hot path scope")
+    return inv_freq, attention_scaling, time_scale
+
+
+class RopeTables:
+    """cos/sin cache shared by all layers (llama.py:3002-3006), one per device."""
+
+    def __init__(self, config):
+        self.inv_freq, self.attention_scaling, self.time_scale = compute_inv_freq(config)
+        self.max_position_embeddings = getattr(config, "max_position_embeddings", 4096)
+        self.current_rope_size = 0
+        self._cache = {}
+
+    def _build(self, seq_len, device, dtype):
+        t = torch.arange(seq_len, dtype=torch.int64).float() * self.time_scale
+        freqs = torch.outer(t, self.inv_freq)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        cos = (emb.cos() * self.attention_scaling).to(dtype=dtype, device=device)
+        sin = (emb.sin() * self.attention_scaling).to(dtype=dtype, device=device)
+        return cos, sin
+
+    def get(self, seq_len, device, dtype):
+        key = (str(device), dtype)
+        ent = self._cache.get(key)
+        if ent is None or ent[0].shape[0] < seq_len:
+            size = max(min(4 * 8192, self.max_position_embeddings), ((seq_len + 8191) // 8192) * 8192)
+            ent = self._build(size, device, dtype)                  # grows in 8192 steps (:1906-1914)
+            self._cache[key] = ent
+            self.current_rope_size = size
+        return ent
+
+
+# ------------------------------------------------------------------------------------------------
+def original_apply_qkv(self, X):
+    return self.q_proj(X), self.k_proj(X), self.v_proj(X)
+
+
+def original_apply_o(self, X):
+    return self.o_proj(X)
+
+
+def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
+    """causal (GQA, packed, windowed) attention via torch SDPA. Q [B,Hq,T,D], K/V [B,Hk,T,D]."""
+    T = Q.shape[2]
+    window = sliding_window if (sliding_window is not None and T > sliding_window) else None   # mistral.py:116-120
+    if seq_info is None and attention_mask is None and window is None:
+        return F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
+    if seq_info is not None:
+        mask = build_sdpa_packed_attention_mask(seq_info, dtype=Q.dtype, device=Q.device, sliding_window=window)
+    else:
+        pos = torch.arange(T, device=Q.device)
+        allowed = pos[:, None] >= pos[None, :]
+        if window is not None:
+            allowed = allowed & ((pos[:, None] - pos[None, :]) < window)
+        allowed = allowed[None, None]
+        if attention_mask is not None:
+            allowed = allowed & attention_mask.to(torch.bool)[:, None, None, :]
+        mask = torch.zeros(allowed.shape, dtype=Q.dtype, device=Q.device).masked_fill_(~allowed, float("-inf"))
+    return F.scaled_dot_product_attention(Q, K, V, attn_mask=mask, enable_gqa=True)
+
+
+def LlamaAttention_fast_forward(self, hidden_states, cos, sin, rope_position_ids=None, seq_info=None,
+                                attention_mask=None):
+    """llama.py:671-770 (training path: no KV cache)."""
+    bsz, q_len, _ = hidden_states.size()
+    cfg = self.config
+    n_heads, n_kv_heads = cfg.num_attention_heads, cfg.num_key_value_heads
+    head_dim = self.head_dim
+    Q, K, V = self.apply_qkv(self, hidden_states)
+    Q = Q.view(bsz, q_len, n_heads, head_dim).transpose(1, 2)
+    K = K.view(bsz, q_len, n_kv_heads, head_dim).transpose(1, 2)
+    V = V.view(bsz, q_len, n_kv_heads, head_dim).transpose(1, 2)
+    Q, K = fast_rope_embedding(Q, K, cos, sin, rope_position_ids)        # in place on the strided views
+    A = _attention(Q, K, V, seq_info, attention_mask, getattr(cfg, "sliding_window", None))
+    attn_output = A.transpose(1, 2).reshape(bsz, q_len, n_heads * head_dim)
+    return self.apply_o(self, attn_output)
+
+
+def LlamaDecoderLayer_fast_forward(self, hidden_states, cos, sin, rope_position_ids=None, seq_info=None,
+                                   attention_mask=None):
+    """llama.py:823-844."""
+    residual = hidden_states
+    hidden_states = fast_rms_layernorm(self.input_layernorm, hidden_states)
+    hidden_states = LlamaAttention_fast_forward(self.self_attn, hidden_states, cos, sin, rope_position_ids,
+                                                seq_info, attention_mask)
+    hidden_states = residual + hidden_states
+    residual = hidden_states
+    hidden_states = fast_rms_layernorm(self.post_attention_layernorm, hidden_states)
+    hidden_states = self.mlp(hidden_states)
+    hidden_states = residual + hidden_states
+    return hidden_states
+
+
+def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None,
+                            **kwargs):
+    """llama.py:866-1245, training path. `self` is the HF LlamaModel."""
+    if inputs_embeds is None:
+        inputs_embeds = self.embed_tokens(input_ids)
+    dtype = _model_dtype(self)
+    hidden_states = inputs_embeds.to(dtype)                                        # :955-958
+    bsz, q_len, _ = hidden_states.shape
+    seq_info = get_packed_info_from_kwargs(kwargs, hidden_states.device)
+    # padding masks that are all ones are dropped in training (:1017-1019)
+    if attention_mask is not None and (attention_mask.dim() != 2 or bool(torch.all(attention_mask != 0))):
+        attention_mask = None
+    rope_position_ids = None
+    if position_ids is not None:
+        rope_position_ids = position_ids.to(device=hidden_states.device, dtype=torch.int32)    # :945-948
+        if rope_position_ids.dim() == 1:
+            rope_position_ids = rope_position_ids.unsqueeze(0)
+        if rope_position_ids.shape[0] != bsz:
+            rope_position_ids = rope_position_ids.expand(bsz, -1)
+        rope_position_ids = rope_position_ids.reshape(-1)
+    tables = _rope_tables(self)
+    cos, sin = tables.get(max(q_len, 1), hidden_states.device, dtype)
+    if rope_position_ids is not None and os.environ.get("UNSLOTH_AMD_CHECK_POSITIONS", "0") == "1":
+        assert int(rope_position_ids.max()) < cos.shape[0]
+    gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
+    if gc and not hidden_states.requires_grad:
+        hidden_states.requires_grad_(True)      # reentrant checkpoint needs an input that requires grad
+    for layer in self.layers:
+        if gc:
+            # llama.py:1169-1193: reentrant, no RNG state (dropout is 0 on this path)
+            hidden_states = torch.utils.checkpoint.checkpoint(
+                _layer_fn(layer, cos, sin, rope_position_ids, seq_info, attention_mask), hidden_states,
+                use_reentrant=True, preserve_rng_state=False)
+        else:
+            hidden_states = LlamaDecoderLayer_fast_forward(layer, hidden_states, cos, sin, rope_position_ids,
+                                                           seq_info, attention_mask)
+    return fast_rms_layernorm(self.norm, hidden_states)                            # :1228
+
+
+def _layer_fn(layer, cos, sin, pos, seq_info, mask):
+    def custom_forward(h):
+        return LlamaDecoderLayer_fast_forward(layer, h, cos, sin, pos, seq_info, mask)
+    return custom_forward
+
+
+def _model_dtype(model):
+    dt = getattr(model, "_unsloth_amd_dtype", None)
+    if dt is None:
+        dt = getattr(model.config, "dtype", None) or getattr(model.config, "torch_dtype", None) or torch.bfloat16
+        if isinstance(dt, str):
+            dt = getattr(torch, dt)
+    return dt
+
+
+def _rope_tables(model):
+    t = getattr(model, "_unsloth_amd_rope", None)
+    if t is None:
+        t = RopeTables(model.config)
+        model._unsloth_amd_rope = t
+    return t
+
+
+class _EmptyLogits:
+    """Stand-in for `logits` on the fused-CE path (models/_utils.py:3612-3652): any use raises."""
+
+    def __getattr__(self, name):
+        raise NotImplementedError(
+            "Unsloth: logits are not materialised on the fused cross-entropy path. "
+            "Set UNSLOTH_RETURN_LOGITS=1 to get them.")
+
+    def __repr__(self):
+        return "EMPTY_LOGITS"
+
+
+EMPTY_LOGITS = _EmptyLogits()
+
+
+def CausalLM_fast_forward(original_forward):
+    """llama.py:1370-1590. Returns the function installed as LlamaForCausalLM.forward."""
+
+    def _CausalLM_fast_forward(self, input_ids=None, attention_mask=None, position_ids=None,
+                               past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
+                               logits_to_keep=0, num_logits_to_keep=0, return_dict=None, **kwargs):
+        fast = getattr(self, "_unsloth_amd_fast", False)
+        if (not fast) or past_key_values is not None or (use_cache and not self.training and labels is None):
+            # decode / generation: out of scope, HF's own forward over our Linear4bit/LoraLayer modules
+            return original_forward(self, input_ids=input_ids, attention_mask=attention_mask,
+                                    position_ids=position_ids, past_key_values=past_key_values,
+                                    inputs_embeds=inputs_embeds, labels=labels, use_cache=use_cache,
+                                    logits_to_keep=logits_to_keep, **kwargs)
+        hidden_states = LlamaModel_fast_forward(self.model, input_ids=input_ids, attention_mask=attention_mask,
+                                                position_ids=position_ids, inputs_embeds=inputs_embeds, **kwargs)
+        lm_head = self.lm_head.weight
+        logit_softcapping = getattr(self.config, "final_logit_softcapping", 0) or 0
+        logit_scaling = getattr(self.config, "logit_scale", 0) or 0
+        if os.environ.get("UNSLOTH_RETURN_HIDDEN_STATES", "0") == "1":             # :1448-1457
+            return CausalLMOutputWithPast(loss=None, logits=hidden_states)
+        RETURN_LOGITS = os.environ.get("UNSLOTH_RETURN_LOGITS", "0") == "1"
+        n_items = kwargs.get("num_items_in_batch", None)
+        if n_items is None:
+            n_items = kwargs.get("n_items", None)
+        can_fuse = (labels is not None and not RETURN_LOGITS and not lm_head.requires_grad
+                    and self.lm_head.bias is None and not logit_scaling)
+        if can_fuse:
+            labels = mask_packed_boundary_labels(labels.to(hidden_states.device), kwargs.get("packed_seq_lengths"))
+            loss = unsloth_fused_ce_loss(trainer=None, hidden_states=hidden_states, lm_head_weight=lm_head,
+                                         lm_head_bias=None, labels=labels, mask=None, n_items=n_items,
+                                         scaling=getattr(self, "accelerator_scaler", None), target_gb=None,
+                                         torch_compile=True, logit_softcapping=logit_softcapping)
+            if return_dict is False:
+                return (loss, EMPTY_LOGITS)
+            return CausalLMOutputWithPast(loss=loss, logits=EMPTY_LOGITS)
+        keep = max(int(num_logits_to_keep or 0), int(logits_to_keep or 0) if isinstance(logits_to_keep, int) else 0)
+        hs = hidden_states[:, -keep:, :] if keep else hidden_states
+        (logits,) = lora_linear_forward(hs, [(lm_head, None, None, None, None)]) \
+            if hs.dtype in (torch.bfloat16, torch.float16) else (self.lm_head(hs),)
+        loss = None
+        if labels is not None:
+            labels = labels.to(logits.device)
+            shift_labels = torch.empty_like(labels)                                # :1545-1551
+            shift_labels[..., :-1] = labels[..., 1:]
+            shift_labels[..., -1] = -100
+            mask_packed_sequence_boundaries(shift_labels, kwargs.get("packed_seq_lengths"))
+            loss = fast_cross_entropy_loss(logits=logits, labels=shift_labels, logit_softcapping=logit_softcapping,
+                                           logit_scaling=logit_scaling, n_items=n_items)
+        else:
+            if logit_scaling:
+                logits = logit_scaling * logits
+            if logit_softcapping:
+                logits = logit_softcapping * torch.tanh(logits / logit_softcapping)
+        if return_dict is False:
+            return (loss, logits) if loss is not None else (logits,)
+        return CausalLMOutputWithPast(loss=loss, logits=logits)
+
+    return _CausalLM_fast_forward
+
+
+# ------------------------------------------------------------------------------------------------
+_PATCHED = {}
+
+
+def _patch_causal_lm_class(cls):
+    if cls not in _PATCHED:
+        _PATCHED[cls] = cls.forward
+        cls.forward = CausalLM_fast_forward(cls.forward)
+
+
+class FastLlamaModel:
+    """Patcher for Llama-architecture models (Llama, Mistral, Qwen2 share it: qwen2.py:38-97)."""
+
+    @staticmethod
+    def pre_patch():
+        """llama.py:2288-2320: class-level forward replacement + HF RMSNorm class swap + loss mapping."""
+        from transformers.models.llama.modeling_llama import LlamaForCausalLM
+        from ..kernels import patch_loss_functions, patch_rms_layernorm
+        _patch_causal_lm_class(LlamaForCausalLM)
+        try:
+            from transformers.models.mistral.modeling_mistral import MistralForCausalLM
+            _patch_causal_lm_class(MistralForCausalLM)
+        except Exception:
+            pass
+        try:
+            from transformers.models.qwen2.modeling_qwen2 import Qwen2ForCausalLM
+            _patch_causal_lm_class(Qwen2ForCausalLM)
+        except Exception:
+            pass
+        patch_rms_layernorm()
+        patch_loss_functions()
+
+    @staticmethod
+    def post_load(model, max_seq_length, dtype):
+        """Per-instance setup after weights exist: default hooks (llama.py:2851-2853), shared rope
+        tables rebuilt from config (:3002-3006), bookkeeping."""
+        inner = model.model
+        inner._unsloth_amd_dtype = dtype
+        inner._unsloth_amd_rope = RopeTables(model.config)
+        for layer in inner.layers:
+            layer.self_attn.apply_qkv = original_apply_qkv
+            layer.self_attn.apply_o = original_apply_o
+        model._unsloth_amd_fast = True
+        model.max_seq_length = max_seq_length
+        m = model
+        while hasattr(m, "model"):
+            m.max_seq_length = max_seq_length
+            m = m.model
+        m.max_seq_length = max_seq_length
+        model._unsloth_disable_data_parallel = True           # _utils.py:244-249
+        return model
+
+    @staticmethod
+    def get_peft_model(model, r=16, target_modules=("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj",
+                                                    "up_proj", "down_proj"),
+                       lora_alpha=16, lora_dropout=0.0, bias="none", layers_to_transform=None,
+                       layers_pattern=None, use_gradient_checkpointing="unsloth", random_state=3407,
+                       max_seq_length=2048, use_rslora=False, modules_to_save=None, init_lora_weights=True,
+                       loftq_config={}, temporary_location="_unsloth_temporary_saved_buffers", qat_scheme=None,
+                       **kwargs):
+        """llama.py:3061-3597."""
+        if isinstance(model, _lora.PeftModelForCausalLM):
+            # idempotent re-call with equal settings (:3145-3233), else TypeError (:3231)
+            cfg = model.peft_config[model.active_adapter]
+            same = (cfg.r == r and cfg.lora_alpha == lora_alpha and cfg.lora_dropout == lora_dropout
+                    and sorted(cfg.target_modules) == sorted(target_modules))
+            if same:
+                return model
+            raise TypeError("Unsloth: Your model already has LoRA adapters. Your new parameters are different.")
+        if not isinstance(r, int) or r <= 0:
+            raise TypeError(f"Unsloth: Rank of {str(r)} must be an integer larger than 0.")   # :3140-3143
+        if bias != "none":
+            raise NotImplementedError("bias != 'none' takes the slow PEFT path in the reference; not implemented")
+        torch.manual_seed(random_state)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(random_state)
+        config = _lora.LoraConfig(r=r, lora_alpha=lora_alpha, target_modules=list(target_modules),
+                                  lora_dropout=lora_dropout, bias=bias, use_rslora=use_rslora,
+                                  modules_to_save=modules_to_save, init_lora_weights=init_lora_weights,
+                                  layers_to_transform=layers_to_transform, loftq_config=loftq_config)
+        peft_model = _lora.get_peft_model(model, config)
+        return FastLlamaModel.patch_peft_model(peft_model, use_gradient_checkpointing)
+
+    @staticmethod
+    def patch_peft_model(model, use_gradient_checkpointing="unsloth"):
+        """llama.py:3599-3821: enable GC, then per layer install the fused hooks iff dropout == 0,
+        bias == 'none', bias-free base layers, no DoRA (:3695-3772); otherwise keep the defaults."""
+        base = model.get_base_model() if hasattr(model, "get_base_model") else model
+        inner = base.model
+        FastLlamaModel.for_training(model, use_gradient_checkpointing)
+        n_mlp = n_qkv = n_o = 0
+
+        def ok(proj):
+            if not isinstance(proj, _lora.LoraLayer):
+                return False
+            ad = proj.active_adapters[0]
+            return (isinstance(proj.lora_dropout[ad], torch.nn.Identity) and proj.base_layer.bias is None
+                    and not proj.use_dora[ad] and len(proj.lora_magnitude_vector) == 0)
+
+        for layer in inner.layers:
+            mlp, attn = layer.mlp, layer.self_attn
+            if all(hasattr(mlp, n) and ok(getattr(mlp, n)) for n in ("gate_proj", "up_proj", "down_proj")):
+                mlp.forward = MethodType(apply_lora_mlp_swiglu, mlp)                # :3725
+                n_mlp += 1
+            if all(ok(getattr(attn, n)) for n in ("q_proj", "k_proj", "v_proj")):
+                attn.apply_qkv = apply_lora_qkv                                     # :3748
+                n_qkv += 1
+            if ok(attn.o_proj):
+                attn.apply_o = apply_lora_o                                         # :3766
+                n_o += 1
+        base._unsloth_amd_patched = (n_qkv, n_o, n_mlp)
+        if os.environ.get("UNSLOTH_ENABLE_LOGGING", "0") == "1":
+            print(f"Unsloth (MI355X) patched {len(inner.layers)} layers with {n_qkv} QKV layers, "
+                  f"{n_o} O layers and {n_mlp} MLP layers.")                        # :3774-3777
+        model.for_training = MethodType(FastLlamaModel.for_training, model)          # :3811-3817
+        model.for_inference = MethodType(FastLlamaModel.for_inference, model)
+        return model
+
+    @staticmethod
+    def for_training(model, use_gradient_checkpointing=True):
+        """llama.py:3824-3885. "unsloth" = offloaded checkpointing in the reference; on 288 GB HBM the
+        layer inputs stay on the device (32 x 16.8 MB at T=2048), so it maps to plain reentrant GC."""
+        base = model.get_base_model() if hasattr(model, "get_base_model") else model
+        gc = bool(use_gradient_checkpointing)
+        base.model.gradient_checkpointing = gc
+        for m in base.modules():
+            if hasattr(m, "gradient_checkpointing"):
+                m.gradient_checkpointing = gc
+        base._unsloth_amd_fast = True
+        model.train()
+        return model
+
+    @staticmethod
+    def for_inference(model):
+        """llama.py:3888-3929."""
+        base = model.get_base_model() if hasattr(model, "get_base_model") else model
+        for m in base.modules():
+            if hasattr(m, "gradient_checkpointing"):
+                m.gradient_checkpointing = False
+        model.eval()
+        return model
+
+
+def quantize_model_nf4_(model, blocksize=64, compress_statistics=True,
+                        names=("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")):
+    """Replace the decoder projections by frozen NF4 layers in place (what loading with
+    BitsAndBytesConfig(nf4, double_quant) gives the reference, llama.py:2615-2626). lm_head and the
+    embeddings stay 16-bit, as bitsandbytes' default skip list does."""
+    for layer in model.model.layers:
+        for parent in (layer.self_attn, layer.mlp):
+            for n in names:
+                lin = getattr(parent, n, None)
+                if isinstance(lin, torch.nn.Linear):
+                    setattr(parent, n, _nf4.Linear4bit.from_linear(lin, blocksize, compress_statistics))
+    return model
