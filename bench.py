@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""bench.py -- train tokens/sec + peak VRAM, Llama-3-8B QLoRA (NF4, r=16, all 7 projections), seq 2048,
+bf16, on N MI355X of one node (BASELINE.json metric, configs[1]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" = forward + backward + LoRA-grad exchange + AdamW step over one synthetic micro-batch per GPU
+(weak scaling: per-GPU work fixed). Weights are random-init at the Llama-3-8B architecture and quantised to
+bitsandbytes-format NF4 by our own quantiser; token ids ~ U[0, V), labels = ids, position_ids = arange
+(int32, exercising the indexed RoPE path). Nothing is skipped inside the timed region.
+
+Rank 0 prints ONE JSON line. Besides the contract fields it carries
+  roofline     : the dominant kernel (the MFMA GEMM), ALGORITHMIC flops of its launches / their HIP-event
+                 durations measured live in the timed region, against the 2.5 PFLOP/s dense bf16 peak
+  cpu_baseline : the reference's torch-fp32 CPU composition timed on this box's host cores (bounded sample)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
+HBM_PEAK_GBPS = 8000.0
+
+
+def llama3_8b_config(n_layers=32, vocab=128256):
+    from transformers import LlamaConfig
+    return LlamaConfig(
+        hidden_size=4096, intermediate_size=14336, num_hidden_layers=n_layers, num_attention_heads=32,
+        num_key_value_heads=8, head_dim=128, vocab_size=vocab, rms_norm_eps=1e-5, max_position_embeddings=8192,
+        rope_parameters={"rope_type": "default", "rope_theta": 500000.0}, tie_word_embeddings=False,
+        attention_bias=False, mlp_bias=False)
+
+
+class GemmTimer:
+    """HIP-event pairs around every MFMA GEMM launch (both instantiations of gemm_nt_kernel), recorded on
+    the stream the kernel is launched on (torch's current stream == the stream passed through the C ABI)."""
+
+    def __init__(self):
+        from unsloth_amd.kernels import utils as U
+        self.U = U
+        self.orig = U._launch_gemm
+        self.records = {"gemm_nt_kernel<bf16,NF4>": [], "gemm_nt_kernel<bf16,dense>": []}
+        self.enabled = False
+
+    def install(self):
+        U, orig, recs = self.U, self.orig, self.records
+
+        def timed(X2d, groups, nf4, accumulate=False):
+            if not self.enabled:
+                return orig(X2d, groups, nf4, accumulate)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            flops = 2.0 * X2d.shape[0] * X2d.shape[1] * sum(g.N for g in groups)
+            flops += sum(2.0 * X2d.shape[0] * g.R * g.N for g in groups if g.lora_xa)
+            s.record()
+            orig(X2d, groups, nf4, accumulate)
+            e.record()
+            recs["gemm_nt_kernel<bf16,NF4>" if nf4 else "gemm_nt_kernel<bf16,dense>"].append((s, e, flops))
+
+        U._launch_gemm = timed
+        import unsloth_amd.kernels.cross_entropy_loss as ce
+        ce._u._launch_gemm = timed
+
+    def summary(self):
+        out = {}
+        for name, recs in self.records.items():
+            if not recs:
+                continue
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[name] = dict(launches=len(recs), total_ms=ms, avg_us=ms * 1e3 / len(recs), flops=fl,
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+        return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("BENCH_BATCH", 4)), help="sequences per GPU per step")
+    ap.add_argument("--seq", type=int, default=2048)
+    ap.add_argument("--layers", type=int, default=32)
+    ap.add_argument("--rank", type=int, default=16)
+    ap.add_argument("--gc", choices=["on", "off"], default=os.environ.get("BENCH_GC", "on"),
+                    help="gradient checkpointing (reference default use_gradient_checkpointing='unsloth')")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda unavailable); the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
+    if a.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.dp import LoRAGradArena
+    from unsloth_amd.trainer import make_optimizer, training_step
+
+    cfg = llama3_8b_config(a.layers)
+    t_setup = time.time()
+    model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
+                                                 load_in_4bit=True, device=dev, random_state=3407,
+                                                 use_gradient_checkpointing=(a.gc == "on"))
+    model = FastLanguageModel.get_peft_model(model, r=a.rank, lora_alpha=a.rank, lora_dropout=0.0, bias="none",
+                                             use_gradient_checkpointing=(a.gc == "on"), random_state=3407)
+    g = torch.Generator(device="cpu").manual_seed(3407)
+    n_train = 0
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            n_train += p.numel()
+            if "lora_B" in n:           # non-zero B so every LoRA gradient is exercised with real numbers
+                p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+    opt = make_optimizer(model, lr=2e-4)
+    arena = LoRAGradArena(model) if world > 1 else None
+    B, T, V = a.batch, a.seq, cfg.vocab_size
+    gi = torch.Generator(device="cpu").manual_seed(rank)       # different data per rank
+    batches = []
+    for _ in range(2):
+        ids = torch.randint(0, V, (B, T), generator=gi).to(dev)
+        pos = torch.arange(T, dtype=torch.int32, device=dev).unsqueeze(0).expand(B, T).contiguous()
+        batches.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
+    n_items = torch.tensor((T - 1) * B * world, device=dev)      # global non-ignored targets per step
+    timer = GemmTimer()
+    timer.install()
+    setup_s = time.time() - t_setup
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = []
+    for i in range(a.warmup):
+        losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
+    sync()
+    torch.cuda.reset_peak_memory_stats()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    peak = torch.cuda.max_memory_allocated()
+    if world > 1:
+        pk = torch.tensor([peak], device=dev, dtype=torch.int64)
+        dist.all_reduce(pk, op=dist.ReduceOp.MAX)
+        peak = int(pk)
+    loss_vals = [float(l) for l in losses]
+
+    if rank == 0:
+        tokens = B * T * a.steps * world
+        gs = timer.summary()
+        dom = max(gs.values(), key=lambda r: r["total_ms"]) if gs else None
+        dom_name = [k for k, v in gs.items() if v is dom][0] if dom else None
+        roofline = None
+        if dom:
+            roofline = dict(bound="mfma", kernel=dom_name, achieved=round(dom["tflops"], 1), peak=MFMA_PEAK_TFLOPS,
+                            unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            launches_per_step=dom["launches"] // a.steps, avg_launch_us=round(dom["avg_us"], 1),
+                            share_of_step=round(dom["total_ms"] / (dt * 1e3), 3),
+                            other={k: dict(tflops=round(v["tflops"], 1), avg_us=round(v["avg_us"], 1),
+                                           share_of_step=round(v["total_ms"] / (dt * 1e3), 3))
+                                   for k, v in gs.items() if k != dom_name})
+        cpu = None
+        if not a.no_cpu_baseline:
+            from oracle.cpu_baseline import time_layer
+            cpu = time_layer(n_layers=a.layers, budget_s=a.cpu_budget)
+            cpu["value"] = round(cpu["value"], 2)
+        rec = {
+            "metric": "train tokens/sec, Llama-3-8B QLoRA (NF4) r=16 seq2048 bf16", "value": round(tokens / dt, 1),
+            "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init Llama-3-8B-shaped weights -> NF4, "
+            "uniform random token ids)",
+            "config": {"workload": "Llama-3-8B QLoRA NF4 r=16 (q,k,v,o,gate,up,down) seq2048 bf16, fwd+bwd+AdamW",
+                       "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
+                       "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
+                       "gradient_checkpointing": a.gc == "on", "trainable_params": n_train,
+                       "attention": "torch SDPA (flash)", "optimizer": "AdamW(fused) fp32 on LoRA params"},
+            "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T,
+            "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,92 @@
+"""CPU, world_size 2 over gloo: the LoRA-grad arena's bucketed all-reduce (unsloth_amd/dp.py) gives every
+rank the SUM of the per-rank gradients, overlapped (hook-launched) and non-overlapped alike, keeps
+p.grad as views of one arena, and the global token count matches. This is the N>1 path of bench.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+class Tiny(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.model = torch.nn.Module()
+        self.model.layers = torch.nn.ModuleList()
+        for _ in range(3):
+            blk = torch.nn.Module()
+            blk.lora_A = torch.nn.Linear(8, 4, bias=False)
+            blk.lora_B = torch.nn.Linear(4, 8, bias=False)
+            blk.frozen = torch.nn.Linear(8, 8, bias=False)
+            blk.frozen.weight.requires_grad_(False)
+            self.model.layers.append(blk)
+
+    def forward(self, x):
+        for blk in self.model.layers:
+            x = blk.frozen(x) + blk.lora_B(blk.lora_A(x))
+        return x
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, overlap, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unsloth_amd.dp import LoRAGradArena, global_num_items
+    torch.manual_seed(0)
+    m = Tiny()
+    arena = LoRAGradArena(m, bucket_bytes=64, overlap=overlap)
+    assert len(arena.buckets) == 3, arena.describe()                  # one per layer
+    # every grad is a view into the arena
+    base = arena.arena.data_ptr()
+    assert all(base <= p.grad.data_ptr() < base + arena.nbytes for p in arena.params)
+    x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank))
+    labels = torch.tensor([[1, 2, -100, 4]]) if rank == 0 else torch.tensor([[-100, -100, 3, 5]])
+    n = global_num_items(labels)
+    m(x).square().sum().backward()
+    arena.finish()
+    local = [p.grad.clone() for p in arena.params]
+    # reference: recompute both ranks' grads locally
+    want = [torch.zeros_like(p) for p in arena.params]
+    for r in range(world):
+        m2 = Tiny()
+        m2.load_state_dict(m.state_dict())
+        xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + r))
+        m2(xr).square().sum().backward()
+        named = dict(m2.named_parameters())
+        for w, name in zip(want, arena.names):
+            w += named[name].grad
+    ok = all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(local, want))
+    # second step after zero_grad: no_sync() keeps the local (un-reduced) gradient
+    arena.zero_grad()
+    with arena.no_sync():
+        m(x).square().sum().backward()
+        arena.finish()
+    unsynced = any(not torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(arena.params, want))
+    q.put((rank, ok, int(n), unsynced))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [True, False])
+def test_lora_grad_arena_allreduce_world2(overlap):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, overlap, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True], res
+    assert [r[2] for r in res] == [4, 4], res        # rank0 shifted targets {2,4}; rank1 {3,5} -> global 4
+    assert all(r[3] for r in res)

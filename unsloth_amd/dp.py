@@ -1,0 +1,140 @@
+"""Data-parallel glue for QLoRA replicas.
+
+The reference has no collective call sites: PyTorch DDP (via accelerate) all-reduces whatever
+requires grad, and unsloth only pins one replica per device (`prepare_device_map`,
+models/loader_utils.py:91-106), excludes rotary buffers from DDP (:849-865) and suppresses
+nn.DataParallel (models/_utils.py:187-249). The frozen NF4 base is replicated; the ONLY exchange per
+optimizer step is the sum of the LoRA gradients (41,943,040 fp32 = 167.8 MB for Llama-3-8B r=16).
+
+MI355X-first version of that exchange:
+  * all trainable grads live in ONE contiguous fp32 arena (p.grad are views), so a bucket is a slice,
+    not a flatten/unflatten copy;
+  * buckets follow the decoder-layer order (>= bucket_bytes each); a bucket is all-reduced (SUM, RCCL
+    over xGMI) from the post-accumulate hook of its LAST gradient, i.e. while the remaining layers'
+    backward is still running (async collective on RCCL's stream);
+  * the loss is normalised by the GLOBAL token count on every rank, so the reduction is a plain SUM
+    with no 1/world_size (reference semantics: num_items_in_batch, _utils.py:3142-3197);
+  * deterministic: fixed bucket order, fp32 sum.
+Works unchanged on gloo/CPU (tests/test_dp_gloo.py, world_size 2).
+"""
+import re
+from contextlib import contextmanager
+
+import torch
+import torch.distributed as dist
+
+
+def _layer_index(name):
+    m = re.search(r"\.layers\.(\d+)\.", name)
+    return int(m.group(1)) if m else -1
+
+
+class LoRAGradArena:
+    def __init__(self, model, process_group=None, bucket_bytes=4 << 20, overlap=True):
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("no trainable parameters")
+        # backward produces the LAST layer first: buckets are laid out in that order
+        named.sort(key=lambda np_: -_layer_index(np_[0]))
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.arena = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.group = process_group
+        self.overlap = overlap
+        self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.buckets = []          # (start, end, n_params)
+        self._bucket_of = {}
+        off, b_start, b_count = 0, 0, 0
+        last_layer = None
+        for n, p in named:
+            layer = _layer_index(n)
+            if b_count and layer != last_layer and (off - b_start) * 4 >= bucket_bytes:
+                self.buckets.append([b_start, off, b_count])
+                b_start, b_count = off, 0
+            if p.dtype != torch.float32:
+                raise TypeError(f"{n}: LoRA parameters are expected in fp32 (SURVEY 9.10), got {p.dtype}")
+            p.grad = self.arena[off:off + p.numel()].view_as(p)
+            self._bucket_of[id(p)] = len(self.buckets)
+            off += p.numel()
+            b_count += 1
+            last_layer = layer
+        self.buckets.append([b_start, off, b_count])
+        self._pending = [0] * len(self.buckets)
+        self._handles = []
+        self._sync = True
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    # ------------------------------------------------------------------------------------------
+    def _hook(self, p):
+        b = self._bucket_of[id(p)]
+        self._pending[b] += 1
+        if self._pending[b] == self.buckets[b][2]:
+            self._pending[b] = 0
+            if self._sync and self.overlap and self.world_size > 1:
+                self._launch(b)
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        h = dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._handles.append(h)
+
+    def finish(self):
+        """Call after backward, before optimizer.step(): launches anything not overlapped and waits."""
+        if self.world_size > 1 and self._sync:
+            if not self.overlap:
+                for b in range(len(self.buckets)):
+                    self._launch(b)
+            for h in self._handles:
+                h.wait()
+        self._handles = []
+        self._pending = [0] * len(self.buckets)
+
+    @contextmanager
+    def no_sync(self):
+        """Gradient accumulation: skip the exchange on all but the last micro-step."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
+    def zero_grad(self):
+        """Keeps the views: the arena is zeroed in one memset instead of N small ones."""
+        self.arena.zero_()
+        for p, (s, n) in zip(self.params, self._offsets()):
+            if p.grad is None or p.grad.data_ptr() != self.arena.data_ptr() + 4 * s:
+                p.grad = self.arena[s:s + n].view_as(p)
+
+    def _offsets(self):
+        off = 0
+        for p in self.params:
+            yield off, p.numel()
+            off += p.numel()
+
+    def grad_norm(self):
+        return self.arena.norm()
+
+    @property
+    def nbytes(self):
+        return self.arena.numel() * 4
+
+    def describe(self):
+        return dict(params=len(self.params), numel=self.arena.numel(), bytes=self.nbytes,
+                    buckets=[(e - s) * 4 for s, e, _ in self.buckets], world_size=self.world_size)
+
+
+def global_num_items(labels, group=None):
+    """Non-ignored target count over ALL ranks (what every rank divides its loss sum by)."""
+    shift = labels[..., 1:]
+    n = torch.count_nonzero(shift != -100).to(torch.int64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    return n
+
+
+def exclude_rope_inv_freq_from_ddp(model):
+    """loader_utils.py:849-865 equivalent: rotary tables are not module buffers here (RopeTables keeps
+    them out of state_dict and of any broadcast), so there is nothing to exclude; kept for API parity."""
+    return model

@@ -1,0 +1,94 @@
+"""Trainer surface; mirror of unsloth/trainer.py.
+
+`UnslothTrainer(SFTTrainer)` / `UnslothTrainingArguments` (trainer.py:445-623) subclass TRL when it is
+installed (it is not in this image: then they raise with an explanation), and `unsloth_train`
+(trainer.py:49-57) is provided as a minimal self-contained loop over pre-tokenised batches -- forward
+through the fused path, backward, LoRA-grad exchange (unsloth_amd/dp.py), optimizer step -- which is
+also what bench.py times. Loss normalisation follows the reference's contract: sum of
+token losses / global non-ignored token count, passed as `num_items_in_batch`.
+"""
+import time
+
+import torch
+
+from .dp import LoRAGradArena, global_num_items
+
+try:
+    from trl import SFTConfig as _SFTConfig, SFTTrainer as _SFTTrainer
+    HAS_TRL = True
+except Exception:
+    HAS_TRL = False
+
+
+if HAS_TRL:
+    class UnslothTrainingArguments(_SFTConfig):
+        def __init__(self, embedding_learning_rate=None, q_galore_config=None, *args, **kwargs):
+            self.embedding_learning_rate = embedding_learning_rate
+            self.q_galore_config = q_galore_config
+            super().__init__(*args, **kwargs)
+
+    class UnslothTrainer(_SFTTrainer):
+        """trainer.py:502-623: embedding-LR param groups; everything else is TRL/HF."""
+
+        def create_optimizer(self):
+            lr = getattr(self.args, "embedding_learning_rate", None)
+            if lr is None or self.optimizer is not None:
+                return super().create_optimizer()
+            cls, kw = self.get_optimizer_cls_and_kwargs(self.args)
+            emb, rest = [], []
+            for n, p in self.model.named_parameters():
+                if p.requires_grad:
+                    (emb if n.endswith("modules_to_save.default.weight") else rest).append(p)
+            groups = [dict(params=rest, lr=kw.get("lr", self.args.learning_rate)), dict(params=emb, lr=lr)]
+            kw.pop("lr", None)
+            self.optimizer = cls(groups, **kw)
+            return self.optimizer
+else:
+    class _NeedsTRL:
+        def __init__(self, *a, **k):
+            raise ImportError("UnslothTrainer / UnslothTrainingArguments subclass trl.SFTTrainer / SFTConfig "
+                              "(unsloth/trainer.py:445-623); `trl` is not installed in this environment. "
+                              "Use unsloth_amd.trainer.unsloth_train for pre-tokenised batches.")
+
+    UnslothTrainer = UnslothTrainingArguments = _NeedsTRL
+
+
+def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999)):
+    params = [p for p in model.parameters() if p.requires_grad]
+    fused = params[0].is_cuda
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
+
+
+def training_step(model, batch, optimizer, arena=None, num_items=None):
+    """One optimizer step on one micro-batch. Returns the (detached) loss tensor, no host sync."""
+    if num_items is None:
+        num_items = global_num_items(batch["labels"])
+    out = model(**batch, num_items_in_batch=num_items)
+    loss = out.loss
+    loss.backward()
+    if arena is not None:
+        arena.finish()
+    optimizer.step()
+    if arena is not None:
+        arena.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    return loss.detach()
+
+
+def unsloth_train(model, batches, optimizer=None, arena=None, max_steps=None, log_every=0):
+    """trainer.py:49-57 counterpart for pre-tokenised batches (dicts with input_ids/labels[/position_ids/
+    packed_seq_lengths] already on the model's device). Returns the list of per-step losses."""
+    model.train()
+    if optimizer is None:
+        optimizer = make_optimizer(model)
+    if arena is None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        arena = LoRAGradArena(model)
+    losses, t0 = [], time.time()
+    for step, batch in enumerate(batches):
+        if max_steps is not None and step >= max_steps:
+            break
+        losses.append(training_step(model, batch, optimizer, arena))
+        if log_every and (step + 1) % log_every == 0:
+            print(f"step {step + 1}: loss {float(losses[-1]):.4f}  ({time.time() - t0:.1f}s)", flush=True)
+    return [float(l) for l in losses]
