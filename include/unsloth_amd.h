@@ -6,7 +6,7 @@
  * Python plus ONE ctypes binding, to bitsandbytes' C library (unsloth/kernels/utils.py:266-284).
  * This header therefore declares
  *   (1) the bitsandbytes symbols that binding uses, with bitsandbytes' exact C signatures, and
- *   (2) one `uamd_*` entry point per Triton kernel launch of unsloth/kernels/*.py, following the
+ *   (2) one `uamd_*` entry point per Triton kernel launch of the unsloth/kernels python modules, following the
  *       calling convention the reference already uses for native code (utils.py:198-202,242-253):
  *       raw device pointers, C int / int64 scalars, the CURRENT stream of the tensor's device
  *       passed as an opaque pointer, no allocation, no synchronisation.
@@ -169,6 +169,10 @@ typedef struct {
 
 int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                  int n_groups, int accumulate, int dtype, void* stream);
+/* uamd_gemm_nt_256: same contract as uamd_gemm_nt with 256x256x64 tiles, LDS-DMA staging and two wave
+ * groups in anti-phase (csrc/gemm256.hip); for large M. Requires K % 64 == 0. */
+int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                     int n_groups, int accumulate, int dtype, void* stream);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
 int uamd_lora_xa(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,

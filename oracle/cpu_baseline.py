@@ -15,6 +15,19 @@ import torch
 import torch.nn.functional as F
 
 
+def usable_cores():
+    """Threads this process may really use: affinity mask AND the cgroup CPU quota (os.cpu_count() reports the
+    host's 256 hardware threads inside a quota-limited container, and oversubscribing them is 100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def _rope(x, cos, sin):
     half = x.shape[-1] // 2
     rh = torch.cat((-x[..., half:], x[..., :half]), dim=-1)
@@ -28,7 +41,7 @@ def _lin(x, W, A, B, s):
 def time_layer(hidden=4096, inter=14336, n_heads=32, n_kv=8, head_dim=128, vocab=128256, r=16, tokens=256,
                n_layers=32, budget_s=25.0, seed=3407):
     torch.manual_seed(seed)
-    threads = os.cpu_count() or 1
+    threads = usable_cores()
     torch.set_num_threads(threads)
     f32 = torch.float32
     mk = lambda o, i: (torch.randn(o, i, dtype=f32) * 0.02, (torch.randn(r, i, dtype=f32) * 0.02).requires_grad_(True),

@@ -7,6 +7,7 @@ FastLanguageModel's fused path must compute: HF transformers + PEFT arithmetic, 
 LoRA gradients follow from dL/dW_eff:  dA = s * B^T @ dW,  dB = s * dW @ A^T.
 """
 import copy
+from contextlib import contextmanager
 
 import torch
 
@@ -36,6 +37,22 @@ def _cpu_state(qs):
     return qs
 
 
+@contextmanager
+def _stock_hf_classes():
+    """The product's pre_patch() swaps transformers' LlamaRMSNorm class for its fast subclass
+    (as unsloth/kernels/rms_layernorm.py:277-286 does). The oracle must be built from the STOCK class."""
+    import transformers.models.llama.modeling_llama as m
+    cur = m.LlamaRMSNorm
+    stock = cur
+    while stock.__name__ != "LlamaRMSNorm" and len(stock.__mro__) > 1:
+        stock = stock.__mro__[1]
+    m.LlamaRMSNorm = stock
+    try:
+        yield
+    finally:
+        m.LlamaRMSNorm = cur
+
+
 NAMES = (("self_attn", "q_proj"), ("self_attn", "k_proj"), ("self_attn", "v_proj"), ("self_attn", "o_proj"),
          ("mlp", "gate_proj"), ("mlp", "up_proj"), ("mlp", "down_proj"))
 
@@ -47,7 +64,8 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
     cfg = copy.deepcopy(base.config)
     cfg.dtype = torch.float32
     cfg._attn_implementation = "eager"
-    ref = AutoModelForCausalLM.from_config(cfg).to(torch.float32)
+    with _stock_hf_classes():
+        ref = AutoModelForCausalLM.from_config(cfg).to(torch.float32)
     # the product patches LlamaForCausalLM.forward at class level: make sure THIS instance runs stock HF
     ref._unsloth_amd_fast = False
     with torch.no_grad():

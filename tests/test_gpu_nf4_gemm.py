@@ -208,3 +208,65 @@ def test_lora_xa(M, K, Rs):
     # deterministic split-K: two runs are bitwise identical
     out2, _ = lora_xa(X.to(DEV), [a.to(DEV) for a in As])
     assert torch.equal(out, out2)
+
+
+# ---------------------------------------------------------------- 256x256 LDS-DMA ping-pong kernel
+@pytest.fixture
+def force256():
+    from unsloth_amd.kernels import utils as U
+    old = U.GEMM256_MODE
+    U.GEMM256_MODE = "on"
+    yield
+    U.GEMM256_MODE = old
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 260, 192), (1, 256, 4096),
+                                   (4096, 4096, 4096), (1000, 1024, 14336)])
+def test_gemm256_dense(force256, dtype, M, N, K):
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    X = torch.randn(M, K, generator=g(105)).to(dtype)
+    W = (torch.randn(N, K, generator=g(106)) * 0.05).to(dtype)
+    (Y,) = lora_linear_forward(X.to(DEV), [(W.to(DEV), None, None, None, None)])
+    _check_gemm(Y, _ref_mm(X, W), dtype, K, f"gemm256 {M}x{N}x{K}")
+    # run-to-run bitwise determinism (catches LDS races that only sometimes bite)
+    for _ in range(3):
+        (Y2,) = lora_linear_forward(X.to(DEV), [(W.to(DEV), None, None, None, None)])
+        assert torch.equal(Y, Y2)
+
+
+def test_gemm256_transpose_detecting_and_k_order(force256):
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    M, N, K = 512, 512, 256
+    X = torch.zeros(M, K)
+    W = torch.zeros(N, K)
+    for k in range(0, K, 37):                    # a few isolated k positions with distinct weights
+        X[:, k] = (torch.arange(M) % 7 + 1).float() * (1 + k % 3)
+        W[:, k] = (torch.arange(N) % 5 + 1).float() * (1 + k % 2)
+    (Y,) = lora_linear_forward(X.to(torch.bfloat16).to(DEV), [(W.to(torch.bfloat16).to(DEV), None, None, None, None)])
+    assert torch.equal(Y.float().cpu(), (X @ W.t()).to(torch.bfloat16).float())
+
+
+def test_gemm256_groups_lora_accumulate(force256):
+    from unsloth_amd.kernels.utils import lora_linear_forward, _group, _launch_gemm
+    dtype = torch.bfloat16
+    M, K, r = 700, 512, 16
+    Ns = [512, 300, 128]
+    X = torch.randn(M, K, generator=g(107)).to(dtype)
+    projs, refs = [], []
+    for i, N in enumerate(Ns):
+        W = (torch.randn(N, K, generator=g(110 + i)) * 0.05).to(dtype)
+        A = torch.randn(r, K, generator=g(120 + i)) * 0.05
+        B = torch.randn(N, r, generator=g(130 + i)) * 0.05
+        projs.append((W.to(DEV), None, A.to(DEV), B.to(DEV), 0.5))
+        xa = (X.float() @ A.to(dtype).float().t()).to(dtype).float()
+        refs.append(_ref_mm(X, W) + 0.5 * xa @ B.to(dtype).float().t())
+    outs = lora_linear_forward(X.to(DEV), projs)
+    for o, ref, N in zip(outs, refs, Ns):
+        _check_gemm(o, ref, dtype, K, f"gemm256 grouped lora N={N}")
+    # accumulate: C += A @ B^T
+    C0 = torch.randn(M, Ns[0], generator=g(140)).to(dtype)
+    C = C0.clone().to(DEV)
+    Wd = projs[0][0]
+    _launch_gemm(X.to(DEV), [_group(Wd, C, Ns[0], Wd.stride(0))], nf4=False, accumulate=True)
+    _check_gemm(C, C0.float() + _ref_mm(X, Wd.cpu()), dtype, K, "gemm256 accumulate")

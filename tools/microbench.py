@@ -48,11 +48,12 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--tokens", type=int, nargs="+", default=[2048, 8192])
     ap.add_argument("--skip-gemm", action="store_true")
+    ap.add_argument("--only-gemm", action="store_true")
     a = ap.parse_args()
     out = open(a.out, "w") if a.out else None
     bf = torch.bfloat16
     H, I, V, Hq, Hk, D = 4096, 14336, 128256, 32, 8, 128
-    for T in a.tokens:
+    for T in ([] if a.only_gemm else a.tokens):
         X = torch.randn(T, H, device=DEV, dtype=bf)
         W = torch.rand(H, device=DEV, dtype=bf)
         dY = torch.randn(T, H, device=DEV, dtype=bf)
@@ -107,7 +108,11 @@ def main():
             p, q = quantize_nf4(Wf)
             fl = 2.0 * T * N * Kd
             emit(out, f"torch_matmul_{tag}", timeit(lambda: Xin @ Wf.t()), flops=fl, T=T)
-            emit(out, f"gemm_dense_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
+            U.GEMM256_MODE = "off"
+            emit(out, f"gemm_dense128_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
+            U.GEMM256_MODE = "on"
+            emit(out, f"gemm_dense256_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
+            U.GEMM256_MODE = "auto"
             U.FUSED_NF4 = True
             emit(out, f"gemm_nf4_fused_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(p, q, None, None, None)])), flops=fl, T=T)
             U.FUSED_NF4 = False

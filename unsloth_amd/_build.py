@@ -24,6 +24,7 @@ SOURCES = [
     "cross_entropy_loss.hip",
     "nf4.hip",
     "gemm.hip",
+    "gemm256.hip",
 ]
 
 

@@ -1,0 +1,365 @@
+// 256x256x64 "ping-pong" MFMA GEMM for gfx950: C[M,N] (+)= A[M,K] @ B[N,K]^T (+ LoRA term), bf16/fp16.
+//
+// Same contract as gemm_nt_kernel (gemm.hip; replaces unsloth/kernels/utils.py:1128-1170 matmul_lora and the
+// dX products of unsloth/kernels/fast_lora.py), built for large M (tokens >= 4096) where a 256x256 tile still
+// gives >= 2 tiles per CU. Why a second kernel: the 128x128 register-staged kernel is LDS-bound on CDNA4 --
+// every operand byte crosses the VGPR->LDS store path (ds_write_b128 = 13 cycles / KiB) -- and tops out near
+// 0.85 PFLOP/s. Here:
+//   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write;
+//   * one 1-KiB DMA instruction fills exactly one [16 rows x 32 k] MFMA sub-tile; the bank swizzle
+//     (16-byte slot ^= 2 for rows 8..15, conflict-free for ds_read_b128) is applied on the per-lane SOURCE
+//     address because the DMA destination is lane-linear;
+//   * 8 waves = 2 groups of 4 (group = wave>>2 owns 128 rows). The groups run in ANTI-PHASE: in every
+//     barrier-delimited slot one group issues its LDS fragment reads + next tiles' DMA while the other group
+//     owns the matrix pipe for 16 back-to-back MFMAs (two waves share a SIMD: one computes, one loads);
+//   * K tiles are double-buffered in LDS (2 x 64 KiB); a wave's 8 DMA pieces of tile t+1 are issued 3/3/2
+//     over three load slots starting as soon as tile t-1's buffer is drained, and retired by ONE counted
+//     `s_waitcnt vmcnt(3)` per tile (never a full drain in the loop).
+// Slot timeline for tile t (group 1 is one slot behind):
+//   L0: read A[rows 0..63] (8 frags) + B[cols 0..31] (4) | DMA pieces 3,4,5 of tile t+1 | lgkmcnt(0) | barrier
+//   M0: 16 MFMA (quadrant 0,0)                                                                     | barrier
+//   L1: read B[cols 32..63] (4)                          | DMA pieces 6,7 of tile t+1   | lgkmcnt(0) | barrier
+//   M1: 16 MFMA (0,1)                                                                               | barrier
+//   L2: read A[rows 64..127] (8)                                                        | lgkmcnt(0) | barrier
+//   M2: 16 MFMA (1,1)                                                                               | barrier
+//   L3: DMA pieces 0,1,2 of tile t+2 (buffer of tile t is drained) | vmcnt(3): tile t+1 landed      | barrier
+//   M3: 16 MFMA (1,0)                                                                               | barrier
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+namespace {
+
+template <typename T> struct Mfma2;
+template <> struct Mfma2<bf16_t> {
+    typedef bf16x8_t frag;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma2<f16_t> {
+    typedef f16x8_t frag;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int STAGE_BYTES = (TM + TN) * TK * 2;   // 64 KiB
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;        // 128 KiB
+#define UAMD_G256_MAX_GROUPS 3
+
+struct G256Args {
+    const void* A;
+    int64_t lda;
+    int M, K;
+    int n_groups;
+    int accumulate;
+    int tiles_m;
+    int total_tiles;
+    int tile_start[UAMD_G256_MAX_GROUPS + 1];
+    uamd_gemm_group g[UAMD_G256_MAX_GROUPS];
+};
+
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+// One wave-instruction of LDS-DMA: 64 lanes x 16 B from per-lane global addresses -> LDS [lds_addr,
+// lds_addr + 1024). Issued through inline asm ON PURPOSE: with the builtin, hipcc treats every later ds_read
+// as possibly aliasing the in-flight DMA and emits `s_waitcnt vmcnt(0)` in front of each fragment-read group,
+// which serialises the pipeline. In asm the compiler neither counts nor waits for it; completion is tracked
+// by the hand-placed counted `s_waitcnt vmcnt(N)` + barrier (cdna guide 5.7: M0 is written in the same
+// statement that reads it, and restored).
+__device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(lds_addr)
+        : "memory");
+}
+
+#define SLOT_BARRIER()                          \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Mfma2<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;      // group owns rows grp*128.., wave owns cols wn*64..
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    // ---- tile mapping with an XCD-aware, bijective remap (block b runs on XCD b % 8): each XCD gets a
+    //      contiguous run of tiles, so the A/B panels it re-reads stay in ITS 4 MiB L2.
+    int tile = blockIdx.x;
+    {
+        const int nt = p.total_tiles, q = nt >> 3, r = nt & 7, x = tile & 7, j = tile >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    const int tn_lin = tile / p.tiles_m;
+    const int tm = tile - tn_lin * p.tiles_m;
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < UAMD_G256_MAX_GROUPS; ++i)
+        if (i < p.n_groups && tn_lin >= p.tile_start[i]) gi = i;
+    const uamd_gemm_group& g = p.g[gi];
+    const int m0 = tm * TM, n0 = (tn_lin - p.tile_start[gi]) * TN;
+    const int M = p.M, K = p.K, N = g.N;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- LoRA term first (same as gemm.hip): acc = s * (T(XA) @ LB^T)
+    if (g.lora_xa != nullptr) {
+        const int R = g.R;
+        for (int k0 = 0; k0 < R; k0 += 32) {
+            const int k = k0 + l4 * 8;
+            frag_t lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l15;
+                uint4 raw = make_uint4(0, 0, 0, 0);
+                if (n < N && k < R)
+                    raw = *reinterpret_cast<const uint4*>((const T*)g.lora_b + (int64_t)n * g.ld_lb + k);
+                union { uint4 r; frag_t f; } u; u.r = raw; lb[j] = u.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + grp * 128 + i * 16 + l15;
+                Vec16<T> v;
+                v.raw = make_uint4(0, 0, 0, 0);
+                if (m < M && k < R) {
+                    const float* src = g.lora_xa + (int64_t)m * g.ld_xa + k;
+                    const float4 f0 = *reinterpret_cast<const float4*>(src);
+                    const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
+                    v.e[0] = from_f32<T>(f0.x); v.e[1] = from_f32<T>(f0.y);
+                    v.e[2] = from_f32<T>(f0.z); v.e[3] = from_f32<T>(f0.w);
+                    v.e[4] = from_f32<T>(f1.x); v.e[5] = from_f32<T>(f1.y);
+                    v.e[6] = from_f32<T>(f1.z); v.e[7] = from_f32<T>(f1.w);
+                }
+                union { uint4 r; frag_t f; } u; u.r = v.raw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma2<T>::run(lb[j], u.f, acc[i][j]);
+            }
+        }
+        const float s = g.lora_scale;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= s;
+    }
+
+    // ---- DMA source pointers. Piece c (0..7) of a tile, issued by wave w, fills sub-tile u = c*8 + w:
+    //      u < 32: A rows rg*16.. (rg = (u>>1)&15), k half kh = u&1 ; u >= 32: B likewise.
+    //      lane -> (row = lane>>2, 16-byte slot = (lane&3) ^ (row>=8 ? 2 : 0)) inside the sub-tile.
+    const int sub_row = lane >> 2;
+    const int sub_slot = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    const int rg_w = wave >> 1, kh_w = wave & 1;
+    const T* a_src[4];
+    const T* b_src[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int ra = m0 + (c * 4 + rg_w) * 16 + sub_row;
+        int rb = n0 + (c * 4 + rg_w) * 16 + sub_row;
+        ra = ra < M ? ra : M - 1;          // clamped rows are never stored
+        rb = rb < N ? rb : N - 1;
+        a_src[c] = (const T*)p.A + (int64_t)ra * p.lda + kh_w * 32 + sub_slot * 8;
+        b_src[c] = (const T*)g.B + (int64_t)rb * g.ldb + kh_w * 32 + sub_slot * 8;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
+    auto issue = [&](int c, int kt, int stage) {       // c, stage are compile-time at every call site
+        const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
+        const T* src = (c < 4 ? a_src[c] : b_src[c - 4]) + (int64_t)kt * TK;
+        dma16(src, dst);
+    };
+
+    // ---- fragment read offsets (bytes inside a stage)
+    const int frag_off = l15 * 64 + ((l4 ^ ((l15 >> 3) << 1)) << 4);
+    const int a_base = (grp * 8) * 2048 + frag_off;               // A sub-tile (rg, kh) at (rg*2+kh)*1024
+    const int b_base = 32 * 1024 + (wn * 4) * 2048 + frag_off;
+    frag_t af[4][2], bf[4][2];     // A: 4 m-tiles of the current 64-row half x 2 k-halves; B: 4 n-tiles x 2
+    auto read_a = [&](int stage, int mq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { uint4 r; frag_t f; } u;
+                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + a_base + ((mq * 4 + i) * 2 + ks) * 1024);
+                af[i][ks] = u.f;
+            }
+    };
+    auto read_b = [&](int stage, int nq) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { uint4 r; frag_t f; } u;
+                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + b_base + ((nq * 2 + j) * 2 + ks) * 1024);
+                bf[nq * 2 + j][ks] = u.f;
+            }
+    };
+    auto mma = [&](int mq, int nq) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mq * 4 + i][nq * 2 + j] = Mfma2<T>::run(bf[nq * 2 + j][ks], af[i][ks], acc[mq * 4 + i][nq * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = K / TK;     // host guarantees K % 64 == 0
+    // ---- prologue: tile 0 completely, first 3 pieces of tile 1
+#pragma unroll
+    for (int c = 0; c < 8; ++c) issue(c, 0, 0);
+    if (nk > 1) {
+        issue(0, 1, 1); issue(1, 1, 1); issue(2, 1, 1);
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    SLOT_BARRIER();
+    if (grp == 1) SLOT_BARRIER();          // anti-phase: group 1 runs one slot behind
+
+#define TILE_BODY(STAGE, KT)                                                             \
+    do {                                                                                 \
+        /* L0 */                                                                         \
+        read_a(STAGE, 0); read_b(STAGE, 0);                                              \
+        if ((KT) + 1 < nk) { issue(3, (KT) + 1, (STAGE) ^ 1); issue(4, (KT) + 1, (STAGE) ^ 1); issue(5, (KT) + 1, (STAGE) ^ 1); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(0, 0); SLOT_BARRIER();                                                       \
+        /* L1 */                                                                         \
+        read_b(STAGE, 1);                                                                \
+        if ((KT) + 1 < nk) { issue(6, (KT) + 1, (STAGE) ^ 1); issue(7, (KT) + 1, (STAGE) ^ 1); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(0, 1); SLOT_BARRIER();                                                       \
+        /* L2 */                                                                         \
+        read_a(STAGE, 1);                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(1, 1); SLOT_BARRIER();                                                       \
+        /* L3: this stage is drained by BOTH groups (their last reads ended >= 1 barrier ago) */ \
+        if ((KT) + 2 < nk) {                                                             \
+            issue(0, (KT) + 2, STAGE); issue(1, (KT) + 2, STAGE); issue(2, (KT) + 2, STAGE); \
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                             \
+        } else {                                                                         \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
+        }                                                                                \
+        SLOT_BARRIER();                                                                  \
+        mma(1, 0); SLOT_BARRIER();                                                       \
+    } while (0)
+
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        TILE_BODY(0, kt);
+        TILE_BODY(1, kt + 1);
+    }
+    if (kt < nk) TILE_BODY(0, kt);
+#undef TILE_BODY
+    if (grp == 0) SLOT_BARRIER();          // match group 1's extra barrier
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = ..+4*l4 (operands were passed swapped)
+    T* Cg = (T*)g.C;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + grp * 128 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+            if (n >= N) continue;
+            T* dst = Cg + (int64_t)m * g.ldc + n;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (n + 3 < N && vec_ok) {
+                union { uint2 raw; T e[4]; } o;
+                if (p.accumulate) {
+                    o.raw = *reinterpret_cast<const uint2*>(dst);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
+                *reinterpret_cast<uint2*>(dst) = o.raw;
+            } else {
+                for (int r = 0; r < 4 && n + r < N; ++r) {
+                    float x = v[r];
+                    if (p.accumulate) x += to_f32(dst[r]);
+                    dst[r] = from_f32<T>(x);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch256(const G256Args& a, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_nt256_kernel<T>), dim3((unsigned)a.total_tiles), dim3(512), LDS_BYTES, st, a);
+    return uamd_launch_status();
+}
+
+}  // namespace
+
+// Same contract as uamd_gemm_nt (dense B), 256x256x64 tiles. Requires K % 64 == 0.
+extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                                int n_groups, int accumulate, int dtype, void* stream) {
+    if (M < 0 || K <= 0 || n_groups < 1 || n_groups > UAMD_G256_MAX_GROUPS || !groups) return UAMD_ERR_ARG;
+    if (M == 0) return UAMD_OK;
+    if ((K & 63) || (lda & 7) || !aligned16(A)) return UAMD_ERR_ALIGN;
+    G256Args a;
+    a.A = A; a.lda = lda; a.M = M; a.K = K; a.n_groups = n_groups; a.accumulate = accumulate;
+    a.tiles_m = (M + TM - 1) / TM;
+    int tn = 0;
+    for (int i = 0; i < UAMD_G256_MAX_GROUPS; ++i) {
+        a.tile_start[i] = tn;
+        if (i < n_groups) {
+            const uamd_gemm_group& g = groups[i];
+            if (g.N <= 0 || !g.B || !g.C) return UAMD_ERR_ARG;
+            if ((g.ldb & 7) || !aligned16(g.B)) return UAMD_ERR_ALIGN;
+            if (g.lora_xa) {
+                if (!g.lora_b || g.R <= 0 || (g.R & 7) || (g.ld_xa & 3) || (g.ld_lb & 7) ||
+                    !aligned16(g.lora_xa) || !aligned16(g.lora_b))
+                    return UAMD_ERR_ALIGN;
+            }
+            a.g[i] = g;
+            tn += (g.N + TN - 1) / TN;
+        } else {
+            a.g[i] = groups[0];
+        }
+    }
+    a.tile_start[UAMD_G256_MAX_GROUPS] = tn;
+    const int64_t total = (int64_t)tn * a.tiles_m;
+    if (total > 0x7fffffffLL) return UAMD_ERR_ARG;
+    a.total_tiles = (int)total;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UAMD_BF16) return launch256<bf16_t>(a, st);
+    if (dtype == UAMD_F16) return launch256<f16_t>(a, st);
+    return UAMD_ERR_DTYPE;
+}

@@ -26,6 +26,10 @@ next_power_of_2 = lambda n: 1 << (max(int(n), 1) - 1).bit_length()
 
 # fused NF4-decode-in-GEMM forward (no bf16 copy of W in HBM) vs dequant-to-scratch + dense GEMM
 FUSED_NF4 = os.environ.get("UNSLOTH_AMD_FUSED_NF4", "1") == "1"
+# dense GEMM tile selection: "auto" = the 256x256 LDS-DMA ping-pong kernel (csrc/gemm256.hip) once the launch
+# has enough 256x256 tiles to fill the 256 CUs, else the 128x128 kernel; "on"/"off" force it.
+GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
+GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "192"))
 
 
 def calculate_settings(n):
@@ -111,13 +115,29 @@ def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0)
         N=N, R=R, lora_scale=float(scale), _pad=0)
 
 
+def _use_gemm256(M, K, groups):
+    if GEMM256_MODE == "off" or K % 64:
+        return False
+    if GEMM256_MODE == "on":
+        return True
+    tiles = ((M + 255) // 256) * sum((g.N + 255) // 256 for g in groups)
+    return tiles >= GEMM256_MIN_TILES
+
+
 def _launch_gemm(X2d, groups, nf4, accumulate=False):
     arr = (GemmGroup * len(groups))(*groups)
-    fn = _lib.lib().uamd_gemm_nt_nf4 if nf4 else _lib.lib().uamd_gemm_nt
+    L = _lib.lib()
+    M, K = X2d.shape
+    if nf4:
+        fn, name = L.uamd_gemm_nt_nf4, "uamd_gemm_nt_nf4"
+    elif _use_gemm256(M, K, groups):
+        fn, name = L.uamd_gemm_nt_256, "uamd_gemm_nt_256"
+    else:
+        fn, name = L.uamd_gemm_nt, "uamd_gemm_nt"
     with _lib.device_ctx(X2d):
-        rc = fn(_lib.ptr(X2d), X2d.stride(0), X2d.shape[0], X2d.shape[1], arr, len(groups),
-                int(accumulate), _lib.dtype_code(X2d.dtype), _lib.stream_of(X2d))
-    _lib.check(rc, "uamd_gemm_nt_nf4" if nf4 else "uamd_gemm_nt")
+        rc = fn(_lib.ptr(X2d), X2d.stride(0), M, K, arr, len(groups), int(accumulate),
+                _lib.dtype_code(X2d.dtype), _lib.stream_of(X2d))
+    _lib.check(rc, name)
 
 
 def _rows2d(X):
