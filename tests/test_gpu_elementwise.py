@@ -152,15 +152,19 @@ def test_glu(dtype, kind, shape):
     gg = torch.randn(*shape, generator=g(12)).to(dtype)
     DW = torch.randn(shape[0] * shape[1], shape[2], generator=g(13)).to(dtype)
     h = fwd(e.to(DEV), gg.to(DEV))
-    assert_ulp(h, R.glu_forward(e, gg, kind), dtype, ulps=U(dtype, 1), what=f"{kind} fwd", allow_frac=5e-3)
+    # fp32: 1 + erf(x) / 1 + tanh(x) cancel for x << 0, so the result carries the ABSOLUTE accuracy of the
+    # transcendental (about 1 ulp of 1.0, times |e g|), not a relative one: allow 1e-6 absolute on O(1) data.
+    at = 1e-6 if dtype == torch.float32 else None
+    assert_ulp(h, R.glu_forward(e, gg, kind), dtype, ulps=U(dtype, 1), atol=at, what=f"{kind} fwd", allow_frac=5e-3)
     e2, g2, d2 = e.view(-1, shape[2]).to(DEV), gg.view(-1, shape[2]).to(DEV), DW.to(DEV)
     ptrs = (d2.data_ptr(), e2.data_ptr(), g2.data_ptr())
     ho, dfo, deo = R.glu_backward(DW, e.view(-1, shape[2]), gg.view(-1, shape[2]), kind)
     hh, df, de = bwd(d2, e2, g2)
     assert (hh.data_ptr(), df.data_ptr(), de.data_ptr()) == ptrs, "backward must overwrite DW, e, g"
-    assert_ulp(hh, ho, dtype, ulps=U(dtype, 1), what=f"{kind} bwd h", allow_frac=5e-3)
-    assert_ulp(df, dfo, dtype, ulps=U(dtype, 1), what=f"{kind} bwd df", allow_frac=5e-3)
-    assert_ulp(de, deo, dtype, ulps=U(dtype, 2), what=f"{kind} bwd de", allow_frac=5e-3)
+    at = 4e-6 if dtype == torch.float32 else None      # |DW| multiplies the same absolute error
+    assert_ulp(hh, ho, dtype, ulps=U(dtype, 1), atol=at, what=f"{kind} bwd h", allow_frac=5e-3)
+    assert_ulp(df, dfo, dtype, ulps=U(dtype, 1), atol=at, what=f"{kind} bwd df", allow_frac=5e-3)
+    assert_ulp(de, deo, dtype, ulps=U(dtype, 2), atol=at, what=f"{kind} bwd de", allow_frac=5e-3)
 
 
 def test_glu_golden(golden):
