@@ -40,15 +40,19 @@ def llama3_8b_config(n_layers=32, vocab=128256):
         attention_bias=False, mlp_bias=False)
 
 
+KERNEL_OF = {"uamd_gemm_nt_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nt": "gemm_nt_kernel<bf16,dense>",
+             "uamd_gemm_nt_nf4": "gemm_nt_kernel<bf16,NF4>"}
+
+
 class GemmTimer:
-    """HIP-event pairs around every MFMA GEMM launch (both instantiations of gemm_nt_kernel), recorded on
-    the stream the kernel is launched on (torch's current stream == the stream passed through the C ABI)."""
+    """HIP-event pairs around every MFMA GEMM launch, recorded on the stream the kernel is launched on (torch's
+    current stream == the stream passed through the C ABI). One record per launch: (start, end, flops, kernel)."""
 
     def __init__(self):
         from unsloth_amd.kernels import utils as U
         self.U = U
         self.orig = U._launch_gemm
-        self.records = {"gemm_nt_kernel<bf16,NF4>": [], "gemm_nt_kernel<bf16,dense>": []}
+        self.records = {}
         self.enabled = False
 
     def install(self):
@@ -61,13 +65,15 @@ class GemmTimer:
             flops = 2.0 * X2d.shape[0] * X2d.shape[1] * sum(g.N for g in groups)
             flops += sum(2.0 * X2d.shape[0] * g.R * g.N for g in groups if g.lora_xa)
             s.record()
-            orig(X2d, groups, nf4, accumulate)
+            name = orig(X2d, groups, nf4, accumulate)
             e.record()
-            recs["gemm_nt_kernel<bf16,NF4>" if nf4 else "gemm_nt_kernel<bf16,dense>"].append((s, e, flops))
+            recs.setdefault(KERNEL_OF[name], []).append((s, e, flops))
+            return name
 
         U._launch_gemm = timed
-        import unsloth_amd.kernels.cross_entropy_loss as ce
-        ce._u._launch_gemm = timed
+
+    def reset(self):
+        self.records.clear()
 
     def summary(self):
         out = {}
@@ -90,8 +96,12 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--gc", choices=["on", "off"], default=os.environ.get("BENCH_GC", "on"),
-                    help="gradient checkpointing (reference default use_gradient_checkpointing='unsloth')")
+    ap.add_argument("--gc", choices=["on", "off"], default=os.environ.get("BENCH_GC", "off"),
+                    help="gradient checkpointing for the primary number. off: activations stay in the 288 GB HBM "
+                         "(no recompute); on: the reference default use_gradient_checkpointing='unsloth' semantics "
+                         "(layer inputs only, one extra forward per layer)")
+    ap.add_argument("--alt-steps", type=int, default=int(os.environ.get("BENCH_ALT_STEPS", 3)),
+                    help="also time this many steps in the OTHER checkpointing mode (reported under 'alt'); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -119,6 +129,7 @@ def main():
     model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
                                                  load_in_4bit=True, device=dev, random_state=3407,
                                                  use_gradient_checkpointing=(a.gc == "on"))
+    # NOTE: for_training() below re-applies the checkpointing mode per measurement
     model = FastLanguageModel.get_peft_model(model, r=a.rank, lora_alpha=a.rank, lora_dropout=0.0, bias="none",
                                              use_gradient_checkpointing=(a.gc == "on"), random_state=3407)
     g = torch.Generator(device="cpu").manual_seed(3407)
@@ -147,32 +158,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    losses = []
-    for i in range(a.warmup):
-        losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
-    sync()
-    torch.cuda.reset_peak_memory_stats()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
-    sync()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    peak = torch.cuda.max_memory_allocated()
-    if world > 1:
-        pk = torch.tensor([peak], device=dev, dtype=torch.int64)
-        dist.all_reduce(pk, op=dist.ReduceOp.MAX)
-        peak = int(pk)
-    loss_vals = [float(l) for l in losses]
+    def measure(gc_on, steps, warmup):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        model.for_training(use_gradient_checkpointing=gc_on)
+        losses = []
+        for i in range(warmup):
+            losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
+        sync()
+        torch.cuda.reset_peak_memory_stats()
+        timer.reset()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for i in range(steps):
+            losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
+        sync()
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        peak = torch.cuda.max_memory_allocated()
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax)
+            pk = torch.tensor([peak], device=dev, dtype=torch.int64)
+            dist.all_reduce(pk, op=dist.ReduceOp.MAX)
+            peak = int(pk)
+        return dt, peak, [float(l) for l in losses], timer.summary()
+
+    gc_primary = a.gc == "on"
+    alt = None
+    if a.alt_steps > 0:
+        # the other checkpointing mode, short, BEFORE the primary run (so the primary's timers/peak stand last)
+        adt, apeak, _, _ = measure(not gc_primary, a.alt_steps, 1)
+        alt = {"gradient_checkpointing": not gc_primary, "value": round(B * T * a.alt_steps * world / adt, 1),
+               "ms_per_step": round(adt / a.alt_steps * 1e3, 2), "peak_vram_gb": round(apeak / 2**30, 2),
+               "steps": a.alt_steps}
+        torch.cuda.empty_cache()
+    dt, peak, loss_vals, gs = measure(gc_primary, a.steps, a.warmup)
 
     if rank == 0:
         tokens = B * T * a.steps * world
-        gs = timer.summary()
         dom = max(gs.values(), key=lambda r: r["total_ms"]) if gs else None
         dom_name = [k for k, v in gs.items() if v is dom][0] if dom else None
         roofline = None
@@ -202,7 +226,7 @@ def main():
                        "attention": "torch SDPA (flash)", "optimizer": "AdamW(fused) fp32 on LoRA params"},
             "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T,
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }
         print(json.dumps(rec), flush=True)
     if world > 1:

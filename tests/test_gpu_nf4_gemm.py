@@ -156,14 +156,17 @@ def test_gemm_nf4_fused_matches_dequant_then_gemm(M, N, K):
     packed, qs = quantize_nf4(W, compress_statistics=True)
     Wd = R.nf4_dequantize_state(packed, qs)                       # oracle-decoded weight
     want = _ref_mm(X.cpu(), Wd)
-    old = U.FUSED_NF4
+    old = (U.FUSED_NF4, U.FUSED_NF4_MAX_M)
     try:
         for fused in (True, False):
-            U.FUSED_NF4 = fused
+            U.FUSED_NF4, U.FUSED_NF4_MAX_M = fused, 1 << 30        # force the decode-in-GEMM kernel at any M
             (Y,) = U.lora_linear_forward(X, [(packed, qs, None, None, None)])
             _check_gemm(Y, want, dtype, K, f"nf4 gemm fused={fused} {M}x{N}x{K}")
+        U.FUSED_NF4, U.FUSED_NF4_MAX_M = old                       # the shipped policy picks by M
+        (Y,) = U.lora_linear_forward(X, [(packed, qs, None, None, None)])
+        _check_gemm(Y, want, dtype, K, f"nf4 gemm policy {M}x{N}x{K}")
     finally:
-        U.FUSED_NF4 = old
+        U.FUSED_NF4, U.FUSED_NF4_MAX_M = old
 
 
 def test_lora_linear_dx_accumulates_groups():

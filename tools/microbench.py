@@ -113,7 +113,7 @@ def main():
             U.GEMM256_MODE = "on"
             emit(out, f"gemm_dense256_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
             U.GEMM256_MODE = "auto"
-            U.FUSED_NF4 = True
+            U.FUSED_NF4, U.FUSED_NF4_MAX_M = True, 1 << 30
             emit(out, f"gemm_nf4_fused_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(p, q, None, None, None)])), flops=fl, T=T)
             U.FUSED_NF4 = False
             emit(out, f"gemm_nf4_unfused_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(p, q, None, None, None)])), flops=fl, T=T)

@@ -17,6 +17,7 @@ GEMM (torch.matmul/addmm_), as in the reference (:172-189): they are tiny and la
 import torch
 
 from .utils import (
+    cast_lora,
     get_lora_parameters,
     lora_linear_dx,
     lora_linear_forward,
@@ -42,7 +43,7 @@ def _lora_grads(X2d, dY2d, A, B, s, dtype):
     un-transposed layout. Returns (None, None) when the adapter is absent."""
     if A is None:
         return None, None
-    At, Bt = A.to(dtype).t(), B.to(dtype).t()          # [in,r], [r,out]
+    At, Bt = cast_lora(A, dtype).t(), cast_lora(B, dtype).t()          # [in,r], [r,out]
     dA_t = torch.empty_like(At)                          # [in, r]
     dB_t = torch.empty_like(Bt)                          # [r, out]
     # d_A = X^T @ (dY @ B^T-as-stored) ; d_B = (A^T-as-stored @ X^T) @ dY     (:172-173)

@@ -24,8 +24,12 @@ from .._lib import GemmGroup
 MAX_FUSED_SIZE = 65536
 next_power_of_2 = lambda n: 1 << (max(int(n), 1) - 1).bit_length()
 
-# fused NF4-decode-in-GEMM forward (no bf16 copy of W in HBM) vs dequant-to-scratch + dense GEMM
+# NF4 forward policy. Decoding NF4 inside the GEMM (csrc/gemm.hip, no bf16 copy of W in HBM) repeats the decode
+# once per 128-row M tile, so it only pays while the launch is weight-bandwidth-bound (few tokens). From
+# FUSED_NF4_MAX_M tokens on, W is decoded ONCE into a per-device bf16 scratch (2.5 B/param of HBM traffic,
+# ~3 % of the GEMM time at 8192 tokens) and the dense 256x256 LDS-DMA kernel runs at ~2x the fused rate.
 FUSED_NF4 = os.environ.get("UNSLOTH_AMD_FUSED_NF4", "1") == "1"
+FUSED_NF4_MAX_M = int(os.environ.get("UNSLOTH_AMD_FUSED_NF4_MAX_M", "512"))
 # dense GEMM tile selection: "auto" = the 256x256 LDS-DMA ping-pong kernel (csrc/gemm256.hip) once the launch
 # has enough 256x256 tiles to fill the 256 CUs, else the 128x128 kernel; "on"/"off" force it.
 GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
@@ -138,6 +142,7 @@ def _launch_gemm(X2d, groups, nf4, accumulate=False):
         rc = fn(_lib.ptr(X2d), X2d.stride(0), M, K, arr, len(groups), int(accumulate),
                 _lib.dtype_code(X2d.dtype), _lib.stream_of(X2d))
     _lib.check(rc, name)
+    return name
 
 
 def _rows2d(X):
@@ -145,6 +150,30 @@ def _rows2d(X):
     if X2d.stride(1) != 1 or (X2d.stride(0) % 8) or (X2d.data_ptr() % 16):
         X2d = X2d.contiguous()
     return X2d
+
+
+# LoRA factors are fp32 parameters used in the activation dtype (utils.py:1166-1167). A training step reads each
+# factor up to 3 times (forward, checkpoint recompute, backward): convert once per parameter VERSION instead of
+# once per use. Entries die with the parameter (weak keys) and are replaced when the optimizer bumps _version.
+import weakref
+_CAST_CACHE = {}     # id(param) -> (weakref, version, data_ptr, {(tag, dtype): tensor})
+
+
+def _cached_cast(P, tag, dtype, build):
+    if not isinstance(P, torch.nn.Parameter):
+        return build()
+    pid = id(P)
+    ent = _CAST_CACHE.get(pid)
+    if ent is None or ent[0]() is not P or ent[1] != P._version or ent[2] != P.data_ptr():
+        ent = (weakref.ref(P, lambda _, pid=pid: _CAST_CACHE.pop(pid, None)), P._version, P.data_ptr(), {})
+        _CAST_CACHE[pid] = ent
+    key = (tag, dtype)
+    out = ent[3].get(key)
+    if out is None:
+        with torch.no_grad():
+            out = build()
+        ent[3][key] = out
+    return out
 
 
 def lora_xa(X2d, A_list):
@@ -155,7 +184,8 @@ def lora_xa(X2d, A_list):
     Rp = [(r + 7) // 8 * 8 for r in Rs]
     K = X2d.shape[1]
     if len(A_list) == 1 and Rs[0] == Rp[0]:
-        Acat = A_list[0].to(dtype).contiguous()                       # A.to(dtype), utils.py:1166
+        A0 = A_list[0]
+        Acat = _cached_cast(A0, "rowmajor", dtype, lambda: A0.to(dtype).contiguous())   # A.to(dtype), utils.py:1166
     else:
         Acat = torch.zeros((sum(Rp), K), dtype=dtype, device=X2d.device)
         o = 0
@@ -178,11 +208,16 @@ def lora_xa(X2d, A_list):
     return out, offs
 
 
+def cast_lora(P, dtype):
+    """P.to(dtype) (row-major, contiguous), converted once per parameter version."""
+    return _cached_cast(P, "rowmajor", dtype, lambda: P.to(dtype).contiguous())
+
+
 def _pad_rank(B, Rp, dtype):
     """LoRA B [N, r] -> contiguous [N, Rp] in the activation dtype (B.to(dtype), utils.py:1167)."""
     N, r = B.shape
     if r == Rp:
-        return B.to(dtype).contiguous()
+        return _cached_cast(B, "rowmajor", dtype, lambda: B.to(dtype).contiguous())
     out = torch.zeros((N, Rp), dtype=dtype, device=B.device)
     out[:, :r] = B
     return out
@@ -219,12 +254,13 @@ def lora_linear_forward(X, projs, outs=None):
             lb = _pad_rank(B, rp, dtype)
             keep.append(lb)
             kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
-        if W_quant is not None and FUSED_NF4 and W_quant.blocksize == 64 and K % 64 == 0:
+        if W_quant is not None and FUSED_NF4 and M < FUSED_NF4_MAX_M and W_quant.blocksize == 64 and K % 64 == 0:
             nf4_groups.append(_group(W, C, N, 0, absmax=_nf4.absmax_f32(W_quant), **kw))
         else:
             Wd = W
             if W_quant is not None:
-                Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=(len(projs) == 1))
+                # one scratch slot per group member: the grouped launch reads all of them
+                Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=True, slot=8 + gi)
             elif Wd.dtype != dtype or Wd.stride(1) != 1 or Wd.stride(0) % 8:
                 Wd = Wd.to(dtype).contiguous()
             keep.append(Wd)
@@ -257,10 +293,13 @@ def lora_linear_dx(dYs, projs, out=None):
             out = torch.empty((M, Kin), dtype=dtype, device=dY.device)
         kw = {}
         if A is not None:
-            Bt = B.to(dtype).t().contiguous()                       # [r, N]
+            Bt = _cached_cast(B, "T", dtype, lambda: B.to(dtype).t().contiguous())        # [r, N]
             xa, offs = lora_xa(dY2d, [Bt])                          # dY @ B
             rp = offs[0][1]
-            lb = _pad_rank(A.to(dtype).t(), rp, dtype)              # A^T [Kin, r]
+            if A.shape[0] == rp:
+                lb = _cached_cast(A, "T", dtype, lambda: A.to(dtype).t().contiguous())    # A^T [Kin, r]
+            else:
+                lb = _pad_rank(A.to(dtype).t(), rp, dtype)
             kw = dict(xa=xa, ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
         g = _group(Wt, out, Kin, Wt.stride(0), **kw)
         _launch_gemm(dY2d, [g], nf4=False, accumulate=not first)

@@ -200,7 +200,7 @@ def scratch(device, numel, dtype, slot=0):
 
 
 def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_buffer=False,
-                   cache_absmax=True):
+                   cache_absmax=True, slot=None):
     """Dense [out,in] (or [in,out] when transpose) matrix in quant_state.dtype: ONE launch for the
     nested-absmax + NF4 decode that the reference does in three (utils.py:650-675)."""
     qs = quant_state
@@ -212,7 +212,9 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
     shape = (cols, rows) if transpose else (rows, cols)
     if out is None:
         if use_global_buffer:
-            out = scratch(packed.device, rows * cols, dtype, slot=1 if transpose else 0).view(shape)
+            if slot is None:
+                slot = 1 if transpose else 0
+            out = scratch(packed.device, rows * cols, dtype, slot=slot).view(shape)
         else:
             out = torch.empty(shape, dtype=dtype, device=packed.device)
     else:
