@@ -153,10 +153,24 @@ def _rows2d(X):
 
 
 # LoRA factors are fp32 parameters used in the activation dtype (utils.py:1166-1167). A training step reads each
-# factor up to 3 times (forward, checkpoint recompute, backward): convert once per parameter VERSION instead of
-# once per use. Entries die with the parameter (weak keys) and are replaced when the optimizer bumps _version.
+# factor up to 3 times (forward, checkpoint recompute, backward): convert once per parameter UPDATE instead of
+# once per use. An entry is valid while (a) the parameter object, its _version and its storage are unchanged and
+# (b) no optimizer has stepped since (fused optimizers update in place WITHOUT bumping _version, so a global
+# optimizer post-step hook and every top-level model forward advance an epoch that invalidates everything).
 import weakref
-_CAST_CACHE = {}     # id(param) -> (weakref, version, data_ptr, {(tag, dtype): tensor})
+_CAST_CACHE = {}     # id(param) -> (weakref, version, data_ptr, epoch, {(tag, dtype): tensor})
+_CAST_EPOCH = [0]
+
+
+def invalidate_cast_cache(*_a, **_k):
+    _CAST_EPOCH[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_hook
+    _reg_hook(invalidate_cast_cache)
+except Exception:  # pragma: no cover
+    pass
 
 
 def _cached_cast(P, tag, dtype, build):
@@ -164,15 +178,17 @@ def _cached_cast(P, tag, dtype, build):
         return build()
     pid = id(P)
     ent = _CAST_CACHE.get(pid)
-    if ent is None or ent[0]() is not P or ent[1] != P._version or ent[2] != P.data_ptr():
-        ent = (weakref.ref(P, lambda _, pid=pid: _CAST_CACHE.pop(pid, None)), P._version, P.data_ptr(), {})
+    if (ent is None or ent[0]() is not P or ent[1] != P._version or ent[2] != P.data_ptr()
+            or ent[3] != _CAST_EPOCH[0]):
+        ent = (weakref.ref(P, lambda _, pid=pid: _CAST_CACHE.pop(pid, None)), P._version, P.data_ptr(),
+               _CAST_EPOCH[0], {})
         _CAST_CACHE[pid] = ent
     key = (tag, dtype)
-    out = ent[3].get(key)
+    out = ent[4].get(key)
     if out is None:
         with torch.no_grad():
             out = build()
-        ent[3][key] = out
+        ent[4][key] = out
     return out
 
 

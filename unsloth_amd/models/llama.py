@@ -35,7 +35,7 @@ from ..kernels import (
     fast_rope_embedding,
     unsloth_fused_ce_loss,
 )
-from ..kernels.utils import lora_linear_forward
+from ..kernels.utils import invalidate_cast_cache, lora_linear_forward
 from ..utils.packing import (
     build_sdpa_packed_attention_mask,
     get_packed_info_from_kwargs,
@@ -177,6 +177,7 @@ def LlamaDecoderLayer_fast_forward(self, hidden_states, cos, sin, rope_position_
 def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None,
                             **kwargs):
     """llama.py:866-1245, training path. `self` is the HF LlamaModel."""
+    invalidate_cast_cache()          # cached bf16 copies of the LoRA factors live for ONE forward/backward
     if inputs_embeds is None:
         inputs_embeds = self.embed_tokens(input_ids)
     dtype = _model_dtype(self)
