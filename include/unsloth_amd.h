@@ -173,6 +173,19 @@ int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group
  * groups in anti-phase (csrc/gemm256.hip); for large M. Requires K % 64 == 0. */
 int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
+/* uamd_gemm_nt_w4: same contract as uamd_gemm_nt with 256x256x32 tiles, FOUR waves (one per SIMD, 128x128 each,
+ * v_mfma_f32_32x32x16), 4-stage LDS-DMA ring with two tiles in flight across the single barrier per K tile
+ * (csrc/gemm_w4.hip); the large-M kernel. Requires K % 32 == 0, lda/ldb <= 2^22 elements. */
+int uamd_gemm_nt_w4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                    int n_groups, int accumulate, int dtype, void* stream);
+/* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
+ *   UAMD_TUNE_W4_VARIANT  (UAMD_W4_VARIANT)   instruction-schedule variant of the w4 K-tile body: 0 free,
+ *                                             1 chunk-pinned, 2 MFMA/ds_read alternating 1:1
+ *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernels (L2 reuse) */
+#define UAMD_TUNE_W4_VARIANT 0
+#define UAMD_TUNE_GROUP_M 1
+#define UAMD_TUNE_COUNT 2
+int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
 int uamd_lora_xa(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,

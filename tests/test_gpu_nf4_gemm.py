@@ -214,19 +214,23 @@ def test_lora_xa(M, K, Rs):
 
 
 # ---------------------------------------------------------------- 256x256 LDS-DMA ping-pong kernel
-@pytest.fixture
-def force256():
+@pytest.fixture(params=["w4", "pp"])
+def force256(request):
+    """Force a 256x256 kernel for every shape: "w4" = csrc/gemm_w4.hip, "pp" = csrc/gemm256.hip."""
     from unsloth_amd.kernels import utils as U
-    old = U.GEMM256_MODE
-    U.GEMM256_MODE = "on"
-    yield
-    U.GEMM256_MODE = old
+    old = (U.GEMM256_MODE, U.LARGE_KERNEL)
+    U.GEMM256_MODE, U.LARGE_KERNEL = "on", request.param
+    yield request.param
+    U.GEMM256_MODE, U.LARGE_KERNEL = old
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 256), (300, 260, 192), (1, 256, 4096),
-                                   (4096, 4096, 4096), (1000, 1024, 14336)])
+                                   (4096, 4096, 4096), (1000, 1024, 14336), (260, 516, 32), (256, 256, 96),
+                                   (777, 333, 160)])
 def test_gemm256_dense(force256, dtype, M, N, K):
+    if force256 == "pp" and K % 64:
+        pytest.skip("gemm256.hip needs K % 64 == 0")
     from unsloth_amd.kernels.utils import lora_linear_forward
     X = torch.randn(M, K, generator=g(105)).to(dtype)
     W = (torch.randn(N, K, generator=g(106)) * 0.05).to(dtype)

@@ -1,0 +1,72 @@
+"""A/B of the large-M GEMM kernels on one MI355X (one process, interleaved rounds, random N(0,1)*0.02-scale data):
+torch.matmul (hipBLASLt), gemm256.hip ("pp"), gemm_w4.hip schedule variants 0/1/2. Checks each against torch first."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unsloth_amd import _lib  # noqa: E402
+from unsloth_amd.kernels import utils as U  # noqa: E402
+
+DEV = "cuda"
+
+
+def run(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    bf = torch.bfloat16
+    L = _lib.lib()
+    shapes = [(8192, 4096, 4096, "o"), (8192, 14336, 4096, "gate"), (8192, 4096, 14336, "down"),
+              (8192, 28672, 4096, "gate+up"), (2048, 14336, 4096, "gate@2k"), (4096, 128256, 4096, "lm_head@4k")]
+    for M, N, K, tag in shapes:
+        X = torch.randn(M, K, device=DEV, dtype=bf)
+        W = (torch.randn(N, K, device=DEV) * 0.02).to(bf)
+        ref = X @ W.t()
+        cands = {"torch": lambda: X @ W.t()}
+
+        def mk(kern, var=None, gm=8):
+            def f():
+                if var is not None:
+                    L.uamd_set_tuning(0, var)
+                L.uamd_set_tuning(1, gm)
+                U.GEMM256_MODE, U.LARGE_KERNEL = "on", kern
+                return U.lora_linear_forward(X, [(W, None, None, None, None)])[0]
+            return f
+        for gm in (64, 4, 8, 16):               # 64 >= tiles_m: the old m-fastest raster
+            cands[f"pp_g{gm}"] = mk("pp", None, gm)
+        cands["w4v2_g8"] = mk("w4", 2, 8)
+        cands["w4v2_g64"] = mk("w4", 2, 64)
+        for name, f in cands.items():
+            y = f()
+            err = float((y.float() - ref.float()).abs().max())
+            rel = float((y.float() - ref.float()).norm() / ref.float().norm())
+            if rel > 2e-2 or err != err:
+                print(json.dumps(dict(shape=tag, kernel=name, ERROR="mismatch", max_abs=err, rel=rel)), flush=True)
+        for f in cands.values():
+            run(f, 3)
+        best = {k: 1e9 for k in cands}
+        for _ in range(5):                      # interleaved rounds
+            for name, f in cands.items():
+                best[name] = min(best[name], run(f, 10))
+        fl = 2.0 * M * N * K
+        rec = dict(shape=tag, M=M, N=N, K=K, **{k: round(fl / v / 1e12, 1) for k, v in best.items()})
+        print(json.dumps(rec), flush=True)
+        if out:
+            out.write(json.dumps(rec) + "\n")
+            out.flush()
+        del X, W, ref
+
+
+if __name__ == "__main__":
+    main()

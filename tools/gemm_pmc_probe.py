@@ -1,0 +1,27 @@
+"""Launch each large-M GEMM kernel a few times on one shape so that `rocprofv3 --pmc ...` can attribute counters.
+usage: rocprofv3 --kernel-trace --pmc <counters> -d out -- python tools/gemm_pmc_probe.py [M N K]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unsloth_amd import _lib  # noqa: E402
+from unsloth_amd.kernels import utils as U  # noqa: E402
+
+M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (8192, 14336, 4096)
+bf = torch.bfloat16
+X = torch.randn(M, K, device="cuda", dtype=bf)
+W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
+L = _lib.lib()
+U.GEMM256_MODE = "on"
+for kern, var in (("pp", None), ("w4", 0), ("w4", 2)):
+    U.LARGE_KERNEL = kern
+    if var is not None:
+        L.uamd_set_tuning(0, var)
+    for _ in range(3):
+        U.lora_linear_forward(X, [(W, None, None, None, None)])
+    torch.cuda.synchronize()
+for _ in range(3):
+    X @ W.t()
+torch.cuda.synchronize()

@@ -25,6 +25,7 @@ SOURCES = [
     "nf4.hip",
     "gemm.hip",
     "gemm256.hip",
+    "gemm_w4.hip",
 ]
 
 

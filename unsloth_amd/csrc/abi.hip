@@ -1,4 +1,29 @@
-// ABI version + build info of libunsloth_amd.so
+// ABI version + process-wide tuning knobs of libunsloth_amd.so
+#include <stdlib.h>
+
 #include "common.h"
 
-extern "C" int uamd_version(void) { return (0 << 16) | 1; }
+extern "C" int uamd_version(void) { return (0 << 16) | 2; }
+
+namespace {
+int g_knob[UAMD_TUNE_COUNT] = {-1, -1};
+const char* const kEnv[UAMD_TUNE_COUNT] = {"UAMD_W4_VARIANT", "UAMD_GEMM_GROUP_M"};
+const int kDefault[UAMD_TUNE_COUNT] = {2, 8};
+}  // namespace
+
+// value of a knob: uamd_set_tuning() > environment variable > built-in default (the measured-fastest setting)
+int uamd_tuning_get(int knob) {
+    if (knob < 0 || knob >= UAMD_TUNE_COUNT) return 0;
+    if (g_knob[knob] < 0) {
+        const char* e = getenv(kEnv[knob]);
+        g_knob[knob] = (e && *e) ? atoi(e) : kDefault[knob];
+        if (g_knob[knob] < 0) g_knob[knob] = kDefault[knob];
+    }
+    return g_knob[knob];
+}
+
+extern "C" int uamd_set_tuning(int knob, int value) {
+    if (knob < 0 || knob >= UAMD_TUNE_COUNT || value < 0) return UAMD_ERR_ARG;
+    g_knob[knob] = value;
+    return UAMD_OK;
+}

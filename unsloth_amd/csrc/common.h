@@ -6,6 +6,8 @@
 
 #include "unsloth_amd.h"   // C ABI: error codes, dtype codes, entry-point prototypes
 
+int uamd_tuning_get(int knob);   // abi.hip
+
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;
 
