@@ -191,6 +191,26 @@ int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 int uamd_lora_xa(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,
                  int64_t ld_out, int M, int K, int R, int out_cols, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * LoRA gradient products (fast_lora.py:172-189, :476-495, :632-637): up to 8 problems per launch,
+ *     out = scale * P[M, R]^T @ Z[M, N]          (R <= 16; split wider ranks into 16-column problems)
+ * P is fp32 (an uamd_lora_xa result) and is rounded to `dtype` on load, where the reference holds a tensor of
+ * the activation dtype; Z is [M, N] in `dtype`; out is fp32, [R, N] (out_nr = 0, lora_A.grad layout) or
+ * [N, R] (out_nr = 1, lora_B.grad layout). Deterministic: fixed-order two-stage reduction over M through
+ * `workspace` (fp32, >= sum_i ceil(M/512) * 16 * ceil(N_i/256)*256 floats). N % 4 == 0. */
+typedef struct {
+    const float* P;
+    const void* Z;
+    float* out;
+    int64_t ldp, ldz, ldo;
+    int N;
+    int R;
+    int out_nr;
+    float scale;
+} uamd_lora_tn_problem;
+int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* workspace,
+                 int64_t workspace_floats, int dtype, void* stream);
+
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
 int uamd_debug_mfma_probe(float* out, void* stream);
 

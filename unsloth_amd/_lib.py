@@ -33,6 +33,13 @@ class GemmGroup(ctypes.Structure):
     ]
 
 
+class LoraTnProblem(ctypes.Structure):
+    """uamd_lora_tn_problem (include/unsloth_amd.h)."""
+
+    _fields_ = [("P", c_void_p), ("Z", c_void_p), ("out", c_void_p), ("ldp", c_int64), ("ldz", c_int64),
+                ("ldo", c_int64), ("N", c_int), ("R", c_int), ("out_nr", c_int), ("scale", c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/unsloth_amd.h declares
 SIGNATURES = {
     "uamd_version": (c_int, []),
@@ -76,6 +83,7 @@ SIGNATURES = {
                                  c_int, c_int, c_void_p]),
     "uamd_lora_xa": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                              c_int, c_int, c_int, c_void_p]),
+    "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_debug_mfma_probe": (c_int, [c_void_p, c_void_p]),
 }
 

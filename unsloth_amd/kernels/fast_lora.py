@@ -19,8 +19,11 @@ import torch
 from .utils import (
     cast_lora,
     get_lora_parameters,
+    lora_dx_terms,
     lora_linear_dx,
     lora_linear_forward,
+    lora_tn,
+    lora_tn_supported,
 )
 from .swiglu import swiglu_fg_kernel, swiglu_DWf_DW_dfg_kernel
 from .geglu import (
@@ -40,7 +43,8 @@ except Exception:  # pragma: no cover
 
 def _lora_grads(X2d, dY2d, A, B, s, dtype):
     """(dA [r,in], dB [out,r]) for Y = X W^T + s (X A^T) B^T; fast_lora.py:172-189 in the
-    un-transposed layout. Returns (None, None) when the adapter is absent."""
+    un-transposed layout, through the library GEMM (used when the fused products below do not apply).
+    Returns (None, None) when the adapter is absent."""
     if A is None:
         return None, None
     At, Bt = cast_lora(A, dtype).t(), cast_lora(B, dtype).t()          # [in,r], [r,out]
@@ -52,19 +56,37 @@ def _lora_grads(X2d, dY2d, A, B, s, dtype):
     return dA_t.t(), dB_t.t()
 
 
+def _lora_grads_fused(items):
+    """items: [(X2d, dY2d, A, B, s, XA, P)] with XA = X @ A^T (fp32, saved by the forward) and P = dY @ B (fp32,
+    shared with the dX GEMM). Returns [(dA, dB)] in fp32, all products of the block in ONE launch per 8:
+        dA = s * P^T @ X   [r, in]          dB = s * dY^T @ XA   [out, r]          (fast_lora.py:172-189)"""
+    probs, slots = [], []
+    for (X2d, dY2d, A, B, s, XA, P) in items:
+        if A is None:
+            slots.append(None)
+            continue
+        r = A.shape[0]
+        slots.append(len(probs))
+        probs.append((P, X2d, r, False, s))
+        probs.append((XA, dY2d, r, True, s))
+    outs = lora_tn(probs)
+    return [(None, None) if k is None else (outs[k], outs[k + 1]) for k in slots]
+
+
 class LoRA_MLP(torch.autograd.Function):
     @staticmethod
     @_custom_fwd
     def forward(ctx, X, gateW, gateW_quant, gateA, gateB, gateS, upW, upW_quant, upA, upB, upS,
                 downW, downW_quant, downA, downB, downS, _forward_function, _backward_function,
                 inplace=True):
-        e, g = lora_linear_forward(X, [(gateW, gateW_quant, gateA, gateB, gateS),
-                                       (upW, upW_quant, upA, upB, upS)])
+        (e, g), xa_gu = lora_linear_forward(X, [(gateW, gateW_quant, gateA, gateB, gateS),
+                                                (upW, upW_quant, upA, upB, upS)], return_xa=True)
         h = _forward_function(e, g)
-        (i,) = lora_linear_forward(h, [(downW, downW_quant, downA, downB, downS)])
+        (i,), xa_d = lora_linear_forward(h, [(downW, downW_quant, downA, downB, downS)], return_xa=True)
         ctx.custom_saved_tensors = (gateW, gateW_quant, gateS, upW, upW_quant, upS, downW,
                                     downW_quant, downS, _backward_function)
         ctx.save_for_backward(gateA, gateB, upA, upB, downA, downB, X, e, g)
+        ctx.xa = (xa_gu[0], xa_gu[1], xa_d[0])      # X A_g^T, X A_u^T, h A_d^T (fp32 [M, r]): tiny, no grad
         ctx.inplace = inplace
         return i
 
@@ -74,26 +96,36 @@ class LoRA_MLP(torch.autograd.Function):
         (gateW, gateW_quant, gateS, upW, upW_quant, upS, downW, downW_quant, downS,
          _backward_function) = ctx.custom_saved_tensors
         gateA, gateB, upA, upB, downA, downB, X, e, g = ctx.saved_tensors
+        xa_g, xa_u, xa_d = ctx.xa
         shape = X.shape
         dY = dY.reshape(-1, dY.shape[-1])
         X2 = X.reshape(-1, X.shape[-1])
         e = e.view(-1, e.shape[-1])
         g = g.view(-1, g.shape[-1])
         dtype = X2.dtype
+        down = (downW, downW_quant, downA, downB, downS)
+        up = (upW, upW_quant, upA, upB, upS)
+        gate = (gateW, gateW_quant, gateA, gateB, gateS)
 
         # DW = dY @ W_down (+ LoRA)                                     fast_lora.py:156
-        DW = lora_linear_dx([dY], [(downW, downW_quant, downA, downB, downS)])
+        (p_d,) = lora_dx_terms([dY], [down])
+        DW = lora_linear_dx([dY], [down], terms=[p_d])
         DW, e, g = _backward_function(DW, e, g)                        # in place (:157)
         h, df, de = DW, e, g
 
-        d_downA, d_downB = _lora_grads(h, dY, downA, downB, downS, dtype)
-        d_upA, d_upB = _lora_grads(X2, df, upA, upB, upS, dtype)
-        d_gateA, d_gateB = _lora_grads(X2, de, gateA, gateB, gateS, dtype)
+        p_u, p_g = lora_dx_terms([df, de], [up, gate])
+        if lora_tn_supported([h, dY, X2, df, de]):
+            (d_downA, d_downB), (d_upA, d_upB), (d_gateA, d_gateB) = _lora_grads_fused([
+                (h, dY, downA, downB, downS, xa_d, p_d), (X2, df, upA, upB, upS, xa_u, p_u),
+                (X2, de, gateA, gateB, gateS, xa_g, p_g)])
+        else:
+            d_downA, d_downB = _lora_grads(h, dY, downA, downB, downS, dtype)
+            d_upA, d_upB = _lora_grads(X2, df, upA, upB, upS, dtype)
+            d_gateA, d_gateB = _lora_grads(X2, de, gateA, gateB, gateS, dtype)
 
         # dX = df @ W_up + de @ W_gate (+ LoRA terms), into X's buffer when inplace (:193-204)
-        dX = lora_linear_dx([df, de], [(upW, upW_quant, upA, upB, upS),
-                                       (gateW, gateW_quant, gateA, gateB, gateS)],
-                            out=X2 if (ctx.inplace and X2.is_contiguous()) else None)
+        dX = lora_linear_dx([df, de], [up, gate], out=X2 if (ctx.inplace and X2.is_contiguous()) else None,
+                            terms=[p_u, p_g])
         return (dX.view(shape), None, None, d_gateA, d_gateB, None, None, None, d_upA, d_upB, None,
                 None, None, d_downA, d_downB, None, None, None, None)
 
@@ -123,10 +155,11 @@ class LoRA_QKV(torch.autograd.Function):
     @_custom_fwd
     def forward(ctx, X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB, VS,
                 inplace=True):
-        Q, K, V = lora_linear_forward(X, [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS),
-                                          (VW, VW_quant, VA, VB, VS)])
+        (Q, K, V), xa = lora_linear_forward(X, [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS),
+                                                (VW, VW_quant, VA, VB, VS)], return_xa=True)
         ctx.custom_saved_tensors = (QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS)
         ctx.save_for_backward(X, QA, QB, KA, KB, VA, VB)
+        ctx.xa = tuple(xa)
         ctx.inplace = inplace
         return Q, K, V
 
@@ -135,19 +168,25 @@ class LoRA_QKV(torch.autograd.Function):
     def backward(ctx, dQ, dK, dV):
         QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS = ctx.custom_saved_tensors
         X, QA, QB, KA, KB, VA, VB = ctx.saved_tensors
+        xa_q, xa_k, xa_v = ctx.xa
         shape = X.shape
         dQ = dQ.reshape(-1, dQ.shape[-1])
         dK = dK.reshape(-1, dK.shape[-1])
         dV = dV.reshape(-1, dV.shape[-1])
         X2 = X.reshape(-1, X.shape[-1])
         dtype = X2.dtype
-        d_QA, d_QB = _lora_grads(X2, dQ, QA, QB, QS, dtype)
-        d_KA, d_KB = _lora_grads(X2, dK, KA, KB, KS, dtype)
-        d_VA, d_VB = _lora_grads(X2, dV, VA, VB, VS, dtype)
+        projs = [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS)]
+        p_q, p_k, p_v = lora_dx_terms([dQ, dK, dV], projs)
+        if lora_tn_supported([X2, dQ, dK, dV]):
+            (d_QA, d_QB), (d_KA, d_KB), (d_VA, d_VB) = _lora_grads_fused([
+                (X2, dQ, QA, QB, QS, xa_q, p_q), (X2, dK, KA, KB, KS, xa_k, p_k), (X2, dV, VA, VB, VS, xa_v, p_v)])
+        else:
+            d_QA, d_QB = _lora_grads(X2, dQ, QA, QB, QS, dtype)
+            d_KA, d_KB = _lora_grads(X2, dK, KA, KB, KS, dtype)
+            d_VA, d_VB = _lora_grads(X2, dV, VA, VB, VS, dtype)
         # dX accumulated over q, k, v; overwrites X when inplace (fast_lora.py:497-517)
-        dX = lora_linear_dx([dQ, dK, dV], [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS),
-                                           (VW, VW_quant, VA, VB, VS)],
-                            out=X2 if (ctx.inplace and X2.is_contiguous()) else None)
+        dX = lora_linear_dx([dQ, dK, dV], projs, out=X2 if (ctx.inplace and X2.is_contiguous()) else None,
+                            terms=[p_q, p_k, p_v])
         return (dX.view(shape), None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None,
                 d_VA, d_VB, None, None)
 
@@ -164,9 +203,10 @@ class LoRA_W(torch.autograd.Function):
     @staticmethod
     @_custom_fwd
     def forward(ctx, X, W, W_quant, A, B, S):
-        (XW,) = lora_linear_forward(X, [(W, W_quant, A, B, S)])
+        (XW,), xa = lora_linear_forward(X, [(W, W_quant, A, B, S)], return_xa=True)
         ctx.custom_saved_tensors = (W, W_quant, S)
         ctx.save_for_backward(A, B, X)
+        ctx.xa = xa[0]
         return XW
 
     @staticmethod
@@ -177,8 +217,12 @@ class LoRA_W(torch.autograd.Function):
         shape = X.shape
         dY = dY.reshape(-1, dY.shape[-1])
         X2 = X.reshape(-1, X.shape[-1])
-        d_A, d_B = _lora_grads(X2, dY, A, B, S, X2.dtype)
-        dX = lora_linear_dx([dY], [(W, W_quant, A, B, S)])
+        (p,) = lora_dx_terms([dY], [(W, W_quant, A, B, S)])
+        if lora_tn_supported([X2, dY]):
+            ((d_A, d_B),) = _lora_grads_fused([(X2, dY, A, B, S, ctx.xa, p)])
+        else:
+            d_A, d_B = _lora_grads(X2, dY, A, B, S, X2.dtype)
+        dX = lora_linear_dx([dY], [(W, W_quant, A, B, S)], terms=[p])
         return dX.view(shape), None, None, d_A, d_B, None
 
 

@@ -247,7 +247,7 @@ def _pad_rank(B, Rp, dtype):
     return out
 
 
-def lora_linear_forward(X, projs, outs=None):
+def lora_linear_forward(X, projs, outs=None, return_xa=False):
     """Y_g = X @ W_g^T + s_g * (X @ A_g^T) @ B_g^T for projections `projs` = [(W, W_quant, A, B, s)]
     that share X. Returns a list of [.., N_g] tensors. This is matmul_lora (utils.py:1128-1170)
     for q/k/v or gate/up at once."""
@@ -294,17 +294,47 @@ def lora_linear_forward(X, projs, outs=None):
         _launch_gemm(X2d, nf4_groups, nf4=True)
     if dense_groups:
         _launch_gemm(X2d, dense_groups, nf4=False)
-    return [r.view(*lead, r.shape[-1]) for r in results]
+    results = [r.view(*lead, r.shape[-1]) for r in results]
+    if return_xa:
+        # per projection: fp32 [M, Rp] view of X @ A^T (None without adapter), kept for d_B = s * dY^T (X A^T)
+        views, li = [], 0
+        for (W, W_quant, A, B, s) in projs:
+            if A is None:
+                views.append(None)
+            else:
+                o, rp = offs[li]
+                li += 1
+                views.append(xa[:, o:o + rp])
+        return results, views
+    return results
 
 
-def lora_linear_dx(dYs, projs, out=None):
+def lora_dx_terms(dYs, projs):
+    """P_g = dY_g @ B_g (fp32 [M, Rp]) for every projection with an adapter (None otherwise): the rank-r factor
+    shared by dX += s (dY B) A and by d_A = s (dY B)^T X (fast_lora.py:172-189)."""
+    terms = []
+    for dY, (W, W_quant, A, B, s) in zip(dYs, projs):
+        if A is None:
+            terms.append(None)
+            continue
+        dY2d = _rows2d(dY)
+        dtype = dY2d.dtype
+        Bt = _cached_cast(B, "T", dtype, lambda B=B, dtype=dtype: B.to(dtype).t().contiguous())        # [r, N]
+        xa, offs = lora_xa(dY2d, [Bt])                              # dY @ B
+        terms.append(xa[:, :offs[0][1]])
+    return terms
+
+
+def lora_linear_dx(dYs, projs, out=None, terms=None):
     """dX = sum_g dY_g @ W_g + s_g * (dY_g @ B_g) @ A_g   (fast_lora.py:193-204, 497-517, 639-647).
     The contraction runs over `out`, so the NF4 weight is decoded TRANSPOSED into the per-device
     scratch (one launch) and fed to the same NT GEMM. `out` (e.g. the saved X, reference's
-    inplace=True) receives the result."""
+    inplace=True) receives the result. `terms` = lora_dx_terms(dYs, projs) when the caller already has them."""
     dtype = dYs[0].dtype
+    if terms is None:
+        terms = lora_dx_terms(dYs, projs)
     first = True
-    for dY, (W, W_quant, A, B, s) in zip(dYs, projs):
+    for dY, (W, W_quant, A, B, s), xa in zip(dYs, projs, terms):
         dY2d = _rows2d(dY)
         M, N = dY2d.shape
         if W_quant is not None:
@@ -317,11 +347,9 @@ def lora_linear_dx(dYs, projs, out=None):
             out = torch.empty((M, Kin), dtype=dtype, device=dY.device)
         kw = {}
         if A is not None:
-            Bt = _cached_cast(B, "T", dtype, lambda: B.to(dtype).t().contiguous())        # [r, N]
-            xa, offs = lora_xa(dY2d, [Bt])                          # dY @ B
-            rp = offs[0][1]
+            rp = xa.shape[1]
             if A.shape[0] == rp:
-                lb = _cached_cast(A, "T", dtype, lambda: A.to(dtype).t().contiguous())    # A^T [Kin, r]
+                lb = _cached_cast(A, "T", dtype, lambda A=A, dtype=dtype: A.to(dtype).t().contiguous())    # A^T [Kin, r]
             else:
                 lb = _pad_rank(A.to(dtype).t(), rp, dtype)
             kw = dict(xa=xa, ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
@@ -329,6 +357,48 @@ def lora_linear_dx(dYs, projs, out=None):
         _launch_gemm(dY2d, [g], nf4=False, accumulate=not first)
         first = False
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# LoRA gradient products  G = s * P^T @ Z  (csrc/lora_side.hip)
+def lora_tn_supported(Zs):
+    return all(Z.is_cuda and Z.dtype in (torch.bfloat16, torch.float16) and Z.shape[-1] % 4 == 0 for Z in Zs)
+
+
+def lora_tn(problems):
+    """problems: [(P fp32 [M, >=R] with unit column stride, Z [M, N], R, out_nr, scale)].
+    Returns the fp32 products, [R, N] (out_nr False: lora_A.grad layout) or [N, R] (True: lora_B.grad layout).
+    One launch per 8 sixteen-rank problems; deterministic."""
+    if not problems:
+        return []
+    M = problems[0][1].shape[0]
+    dev = problems[0][1].device
+    dtype = problems[0][1].dtype
+    outs, descs, keep = [], [], []
+    for (P, Z, R, out_nr, scale) in problems:
+        Z2 = _rows2d(Z)
+        assert Z2.shape[0] == M and P.shape[0] == M and P.dtype == torch.float32 and P.stride(1) == 1
+        N = Z2.shape[1]
+        out = torch.empty((N, R) if out_nr else (R, N), dtype=torch.float32, device=dev)
+        outs.append(out)
+        keep.append(Z2)
+        for r0 in range(0, R, 16):
+            rc = min(16, R - r0)
+            optr = out.data_ptr() + (4 * r0 if out_nr else 4 * r0 * N)
+            descs.append(_lib.LoraTnProblem(P=P.data_ptr() + 4 * r0, Z=Z2.data_ptr(), out=optr, ldp=P.stride(0),
+                                            ldz=Z2.stride(0), ldo=(R if out_nr else N), N=N, R=rc,
+                                            out_nr=int(bool(out_nr)), scale=float(scale)))
+    S = (M + 511) // 512
+    L = _lib.lib()
+    for i in range(0, len(descs), 8):
+        chunk = descs[i:i + 8]
+        need = sum(S * 16 * ((d.N + 255) // 256) * 256 for d in chunk)
+        ws = _nf4.scratch(dev, need, torch.float32, slot=40)
+        arr = (_lib.LoraTnProblem * len(chunk))(*chunk)
+        with _lib.device_ctx(ws):
+            rc = L.uamd_lora_tn(arr, len(chunk), M, _lib.ptr(ws), need, _lib.dtype_code(dtype), _lib.stream_of(ws))
+        _lib.check(rc, "uamd_lora_tn")
+    return outs
 
 
 def matmul_lora(X, W, W_quant, A, B, s, out=None):
