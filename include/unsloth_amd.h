@@ -184,7 +184,9 @@ int uamd_gemm_nt_w4(const void* A, int64_t lda, int M, int K, const uamd_gemm_gr
  *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernels (L2 reuse) */
 #define UAMD_TUNE_W4_VARIANT 0
 #define UAMD_TUNE_GROUP_M 1
-#define UAMD_TUNE_COUNT 2
+#define UAMD_TUNE_STREAM_NT 2   /* (UAMD_STREAM_NT) streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
+#define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64 */
+#define UAMD_TUNE_COUNT 4
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

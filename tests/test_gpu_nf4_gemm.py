@@ -65,6 +65,25 @@ def test_nf4_dequantize_bit_exact(dtype, nested):
     assert err < 0.16 * W.float().abs().max()
 
 
+@pytest.mark.parametrize("rows,cols", [(1024, 4096), (200, 264), (64, 256), (130, 1032)])
+@pytest.mark.parametrize("knob", [0, 1])
+def test_nf4_dequantize_transposed_kernels_bit_exact(rows, cols, knob):
+    """Both transposing kernels (64x64 tile, 64x256 tile) against the CPU restatement; ragged rows/cols, absmax
+    blocks that straddle W rows (cols % 64 != 0), nested statistics."""
+    from unsloth_amd import _lib
+    from unsloth_amd.nf4 import quantize_nf4, dequantize_nf4
+    W = (torch.randn(rows, cols, generator=g(4)) * 0.02).to(torch.bfloat16)
+    packed, qs = quantize_nf4(W.to(DEV), compress_statistics=True)
+    want = R.nf4_dequantize_state(packed, qs)
+    L = _lib.lib()
+    try:
+        assert L.uamd_set_tuning(3, knob) == 0
+        got_t = dequantize_nf4(packed, qs, transpose=True)
+        assert torch.equal(got_t.cpu(), want.t())
+    finally:
+        L.uamd_set_tuning(3, 1)
+
+
 def test_bnb_compat_entry_points():
     """The symbols the reference binds (unsloth/kernels/utils.py:272-275), called the way
     fast_dequantize calls them (:650-675): nested absmax -> += offset -> NF4."""

@@ -1,0 +1,100 @@
+"""A/B of the streaming (HBM-bound) kernels on one MI355X at the bench's per-launch sizes (T = 8192 tokens):
+non-temporal load/store modes for RMSNorm / SwiGLU, the two transposing NF4 dequant kernels, lora_xa, lora_tn.
+Interleaved rounds, min over rounds; GB/s = ALGORITHMIC bytes / time."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unsloth_amd import _lib  # noqa: E402
+import unsloth_amd.kernels as K  # noqa: E402
+from unsloth_amd.kernels import utils as U  # noqa: E402
+from unsloth_amd.nf4 import quantize_nf4, dequantize_nf4  # noqa: E402
+
+DEV = "cuda"
+L = _lib.lib()
+
+
+def run(fn, iters=10):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def ab(out, name, nbytes, cands, rounds=5):
+    for f in cands.values():
+        f()
+    torch.cuda.synchronize()
+    best = {k: 1e9 for k in cands}
+    for _ in range(rounds):
+        for k, f in cands.items():
+            best[k] = min(best[k], run(f))
+    rec = dict(kernel=name, MB=round(nbytes / 1e6, 1), **{k: dict(us=round(v * 1e6, 1), GBps=round(nbytes / v / 1e9))
+                                                         for k, v in best.items()})
+    print(json.dumps(rec), flush=True)
+    if out:
+        out.write(json.dumps(rec) + "\n")
+        out.flush()
+
+
+def main():
+    out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    bf = torch.bfloat16
+    T, H, I = 8192, 4096, 14336
+    X = torch.randn(T, H, device=DEV, dtype=bf)
+    W = torch.rand(H, device=DEV, dtype=bf)
+    dY = torch.randn(T, H, device=DEV, dtype=bf)
+    r = torch.rand(T, device=DEV)
+
+    def nt(mode, f):
+        def g():
+            L.uamd_set_tuning(2, mode)
+            return f()
+        return g
+
+    def rms_b():
+        L.uamd_rms_layernorm_bwd(_lib.ptr(dY), _lib.ptr(dY), _lib.ptr(X), _lib.ptr(W), _lib.ptr(r), T, H, H, H, H, 0, 2, 2,
+                                 _lib.stream_of(X))
+    ab(out, "rms_fwd", 2 * T * H * 2 + H * 2 + T * 4,
+       {f"nt{m}": nt(m, lambda: K.Fast_RMS_Layernorm.apply(X, W, 1e-5, False)) for m in (0, 1, 2, 3)})
+    ab(out, "rms_bwd", 3 * T * H * 2 + H * 2 + T * 4, {f"nt{m}": nt(m, rms_b) for m in (0, 1, 2, 3)})
+    e = torch.randn(T, I, device=DEV, dtype=bf)
+    g_ = torch.randn(T, I, device=DEV, dtype=bf)
+    DW = torch.randn(T, I, device=DEV, dtype=bf)
+    ab(out, "swiglu_fwd", 3 * T * I * 2, {f"nt{m}": nt(m, lambda: K.swiglu_fg_kernel(e, g_)) for m in (0, 1, 2, 3)})
+    ab(out, "swiglu_bwd", 6 * T * I * 2, {f"nt{m}": nt(m, lambda: K.swiglu_DWf_DW_dfg_kernel(DW, e, g_)) for m in (0, 1, 2, 3)})
+    L.uamd_set_tuning(2, 0)
+    # transposing dequant
+    Wd = (torch.randn(I, H, device=DEV) * 0.02).to(bf)
+    packed, qs = quantize_nf4(Wd)
+
+    def dq(knob):
+        def f():
+            L.uamd_set_tuning(3, knob)
+            return dequantize_nf4(packed, qs, transpose=True, use_global_buffer=True)
+        return f
+    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t64": dq(0), "t256": dq(1),
+                                                   "plain": lambda: dequantize_nf4(packed, qs, use_global_buffer=True)})
+    L.uamd_set_tuning(3, 1)
+    # lora_xa / lora_tn
+    A3 = [torch.nn.Parameter(torch.randn(16, H, device=DEV) * 0.02) for _ in range(3)]
+    ab(out, "lora_xa qkv (R=48)", T * H * 2, {"v1": lambda: U.lora_xa(X, A3)})
+    ab(out, "lora_xa o (R=16)", T * H * 2, {"v1": lambda: U.lora_xa(X, A3[:1])})
+    A1 = [torch.nn.Parameter(torch.randn(16, I, device=DEV) * 0.02)]
+    ab(out, "lora_xa down (R=16,K=14336)", T * I * 2, {"v1": lambda: U.lora_xa(e, A1)})
+    P = torch.randn(T, 16, device=DEV)
+    ab(out, "lora_tn dA (Z=X)", T * H * 2, {"v1": lambda: U.lora_tn([(P, X, 16, False, 1.0)])})
+    ab(out, "lora_tn dB (Z=e)", T * I * 2, {"v1": lambda: U.lora_tn([(P, e, 16, True, 1.0)])})
+    ab(out, "lora_tn MLP (6 problems)", (3 * T * I + 3 * T * H) * 2,
+       {"v1": lambda: U.lora_tn([(P, e, 16, False, 1.0), (P, dY, 16, True, 1.0), (P, X, 16, False, 1.0),
+                                 (P, g_, 16, True, 1.0), (P, X, 16, False, 1.0), (P, DW, 16, True, 1.0)])})
+
+
+if __name__ == "__main__":
+    main()

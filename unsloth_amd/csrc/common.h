@@ -34,6 +34,28 @@ __device__ __forceinline__ void st16(T* p, const Vec16<T>& v) {
     *reinterpret_cast<uint4*>(p) = v.raw;
 }
 
+// streaming (non-temporal) variants: data read or written exactly once by the whole grid
+typedef __attribute__((ext_vector_type(4))) unsigned int uamd_u32x4;
+template <typename T>
+__device__ __forceinline__ Vec16<T> ld16_nt(const T* p) {
+    Vec16<T> v;
+    const uamd_u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const uamd_u32x4*>(p));
+    v.raw = make_uint4(r[0], r[1], r[2], r[3]);
+    return v;
+}
+template <typename T>
+__device__ __forceinline__ void st16_nt(T* p, const Vec16<T>& v) {
+    const uamd_u32x4 r = {v.raw.x, v.raw.y, v.raw.z, v.raw.w};
+    __builtin_nontemporal_store(r, reinterpret_cast<uamd_u32x4*>(p));
+}
+// mode bit0: non-temporal loads, bit1: non-temporal stores (UAMD_TUNE_STREAM_NT)
+template <typename T>
+__device__ __forceinline__ Vec16<T> ld16_m(const T* p, int mode) { return (mode & 1) ? ld16_nt(p) : ld16(p); }
+template <typename T>
+__device__ __forceinline__ void st16_m(T* p, const Vec16<T>& v, int mode) {
+    if (mode & 2) st16_nt(p, v); else st16(p, v);
+}
+
 template <typename T> __device__ __forceinline__ float to_f32(T x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T)x; }
 

@@ -62,19 +62,19 @@ __device__ __forceinline__ void act_bwd(float e, float& f, float& dfde) {
 
 template <typename T, int ACT>
 __global__ void __launch_bounds__(256)
-glu_fwd_kernel(const T* __restrict__ E, const T* __restrict__ G, T* __restrict__ H, int64_t n) {
+glu_fwd_kernel(const T* __restrict__ E, const T* __restrict__ G, T* __restrict__ H, int64_t n, int mode) {
     constexpr int VEC = Vec16<T>::N;
     const int64_t nvec = n / VEC;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
-        Vec16<T> e = ld16(E + i * VEC), g = ld16(G + i * VEC), h;
+        Vec16<T> e = ld16_m(E + i * VEC, mode), g = ld16_m(G + i * VEC, mode), h;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float f;
             act_fwd<ACT>(to_f32(e.e[j]), f);
             h.e[j] = from_f32<T>(round_to<T>(f) * to_f32(g.e[j]));
         }
-        st16(H + i * VEC, h);
+        st16_m(H + i * VEC, h, mode);
     }
     // tail (n not a multiple of VEC)
     if (blockIdx.x == 0) {
@@ -106,18 +106,18 @@ __device__ __forceinline__ void bwd_one(T dw, T e, T g, T& h, T& df, T& de) {
 }
 
 template <typename T, int ACT>
-__global__ void __launch_bounds__(256) glu_bwd_kernel(T* DW, T* E, T* G, int64_t n) {
+__global__ void __launch_bounds__(256) glu_bwd_kernel(T* DW, T* E, T* G, int64_t n, int mode) {
     constexpr int VEC = Vec16<T>::N;
     const int64_t nvec = n / VEC;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
-        Vec16<T> dw = ld16(DW + i * VEC), e = ld16(E + i * VEC), g = ld16(G + i * VEC);
+        Vec16<T> dw = ld16_m(DW + i * VEC, mode), e = ld16_m(E + i * VEC, mode), g = ld16_m(G + i * VEC, mode);
         Vec16<T> h, df, de;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) bwd_one<T, ACT>(dw.e[j], e.e[j], g.e[j], h.e[j], df.e[j], de.e[j]);
-        st16(DW + i * VEC, h);   // swiglu.py:107-109
-        st16(E + i * VEC, df);
-        st16(G + i * VEC, de);
+        st16_m(DW + i * VEC, h, mode);   // swiglu.py:107-109
+        st16_m(E + i * VEC, df, mode);
+        st16_m(G + i * VEC, de, mode);
     }
     if (blockIdx.x == 0) {
         for (int64_t k = nvec * VEC + threadIdx.x; k < n; k += 256) {
@@ -139,14 +139,14 @@ template <typename T, int ACT>
 int launch_fwd(const void* e, const void* g, void* h, int64_t n, hipStream_t st) {
     if (!aligned16(e) || !aligned16(g) || !aligned16(h)) return UAMD_ERR_ALIGN;
     hipLaunchKernelGGL((glu_fwd_kernel<T, ACT>), dim3(grid_for(n / Vec16<T>::N)), dim3(256), 0, st,
-                       (const T*)e, (const T*)g, (T*)h, n);
+                       (const T*)e, (const T*)g, (T*)h, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
     return uamd_launch_status();
 }
 template <typename T, int ACT>
 int launch_bwd(void* dw, void* e, void* g, int64_t n, hipStream_t st) {
     if (!aligned16(dw) || !aligned16(e) || !aligned16(g)) return UAMD_ERR_ALIGN;
     hipLaunchKernelGGL((glu_bwd_kernel<T, ACT>), dim3(grid_for(n / Vec16<T>::N)), dim3(256), 0, st,
-                       (T*)dw, (T*)e, (T*)g, n);
+                       (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
     return uamd_launch_status();
 }
 

@@ -166,6 +166,83 @@ nf4_dequant_t_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const flo
     }
 }
 
+// Transposed output, large-tile version (the one the backward uses): 64 rows x 256 columns per block.
+//   * packed read: 32 consecutive lanes cover 128 B of one W row (4 B = 8 codes per lane), two rows per lane;
+//   * the lane packs (row r, row r+1) of each of its 8 columns into one 32-bit word and writes it to the
+//     transposed LDS tile [256 columns][32 row pairs] with the pair index XOR-ed by (column >> 3): the 32 lanes
+//     of a ds_write_b32 hit 32 distinct banks;
+//   * transposed write: 8 consecutive lanes cover 128 B of one output row (16 B per lane from one
+//     ds_read_b128; the XOR only permutes the four words inside it, undone with register selects).
+// 2.5 B/param of HBM traffic, both sides moved in >= 128-byte contiguous segments.
+template <typename T>
+__global__ void __launch_bounds__(256)
+nf4_dequant_t2_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const float* __restrict__ lut_g,
+                      T* __restrict__ out, int rows, int cols, int64_t ld_out, int blocksize) {
+    __shared__ float lut[16];
+    __shared__ float code2[256];
+    __shared__ __attribute__((aligned(16))) uint32_t tile[256 * 32];        // 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 16) lut[tid] = lut_g ? lut_g[tid] : kNF4[tid];
+    if (am.u8) code2[tid] = am.code2[tid];
+    __syncthreads();
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 256;
+    const int cg = lane & 31;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int rp = wave * 2 + (lane >> 5) + 8 * it;         // row pair 0..31
+        const int gr = r0 + 2 * rp, gc = c0 + cg * 8;
+        uint32_t wA = 0x77777777u, wB = 0x77777777u;            // code 7 = 0.0
+        float aA = 0.f, aB = 0.f;
+        if (gc < cols) {
+            if (gr < rows) {
+                const int64_t e0 = (int64_t)gr * cols + gc;
+                wA = *reinterpret_cast<const uint32_t*>(packed + (e0 >> 1));
+                aA = absmax_at(am, code2, e0 / blocksize);
+            }
+            if (gr + 1 < rows) {
+                const int64_t e1 = (int64_t)(gr + 1) * cols + gc;
+                wB = *reinterpret_cast<const uint32_t*>(packed + (e1 >> 1));
+                aB = absmax_at(am, code2, e1 / blocksize);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t ba = (wA >> (8 * b)) & 0xff, bb = (wB >> (8 * b)) & 0xff;
+            union { T h[2]; uint32_t u; } hi, lo;
+            hi.h[0] = from_f32<T>(lut[ba >> 4] * aA);  hi.h[1] = from_f32<T>(lut[bb >> 4] * aB);     // column 2b
+            lo.h[0] = from_f32<T>(lut[ba & 15] * aA);  lo.h[1] = from_f32<T>(lut[bb & 15] * aB);     // column 2b+1
+            tile[(cg * 8 + 2 * b) * 32 + (rp ^ cg)] = hi.u;
+            tile[(cg * 8 + 2 * b + 1) * 32 + (rp ^ cg)] = lo.u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int u = tid + 256 * it;
+        const int c = u >> 3, k = u & 7;                        // column c, W rows 8k..8k+7
+        const int ccg = c >> 3;
+        const uint4 w = *reinterpret_cast<const uint4*>(&tile[c * 32 + ((k ^ (ccg >> 2)) << 2)]);
+        const uint32_t wv[4] = {w.x, w.y, w.z, w.w};
+        const int x = ccg & 3;
+        uint4 o;
+        o.x = x == 0 ? wv[0] : x == 1 ? wv[1] : x == 2 ? wv[2] : wv[3];            // o[i] = w[i ^ x]
+        o.y = x == 0 ? wv[1] : x == 1 ? wv[0] : x == 2 ? wv[3] : wv[2];
+        o.z = x == 0 ? wv[2] : x == 1 ? wv[3] : x == 2 ? wv[0] : wv[1];
+        o.w = x == 0 ? wv[3] : x == 1 ? wv[2] : x == 2 ? wv[1] : wv[0];
+        const int gc = c0 + c, gr = r0 + 8 * k;
+        if (gc < cols && gr < rows) {
+            T* dst = out + (int64_t)gc * ld_out + gr;
+            if (gr + 8 <= rows && ((ld_out & 7) == 0)) {
+                *reinterpret_cast<uint4*>(dst) = o;
+            } else {
+                union { uint4 q; T e[8]; } v;
+                v.q = o;
+                for (int j = 0; j < 8 && gr + j < rows; ++j) dst[j] = v.e[j];
+            }
+        }
+    }
+}
+
 // Blockwise NF4 quantiser: absmax per block, nearest code by the midpoint decision
 // boundaries (strict '>' like bnb's dQuantizeNF4). 8 elements per lane, blocksize/8 lanes
 // cooperate through xor-shuffles, so blocksize must be a power of two in [8, 512].
@@ -229,9 +306,15 @@ int launch_dequant(const uint8_t* packed, const AbsmaxSrc& am, const float* lut,
                            am, lut, (T*)out, n, blocksize);
     } else {
         if (sizeof(T) != 2 || (cols & 7)) return UAMD_ERR_ARG;
-        dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
-        hipLaunchKernelGGL((nf4_dequant_t_kernel<T>), grid, dim3(256), 0, st, packed, am, lut,
-                           (T*)out, (int)rows, (int)cols, ld_out, blocksize);
+        if ((blocksize & 7) == 0 && uamd_tuning_get(UAMD_TUNE_DEQUANT_T) != 0) {
+            dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + 63) / 64));
+            hipLaunchKernelGGL((nf4_dequant_t2_kernel<T>), grid, dim3(256), 0, st, packed, am, lut,
+                               (T*)out, (int)rows, (int)cols, ld_out, blocksize);
+        } else {
+            dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+            hipLaunchKernelGGL((nf4_dequant_t_kernel<T>), grid, dim3(256), 0, st, packed, am, lut,
+                               (T*)out, (int)rows, (int)cols, ld_out, blocksize);
+        }
     }
     return uamd_launch_status();
 }

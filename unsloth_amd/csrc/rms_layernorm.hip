@@ -17,7 +17,7 @@ namespace {
 template <typename T, typename WT, int ITERS, bool GEMMA>
 __global__ void __launch_bounds__(256)
 rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ Y,
-             float* __restrict__ R, int64_t n_rows, int n_cols, int64_t xs, int64_t ys, float eps) {
+             float* __restrict__ R, int64_t n_rows, int n_cols, int64_t xs, int64_t ys, float eps, int mode) {
     constexpr int VEC = Vec16<T>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -28,7 +28,7 @@ rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ 
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int c = (lane + 64 * i) * VEC;
-        if (c < n_cols) xv[i] = ld16(x + c);
+        if (c < n_cols) xv[i] = ld16_m(x + c, mode);
         else xv[i].raw = make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
@@ -56,7 +56,7 @@ rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ 
                     o.e[j] = from_f32<T>(round_to<WT>(round_to<WT>(normed) * wf[j]));
                 }
             }
-            st16(y + c, o);
+            st16_m(y + c, o, mode);
         }
     }
 }
@@ -65,7 +65,7 @@ template <typename T, typename WT, int ITERS, bool GEMMA>
 __global__ void __launch_bounds__(256)
 rms_bwd_wave(const T* dY, T* dX, const T* __restrict__ X,
              const WT* __restrict__ W, const float* __restrict__ R, int64_t n_rows, int n_cols,
-             int64_t dys, int64_t dxs, int64_t xs) {
+             int64_t dys, int64_t dxs, int64_t xs, int mode) {
     constexpr int VEC = Vec16<T>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -76,7 +76,7 @@ rms_bwd_wave(const T* dY, T* dX, const T* __restrict__ X,
 #pragma unroll
     for (int i = 0; i < ITERS; ++i) {
         const int c = (lane + 64 * i) * VEC;
-        if (c < n_cols) { dv[i] = ld16(dy + c); xv[i] = ld16(x + c); }
+        if (c < n_cols) { dv[i] = ld16_m(dy + c, mode); xv[i] = ld16_m(x + c, mode); }
         else { dv[i].raw = make_uint4(0, 0, 0, 0); xv[i].raw = make_uint4(0, 0, 0, 0); }
     }
     const float inv = R[row];
@@ -114,7 +114,7 @@ rms_bwd_wave(const T* dY, T* dX, const T* __restrict__ X,
                 // rms_layernorm.py:112
                 o.e[j] = from_f32<T>(inv / n * (n * dyw - normed * rs));
             }
-            st16(dx + c, o);
+            st16_m(dx + c, o, mode);
         }
     }
 }
@@ -178,7 +178,8 @@ int launch_fwd(const void* X, const void* W, void* Y, float* R, int64_t n_rows, 
     if (vec_ok) {
         const int iters = (n_cols + 64 * VEC - 1) / (64 * VEC);
         dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
-#define L(I) hipLaunchKernelGGL((rms_fwd_wave<T, WT, I, GEMMA>), grid, block, 0, st, x, w, y, R, n_rows, n_cols, xs, ys, eps)
+        const int mode = uamd_tuning_get(UAMD_TUNE_STREAM_NT);
+#define L(I) hipLaunchKernelGGL((rms_fwd_wave<T, WT, I, GEMMA>), grid, block, 0, st, x, w, y, R, n_rows, n_cols, xs, ys, eps, mode)
         if (iters <= 1) L(1); else if (iters <= 2) L(2); else if (iters <= 4) L(4);
         else if (iters <= 8) L(8); else L(16);
 #undef L
@@ -200,7 +201,8 @@ int launch_bwd(const void* dY, void* dX, const void* X, const void* W, const flo
     if (vec_ok) {
         const int iters = (n_cols + 64 * VEC - 1) / (64 * VEC);
         dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
-#define L(I) hipLaunchKernelGGL((rms_bwd_wave<T, WT, I, GEMMA>), grid, block, 0, st, dy, dx, x, w, R, n_rows, n_cols, dys, dxs, xs)
+        const int mode = uamd_tuning_get(UAMD_TUNE_STREAM_NT);
+#define L(I) hipLaunchKernelGGL((rms_bwd_wave<T, WT, I, GEMMA>), grid, block, 0, st, dy, dx, x, w, R, n_rows, n_cols, dys, dxs, xs, mode)
         if (iters <= 1) L(1); else if (iters <= 2) L(2); else if (iters <= 4) L(4); else L(8);
 #undef L
     } else {
