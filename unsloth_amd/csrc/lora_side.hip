@@ -10,10 +10,12 @@
 // These are memory-bound streaming passes over Z (2 B per 2*r flops), not GEMM-shaped work for the matrix
 // cores: Z is read exactly once, 8 bytes per lane per row (a wave covers a 256-column slab), the r <= 16
 // coefficients of a row PAIR are wave-uniform and come from a 1 KiB LDS table by broadcast ds_read_b128, and
-// the arithmetic is v_dot2c_f32_bf16 (two rows per instruction, fp32 accumulate): 64 dot2 + 4 v_perm per
-// 2 rows x 4 columns, which keeps the VALU under the HBM time. Up to 8 problems (all products of one
-// autograd Function) go in ONE launch. Split over the token dimension is deterministic: each block reduces its
-// 4 waves through LDS and writes one partial slab; a second tiny kernel sums the partials in fixed order.
+// the arithmetic is v_pk_fma_f32 (two columns per instruction, fp32): 32 packed FMAs + 4 unpack ops per row x 4
+// columns, which keeps the VALU under the HBM time (v_dot2c_f32_bf16 was tried first: it issues at a fraction
+// of the VALU rate on gfx950 and held the kernel at 2.7 TB/s). Up to 8 problems (all products of one
+// autograd Function) go in ONE launch. Split over the token dimension is deterministic: every wave owns one
+// (256-column slab, row chunk) unit and writes one partial slab; a second tiny kernel sums the partials in fixed
+// order. No LDS reduction, no barrier: occupancy is bounded by registers only.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -24,17 +26,14 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 namespace {
 
 constexpr int TN_COLS = 256;          // columns per slab (4 per lane)
-constexpr int TN_ROWS_WAVE = 128;     // rows per wave
-constexpr int TN_ROWS_BLOCK = 512;    // rows per block (4 waves)
 constexpr int TN_R = 16;
-constexpr int TN_LDS_RED = 4 * 64 * 64 * 4;          // 64 KiB: [wave][acc][lane]
-constexpr int TN_LDS_P = 4 * 16 * 16 * 4;            // 4 KiB: per wave [16 pairs][16 r] packed 2x16-bit
-constexpr int TN_LDS = TN_LDS_RED + TN_LDS_P;
+constexpr int TN_LDS_P = 4 * 32 * 16 * 4;            // 8 KiB: per wave [32 rows][16 ranks] fp32
 
 struct TnArgs {
     int n_probs;
     int M;
-    int S;                                   // number of 512-row blocks
+    int S;                                   // number of row chunks (partials per problem)
+    int rows_per_wave;                       // 128 / 256 / 512: one wave = one (slab, row chunk) unit
     int total_slabs;
     int slab_start[UAMD_TN_MAX_PROBLEMS + 1];
     int64_t ws_off[UAMD_TN_MAX_PROBLEMS];    // float offset of the problem's partials in `ws`
@@ -42,39 +41,34 @@ struct TnArgs {
     uamd_lora_tn_problem p[UAMD_TN_MAX_PROBLEMS];
 };
 
-template <typename T> struct Dot2;
-template <> struct Dot2<bf16_t> {
-    static __device__ __forceinline__ float run(uint32_t a, uint32_t b, float c) {
-        union { uint32_t u; bf16x2_t v; } x, y;
-        x.u = a; y.u = b;
-        return __builtin_amdgcn_fdot2_f32_bf16(x.v, y.v, c, false);
-    }
-};
-template <> struct Dot2<f16_t> {
-    static __device__ __forceinline__ float run(uint32_t a, uint32_t b, float c) {
-        union { uint32_t u; f16x2_t v; } x, y;
-        x.u = a; y.u = b;
-        return __builtin_amdgcn_fdot2(x.v, y.v, c, false);
-    }
-};
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
-template <typename T>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    union { T h[2]; uint32_t u; } v;
-    v.h[0] = from_f32<T>(lo);
-    v.h[1] = from_f32<T>(hi);
-    return v.u;
+// 16-bit float pair (one 32-bit word, little endian) -> two fp32
+template <typename T> __device__ __forceinline__ f32x2_t unpack2(uint32_t w);
+template <> __device__ __forceinline__ f32x2_t unpack2<bf16_t>(uint32_t w) {
+    f32x2_t r;
+    r.x = __uint_as_float(w << 16);
+    r.y = __uint_as_float(w & 0xffff0000u);
+    return r;
+}
+template <> __device__ __forceinline__ f32x2_t unpack2<f16_t>(uint32_t w) {
+    union { uint32_t u; f16_t h[2]; } v;
+    v.u = w;
+    f32x2_t r;
+    r.x = (float)v.h[0];
+    r.y = (float)v.h[1];
+    return r;
 }
 
 template <typename T>
-__global__ void __launch_bounds__(256) lora_tn_kernel(TnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* red = reinterpret_cast<float*>(smem);                                   // [4][64][64]
-    uint32_t* ptab = reinterpret_cast<uint32_t*>(smem + TN_LDS_RED);               // [4][16][16]
+__global__ void __launch_bounds__(256, 4) lora_tn_kernel(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) float ptab[4 * 32 * 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int slab_lin = blockIdx.x % a.total_slabs;
-    const int sblk = blockIdx.x / a.total_slabs;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+    if (unit >= (int64_t)a.total_slabs * a.S) return;          // wave-uniform; no block-level sync below
+    const int slab_lin = (int)(unit % a.total_slabs);
+    const int sblk = (int)(unit / a.total_slabs);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < UAMD_TN_MAX_PROBLEMS; ++i)
@@ -87,77 +81,60 @@ __global__ void __launch_bounds__(256) lora_tn_kernel(TnArgs a) {
     const bool col_ok = n0 < N;                         // N % 4 == 0 (host-checked)
     const T* Z = (const T*)pr.Z;
     const float* P = pr.P;
-    uint32_t* mytab = ptab + wave * 256;
+    float* mytab = ptab + wave * 512;          // [32 rows][16 ranks] fp32
 
-    float acc[TN_R][4];
+    f32x2_t acc[TN_R][2];
 #pragma unroll
-    for (int r = 0; r < TN_R; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = 0.f;
+    for (int r = 0; r < TN_R; ++r) { acc[r][0] = f32x2_t{0.f, 0.f}; acc[r][1] = f32x2_t{0.f, 0.f}; }
 
-    const int m_base = sblk * TN_ROWS_BLOCK + wave * TN_ROWS_WAVE;
-    for (int ch = 0; ch < TN_ROWS_WAVE / 32; ++ch) {
+    const int m_base = sblk * a.rows_per_wave;
+    for (int ch = 0; ch < a.rows_per_wave / 32; ++ch) {
         const int mrow0 = m_base + ch * 32;
         if (mrow0 >= M) break;                          // wave-uniform
-        // ---- stage the coefficient pairs of these 32 rows: lane -> (pair = lane>>2, 4 ranks at (lane&3)*4)
+        // ---- stage the coefficients of these 32 rows, rounded to the activation dtype (the reference holds
+        //      dY @ B / X @ A^T as tensors of that dtype): lane -> (row = lane>>1, 8 ranks at (lane&1)*8)
         {
-            const int pair = lane >> 2, rq = (lane & 3) * 4;
-            const int rA = mrow0 + 2 * pair, rB = rA + 1;
-            float pa[4], pb[4];
+            const int row = lane >> 1, rq = (lane & 1) * 8;
+            const int gm = mrow0 + row;
+            float pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x = (gm < M && rq + i < R) ? P[(int64_t)gm * pr.ldp + rq + i] : 0.f;
+                pv[i] = round_to<T>(x);
+            }
+            *reinterpret_cast<float4*>(mytab + row * 16 + rq) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            *reinterpret_cast<float4*>(mytab + row * 16 + rq + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
+        }
+        // ---- stream the 32 rows (same wave wrote the table: LDS is in order per wave). Per row: one 8-byte
+        //      load, 4 unpack ops, 32 v_pk_fma_f32 (rank coefficient broadcast to both halves).
+#pragma unroll 4
+        for (int rr = 0; rr < 32; ++rr) {
+            const int gm = mrow0 + rr;
+            uint2 z = make_uint2(0, 0);
+            if (col_ok && gm < M) z = *reinterpret_cast<const uint2*>(Z + (int64_t)gm * pr.ldz + n0);
+            const f32x2_t z01 = unpack2<T>(z.x), z23 = unpack2<T>(z.y);
+            float pc[16];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                pa[i] = (rA < M && rq + i < R) ? P[(int64_t)rA * pr.ldp + rq + i] : 0.f;
-                pb[i] = (rB < M && rq + i < R) ? P[(int64_t)rB * pr.ldp + rq + i] : 0.f;
+                const float4 q = *reinterpret_cast<const float4*>(mytab + rr * 16 + i * 4);   // broadcast read
+                pc[4 * i] = q.x; pc[4 * i + 1] = q.y; pc[4 * i + 2] = q.z; pc[4 * i + 3] = q.w;
             }
-            uint4 w;
-            w.x = pack2<T>(pa[0], pb[0]); w.y = pack2<T>(pa[1], pb[1]);
-            w.z = pack2<T>(pa[2], pb[2]); w.w = pack2<T>(pa[3], pb[3]);
-            *reinterpret_cast<uint4*>(mytab + pair * 16 + rq) = w;
-        }
-        // ---- stream the 16 row pairs (same wave wrote the table: LDS is in order per wave)
-#pragma unroll 4
-        for (int pq = 0; pq < 16; ++pq) {
-            const int rA = mrow0 + 2 * pq, rB = rA + 1;
-            uint2 za = make_uint2(0, 0), zb = make_uint2(0, 0);
-            if (col_ok && rA < M) za = *reinterpret_cast<const uint2*>(Z + (int64_t)rA * pr.ldz + n0);
-            if (col_ok && rB < M) zb = *reinterpret_cast<const uint2*>(Z + (int64_t)rB * pr.ldz + n0);
-            uint32_t q[4];
-            q[0] = __builtin_amdgcn_perm(zb.x, za.x, 0x05040100u);      // (z[rA][n0+0], z[rB][n0+0])
-            q[1] = __builtin_amdgcn_perm(zb.x, za.x, 0x07060302u);
-            q[2] = __builtin_amdgcn_perm(zb.y, za.y, 0x05040100u);
-            q[3] = __builtin_amdgcn_perm(zb.y, za.y, 0x07060302u);
-            uint4 pw[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pw[i] = *reinterpret_cast<const uint4*>(mytab + pq * 16 + i * 4);
-            const uint32_t pv[16] = {pw[0].x, pw[0].y, pw[0].z, pw[0].w, pw[1].x, pw[1].y, pw[1].z, pw[1].w,
-                                     pw[2].x, pw[2].y, pw[2].z, pw[2].w, pw[3].x, pw[3].y, pw[3].z, pw[3].w};
-#pragma unroll
-            for (int r = 0; r < TN_R; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = Dot2<T>::run(pv[r], q[c], acc[r][c]);
+            for (int r = 0; r < TN_R; ++r) {
+                const f32x2_t pp = {pc[r], pc[r]};
+                acc[r][0] = __builtin_elementwise_fma(pp, z01, acc[r][0]);
+                acc[r][1] = __builtin_elementwise_fma(pp, z23, acc[r][1]);
+            }
         }
     }
 
-    // ---- block reduction (fixed order) and partial store: part[sblk][r][n], n padded to whole slabs
+    // ---- partial store: part[sblk][r][n], n padded to whole slabs (1 KiB contiguous per rank per wave)
+    const int64_t npad = (int64_t)n_slabs * TN_COLS;
+    float* part = a.ws + a.ws_off[pi] + (int64_t)sblk * TN_R * npad + slab * TN_COLS + lane * 4;
 #pragma unroll
     for (int r = 0; r < TN_R; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) red[(wave * 64 + r * 4 + c) * 64 + lane] = acc[r][c];
-    __syncthreads();
-    const int64_t npad = (int64_t)n_slabs * TN_COLS;
-    float* part = a.ws + a.ws_off[pi] + (int64_t)sblk * TN_R * npad;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = wave * 4 + i;
-        float4 o;
-        float* ov = reinterpret_cast<float*>(&o);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = (r * 4 + c) * 64 + lane;
-            ov[c] = ((red[e] + red[64 * 64 + e]) + red[2 * 64 * 64 + e]) + red[3 * 64 * 64 + e];
-        }
-        *reinterpret_cast<float4*>(part + (int64_t)r * npad + slab * TN_COLS + lane * 4) = o;
-    }
+        *reinterpret_cast<float4*>(part + (int64_t)r * npad) =
+            make_float4(acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y);
 }
 
 // out = scale * sum_s part[s]; out_nr == 0: out[r * ldo + n], else out[n * ldo + r]
@@ -185,7 +162,15 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
     if (!probs || n_probs < 1 || n_probs > UAMD_TN_MAX_PROBLEMS || M < 0 || !workspace) return UAMD_ERR_ARG;
     if (M == 0) return UAMD_OK;
     TnArgs a;
-    a.n_probs = n_probs; a.M = M; a.S = (M + TN_ROWS_BLOCK - 1) / TN_ROWS_BLOCK; a.ws = workspace;
+    a.n_probs = n_probs; a.M = M; a.ws = workspace;
+    {   // rows per wave: as many as keep >= 4096 waves in the launch (4 per SIMD), fewer partials otherwise
+        int64_t slabs_all = 0;
+        for (int i = 0; i < n_probs; ++i) slabs_all += (probs[i].N + TN_COLS - 1) / TN_COLS;
+        int rpw = 512;
+        while (rpw > 128 && slabs_all * ((M + rpw - 1) / rpw) < 4096) rpw >>= 1;
+        a.rows_per_wave = rpw;
+        a.S = (M + rpw - 1) / rpw;
+    }
     int slabs = 0;
     int64_t off = 0;
     int max_rn_blocks = 1;
@@ -211,28 +196,13 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
     for (int i = n_probs; i < UAMD_TN_MAX_PROBLEMS; ++i) a.slab_start[i + 1] = slabs;
     a.total_slabs = slabs;
     if (off > workspace_floats) return UAMD_ERR_ARG;
-    const int64_t blocks = (int64_t)slabs * a.S;
+    const int64_t blocks = ((int64_t)slabs * a.S + 3) / 4;
     if (blocks > 0x7fffffffLL) return UAMD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set[2][64] = {{false}};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (dtype == UAMD_BF16) {
-        if (!attr_set[0][dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_tn_kernel<bf16_t>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
-            if (e != hipSuccess) return (int)e;
-            attr_set[0][dev] = true;
-        }
-        hipLaunchKernelGGL((lora_tn_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), TN_LDS, st, a);
+        hipLaunchKernelGGL((lora_tn_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else if (dtype == UAMD_F16) {
-        if (!attr_set[1][dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_tn_kernel<f16_t>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
-            if (e != hipSuccess) return (int)e;
-            attr_set[1][dev] = true;
-        }
-        hipLaunchKernelGGL((lora_tn_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), TN_LDS, st, a);
+        hipLaunchKernelGGL((lora_tn_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a);
     } else {
         return UAMD_ERR_DTYPE;
     }

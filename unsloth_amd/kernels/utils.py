@@ -388,7 +388,7 @@ def lora_tn(problems):
             descs.append(_lib.LoraTnProblem(P=P.data_ptr() + 4 * r0, Z=Z2.data_ptr(), out=optr, ldp=P.stride(0),
                                             ldz=Z2.stride(0), ldo=(R if out_nr else N), N=N, R=rc,
                                             out_nr=int(bool(out_nr)), scale=float(scale)))
-    S = (M + 511) // 512
+    S = (M + 127) // 128            # upper bound on the row chunks the kernel may choose
     L = _lib.lib()
     for i in range(0, len(descs), 8):
         chunk = descs[i:i + 8]
