@@ -25,9 +25,9 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 namespace {
 
-constexpr int TN_COLS = 256;          // columns per slab (4 per lane)
-constexpr int TN_R = 16;
-constexpr int TN_LDS_P = 4 * 32 * 16 * 4;            // 8 KiB: per wave [32 rows][16 ranks] fp32
+constexpr int TN_COLS = 512;          // columns per slab (8 per lane)
+constexpr int TN_R = 16;              // ranks per problem
+constexpr int TN_RW = 8;              // ranks per wave
 
 struct TnArgs {
     int n_probs;
@@ -60,15 +60,20 @@ template <> __device__ __forceinline__ f32x2_t unpack2<f16_t>(uint32_t w) {
     return r;
 }
 
+// One wave = one unit (512-column slab, 8 of the 16 ranks, row chunk). The two rank halves of a (slab, chunk) are
+// adjacent waves of one block, so the second read of Z hits L1/L2. Bytes in flight are what bounds a streaming
+// kernel here (~2.5 us loaded latency): 64 accumulator registers per lane leave room for 8 x 16-byte loads in
+// flight per lane at 4 waves per SIMD = 128 KiB per CU.
 template <typename T>
-__global__ void __launch_bounds__(256, 4) lora_tn_kernel(TnArgs a) {
-    __shared__ __attribute__((aligned(16))) float ptab[4 * 32 * 16];
+__global__ void __launch_bounds__(256, 3) lora_tn_kernel(TnArgs a) {
+    __shared__ __attribute__((aligned(16))) float ptab[4 * 32 * 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
-    if (unit >= (int64_t)a.total_slabs * a.S) return;          // wave-uniform; no block-level sync below
-    const int slab_lin = (int)(unit % a.total_slabs);
-    const int sblk = (int)(unit / a.total_slabs);
+    if (unit >= (int64_t)a.total_slabs * a.S * 2) return;      // wave-uniform; no block-level sync below
+    const int half = (int)(unit & 1);
+    const int slab_lin = (int)((unit >> 1) % a.total_slabs);
+    const int sblk = (int)((unit >> 1) / a.total_slabs);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < UAMD_TN_MAX_PROBLEMS; ++i)
@@ -77,64 +82,94 @@ __global__ void __launch_bounds__(256, 4) lora_tn_kernel(TnArgs a) {
     const int slab = slab_lin - a.slab_start[pi];
     const int n_slabs = a.slab_start[pi + 1] - a.slab_start[pi];
     const int M = a.M, N = pr.N, R = pr.R;
-    const int n0 = slab * TN_COLS + lane * 4;
-    const bool col_ok = n0 < N;                         // N % 4 == 0 (host-checked)
+    const int r_lo = half * TN_RW;
+    const int n0 = slab * TN_COLS + lane * 8;
+    // lanes past the last column read the last valid 16 bytes instead (their partials are never summed)
+    const int n0c = n0 + 8 <= N ? n0 : (N >= 8 ? N - 8 : 0);
+    const bool col_ok = n0 + 8 <= N;                  // else: ragged tail handled by the guarded path
     const T* Z = (const T*)pr.Z;
     const float* P = pr.P;
-    float* mytab = ptab + wave * 512;          // [32 rows][16 ranks] fp32
+    float* mytab = ptab + wave * 256;                  // [32 rows][8 ranks] fp32
 
-    f32x2_t acc[TN_R][2];
+    f32x2_t acc[TN_RW][4];
 #pragma unroll
-    for (int r = 0; r < TN_R; ++r) { acc[r][0] = f32x2_t{0.f, 0.f}; acc[r][1] = f32x2_t{0.f, 0.f}; }
+    for (int r = 0; r < TN_RW; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = f32x2_t{0.f, 0.f};
 
+    const bool tail_cols = (N & 7) != 0 || N < 8;     // problem-uniform: N % 4 == 0 only
     const int m_base = sblk * a.rows_per_wave;
     for (int ch = 0; ch < a.rows_per_wave / 32; ++ch) {
         const int mrow0 = m_base + ch * 32;
         if (mrow0 >= M) break;                          // wave-uniform
         // ---- stage the coefficients of these 32 rows, rounded to the activation dtype (the reference holds
-        //      dY @ B / X @ A^T as tensors of that dtype): lane -> (row = lane>>1, 8 ranks at (lane&1)*8)
+        //      dY @ B / X @ A^T as tensors of that dtype): lane -> (row = lane>>1, 4 ranks at (lane&1)*4)
         {
-            const int row = lane >> 1, rq = (lane & 1) * 8;
+            const int row = lane >> 1, rq = (lane & 1) * 4;
             const int gm = mrow0 + row;
-            float pv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float x = (gm < M && rq + i < R) ? P[(int64_t)gm * pr.ldp + rq + i] : 0.f;
-                pv[i] = round_to<T>(x);
-            }
-            *reinterpret_cast<float4*>(mytab + row * 16 + rq) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-            *reinterpret_cast<float4*>(mytab + row * 16 + rq + 4) = make_float4(pv[4], pv[5], pv[6], pv[7]);
-        }
-        // ---- stream the 32 rows (same wave wrote the table: LDS is in order per wave). Per row: one 8-byte
-        //      load, 4 unpack ops, 32 v_pk_fma_f32 (rank coefficient broadcast to both halves).
-#pragma unroll 4
-        for (int rr = 0; rr < 32; ++rr) {
-            const int gm = mrow0 + rr;
-            uint2 z = make_uint2(0, 0);
-            if (col_ok && gm < M) z = *reinterpret_cast<const uint2*>(Z + (int64_t)gm * pr.ldz + n0);
-            const f32x2_t z01 = unpack2<T>(z.x), z23 = unpack2<T>(z.y);
-            float pc[16];
+            float pv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 q = *reinterpret_cast<const float4*>(mytab + rr * 16 + i * 4);   // broadcast read
-                pc[4 * i] = q.x; pc[4 * i + 1] = q.y; pc[4 * i + 2] = q.z; pc[4 * i + 3] = q.w;
+                const int r = r_lo + rq + i;
+                const float x = (gm < M && r < R) ? P[(int64_t)gm * pr.ldp + r] : 0.f;
+                pv[i] = round_to<T>(x);
             }
-#pragma unroll
-            for (int r = 0; r < TN_R; ++r) {
-                const f32x2_t pp = {pc[r], pc[r]};
-                acc[r][0] = __builtin_elementwise_fma(pp, z01, acc[r][0]);
-                acc[r][1] = __builtin_elementwise_fma(pp, z23, acc[r][1]);
+            *reinterpret_cast<float4*>(mytab + row * 8 + rq) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        }
+        const bool full = (mrow0 + 32 <= M) && !tail_cols;          // wave-uniform
+        // ---- stream the 32 rows (same wave wrote the table: LDS is in order per wave). Per row: one 16-byte
+        //      load, 8 unpack ops, 32 v_pk_fma_f32 (rank coefficient broadcast to both halves).
+#define TN_ROW(LOAD)                                                                                     \
+        {                                                                                                \
+            const uint4 z = LOAD;                                                                        \
+            const f32x2_t z0 = unpack2<T>(z.x), z1 = unpack2<T>(z.y), z2 = unpack2<T>(z.z), z3 = unpack2<T>(z.w); \
+            const float4 q0 = *reinterpret_cast<const float4*>(mytab + rr * 8);       /* broadcast reads */  \
+            const float4 q1 = *reinterpret_cast<const float4*>(mytab + rr * 8 + 4);                       \
+            const float pc[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};                         \
+            _Pragma("unroll") for (int r = 0; r < TN_RW; ++r) {                                           \
+                const f32x2_t pp = {pc[r], pc[r]};                                                        \
+                acc[r][0] = __builtin_elementwise_fma(pp, z0, acc[r][0]);                                 \
+                acc[r][1] = __builtin_elementwise_fma(pp, z1, acc[r][1]);                                 \
+                acc[r][2] = __builtin_elementwise_fma(pp, z2, acc[r][2]);                                 \
+                acc[r][3] = __builtin_elementwise_fma(pp, z3, acc[r][3]);                                 \
+            }                                                                                             \
+        }
+        if (full) {
+            const T* zp = Z + (int64_t)mrow0 * pr.ldz + n0c;
+#pragma unroll 8
+            for (int rr = 0; rr < 32; ++rr) TN_ROW(*reinterpret_cast<const uint4*>(zp + (int64_t)rr * pr.ldz))
+        } else {
+            for (int rr = 0; rr < 32; ++rr) {
+                const int gm = mrow0 + rr;
+                uint4 zz = make_uint4(0, 0, 0, 0);
+                if (gm < M) {
+                    if (col_ok) {
+                        zz = *reinterpret_cast<const uint4*>(Z + (int64_t)gm * pr.ldz + n0);
+                    } else if (n0 < N) {               // N % 4 == 0: exactly 4 valid columns
+                        const uint2 h = *reinterpret_cast<const uint2*>(Z + (int64_t)gm * pr.ldz + n0);
+                        zz.x = h.x; zz.y = h.y;
+                    }
+                }
+                TN_ROW(zz)
             }
         }
+#undef TN_ROW
     }
 
-    // ---- partial store: part[sblk][r][n], n padded to whole slabs (1 KiB contiguous per rank per wave)
+    // ---- partial store: part[sblk][r][n], n padded to whole slabs (2 KiB contiguous per rank per wave).
+    //      On the full path, lanes past N hold sums of clamped columns: stored into padding, never reduced.
     const int64_t npad = (int64_t)n_slabs * TN_COLS;
-    float* part = a.ws + a.ws_off[pi] + (int64_t)sblk * TN_R * npad + slab * TN_COLS + lane * 4;
+    float* part = a.ws + a.ws_off[pi] + ((int64_t)sblk * TN_R + r_lo) * npad + slab * TN_COLS + lane * 8;
+    const bool keep = tail_cols || col_ok;              // clamped lanes must not clobber real columns
+    if (keep) {
 #pragma unroll
-    for (int r = 0; r < TN_R; ++r)
-        *reinterpret_cast<float4*>(part + (int64_t)r * npad) =
-            make_float4(acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y);
+        for (int r = 0; r < TN_RW; ++r) {
+            *reinterpret_cast<float4*>(part + (int64_t)r * npad) =
+                make_float4(acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y);
+            *reinterpret_cast<float4*>(part + (int64_t)r * npad + 4) =
+                make_float4(acc[r][2].x, acc[r][2].y, acc[r][3].x, acc[r][3].y);
+        }
+    }
 }
 
 // out = scale * sum_s part[s]; out_nr == 0: out[r * ldo + n], else out[n * ldo + r]
@@ -167,7 +202,7 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
         int64_t slabs_all = 0;
         for (int i = 0; i < n_probs; ++i) slabs_all += (probs[i].N + TN_COLS - 1) / TN_COLS;
         int rpw = 512;
-        while (rpw > 128 && slabs_all * ((M + rpw - 1) / rpw) < 4096) rpw >>= 1;
+        while (rpw > 128 && 2 * slabs_all * ((M + rpw - 1) / rpw) < 4096) rpw >>= 1;
         a.rows_per_wave = rpw;
         a.S = (M + rpw - 1) / rpw;
     }
@@ -196,7 +231,7 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
     for (int i = n_probs; i < UAMD_TN_MAX_PROBLEMS; ++i) a.slab_start[i + 1] = slabs;
     a.total_slabs = slabs;
     if (off > workspace_floats) return UAMD_ERR_ARG;
-    const int64_t blocks = ((int64_t)slabs * a.S + 3) / 4;
+    const int64_t blocks = ((int64_t)slabs * a.S * 2 + 3) / 4;
     if (blocks > 0x7fffffffLL) return UAMD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UAMD_BF16) {

@@ -392,7 +392,7 @@ def lora_tn(problems):
     L = _lib.lib()
     for i in range(0, len(descs), 8):
         chunk = descs[i:i + 8]
-        need = sum(S * 16 * ((d.N + 255) // 256) * 256 for d in chunk)
+        need = sum(S * 16 * ((d.N + 511) // 512) * 512 for d in chunk)
         ws = _nf4.scratch(dev, need, torch.float32, slot=40)
         arr = (_lib.LoraTnProblem * len(chunk))(*chunk)
         with _lib.device_ctx(ws):
