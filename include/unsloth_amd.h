@@ -213,6 +213,15 @@ typedef struct {
 int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* workspace,
                  int64_t workspace_floats, int dtype, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Causal GQA flash attention, head_dim 128 (csrc/attention.hip). The step between RoPE and o_proj that the
+ * reference delegates to flash-attn / xformers / SDPA (unsloth/utils/attention_dispatch.py:298-617, called from
+ * unsloth/models/llama.py:757). Q [B,T,Hq,D], K/V [B,T,Hk,D], O [B,T,Hq,D] given by element strides
+ * `strides` = {q_b,q_t,q_h, k_b,k_t,k_h, v_b,v_t,v_h, o_b,o_t,o_h} (d contiguous, multiples of 8);
+ * LSE [B,Hq,T] fp32 (natural log-sum-exp of the scaled scores, saved for the backward). Hq/Hk in {1,2,4,8}. */
+int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const int64_t* strides,
+                  int B, int T, int Hq, int Hk, int D, float scale, int causal, int dtype, void* stream);
+
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
 int uamd_debug_mfma_probe(float* out, void* stream);
 
