@@ -218,9 +218,16 @@ int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* w
  * reference delegates to flash-attn / xformers / SDPA (unsloth/utils/attention_dispatch.py:298-617, called from
  * unsloth/models/llama.py:757). Q [B,T,Hq,D], K/V [B,T,Hk,D], O [B,T,Hq,D] given by element strides
  * `strides` = {q_b,q_t,q_h, k_b,k_t,k_h, v_b,v_t,v_h, o_b,o_t,o_h} (d contiguous, multiples of 8);
- * LSE [B,Hq,T] fp32 (natural log-sum-exp of the scaled scores, saved for the backward). Hq/Hk in {1,2,4,8}. */
+ * LSE [B,Hq,lse_stride] fp32 (natural log-sum-exp of the scaled scores, saved for the backward; lse_stride =
+ * T rounded up to a multiple of 32, pad zero-filled by the caller). Hq/Hk in {1,2,4,8}.
+ * uamd_attn_bwd: two launches (dQ + Delta = rowsum(dO*O), then dK/dV), deterministic, no atomics. `strides` has
+ * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [B,Hq,lse_stride] fp32 scratch. */
 int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const int64_t* strides,
-                  int B, int T, int Hq, int Hk, int D, float scale, int causal, int dtype, void* stream);
+                  int B, int T, int Hq, int Hk, int D, int lse_stride, float scale, int causal, int dtype,
+                  void* stream);
+int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
+                  void* dQ, void* dK, void* dV, float* Delta, const int64_t* strides, int B, int T, int Hq, int Hk,
+                  int D, int lse_stride, float scale, int causal, int dtype, void* stream);
 
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
 int uamd_debug_mfma_probe(float* out, void* stream);

@@ -52,3 +52,32 @@ def test_attn_forward_matches_fp32_oracle(dtype, B, T, Hq, Hk):
     o2, _ = attn_forward(qd[..., :Hq * D].view(B, T, Hq, D), qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D),
                          qd[..., (Hq + Hk) * D:].view(B, T, Hk, D), scale)
     assert torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,Hq,Hk", [(1, 64, 4, 1), (2, 128, 8, 2), (1, 200, 4, 1), (1, 333, 8, 8), (2, 256, 8, 1),
+                                       (1, 1024, 8, 2), (1, 31, 2, 1), (1, 96, 4, 2)])
+def test_attn_backward_matches_fp32_autograd(dtype, B, T, Hq, Hk):
+    from unsloth_amd.kernels.attention import attn_backward, attn_forward
+    D = 128
+    qkv = (torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(2)) * 1.0).to(dtype)
+    do = torch.randn(B, T, Hq, D, generator=g(3)).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    qr = qkv[..., :Hq * D].view(B, T, Hq, D).float().requires_grad_(True)
+    kr = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D).float().requires_grad_(True)
+    vr = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D).float().requires_grad_(True)
+    o_ref, _ = ref_attention(qr, kr, vr, scale)
+    o_ref.backward(do.float())
+    qd = qkv.to(DEV)
+    q = qd[..., :Hq * D].view(B, T, Hq, D)
+    k = qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qd[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    o, lse = attn_forward(q, k, v, scale)
+    dq, dk, dv = attn_backward(do.to(DEV), q, k, v, o, lse, scale)
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (got.float().cpu() - want).abs().max().item()
+        ref = want.abs().max().item()
+        tol = (3e-2 if dtype == torch.bfloat16 else 6e-3) * max(ref, 1.0)
+        assert err <= tol, (name, err, ref)
+    dq2, dk2, dv2 = attn_backward(do.to(DEV), q, k, v, o, lse, scale)
+    assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)

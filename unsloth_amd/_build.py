@@ -44,7 +44,7 @@ def _flags():
         "-mcode-object-version=5",   # loadable by the ROCm 7.0 runtime bundled with the torch wheel
         "-ffp-contract=off",         # keep the reference's rounding points; no silent fma fusion
         f"-I{INCLUDE}", f"-I{CSRC}",
-    ]
+    ] + os.environ.get("UAMD_EXTRA_CFLAGS", "").split()
 
 
 def _stale(out, deps):

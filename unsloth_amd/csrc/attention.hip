@@ -23,6 +23,8 @@
 //   * Bank conflicts: K rows are read 16 bytes per lane down a column -> 16-byte slot ^= row & 15; V rows are
 //     read by the transposing 8-byte reads, 4 rows x 64 B per 32 lanes -> slot ^= (row & 3) << 2. Both swizzles
 //     are applied on the per-lane DMA SOURCE address (the DMA destination is lane-linear).
+#include <type_traits>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -60,6 +62,7 @@ struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O; float* LSE;
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
     int B, T, Hq, Hk, G, nsub;          // G = Hq / Hk, nsub = 8 / G q-subtiles of 32 rows per block
+    int lse_st;                          // row stride of LSE [B, Hq, lse_st] (T rounded up to 32)
     float scale_log2;                    // softmax scale * log2(e)
 };
 
@@ -268,18 +271,543 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
                 o.y = pack_pair<T>(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv);
                 *reinterpret_cast<uint2*>(op + d) = o;
             }
-        if (lh == 0) p.LSE[((int64_t)b * p.Hq + head) * T_ + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+        if (lh == 0) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward, part 1: dQ (Q-stationary, same tiling as the forward) + Delta[q] = sum_d dO[q][d] O[q][d].
+//   S^T = K Q^T, P^T = exp2(S^T c - LSE2[q]), dP^T = V dO^T, dS^T = P^T (dP^T - Delta[q]) * scale,
+//   dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+// K is read two ways from the same LDS tile: by rows (A operand of S^T, ds_read_b128) and transposed (A operand
+// of dQ^T, ds_read_b64_tr_b16). The swizzle  slot ^= ((row & 3) << 2) | ((row >> 2) & 3)  is conflict-free for
+// both: injective over row & 15 (row reads), and the four rows of a transposing read land in four different
+// 64-byte windows.
+struct AttnBwdArgs {
+    const void* Q; const void* K; const void* V; const void* O; const void* dO; const float* LSE;
+    void* dQ; void* dK; void* dV; float* Delta;
+    int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh;
+    int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
+    int B, T, Hq, Hk, G, nsub, lse_st;
+    float scale, scale_log2;
+};
+
+__device__ __forceinline__ int swz_c(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename MfmaA<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = p.G, T_ = p.T;
+    const int QT = 32 * p.nsub;
+    const int qtile = (int)gridDim.x - 1 - (int)blockIdx.x;
+    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int head = kvh * G + (wave % G);
+    const int qs = qtile * QT + (wave / G) * 32;
+    const int q_pos = qs + l31;
+    const int q_ld = q_pos < T_ ? q_pos : T_ - 1;
+
+    frag_t qf[8], dof[8];
+    float delta = 0.f;
+    {
+        const T* qp = (const T*)p.Q + b * p.q_sb + (int64_t)q_ld * p.q_st + (int64_t)head * p.q_sh + lh * 8;
+        const T* dp_ = (const T*)p.dO + b * p.do_sb + (int64_t)q_ld * p.do_st + (int64_t)head * p.do_sh + lh * 8;
+        const T* op = (const T*)p.O + b * p.o_sb + (int64_t)q_ld * p.o_st + (int64_t)head * p.o_sh + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            union { uint4 r; frag_t f; T e[8]; } u, d, o;
+            u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
+            d.r = *reinterpret_cast<const uint4*>(dp_ + ks * 16);
+            o.r = *reinterpret_cast<const uint4*>(op + ks * 16);
+            qf[ks] = u.f;
+            dof[ks] = d.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) delta += to_f32(d.e[j]) * to_f32(o.e[j]);
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
+    if (lh == 0 && q_pos < T_) p.Delta[stat_idx] = delta;
+    const float lse2 = p.LSE[stat_idx] * 1.4426950408889634f;
+
+    const int nkv_blk = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);
+    int drow[2], dsw[2];
+    unsigned koff[2], voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 4 + (lane >> 4);
+        drow[i] = row;
+        dsw[i] = ((lane & 15) ^ swz_c(row)) * 16;
+        koff[i] = (unsigned)((int64_t)row * p.k_st * 2 + dsw[i]);
+        voff[i] = (unsigned)((int64_t)row * p.v_st * 2 + dsw[i]);
+    }
+    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
+    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    const unsigned dst_w = lds_base + wave * 2048;
+    auto issue = [&](int t, int stage) {
+        const int k0 = t * KT;
+        const unsigned d = dst_w + stage * STAGE_B;
+        if (k0 + KT <= T_) {
+            dma16x2(kbase + (int64_t)k0 * p.k_st, koff[0], koff[1], d, d + 1024);
+            dma16x2(vbase + (int64_t)k0 * p.v_st, voff[0], voff[1], d + TILE_B, d + TILE_B + 1024);
+        } else {
+            unsigned ko[2], vo[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = min(drow[i], T_ - 1 - k0);
+                ko[i] = (unsigned)((int64_t)r * p.k_st * 2 + dsw[i]);
+                vo[i] = (unsigned)((int64_t)r * p.v_st * 2 + dsw[i]);
+            }
+            dma16x2(kbase + (int64_t)k0 * p.k_st, ko[0], ko[1], d, d + 1024);
+            dma16x2(vbase + (int64_t)k0 * p.v_st, vo[0], vo[1], d + TILE_B, d + TILE_B + 1024);
+        }
+    };
+
+    // row reads (K for S^T, V for dP^T): lane -> row l31 (+32 kt), 16 B at logical slot 2 ks + lh
+    const int r_lane = l31 * 256 + ((swz_c(l31 & 15) ^ lh) << 4);
+    // transposing reads of K (A operand of dQ^T), swizzle C: second 4-row block = (addr ^ 32) + 8 rows
+    const int sg = lane & 15, gh = (lane >> 4) & 1;
+    const int t_lane = (4 * lh + (sg >> 2)) * 256 +
+                       ((((sg >> 2) << 2) | (((gh << 1) | ((sg >> 1) & 1)) ^ lh)) << 4) + (sg & 1) * 8;
+
+    f32x16_t dq_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
+
+    issue(0, 0);
+    if (nkv_blk > 1) issue(1, 1);
+    const int last_tile_wave = min(qs + 31, T_ - 1) / KT;
+    for (int t = 0; t < nkv_blk; ++t) {
+        if (t + 1 < nkv_blk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 2 < nkv_blk) issue(t + 2, (t + 2) % NST);
+        if (t > last_tile_wave) continue;
+        const unsigned char* sk = smem + (t % NST) * STAGE_B;
+        const unsigned char* sv = sk + TILE_B;
+        const int k0 = t * KT;
+        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16_t st, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                union { uint4 r; frag_t f; } u, w;
+                u.r = *reinterpret_cast<const uint4*>(sk + kt * 32 * 256 + (r_lane ^ (ks * 32)));
+                w.r = *reinterpret_cast<const uint4*>(sv + kt * 32 * 256 + (r_lane ^ (ks * 32)));
+                st = MfmaA<T>::run(u.f, qf[ks], st);
+                dp = MfmaA<T>::run(w.f, dof[ks], dp);
+            }
+            // dS^T = P^T (dP^T - Delta) * scale, masked entries 0
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pv = __builtin_amdgcn_exp2f(st[r] * p.scale_log2 - lse2);
+                if (need_mask) {
+                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key > q_pos || key >= T_) pv = 0.f;
+                }
+                st[r] = pv * (dp[r] - delta) * p.scale;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                union { uint32_t w[4]; frag_t f; } sb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sb.w[j] = pack_pair<T>(st[8 * c + 2 * j], st[8 * c + 2 * j + 1]);
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int a0 = (kt * 32 + c * 16) * 256 + (t_lane ^ (dt << 6));
+                    union { s16x4_t h[2]; frag_t f; } ka;
+                    ka.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sk + a0));
+                    ka.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sk + (a0 ^ 32) + 8 * 256));
+                    dq_acc[dt] = MfmaA<T>::run(ka.f, sb.f, dq_acc[dt]);
+                }
+            }
+        }
+    }
+    if (q_pos < T_) {
+        T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)q_pos * p.dq_st + (int64_t)head * p.dq_sh;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int d = dt * 32 + qd * 8 + lh * 4;
+                uint2 o;
+                o.x = pack_pair<T>(dq_acc[dt][qd * 4 + 0], dq_acc[dt][qd * 4 + 1]);
+                o.y = pack_pair<T>(dq_acc[dt][qd * 4 + 2], dq_acc[dt][qd * 4 + 3]);
+                *reinterpret_cast<uint2*>(op + d) = o;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward, part 2: dK, dV (KV-stationary). One block = (batch, KV head, 64 keys); wave w = (key half w&1, unit
+// w>>1) where the 4 units are the G query heads of the group (G = 4), or heads x q-slices (G < 4), or two passes
+// of 4 heads (G = 8). Per step every unit takes one 32-row q tile of its head:
+//   S = Q K^T, dP = dO V^T  (C layout: lane = key, registers = q rows; LSE / Delta come per register quad)
+//   P = exp2(S c - LSE2), dS = P (dP - Delta) scale
+//   dV^T[d][key] += dO^T[d][q] P[q][key],   dK^T[d][key] += Q^T[d][q] dS[q][key]
+// Q and dO tiles are staged once per step in LDS (swizzle C) and read both by rows (A operands of S, dP) and
+// transposed (A operands of dV^T, dK^T); K^T lives in registers, V in LDS. The units' partial dK/dV are summed
+// through LDS at the end (fixed order).
+constexpr int KD_STG = 4 * 16384 + 1024;             // 4 units x (Q 8 KiB + dO 8 KiB) + stats (LSE, Delta)
+constexpr int KD_V_OFF = 2 * KD_STG;                 // resident V tile
+constexpr int KD_LDS = KD_V_OFF + TILE_B;            // 149,504 B
+
+__device__ __forceinline__ void dma16x4g(const void* base, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                         unsigned d0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %6\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(d0), "s"(base)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void dma16x1(const void* gptr, unsigned d0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(d0)
+        : "memory");
+}
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename MfmaA<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = p.G, T_ = p.T;
+    const int kh = wave & 1, unit = wave >> 1;
+    const int hpp = G < 4 ? G : 4;                    // heads per pass
+    const int npass = G / hpp, nslice = 4 / hpp;
+    const int hin = unit % hpp, slice = unit / hpp;
+    const int jt = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int k0 = jt * KT;
+    const int key = k0 + kh * 32 + l31;               // this lane's key (C-layout column)
+    const int key_ld = key < T_ ? key : T_ - 1;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+
+    // ---- K^T operand (lane -> key, 8 d at 16 ks + 8 lh): 8 KiB per wave. Keeping it in VGPRs next to the 128
+    //      accumulator registers spills, and the LDS is full (2 x 65 KiB stages + V), so it is re-read from L2 at
+    //      the top of every step into registers that are dead again after the S loop. The loads are inline asm
+    //      (hipcc must not count them): issued BEFORE the step's LDS-DMA, retired by a counted vmcnt that leaves
+    //      exactly the DMA in flight. The V tile stays in LDS (swizzle C, read by rows as the B operand of dP).
+    const T* kp = (const T*)p.K + b * p.k_sb + (int64_t)key_ld * p.k_st + (int64_t)kvh * p.k_sh + lh * 8;
+    {
+        const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh + (int64_t)k0 * p.v_st;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 4 + (lane >> 4);
+            const int r = min(row, T_ - 1 - k0);
+            dma16x1(vbase + (int64_t)r * p.v_st + ((lane & 15) ^ swz_c(row)) * 8,
+                    lds_base + KD_V_OFF + (wave * 2 + i) * 1024);
+        }
+    }
+
+    // piece i = rows 4 i + (lane>>4): source byte offset = row * stride * 2 + (dsw0 ^ ((i & 3) << 4))
+    // (swz_c(row) = ((lane>>4) << 2) | (i & 3) for these rows)
+    const int64_t t_st = kh ? p.do_st : p.q_st;
+    const int dsw0 = ((lane & 15) ^ ((lane >> 4) << 2)) << 4;
+    const unsigned trow0 = (unsigned)((int64_t)(lane >> 4) * t_st * 2);
+    const unsigned tstep = (unsigned)(t_st * 8);                       // 4 rows in bytes
+    const int nq32 = (T_ + 31) / 32;
+    const int q32_first = k0 / 32;
+    const int nsteps = (nq32 - q32_first + nslice - 1) / nslice;
+
+    // per-lane LDS read addresses inside a tile (swizzle C)
+    const int r_lane = l31 * 256 + ((swz_c(l31 & 15) ^ lh) << 4);
+    const int sg = lane & 15, gh = (lane >> 4) & 1;
+    const int t_lane = (4 * lh + (sg >> 2)) * 256 +
+                       ((((sg >> 2) << 2) | (((gh << 1) | ((sg >> 1) & 1)) ^ lh)) << 4) + (sg & 1) * 8;
+
+    f32x16_t dk_acc[4], dv_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
+
+    for (int pass = 0; pass < npass; ++pass) {
+        const int head = kvh * G + pass * hpp + hin;
+        const T* tbase = (kh ? (const T*)p.dO + b * p.do_sb + (int64_t)head * p.do_sh
+                             : (const T*)p.Q + b * p.q_sb + (int64_t)head * p.q_sh);
+        auto q0_of = [&](int step, int sl) { return (q32_first + step * nslice + sl) * 32; };
+        auto issue = [&](int step, int stage) {
+            int q0 = q0_of(step, slice);
+            if (q0 >= T_) q0 = (nq32 - 1) * 32;                  // idle unit this step: any valid tile
+            const unsigned d = lds_base + stage * KD_STG + unit * 16384 + kh * 8192;
+            unsigned o[8];
+            if (q0 + 32 <= T_) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = trow0 + i * tstep + (unsigned)(dsw0 ^ ((i & 3) << 4));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = min(i * 4 + (lane >> 4), T_ - 1 - q0);
+                    o[i] = (unsigned)((int64_t)r * t_st * 2) + (unsigned)(dsw0 ^ ((i & 3) << 4));
+                }
+            }
+            dma16x4g(tbase + (int64_t)q0 * t_st, o[0], o[1], o[2], o[3], d);
+            dma16x4g(tbase + (int64_t)q0 * t_st, o[4], o[5], o[6], o[7], d + 4096);
+            {
+                // stats, 1 KiB: lanes 0-31 LSE, 32-63 Delta; unit (lane>>3)&3, 4 floats at q0_u + 4 (lane&7). Every
+                // wave issues the same copy, so all waves count 9 DMA instructions per step.
+                const int su = (lane >> 3) & 3;
+                int sq0 = q0_of(step, su / hpp);
+                if (sq0 >= T_) sq0 = (nq32 - 1) * 32;
+                const int sh = kvh * G + pass * hpp + (su % hpp);
+                const float* sp = (lane < 32 ? p.LSE : p.Delta) + ((int64_t)b * p.Hq + sh) * p.lse_st + sq0 + 4 * (lane & 7);
+                dma16x1(sp, lds_base + stage * KD_STG + 65536);
+            }
+        };
+
+        issue(0, 0);
+        for (int step = 0; step < nsteps; ++step) {
+            const int stage = step & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // K operand loads first (older than the DMA below), unconditionally: no phi, no compiler copies of
+            // registers whose data has not landed
+            uamd_u32x4 kr0, kr1, kr2, kr3, kr4, kr5, kr6, kr7;
+            asm volatile(
+                "global_load_dwordx4 %0, %8, off\n\t"
+                "global_load_dwordx4 %1, %8, off offset:32\n\t"
+                "global_load_dwordx4 %2, %8, off offset:64\n\t"
+                "global_load_dwordx4 %3, %8, off offset:96\n\t"
+                "global_load_dwordx4 %4, %8, off offset:128\n\t"
+                "global_load_dwordx4 %5, %8, off offset:160\n\t"
+                "global_load_dwordx4 %6, %8, off offset:192\n\t"
+                "global_load_dwordx4 %7, %8, off offset:224"
+                : "=&v"(kr0), "=&v"(kr1), "=&v"(kr2), "=&v"(kr3), "=&v"(kr4), "=&v"(kr5), "=&v"(kr6), "=&v"(kr7)
+                : "v"(kp)
+                : "memory");
+            const bool more = step + 1 < nsteps;
+            if (more) issue(step + 1, stage ^ 1);                          // 9 DMA instructions per wave
+            if (more) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");     // K landed, DMA still in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const int q0 = q0_of(step, slice);
+            if (q0 >= T_ || q0 + 31 < k0 + kh * 32) continue;              // idle / entirely above the diagonal
+            const unsigned char* sq = smem + stage * KD_STG + unit * 16384;
+            const unsigned char* sdo = sq + 8192;
+            const unsigned char* sv = smem + KD_V_OFF + kh * 32 * 256;
+            const float* stats = reinterpret_cast<const float*>(smem + stage * KD_STG + 65536) + unit * 32;
+
+            f32x16_t sc, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                union { uint4 r; frag_t f; } qa;
+                union { uamd_u32x4 r; frag_t f; } kb;
+                qa.r = *reinterpret_cast<const uint4*>(sq + (r_lane ^ (ks * 32)));
+                kb.r = ks == 0 ? kr0 : ks == 1 ? kr1 : ks == 2 ? kr2 : ks == 3 ? kr3 : ks == 4 ? kr4 : ks == 5 ? kr5
+                                                                                               : ks == 6 ? kr6 : kr7;
+                sc = MfmaA<T>::run(qa.f, kb.f, sc);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                union { uint4 r; frag_t f; } da, vb;
+                da.r = *reinterpret_cast<const uint4*>(sdo + (r_lane ^ (ks * 32)));
+                vb.r = *reinterpret_cast<const uint4*>(sv + (r_lane ^ (ks * 32)));
+                dp = MfmaA<T>::run(da.f, vb.f, dp);
+            }
+            const bool need_mask = (q0 < k0 + kh * 32 + 31) || (q0 + 32 > T_) || (k0 + KT > T_);
+            auto soft = [&](auto masked) {
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float4 l4 = *reinterpret_cast<const float4*>(stats + 8 * a + 4 * lh);
+                    const float4 d4 = *reinterpret_cast<const float4*>(stats + 128 + 8 * a + 4 * lh);
+                    const float lvv[4] = {l4.x, l4.y, l4.z, l4.w}, dlv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * a + j;
+                        const float lv = lvv[j], dl = dlv[j];
+                        float pv = __builtin_amdgcn_exp2f(sc[r] * p.scale_log2 - lv * 1.4426950408889634f);
+                        float ds = pv * (dp[r] - dl) * p.scale;
+                        if (decltype(masked)::value) {
+                            const int q = q0 + 8 * a + 4 * lh + j;
+                            if (key > q || q >= T_ || key >= T_) { pv = 0.f; ds = 0.f; }
+                        }
+                        sc[r] = pv;
+                        dp[r] = ds;
+                    }
+                }
+            };
+            if (need_mask) soft(std::true_type{}); else soft(std::false_type{});
+#ifdef UAMD_ATTN_DEBUG
+            if (wave == 0 && step == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+                float* dbg = p.Delta + (int64_t)p.B * p.Hq * p.lse_st;
+                for (int r = 0; r < 16; ++r) { dbg[lane * 32 + r] = sc[r]; dbg[lane * 32 + 16 + r] = dp[r]; }
+            }
+#endif
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                union { uint32_t w[4]; frag_t f; } pb, sb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pb.w[j] = pack_pair<T>(sc[8 * c + 2 * j], sc[8 * c + 2 * j + 1]);
+                    sb.w[j] = pack_pair<T>(dp[8 * c + 2 * j], dp[8 * c + 2 * j + 1]);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int a0 = (c * 16) * 256 + (t_lane ^ (dt << 6));
+                    union { s16x4_t h[2]; frag_t f; } ta, tq;
+                    ta.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sdo + a0));
+                    ta.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sdo + (a0 ^ 32) + 8 * 256));
+                    tq.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq + a0));
+                    tq.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq + (a0 ^ 32) + 8 * 256));
+                    dv_acc[dt] = MfmaA<T>::run(ta.f, pb.f, dv_acc[dt]);
+                    dk_acc[dt] = MfmaA<T>::run(tq.f, sb.f, dk_acc[dt]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_barrier();          // all reads of the last stages done before the next pass / reduction
+    }
+
+    // ---- sum the 4 units per key half through LDS (fixed order), store dV then dK
+    float* red = reinterpret_cast<float*>(smem);              // [8 waves][64 regs][64 lanes] = 128 KiB
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        if (which) __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                red[(wave * 64 + dt * 16 + r) * 64 + lane] = which ? dk_acc[dt][r] : dv_acc[dt][r];
+        __syncthreads();
+        T* outp = which ? (T*)p.dK : (T*)p.dV;
+        const int64_t o_sb = which ? p.dk_sb : p.dv_sb, o_st = which ? p.dk_st : p.dv_st, o_sh = which ? p.dk_sh : p.dv_sh;
+#pragma unroll
+        for (int okh = 0; okh < 2; ++okh) {
+            const int okey = k0 + okh * 32 + l31;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = wave * 8 + j;
+                float a = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += red[((2 * u + okh) * 64 + r) * 64 + lane];
+                v[j] = a;
+            }
+            if (okey < T_) {
+                T* op = outp + b * o_sb + (int64_t)okey * o_st + (int64_t)kvh * o_sh;
+                const int dt = wave >> 1, qd0 = 2 * (wave & 1);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int d = dt * 32 + (qd0 + h2) * 8 + lh * 4;
+                    uint2 o;
+                    o.x = pack_pair<T>(v[4 * h2 + 0], v[4 * h2 + 1]);
+                    o.y = pack_pair<T>(v[4 * h2 + 2], v[4 * h2 + 3]);
+                    *reinterpret_cast<uint2*>(op + d) = o;
+                }
+            }
+        }
     }
 }
 
 }  // namespace
 
+template <typename K_>
+int set_lds_attr(K_ kernel, int bytes, bool* done) {
+    if (!*done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) return (int)e;
+        *done = true;
+    }
+    return 0;
+}
+
+extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
+                             const float* LSE, void* dQ, void* dK, void* dV, float* Delta,
+                             const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
+                             float scale, int causal, int dtype, void* stream) {
+    if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !Delta || !strides) return UAMD_ERR_ARG;
+    if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
+    if (B == 0 || T == 0) return UAMD_OK;
+    if (D != AD || !causal || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
+    const int G = Hq / Hk;
+    if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
+    for (int i = 0; i < 24; ++i)
+        if (strides[i] & 7) return UAMD_ERR_ALIGN;
+    if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O) || !aligned16(dO) || !aligned16(dQ) ||
+        !aligned16(dK) || !aligned16(dV) || !aligned16(LSE) || !aligned16(Delta))
+        return UAMD_ERR_ALIGN;
+    if (strides[1] > (1 << 22) || strides[4] > (1 << 22) || strides[7] > (1 << 22) || strides[13] > (1 << 22))
+        return UAMD_ERR_ARG;
+    AttnBwdArgs a;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.LSE = LSE; a.dQ = dQ; a.dK = dK; a.dV = dV; a.Delta = Delta;
+    a.q_sb = strides[0]; a.q_st = strides[1]; a.q_sh = strides[2];
+    a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
+    a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];
+    a.o_sb = strides[9]; a.o_st = strides[10]; a.o_sh = strides[11];
+    a.do_sb = strides[12]; a.do_st = strides[13]; a.do_sh = strides[14];
+    a.dq_sb = strides[15]; a.dq_st = strides[16]; a.dq_sh = strides[17];
+    a.dk_sb = strides[18]; a.dk_st = strides[19]; a.dk_sh = strides[20];
+    a.dv_sb = strides[21]; a.dv_st = strides[22]; a.dv_sh = strides[23];
+    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
+    a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    const int QT = 32 * a.nsub;
+    dim3 grid_q((unsigned)((T + QT - 1) / QT), (unsigned)Hk, (unsigned)B);
+    dim3 grid_k((unsigned)((T + KT - 1) / KT), (unsigned)Hk, (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set[4][64] = {{false}};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int rc;
+    if (dtype == UAMD_BF16) {
+        if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t>, ATTN_LDS, &attr_set[0][dev]))) return rc;
+        if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<bf16_t>, KD_LDS, &attr_set[1][dev]))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t>), grid_q, dim3(512), ATTN_LDS, st, a);
+        if ((rc = uamd_launch_status())) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), grid_k, dim3(512), KD_LDS, st, a);
+    } else if (dtype == UAMD_F16) {
+        if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t>, ATTN_LDS, &attr_set[2][dev]))) return rc;
+        if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<f16_t>, KD_LDS, &attr_set[3][dev]))) return rc;
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t>), grid_q, dim3(512), ATTN_LDS, st, a);
+        if ((rc = uamd_launch_status())) return rc;
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), grid_k, dim3(512), KD_LDS, st, a);
+    } else {
+        return UAMD_ERR_DTYPE;
+    }
+    return uamd_launch_status();
+}
+
 extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
-                             const int64_t* strides, int B, int T, int Hq, int Hk, int D, float scale,
-                             int causal, int dtype, void* stream) {
+                             const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
+                             float scale, int causal, int dtype, void* stream) {
     if (!Q || !K || !V || !O || !LSE || !strides || B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;
-    if (D != AD || !causal || Hq % Hk) return UAMD_ERR_ARG;
+    if (D != AD || !causal || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
     const int G = Hq / Hk;
     if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
     for (int i = 0; i < 12; ++i)
@@ -293,7 +821,7 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
     a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];
     a.o_sb = strides[9]; a.o_st = strides[10]; a.o_sh = strides[11];
-    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G;
+    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale_log2 = scale * 1.4426950408889634f;
     const int QT = 32 * a.nsub;
     dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)Hk, (unsigned)B);

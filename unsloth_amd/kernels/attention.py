@@ -14,6 +14,7 @@ import torch
 from .. import _lib
 
 _I64x12 = ctypes.c_int64 * 12
+_I64x24 = ctypes.c_int64 * 24
 
 
 def supported(q, k, v):
@@ -26,7 +27,11 @@ def _strides(*ts):
     for t in ts:
         assert t.stride(3) == 1, "head_dim must be contiguous"
         out += [t.stride(0), t.stride(1), t.stride(2)]
-    return _I64x12(*out)
+    return (_I64x12 if len(ts) == 4 else _I64x24)(*out)
+
+
+def _pad32(T):
+    return (T + 31) // 32 * 32
 
 
 def attn_forward(q, k, v, scale=None):
@@ -37,10 +42,57 @@ def attn_forward(q, k, v, scale=None):
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     o = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
-    lse = torch.empty((B, Hq, T), dtype=torch.float32, device=q.device)
+    Tp = _pad32(T)
+    lse = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
     with _lib.device_ctx(q):
         rc = _lib.lib().uamd_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(lse),
-                                      _strides(q, k, v, o), B, T, Hq, Hk, D, float(scale), 1,
+                                      _strides(q, k, v, o), B, T, Hq, Hk, D, Tp, float(scale), 1,
                                       _lib.dtype_code(q.dtype), _lib.stream_of(q))
     _lib.check(rc, "uamd_attn_fwd")
-    return o, lse
+    return o, lse[:, :, :T]
+
+
+def attn_backward(do, q, k, v, o, lse, scale=None):
+    """Gradients of attn_forward: (dq [B,T,Hq,D], dk, dv [B,T,Hk,D]), contiguous, in q's dtype. `lse` is the view
+    attn_forward returned (its storage is padded to a multiple of 32 positions). Two launches, deterministic."""
+    _lib.require_gpu(do, q, k, v, o)
+    B, T, Hq, D = q.shape
+    Hk = k.shape[2]
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    Tp = _pad32(T)
+    assert lse.stride(1) == Tp and lse.stride(2) == 1, "pass the LSE returned by attn_forward"
+    if do.stride(3) != 1:
+        do = do.contiguous()
+    dq = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
+    dk = torch.empty((B, T, Hk, D), dtype=q.dtype, device=q.device)
+    dv = torch.empty((B, T, Hk, D), dtype=q.dtype, device=q.device)
+    delta = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
+    with _lib.device_ctx(q):
+        rc = _lib.lib().uamd_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do),
+                                      _lib.ptr(lse), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(delta),
+                                      _strides(q, k, v, o, do, dq, dk, dv), B, T, Hq, Hk, D, Tp, float(scale), 1,
+                                      _lib.dtype_code(q.dtype), _lib.stream_of(q))
+    _lib.check(rc, "uamd_attn_bwd")
+    return dq, dk, dv
+
+
+class FlashAttention(torch.autograd.Function):
+    """o = causal_attention(q, k, v) on [B,T,H,128] views; saves (q, k, v, o, lse) like flash-attention."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        o, lse = attn_forward(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale)
+        return dq, dk, dv, None
+
+
+def flash_attention(q, k, v, scale=None):
+    return FlashAttention.apply(q, k, v, scale)
