@@ -223,7 +223,7 @@ def main():
                        "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
                        "gradient_checkpointing": a.gc == "on", "trainable_params": n_train,
-                       "attention": "torch SDPA (flash)", "optimizer": "AdamW(fused) fp32 on LoRA params"},
+                       "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": "AdamW(fused) fp32 on LoRA params"},
             "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T,
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,

@@ -44,6 +44,9 @@ from ..utils.packing import (
 )
 from .. import lora as _lora
 from .. import nf4 as _nf4
+from ..kernels import attention as _flash
+
+_USE_FLASH = os.environ.get("UNSLOTH_AMD_FLASH_ATTENTION", "1") == "1"
 
 __version__ = "0.1.0"
 
@@ -123,11 +126,20 @@ def original_apply_o(self, X):
 
 
 def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
-    """causal (GQA, packed, windowed) attention via torch SDPA. Q [B,Hq,T,D], K/V [B,Hk,T,D]."""
-    T = Q.shape[2]
+    """causal (GQA, packed, windowed) attention. Q [B,Hq,T,D], K/V [B,Hk,T,D] (strided views of the [B,T,H,D]
+    projection outputs) -> [B, T, Hq*D].
+    Plain causal batches with head_dim 128 take the hand-written CDNA4 kernels (kernels/attention.py), which read
+    the [B,T,H,D] memory directly and write the o_proj input layout: no transposes, no copies. Packed /
+    masked / windowed batches use torch SDPA with an explicit mask (run_attention's SDPA branch,
+    attention_dispatch.py:560-617)."""
+    B, Hq, T, D = Q.shape
     window = sliding_window if (sliding_window is not None and T > sliding_window) else None   # mistral.py:116-120
     if seq_info is None and attention_mask is None and window is None:
-        return F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
+        q, k, v = Q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2)          # [B,T,H,D] views
+        if _USE_FLASH and _flash.supported(q, k, v):
+            return _flash.flash_attention(q, k, v).reshape(B, T, Hq * D)
+        A = F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
+        return A.transpose(1, 2).reshape(B, T, Hq * D)
     if seq_info is not None:
         mask = build_sdpa_packed_attention_mask(seq_info, dtype=Q.dtype, device=Q.device, sliding_window=window)
     else:
@@ -139,7 +151,8 @@ def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
         if attention_mask is not None:
             allowed = allowed & attention_mask.to(torch.bool)[:, None, None, :]
         mask = torch.zeros(allowed.shape, dtype=Q.dtype, device=Q.device).masked_fill_(~allowed, float("-inf"))
-    return F.scaled_dot_product_attention(Q, K, V, attn_mask=mask, enable_gqa=True)
+    A = F.scaled_dot_product_attention(Q, K, V, attn_mask=mask, enable_gqa=True)
+    return A.transpose(1, 2).reshape(B, T, Hq * D)
 
 
 def LlamaAttention_fast_forward(self, hidden_states, cos, sin, rope_position_ids=None, seq_info=None,
@@ -154,8 +167,7 @@ def LlamaAttention_fast_forward(self, hidden_states, cos, sin, rope_position_ids
     K = K.view(bsz, q_len, n_kv_heads, head_dim).transpose(1, 2)
     V = V.view(bsz, q_len, n_kv_heads, head_dim).transpose(1, 2)
     Q, K = fast_rope_embedding(Q, K, cos, sin, rope_position_ids)        # in place on the strided views
-    A = _attention(Q, K, V, seq_info, attention_mask, getattr(cfg, "sliding_window", None))
-    attn_output = A.transpose(1, 2).reshape(bsz, q_len, n_heads * head_dim)
+    attn_output = _attention(Q, K, V, seq_info, attention_mask, getattr(cfg, "sliding_window", None))
     return self.apply_o(self, attn_output)
 
 
