@@ -300,20 +300,22 @@ def test_gemm256_groups_lora_accumulate(force256):
 
 # ---------------------------------------------------------------- LoRA gradient products (csrc/lora_side.hip)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("M,N,R", [(1000, 260, 8), (512, 256, 16), (2048, 4096, 16), (777, 1028, 40), (3, 4, 1)])
+@pytest.mark.parametrize("M,N,R", [(1000, 264, 8), (512, 256, 16), (2048, 4096, 16), (777, 1032, 40), (3, 8, 1),
+                                   (8192, 1024, 16)])
 def test_lora_tn_matches_fp64(dtype, M, N, R):
     """G = s * P^T @ Z with P rounded to the activation dtype (where the reference holds a bf16 tensor),
     fp32 accumulate. Oracle: the same product in float64 on the CPU. Both output layouts, several problems in one
     launch, ragged M / N / rank, run-to-run bitwise determinism."""
     from unsloth_amd.kernels.utils import lora_tn
-    P = torch.randn(M, R + 3, generator=g(201))                     # extra columns: ldp != R
+    Rp = (R + 3) // 4 * 4
+    P = torch.randn(M, Rp + 4, generator=g(201))                    # ldp != R; second problem starts at column 4
     Z = torch.randn(M, N, generator=g(202)).to(dtype)
     Z2 = torch.randn(M, 2 * N, generator=g(203)).to(dtype)
     Pd, Zd, Z2d = P.to(DEV), Z.to(DEV), Z2.to(DEV)
-    probs = [(Pd[:, :R], Zd, R, False, 0.5), (Pd[:, :R], Zd, R, True, 2.0), (Pd[:, 1:R + 1], Z2d, R, False, 1.0)]
+    probs = [(Pd[:, :R], Zd, R, False, 0.5), (Pd[:, :R], Zd, R, True, 2.0), (Pd[:, 4:4 + R], Z2d, R, False, 1.0)]
     outs = lora_tn(probs)
     Pr = P.to(dtype).double()
-    want = [0.5 * Pr[:, :R].t() @ Z.double(), (2.0 * Pr[:, :R].t() @ Z.double()).t(), Pr[:, 1:R + 1].t() @ Z2.double()]
+    want = [0.5 * Pr[:, :R].t() @ Z.double(), (2.0 * Pr[:, :R].t() @ Z.double()).t(), Pr[:, 4:4 + R].t() @ Z2.double()]
     for o, w in zip(outs, want):
         assert o.dtype == torch.float32 and tuple(o.shape) == tuple(w.shape)
         err = (o.double().cpu() - w).abs().max().item()

@@ -7,15 +7,14 @@
 // uamd_lora_xa, rounded to the activation dtype on load exactly where the reference holds a bf16 tensor) and
 // Z = X, dY, h, df, de ... ([M, N] activations, N = 1024..14336).
 //
-// These are memory-bound streaming passes over Z (2 B per 2*r flops), not GEMM-shaped work for the matrix
-// cores: Z is read exactly once, 8 bytes per lane per row (a wave covers a 256-column slab), the r <= 16
-// coefficients of a row PAIR are wave-uniform and come from a 1 KiB LDS table by broadcast ds_read_b128, and
-// the arithmetic is v_pk_fma_f32 (two columns per instruction, fp32): 32 packed FMAs + 4 unpack ops per row x 4
-// columns, which keeps the VALU under the HBM time (v_dot2c_f32_bf16 was tried first: it issues at a fraction
-// of the VALU rate on gfx950 and held the kernel at 2.7 TB/s). Up to 8 problems (all products of one
+// These are memory-bound streaming passes over Z (2 B per 2*r flops). Two VALU versions were measured first
+// (v_dot2c_f32_bf16, then v_pk_fma_f32 with 16-byte loads): both stalled near 3 TB/s because fp32 FMA throughput
+// (64 flop/clk/SIMD on gfx950, packed or not) is only just the HBM rate for r = 16. This version does the
+// contraction on the matrix cores; the contraction index being the ROW index of Z, the B operand comes from a
+// row-major LDS tile through the transposing read ds_read_b64_tr_b16. Up to 8 problems (all products of one
 // autograd Function) go in ONE launch. Split over the token dimension is deterministic: every wave owns one
-// (256-column slab, row chunk) unit and writes one partial slab; a second tiny kernel sums the partials in fixed
-// order. No LDS reduction, no barrier: occupancy is bounded by registers only.
+// (128-column slab, row chunk) unit and writes one partial slab; a second tiny kernel sums the partials in fixed
+// order.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
@@ -25,9 +24,8 @@ typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 namespace {
 
-constexpr int TN_COLS = 512;          // columns per slab (8 per lane)
+constexpr int TN_COLS = 128;          // columns per slab
 constexpr int TN_R = 16;              // ranks per problem
-constexpr int TN_RW = 8;              // ranks per wave
 
 struct TnArgs {
     int n_probs;
@@ -41,39 +39,64 @@ struct TnArgs {
     uamd_lora_tn_problem p[UAMD_TN_MAX_PROBLEMS];
 };
 
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
 
-// 16-bit float pair (one 32-bit word, little endian) -> two fp32
-template <typename T> __device__ __forceinline__ f32x2_t unpack2(uint32_t w);
-template <> __device__ __forceinline__ f32x2_t unpack2<bf16_t>(uint32_t w) {
-    f32x2_t r;
-    r.x = __uint_as_float(w << 16);
-    r.y = __uint_as_float(w & 0xffff0000u);
-    return r;
-}
-template <> __device__ __forceinline__ f32x2_t unpack2<f16_t>(uint32_t w) {
-    union { uint32_t u; f16_t h[2]; } v;
-    v.u = w;
-    f32x2_t r;
-    r.x = (float)v.h[0];
-    r.y = (float)v.h[1];
-    return r;
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+    typedef bf16x8_t frag;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mfma16<f16_t> {
+    typedef f16x8_t frag;
+    static __device__ __forceinline__ f32x4_t run(frag a, frag b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// One wave = one unit (128-column slab, row chunk), no block-level synchronisation. Per 32-row step:
+//   * the Z tile [32 rows x 256 B] and the P tile [32 rows x 16 ranks fp32] arrive in LDS by LDS-DMA (10 wave
+//     instructions), double-buffered, retired by a counted vmcnt: every byte this kernel reads from global memory
+//     is in flight while the previous step computes, with no VGPRs held for it;
+//   * G[r][n] += sum_m P[m][r] Z[m][n] is 8 v_mfma_f32_16x16x32 (i = rank, j = column, k = row): the A operand
+//     is P^T (8 strided LDS reads, rounded to the activation dtype where the reference holds a bf16 tensor),
+//     the B operand is Z with the contraction index on ROWS, which is what ds_read_b64_tr_b16 delivers from the
+//     row-major tile (32-byte granule ^= (row & 3) | ((row >> 3) & 1) << 2 keeps the 8 rows of a 32-lane half on
+//     8 different granules of the 256-byte bank row; applied on the DMA source address).
+constexpr int TN_ZT = 32 * 256;                  // Z tile bytes
+constexpr int TN_PT = 32 * 64;                   // P tile bytes
+constexpr int TN_STAGE = TN_ZT + TN_PT;          // 10 KiB
+constexpr int TN_WAVE_LDS = 2 * TN_STAGE;        // 20 KiB per wave, 80 KiB per block
+
+__device__ __forceinline__ void tn_dma(const void* gptr, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(lds_dst)
+        : "memory");
 }
 
-// One wave = one unit (512-column slab, 8 of the 16 ranks, row chunk). The two rank halves of a (slab, chunk) are
-// adjacent waves of one block, so the second read of Z hits L1/L2. Bytes in flight are what bounds a streaming
-// kernel here (~2.5 us loaded latency): 64 accumulator registers per lane leave room for 8 x 16-byte loads in
-// flight per lane at 4 waves per SIMD = 128 KiB per CU.
 template <typename T>
-__global__ void __launch_bounds__(256, 3) lora_tn_kernel(TnArgs a) {
-    __shared__ __attribute__((aligned(16))) float ptab[4 * 32 * 8];
+__global__ void __launch_bounds__(256) lora_tn_kernel(TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Mfma16<T>::frag frag_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
-    if (unit >= (int64_t)a.total_slabs * a.S * 2) return;      // wave-uniform; no block-level sync below
-    const int half = (int)(unit & 1);
-    const int slab_lin = (int)((unit >> 1) % a.total_slabs);
-    const int sblk = (int)((unit >> 1) / a.total_slabs);
+    if (unit >= (int64_t)a.total_slabs * a.S) return;          // wave-uniform; no block-level sync below
+    const int slab_lin = (int)(unit % a.total_slabs);
+    const int sblk = (int)(unit / a.total_slabs);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < UAMD_TN_MAX_PROBLEMS; ++i)
@@ -82,94 +105,96 @@ __global__ void __launch_bounds__(256, 3) lora_tn_kernel(TnArgs a) {
     const int slab = slab_lin - a.slab_start[pi];
     const int n_slabs = a.slab_start[pi + 1] - a.slab_start[pi];
     const int M = a.M, N = pr.N, R = pr.R;
-    const int r_lo = half * TN_RW;
-    const int n0 = slab * TN_COLS + lane * 8;
-    // lanes past the last column read the last valid 16 bytes instead (their partials are never summed)
-    const int n0c = n0 + 8 <= N ? n0 : (N >= 8 ? N - 8 : 0);
-    const bool col_ok = n0 + 8 <= N;                  // else: ragged tail handled by the guarded path
     const T* Z = (const T*)pr.Z;
     const float* P = pr.P;
-    float* mytab = ptab + wave * 256;                  // [32 rows][8 ranks] fp32
+    unsigned char* my = smem + wave * TN_WAVE_LDS;
+    const unsigned my_lds = (unsigned)(uintptr_t)(lds_u8*)my;
 
-    f32x2_t acc[TN_RW][4];
+    // ---- DMA plan. Z: instruction i (0..7) = rows 4i + (lane>>4), stored 16-B unit lane&15 of the 256-B row;
+    //      the stored 32-B granule (unit>>1) holds logical granule ^ f(row). Columns past N re-read the last
+    //      valid 16 bytes (their sums land in the padding of the partial slab and are never reduced).
+    //      P: instruction i (0..1) = rows 16i + (lane>>2), 4 ranks at 4 (lane&3); ranks >= R re-read rank 0.
+    const int zr4 = lane >> 4;
+    int zcol[8];
 #pragma unroll
-    for (int r = 0; r < TN_RW; ++r)
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + zr4;
+        const int f = (row & 3) | (((row >> 3) & 1) << 2);
+        const int u16 = ((((lane & 15) >> 1) ^ f) << 1) | (lane & 1);
+        int col = slab * TN_COLS + u16 * 8;
+        if (col + 8 > N) col = N - 8;
+        zcol[i] = col;
+    }
+    const int prow = lane >> 2;
+    const int pc = (lane & 3) * 4 + 4 <= ((R + 3) & ~3) ? (lane & 3) * 4 : 0;
+    auto issue = [&](int m0, int stage) {
+        const unsigned d = my_lds + stage * TN_STAGE;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[r][c] = f32x2_t{0.f, 0.f};
+        for (int i = 0; i < 8; ++i) {
+            int row = m0 + 4 * i + zr4;
+            row = row < M ? row : M - 1;
+            tn_dma(Z + (int64_t)row * pr.ldz + zcol[i], d + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int row = m0 + 16 * i + prow;
+            row = row < M ? row : M - 1;
+            tn_dma(P + (int64_t)row * pr.ldp + pc, d + TN_ZT + i * 1024);
+        }
+    };
 
-    const bool tail_cols = (N & 7) != 0 || N < 8;     // problem-uniform: N % 4 == 0 only
+    // ---- per-lane LDS read addresses
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int sg2 = l15 >> 2;
+    const int f_rd = sg2 | ((g4 & 1) << 2);
+    // transposing reads of Z: row 8 g4 + sg2 (+4 for the second read), granule jt ^ f, 8 B at 8 (l15 & 3)
+    const int z_lane = (8 * g4 + sg2) * 256 + f_rd * 32 + (l15 & 3) * 8;
+    // P^T: rank l15, rows 8 g4 + e
+    const int p_lane = TN_ZT + (8 * g4) * 64 + l15 * 4;
+
+    f32x4_t acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
     const int m_base = sblk * a.rows_per_wave;
-    for (int ch = 0; ch < a.rows_per_wave / 32; ++ch) {
-        const int mrow0 = m_base + ch * 32;
-        if (mrow0 >= M) break;                          // wave-uniform
-        // ---- stage the coefficients of these 32 rows, rounded to the activation dtype (the reference holds
-        //      dY @ B / X @ A^T as tensors of that dtype): lane -> (row = lane>>1, 4 ranks at (lane&1)*4)
-        {
-            const int row = lane >> 1, rq = (lane & 1) * 4;
-            const int gm = mrow0 + row;
-            float pv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = r_lo + rq + i;
-                const float x = (gm < M && r < R) ? P[(int64_t)gm * pr.ldp + r] : 0.f;
-                pv[i] = round_to<T>(x);
-            }
-            *reinterpret_cast<float4*>(mytab + row * 8 + rq) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-        }
-        const bool full = (mrow0 + 32 <= M) && !tail_cols;          // wave-uniform
-        // ---- stream the 32 rows (same wave wrote the table: LDS is in order per wave). Per row: one 16-byte
-        //      load, 8 unpack ops, 32 v_pk_fma_f32 (rank coefficient broadcast to both halves).
-#define TN_ROW(LOAD)                                                                                     \
-        {                                                                                                \
-            const uint4 z = LOAD;                                                                        \
-            const f32x2_t z0 = unpack2<T>(z.x), z1 = unpack2<T>(z.y), z2 = unpack2<T>(z.z), z3 = unpack2<T>(z.w); \
-            const float4 q0 = *reinterpret_cast<const float4*>(mytab + rr * 8);       /* broadcast reads */  \
-            const float4 q1 = *reinterpret_cast<const float4*>(mytab + rr * 8 + 4);                       \
-            const float pc[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};                         \
-            _Pragma("unroll") for (int r = 0; r < TN_RW; ++r) {                                           \
-                const f32x2_t pp = {pc[r], pc[r]};                                                        \
-                acc[r][0] = __builtin_elementwise_fma(pp, z0, acc[r][0]);                                 \
-                acc[r][1] = __builtin_elementwise_fma(pp, z1, acc[r][1]);                                 \
-                acc[r][2] = __builtin_elementwise_fma(pp, z2, acc[r][2]);                                 \
-                acc[r][3] = __builtin_elementwise_fma(pp, z3, acc[r][3]);                                 \
-            }                                                                                             \
-        }
-        if (full) {
-            const T* zp = Z + (int64_t)mrow0 * pr.ldz + n0c;
-#pragma unroll 8
-            for (int rr = 0; rr < 32; ++rr) TN_ROW(*reinterpret_cast<const uint4*>(zp + (int64_t)rr * pr.ldz))
+    const int m_end = min(m_base + a.rows_per_wave, M);
+    const int nch = (m_end - m_base + 31) / 32;
+    if (nch > 0) issue(m_base, 0);
+    for (int ch = 0; ch < nch; ++ch) {
+        const int m0 = m_base + ch * 32;
+        const int stage = ch & 1;
+        if (ch + 1 < nch) {
+            issue(m0 + 32, stage ^ 1);
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         } else {
-            for (int rr = 0; rr < 32; ++rr) {
-                const int gm = mrow0 + rr;
-                uint4 zz = make_uint4(0, 0, 0, 0);
-                if (gm < M) {
-                    if (col_ok) {
-                        zz = *reinterpret_cast<const uint4*>(Z + (int64_t)gm * pr.ldz + n0);
-                    } else if (n0 < N) {               // N % 4 == 0: exactly 4 valid columns
-                        const uint2 h = *reinterpret_cast<const uint2*>(Z + (int64_t)gm * pr.ldz + n0);
-                        zz.x = h.x; zz.y = h.y;
-                    }
-                }
-                TN_ROW(zz)
-            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#undef TN_ROW
+        const unsigned char* sz = my + stage * TN_STAGE;
+        // A operand: P^T[rank][rows], rounded to T; rows past M and ranks past R contribute zero
+        union { T e[8]; frag_t f; } pa;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = *reinterpret_cast<const float*>(sz + p_lane + e * 64);
+            if (m0 + 8 * g4 + e >= M || l15 >= R) x = 0.f;
+            pa.e[e] = from_f32<T>(x);
+        }
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+            union { s16x4_t h[2]; frag_t f; } zb;
+            const int a0 = z_lane ^ (jt * 32);
+            zb.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sz + a0));
+            zb.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sz + a0 + 4 * 256));
+            acc[jt] = Mfma16<T>::run(pa.f, zb.f, acc[jt]);
+        }
     }
 
-    // ---- partial store: part[sblk][r][n], n padded to whole slabs (2 KiB contiguous per rank per wave).
-    //      On the full path, lanes past N hold sums of clamped columns: stored into padding, never reduced.
+    // ---- partial store: part[sblk][r][n], n padded to whole slabs. C layout: column = lane & 15, rank = 4 (lane>>4) + reg
     const int64_t npad = (int64_t)n_slabs * TN_COLS;
-    float* part = a.ws + a.ws_off[pi] + ((int64_t)sblk * TN_R + r_lo) * npad + slab * TN_COLS + lane * 8;
-    const bool keep = tail_cols || col_ok;              // clamped lanes must not clobber real columns
-    if (keep) {
+    float* part = a.ws + a.ws_off[pi] + (int64_t)sblk * TN_R * npad + slab * TN_COLS + l15;
 #pragma unroll
-        for (int r = 0; r < TN_RW; ++r) {
-            *reinterpret_cast<float4*>(part + (int64_t)r * npad) =
-                make_float4(acc[r][0].x, acc[r][0].y, acc[r][1].x, acc[r][1].y);
-            *reinterpret_cast<float4*>(part + (int64_t)r * npad + 4) =
-                make_float4(acc[r][2].x, acc[r][2].y, acc[r][3].x, acc[r][3].y);
-        }
-    }
+    for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[(int64_t)(4 * g4 + r) * npad + jt * 16] = acc[jt][r];
 }
 
 // out = scale * sum_s part[s]; out_nr == 0: out[r * ldo + n], else out[n * ldo + r]
@@ -190,6 +215,17 @@ __global__ void __launch_bounds__(256) lora_tn_reduce_kernel(TnArgs a) {
     else pr.out[(int64_t)r * pr.ldo + n] = v;
 }
 
+template <typename K_>
+int tn_set_attr(K_ kernel, bool* done) {
+    if (!*done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TN_WAVE_LDS);
+        if (e != hipSuccess) return (int)e;
+        *done = true;
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* workspace,
@@ -202,7 +238,7 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
         int64_t slabs_all = 0;
         for (int i = 0; i < n_probs; ++i) slabs_all += (probs[i].N + TN_COLS - 1) / TN_COLS;
         int rpw = 512;
-        while (rpw > 128 && 2 * slabs_all * ((M + rpw - 1) / rpw) < 4096) rpw >>= 1;
+        while (rpw > 128 && slabs_all * ((M + rpw - 1) / rpw) < 4096) rpw >>= 1;
         a.rows_per_wave = rpw;
         a.S = (M + rpw - 1) / rpw;
     }
@@ -214,7 +250,7 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
         if (i < n_probs) {
             const uamd_lora_tn_problem& p = probs[i];
             if (!p.P || !p.Z || !p.out || p.N <= 0 || p.R <= 0 || p.R > TN_R) return UAMD_ERR_ARG;
-            if ((p.N & 3) || (p.ldz & 3) || (reinterpret_cast<uintptr_t>(p.Z) & 7)) return UAMD_ERR_ALIGN;
+            if ((p.N & 7) || p.N < 8 || (p.ldz & 7) || (p.ldp & 3) || !aligned16(p.Z) || !aligned16(p.P)) return UAMD_ERR_ALIGN;
             a.p[i] = p;
             a.ws_off[i] = off;
             const int ns = (p.N + TN_COLS - 1) / TN_COLS;
@@ -231,17 +267,22 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
     for (int i = n_probs; i < UAMD_TN_MAX_PROBLEMS; ++i) a.slab_start[i + 1] = slabs;
     a.total_slabs = slabs;
     if (off > workspace_floats) return UAMD_ERR_ARG;
-    const int64_t blocks = ((int64_t)slabs * a.S * 2 + 3) / 4;
+    const int64_t blocks = ((int64_t)slabs * a.S + 3) / 4;
     if (blocks > 0x7fffffffLL) return UAMD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    static bool attr_set[2][64] = {{false}};
+    int dev = 0, rc;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (dtype == UAMD_BF16) {
-        hipLaunchKernelGGL((lora_tn_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if ((rc = tn_set_attr(&lora_tn_kernel<bf16_t>, &attr_set[0][dev]))) return rc;
+        hipLaunchKernelGGL((lora_tn_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 4 * TN_WAVE_LDS, st, a);
     } else if (dtype == UAMD_F16) {
-        hipLaunchKernelGGL((lora_tn_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 0, st, a);
+        if ((rc = tn_set_attr(&lora_tn_kernel<f16_t>, &attr_set[1][dev]))) return rc;
+        hipLaunchKernelGGL((lora_tn_kernel<f16_t>), dim3((unsigned)blocks), dim3(256), 4 * TN_WAVE_LDS, st, a);
     } else {
         return UAMD_ERR_DTYPE;
     }
-    int rc = uamd_launch_status();
+    rc = uamd_launch_status();
     if (rc) return rc;
     hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3((unsigned)max_rn_blocks, (unsigned)n_probs), dim3(256), 0, st, a);
     return uamd_launch_status();

@@ -362,7 +362,7 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
 # ------------------------------------------------------------------------------------------------
 # LoRA gradient products  G = s * P^T @ Z  (csrc/lora_side.hip)
 def lora_tn_supported(Zs):
-    return all(Z.is_cuda and Z.dtype in (torch.bfloat16, torch.float16) and Z.shape[-1] % 4 == 0 for Z in Zs)
+    return all(Z.is_cuda and Z.dtype in (torch.bfloat16, torch.float16) and Z.shape[-1] % 8 == 0 for Z in Zs)
 
 
 def lora_tn(problems):
@@ -392,7 +392,7 @@ def lora_tn(problems):
     L = _lib.lib()
     for i in range(0, len(descs), 8):
         chunk = descs[i:i + 8]
-        need = sum(S * 16 * ((d.N + 511) // 512) * 512 for d in chunk)
+        need = sum(S * 16 * ((d.N + 127) // 128) * 128 for d in chunk)
         ws = _nf4.scratch(dev, need, torch.float32, slot=40)
         arr = (_lib.LoraTnProblem * len(chunk))(*chunk)
         with _lib.device_ctx(ws):
