@@ -178,6 +178,10 @@ int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
  * (csrc/gemm_w4.hip); the large-M kernel. Requires K % 32 == 0, lda/ldb <= 2^22 elements. */
 int uamd_gemm_nt_w4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                     int n_groups, int accumulate, int dtype, void* stream);
+/* uamd_gemm_nt_fr: same contract, 256x256x64 tiles, 8 free-running waves (128x64 each, v_mfma_f32_32x32x16,
+ * software-pipelined fragment reads, ONE barrier per K tile; csrc/gemm_fr.hip). Requires K % 64 == 0. */
+int uamd_gemm_nt_fr(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                    int n_groups, int accumulate, int dtype, void* stream);
 /* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
  *   UAMD_TUNE_W4_VARIANT  (UAMD_W4_VARIANT)   instruction-schedule variant of the w4 K-tile body: 0 free,
  *                                             1 chunk-pinned, 2 MFMA/ds_read alternating 1:1
@@ -186,7 +190,8 @@ int uamd_gemm_nt_w4(const void* A, int64_t lda, int M, int K, const uamd_gemm_gr
 #define UAMD_TUNE_GROUP_M 1
 #define UAMD_TUNE_STREAM_NT 2   /* (UAMD_STREAM_NT) streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
 #define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64 */
-#define UAMD_TUNE_COUNT 4
+#define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention dK/dV kernel: 1 = four waves x 512 registers, 0 = eight waves */
+#define UAMD_TUNE_COUNT 5
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

@@ -233,7 +233,7 @@ def test_lora_xa(M, K, Rs):
 
 
 # ---------------------------------------------------------------- 256x256 LDS-DMA ping-pong kernel
-@pytest.fixture(params=["w4", "pp"])
+@pytest.fixture(params=["w4", "pp", "fr"])
 def force256(request):
     """Force a 256x256 kernel for every shape: "w4" = csrc/gemm_w4.hip, "pp" = csrc/gemm256.hip."""
     from unsloth_amd.kernels import utils as U
@@ -248,8 +248,8 @@ def force256(request):
                                    (4096, 4096, 4096), (1000, 1024, 14336), (260, 516, 32), (256, 256, 96),
                                    (777, 333, 160)])
 def test_gemm256_dense(force256, dtype, M, N, K):
-    if force256 == "pp" and K % 64:
-        pytest.skip("gemm256.hip needs K % 64 == 0")
+    if force256 in ("pp", "fr") and K % 64:
+        pytest.skip("gemm256.hip / gemm_fr.hip need K % 64 == 0")
     from unsloth_amd.kernels.utils import lora_linear_forward
     X = torch.randn(M, K, generator=g(105)).to(dtype)
     W = (torch.randn(N, K, generator=g(106)) * 0.05).to(dtype)

@@ -43,10 +43,10 @@ def main():
                 U.GEMM256_MODE, U.LARGE_KERNEL = "on", kern
                 return U.lora_linear_forward(X, [(W, None, None, None, None)])[0]
             return f
-        for gm in (64, 4, 8, 16):               # 64 >= tiles_m: the old m-fastest raster
-            cands[f"pp_g{gm}"] = mk("pp", None, gm)
-        cands["w4v2_g8"] = mk("w4", 2, 8)
-        cands["w4v2_g64"] = mk("w4", 2, 64)
+        cands["pp"] = mk("pp", None, 8)
+        cands["fr"] = mk("fr", None, 8)
+        cands["fr_g4"] = mk("fr", None, 4)
+        cands["w4v2"] = mk("w4", 2, 8)
         for name, f in cands.items():
             y = f()
             err = float((y.float() - ref.float()).abs().max())

@@ -15,7 +15,7 @@ X = torch.randn(M, K, device="cuda", dtype=bf)
 W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
 L = _lib.lib()
 U.GEMM256_MODE = "on"
-for kern, var in (("pp", None), ("w4", 0), ("w4", 2)):
+for kern, var in (("pp", None), ("fr", None)):
     U.LARGE_KERNEL = kern
     if var is not None:
         L.uamd_set_tuning(0, var)

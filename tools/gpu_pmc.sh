@@ -7,8 +7,7 @@ rocprofv3 -L > $OUT/counters_list.txt 2>&1
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT" \
            "SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES GRBM_GUI_ACTIVE" \
-           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" \
-           "FETCH_SIZE" "WRITE_SIZE"; do
+           "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" ${PMC_EXTRA}; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $SET -d $OUT/${TAG}_$i -o pmc -- python $R/tools/gemm_pmc_probe.py $SHAPE > $OUT/${TAG}_$i.log 2>&1
   tail -1 $OUT/${TAG}_$i.log

@@ -26,6 +26,7 @@ SOURCES = [
     "gemm.hip",
     "gemm256.hip",
     "gemm_w4.hip",
+    "gemm_fr.hip",
     "lora_side.hip",
     "attention.hip",
 ]

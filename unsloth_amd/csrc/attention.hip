@@ -62,6 +62,7 @@ struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O; float* LSE;
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
     int B, T, Hq, Hk, G, nsub;          // G = Hq / Hk, nsub = 8 / G q-subtiles of 32 rows per block
+    int nqt;                             // number of q tiles
     int lse_st;                          // row stride of LSE [B, Hq, lse_st] (T rounded up to 32)
     float scale_log2;                    // softmax scale * log2(e)
 };
@@ -101,8 +102,12 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int G = p.G, T_ = p.T;
     const int QT = 32 * p.nsub;
-    const int qtile = (int)gridDim.x - 1 - (int)blockIdx.x;          // heaviest (latest) q tiles first
-    const int kvh = blockIdx.y, b = blockIdx.z;
+    // longest-processing-time-first over the WHOLE grid: all (batch, kv head) pairs of the heaviest q tile are
+    // dispatched first, the one-tile blocks fill the tail
+    const int npairs = p.Hk * p.B;
+    const int qtile = p.nqt - 1 - (int)(blockIdx.x / npairs);
+    const int pair_ = (int)(blockIdx.x % npairs);
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int head = kvh * G + (wave % G);
     const int qs = qtile * QT + (wave / G) * 32;                      // first q position of this wave
     const int q_pos = qs + l31;
@@ -288,7 +293,7 @@ struct AttnBwdArgs {
     void* dQ; void* dK; void* dV; float* Delta;
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh;
     int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
-    int B, T, Hq, Hk, G, nsub, lse_st;
+    int B, T, Hq, Hk, G, nsub, lse_st, nqt;
     float scale, scale_log2;
 };
 
@@ -303,8 +308,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int l31 = lane & 31, lh = lane >> 5;
     const int G = p.G, T_ = p.T;
     const int QT = 32 * p.nsub;
-    const int qtile = (int)gridDim.x - 1 - (int)blockIdx.x;
-    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int npairs = p.Hk * p.B;
+    const int qtile = p.nqt - 1 - (int)(blockIdx.x / npairs);
+    const int pair_ = (int)(blockIdx.x % npairs);
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int head = kvh * G + (wave % G);
     const int qs = qtile * QT + (wave / G) * 32;
     const int q_pos = qs + l31;
@@ -509,7 +516,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     const int hpp = G < 4 ? G : 4;                    // heads per pass
     const int npass = G / hpp, nslice = 4 / hpp;
     const int hin = unit % hpp, slice = unit / hpp;
-    const int jt = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    // key tile 0 sees every q tile (causal): heaviest first over the whole grid
+    const int npairs = p.Hk * p.B;
+    const int jt = (int)(blockIdx.x / npairs);
+    const int pair_ = (int)(blockIdx.x % npairs);
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int k0 = jt * KT;
     const int key = k0 + kh * 32 + l31;               // this lane's key (C-layout column)
     const int key_ld = key < T_ ? key : T_ - 1;
@@ -777,8 +788,9 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     const int QT = 32 * a.nsub;
-    dim3 grid_q((unsigned)((T + QT - 1) / QT), (unsigned)Hk, (unsigned)B);
-    dim3 grid_k((unsigned)((T + KT - 1) / KT), (unsigned)Hk, (unsigned)B);
+    a.nqt = (T + QT - 1) / QT;
+    dim3 grid_q((unsigned)(a.nqt * Hk * B));
+    dim3 grid_k((unsigned)(((T + KT - 1) / KT) * Hk * B));
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set[4][64] = {{false}};
     int dev = 0;
@@ -824,7 +836,8 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale_log2 = scale * 1.4426950408889634f;
     const int QT = 32 * a.nsub;
-    dim3 grid((unsigned)((T + QT - 1) / QT), (unsigned)Hk, (unsigned)B);
+    a.nqt = (T + QT - 1) / QT;
+    dim3 grid((unsigned)(a.nqt * Hk * B));
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set[2][64] = {{false}};
     int dev = 0;

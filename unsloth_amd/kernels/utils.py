@@ -33,7 +33,7 @@ FUSED_NF4_MAX_M = int(os.environ.get("UNSLOTH_AMD_FUSED_NF4_MAX_M", "512"))
 # dense GEMM kernel selection: "auto" = a 256x256 tile kernel once the launch has enough 256x256 tiles to fill the
 # 256 CUs (GEMM256_MIN_TILES), else the 128x128 register-staged kernel (csrc/gemm.hip); "on"/"off" force it.
 # Which 256x256 kernel: LARGE_KERNEL = "w4" (csrc/gemm_w4.hip: 4 waves, 32x32x16 MFMA, 4-stage DMA ring) or
-# "pp" (csrc/gemm256.hip: 8 waves in two anti-phase groups).
+# "pp" (csrc/gemm256.hip: 8 waves in two anti-phase groups) or "fr" (csrc/gemm_fr.hip: 8 free-running waves).
 GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
 GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "192"))
 LARGE_KERNEL = os.environ.get("UNSLOTH_AMD_LARGE_GEMM", "pp")
@@ -125,7 +125,7 @@ def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0)
 def _use_gemm256(M, K, groups):
     if GEMM256_MODE == "off" or K % (32 if LARGE_KERNEL == "w4" else 64):
         return False
-    if LARGE_KERNEL == "w4" and max([g.ldb for g in groups]) > (1 << 22):
+    if LARGE_KERNEL in ("w4", "fr") and max([g.ldb for g in groups]) > (1 << 22):
         return False
     if GEMM256_MODE == "on":
         return True
@@ -142,6 +142,8 @@ def _launch_gemm(X2d, groups, nf4, accumulate=False):
     elif _use_gemm256(M, K, groups):
         if LARGE_KERNEL == "w4":
             fn, name = L.uamd_gemm_nt_w4, "uamd_gemm_nt_w4"
+        elif LARGE_KERNEL == "fr":
+            fn, name = L.uamd_gemm_nt_fr, "uamd_gemm_nt_fr"
         else:
             fn, name = L.uamd_gemm_nt_256, "uamd_gemm_nt_256"
     else:
