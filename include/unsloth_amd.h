@@ -234,6 +234,11 @@ int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
                   void* dQ, void* dK, void* dV, float* Delta, const int64_t* strides, int B, int T, int Hq, int Hk,
                   int D, int lse_stride, float scale, int causal, int dtype, void* stream);
 
+/* uamd_lora_xa2: same contract as uamd_lora_xa for R <= 64, streaming version (csrc/lora_side.hip): 32 rows per
+ * block, K split over 4 waves, X and W through a per-wave LDS-DMA ring, fixed-order reduction. */
+int uamd_lora_xa2(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,
+                  int64_t ld_out, int M, int K, int R, int out_cols, int dtype, void* stream);
+
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
 int uamd_debug_mfma_probe(float* out, void* stream);
 

@@ -215,7 +215,8 @@ def test_lora_linear_dx_accumulates_groups():
     assert_ulp(got, want, dtype, ulps=2, atol=2.0 ** -7 * float(want.abs().mean()), what="dX", allow_frac=1e-3)
 
 
-@pytest.mark.parametrize("M,K,Rs", [(2048, 4096, [16, 16, 16]), (100, 512, [8]), (64, 14336, [64, 64])])
+@pytest.mark.parametrize("M,K,Rs", [(2048, 4096, [16, 16, 16]), (100, 512, [8]), (64, 14336, [64, 64]), (333, 520, [16, 8]),
+                                    (8192, 1024, [16]), (33, 64, [64]), (1, 8, [4])])
 def test_lora_xa(M, K, Rs):
     from unsloth_amd.kernels.utils import lora_xa
     dtype = torch.bfloat16

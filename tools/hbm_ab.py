@@ -84,10 +84,16 @@ def main():
     L.uamd_set_tuning(3, 1)
     # lora_xa / lora_tn
     A3 = [torch.nn.Parameter(torch.randn(16, H, device=DEV) * 0.02) for _ in range(3)]
-    ab(out, "lora_xa qkv (R=48)", T * H * 2, {"v1": lambda: U.lora_xa(X, A3)})
-    ab(out, "lora_xa o (R=16)", T * H * 2, {"v1": lambda: U.lora_xa(X, A3[:1])})
+    def xav(v, f):
+        def g():
+            U.LORA_XA_V2 = (v == 2)
+            return f()
+        return g
+    ab(out, "lora_xa qkv (R=48)", T * H * 2, {"v1": xav(1, lambda: U.lora_xa(X, A3)), "v2": xav(2, lambda: U.lora_xa(X, A3))})
+    ab(out, "lora_xa o (R=16)", T * H * 2, {"v1": xav(1, lambda: U.lora_xa(X, A3[:1])), "v2": xav(2, lambda: U.lora_xa(X, A3[:1]))})
     A1 = [torch.nn.Parameter(torch.randn(16, I, device=DEV) * 0.02)]
-    ab(out, "lora_xa down (R=16,K=14336)", T * I * 2, {"v1": lambda: U.lora_xa(e, A1)})
+    ab(out, "lora_xa down (R=16,K=14336)", T * I * 2, {"v1": xav(1, lambda: U.lora_xa(e, A1)), "v2": xav(2, lambda: U.lora_xa(e, A1))})
+    U.LORA_XA_V2 = True
     P = torch.randn(T, 16, device=DEV)
     ab(out, "lora_tn dA (Z=X)", T * H * 2, {"v1": lambda: U.lora_tn([(P, X, 16, False, 1.0)])})
     ab(out, "lora_tn dB (Z=e)", T * I * 2, {"v1": lambda: U.lora_tn([(P, e, 16, True, 1.0)])})

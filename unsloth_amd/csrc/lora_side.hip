@@ -215,6 +215,190 @@ __global__ void __launch_bounds__(256) lora_tn_reduce_kernel(TnArgs a) {
     else pr.out[(int64_t)r * pr.ldo + n] = v;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// XA[M, R] = X[M, K] @ W[R, K]^T (fp32 out): the skinny LoRA product of the forward (X @ A^T) and of the
+// backward (dY @ B). Replaces the first version in gemm.hip (16 rows per block, fragments straight from
+// global): that one re-read all of W per 16 rows (L2 traffic 3x the HBM traffic at R = 48: 1.3 TB/s) and kept
+// only a few KB in flight per CU.
+// Here a block owns 32 rows; its 4 waves split K four ways and each streams its [32 rows x K/4] slab of X and the
+// matching slab of W through a private double-buffered LDS ring by LDS-DMA (64-deep steps, counted vmcnt, no
+// block-level synchronisation until the end), multiplies with v_mfma_f32_16x16x32 (both operands K-contiguous,
+// plain row reads, 16-byte slot ^= (row >> 1) & 7 against bank conflicts), and the four partial [32 x R] tiles
+// are summed in fixed order through LDS.
+constexpr int XA_KS = 64;                              // k per step
+constexpr int XA_XT = 32 * XA_KS * 2;                  // X tile bytes (4 KiB)
+template <int NT> struct XaCfg {
+    static constexpr int WT = NT * 16 * XA_KS * 2;     // W tile bytes (2 KiB per 16 ranks)
+    static constexpr int STAGE = XA_XT + WT;
+    static constexpr int WAVE = 2 * STAGE;
+    static constexpr int RED = 4 * 32 * NT * 16 * 4;   // final reduction buffer
+    static constexpr int LDS = 4 * WAVE > RED ? 4 * WAVE : RED;
+};
+
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) lora_xa2_kernel(const T* __restrict__ X, int64_t ldx,
+                                                       const T* __restrict__ W, int64_t ldw,
+                                                       float* __restrict__ out, int64_t ld_out,
+                                                       int M, int K, int R, int out_cols) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Mfma16<T>::frag frag_t;
+    typedef XaCfg<NT> C;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int m0 = blockIdx.x * 32;
+    unsigned char* my = smem + wave * C::WAVE;
+    const unsigned my_lds = (unsigned)(uintptr_t)(lds_u8*)my;
+
+    // this wave's K range: whole 64-steps, split as evenly as possible; the ragged K tail (K % 64) goes to the
+    // last wave and is handled by clamping + zeroing
+    const int nsteps_all = (K + XA_KS - 1) / XA_KS;
+    const int s_beg = (nsteps_all * wave) / 4, s_end = (nsteps_all * (wave + 1)) / 4;
+
+    // DMA plan. X: instruction i (0..3) = rows 8i + (lane>>3), stored 16-B slot lane&7 holds logical slot
+    // (lane&7) ^ ((row>>1)&7). W: instruction i (0..2NT-1) = ranks 8i + (lane>>3), same swizzle.
+    const int drow = lane >> 3;
+    int xoff[4], woff[2 * NT];
+    int xslot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + drow;
+        xslot[i] = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        xoff[i] = gm;                                        // row index; column added per step
+    }
+    int wslot[2 * NT];
+#pragma unroll
+    for (int i = 0; i < 2 * NT; ++i) {
+        const int row = 8 * i + drow;
+        wslot[i] = (lane & 7) ^ ((row >> 1) & 7);
+        woff[i] = row < R ? row : R - 1;
+    }
+    auto issue = [&](int step, int stage) {
+        const unsigned d = my_lds + stage * C::STAGE;
+        const int k0 = step * XA_KS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int k = k0 + xslot[i] * 8;
+            k = k + 8 <= K ? k : K - 8;                      // ragged tail: valid bytes, zeroed at use
+            tn_dma(X + (int64_t)xoff[i] * ldx + k, d + i * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * NT; ++i) {
+            int k = k0 + wslot[i] * 8;
+            k = k + 8 <= K ? k : K - 8;
+            tn_dma(W + (int64_t)woff[i] * ldw + k, d + XA_XT + i * 1024);
+        }
+    };
+
+    f32x4_t acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read: row l15 (+16 per tile), logical slot 4 ks + g4 -> stored slot ^ ((row>>1)&7); rows 16..31
+    // have the same (row>>1)&7 pattern shifted: (row>>1)&7 = ((l15>>1) + 8*tile)&7 = (l15>>1)&7
+    const int sw = (l15 >> 1) & 7;
+    const int f_lane = l15 * 128;
+    constexpr int NDMA = 4 + 2 * NT;
+    // every block reads the SAME W slab; blocks start at rotated positions of their K range so that 256 CUs do not
+    // hammer the same L2 lines in the same microsecond (fixed per block: results stay run-to-run identical)
+    const int nst = s_end - s_beg;
+    const int rot = nst > 0 ? (int)(blockIdx.x % nst) : 0;
+    auto step_of = [&](int i) { const int j = i + rot; return s_beg + (j >= nst ? j - nst : j); };
+    if (nst > 0) issue(step_of(0), 0);
+    for (int it = 0; it < nst; ++it) {
+        const int st = step_of(it);
+        const int stage = it & 1;
+        if (it + 1 < nst) {
+            issue(step_of(it + 1), stage ^ 1);
+            if (NDMA == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (NDMA == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (NDMA == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char* sx = my + stage * C::STAGE;
+        const unsigned char* swt = sx + XA_XT;
+        const bool tail = st * XA_KS + XA_KS > K;             // wave-uniform
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ((4 * ks + g4) ^ sw) * 16;
+            union FU { uint4 r; frag_t f; };
+            FU xa[2], wb[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xa[i].r = *reinterpret_cast<const uint4*>(sx + i * 2048 + f_lane + slot);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) wb[j].r = *reinterpret_cast<const uint4*>(swt + j * 2048 + f_lane + slot);
+            if (tail) {
+                // columns past K: the DMA re-read the last 16 valid bytes; contribute nothing
+                if (st * XA_KS + ks * 32 + g4 * 8 + 8 > K) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xa[i].r = make_uint4(0, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc[i][j] = Mfma16<T>::run(xa[i].f, wb[j].f, acc[i][j]);
+        }
+    }
+
+    // ---- fixed-order reduction of the 4 K-quarters; C layout: column (rank) = l15, row = 4 g4 + reg
+    __syncthreads();                                          // every wave is done with its DMA ring
+    float* red = reinterpret_cast<float*>(smem);              // [4][32 rows][NT*16]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(wave * 32 + i * 16 + 4 * g4 + r) * (NT * 16) + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * out_cols; idx += 256) {
+        const int mm = idx / out_cols, c = idx - mm * out_cols;
+        if (m0 + mm < M) {
+            float v = 0.f;
+            if (c < R) {
+                const float* q = red + mm * (NT * 16) + c;
+                v = ((q[0] + q[32 * NT * 16]) + q[2 * 32 * NT * 16]) + q[3 * 32 * NT * 16];
+            }
+            out[(int64_t)(m0 + mm) * ld_out + c] = v;          // columns R..out_cols-1 are zero padding
+        }
+    }
+}
+
+template <typename T, int NT>
+int launch_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out, int M, int K,
+               int R, int out_cols, hipStream_t st) {
+    static bool done[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lora_xa2_kernel<T, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, XaCfg<NT>::LDS);
+        if (e != hipSuccess) return (int)e;
+        done[dev] = true;
+    }
+    hipLaunchKernelGGL((lora_xa2_kernel<T, NT>), dim3((unsigned)((M + 31) / 32)), dim3(256), XaCfg<NT>::LDS, st,
+                       (const T*)X, ldx, (const T*)W, ldw, out, ld_out, M, K, R, out_cols);
+    return uamd_launch_status();
+}
+
+template <typename T>
+int xa2_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out, int M, int K,
+                 int R, int out_cols, hipStream_t st) {
+    const int nt = (R + 15) / 16;
+    if (nt <= 1) return launch_xa2<T, 1>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    if (nt <= 2) return launch_xa2<T, 2>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    if (nt <= 3) return launch_xa2<T, 3>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    if (nt <= 4) return launch_xa2<T, 4>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    return UAMD_ERR_ARG;
+}
+
 template <typename K_>
 int tn_set_attr(K_ kernel, bool* done) {
     if (!*done) {
@@ -286,4 +470,16 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
     if (rc) return rc;
     hipLaunchKernelGGL(lora_tn_reduce_kernel, dim3((unsigned)max_rn_blocks, (unsigned)n_probs), dim3(256), 0, st, a);
     return uamd_launch_status();
+}
+
+// XA[M, out_cols] = X[M, K] @ W[R, K]^T in fp32 (columns >= R zero-filled), streaming version for R <= 64.
+extern "C" int uamd_lora_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out,
+                             int M, int K, int R, int out_cols, int dtype, void* stream) {
+    if (M < 0 || K < 8 || R <= 0 || out_cols < R || R > 64 || out_cols > 256) return UAMD_ERR_ARG;
+    if (M == 0) return UAMD_OK;
+    if ((K & 7) || (ldx & 7) || (ldw & 7) || !aligned16(X) || !aligned16(W)) return UAMD_ERR_ALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UAMD_BF16) return xa2_dispatch<bf16_t>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    if (dtype == UAMD_F16) return xa2_dispatch<f16_t>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    return UAMD_ERR_DTYPE;
 }

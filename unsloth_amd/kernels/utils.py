@@ -37,6 +37,8 @@ FUSED_NF4_MAX_M = int(os.environ.get("UNSLOTH_AMD_FUSED_NF4_MAX_M", "512"))
 GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
 GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "192"))
 LARGE_KERNEL = os.environ.get("UNSLOTH_AMD_LARGE_GEMM", "pp")
+# X @ A^T / dY @ B: streaming LDS-DMA kernel (csrc/lora_side.hip) for total rank <= 64, else the first version
+LORA_XA_V2 = os.environ.get("UNSLOTH_AMD_LORA_XA_V2", "1") == "1"
 
 
 def calculate_settings(n):
@@ -222,11 +224,12 @@ def lora_xa(X2d, A_list):
     if Rt > 192:
         raise NotImplementedError(f"sum of LoRA ranks sharing one input = {Rt} > 192")
     out = torch.empty((X2d.shape[0], Rt), dtype=torch.float32, device=X2d.device)
+    L = _lib.lib()
+    fn, name = (L.uamd_lora_xa2, "uamd_lora_xa2") if (LORA_XA_V2 and Rt <= 64 and K >= 8) else (L.uamd_lora_xa, "uamd_lora_xa")
     with _lib.device_ctx(X2d):
-        rc = _lib.lib().uamd_lora_xa(_lib.ptr(X2d), X2d.stride(0), _lib.ptr(Acat), Acat.stride(0),
-                                     _lib.ptr(out), out.stride(0), X2d.shape[0], K, Rt, Rt,
-                                     _lib.dtype_code(dtype), _lib.stream_of(X2d))
-    _lib.check(rc, "uamd_lora_xa")
+        rc = fn(_lib.ptr(X2d), X2d.stride(0), _lib.ptr(Acat), Acat.stride(0), _lib.ptr(out), out.stride(0),
+                X2d.shape[0], K, Rt, Rt, _lib.dtype_code(dtype), _lib.stream_of(X2d))
+    _lib.check(rc, name)
     offs, o = [], 0
     for rp in Rp:
         offs.append((o, rp))
