@@ -239,6 +239,19 @@ int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
 int uamd_lora_xa2(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,
                   int64_t ld_out, int M, int K, int R, int out_cols, int dtype, void* stream);
 
+/* Activation-dtype copies of fp32 LoRA factors, row-major and transposed, for ALL matrices in one launch (the
+ * reference casts per use: utils.py:1166-1167, fast_lora.py:138-145). `descs_dev` / `tile_prefix_dev` are DEVICE
+ * arrays: n_mats descriptors and the exclusive prefix sum of ceil(rows/32)*ceil(cols/32) tiles per matrix;
+ * total_tiles = their sum. dst_* may be NULL. */
+typedef struct {
+    const void* src;          /* fp32 [rows, cols] row-major */
+    void* dst_rowmajor;       /* dtype [rows, cols] or NULL */
+    void* dst_transposed;     /* dtype [cols, rows] or NULL */
+    int rows, cols;
+} uamd_lora_prep_desc;
+int uamd_lora_prepare(const uamd_lora_prep_desc* descs_dev, const int* tile_prefix_dev, int n_mats,
+                      int total_tiles, int dtype, void* stream);
+
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
 int uamd_debug_mfma_probe(float* out, void* stream);
 

@@ -44,9 +44,21 @@ def main():
                 return U.lora_linear_forward(X, [(W, None, None, None, None)])[0]
             return f
         cands["pp"] = mk("pp", None, 8)
-        cands["fr"] = mk("fr", None, 8)
-        cands["fr_g4"] = mk("fr", None, 4)
-        cands["w4v2"] = mk("w4", 2, 8)
+        pad = int(os.environ.get("GEMM_AB_PAD", "64"))
+        Xp = torch.empty(M, K + pad, device=DEV, dtype=bf)[:, :K]
+        Xp.copy_(X)
+        Wp = torch.empty(N, K + pad, device=DEV, dtype=bf)[:, :K]
+        Wp.copy_(W)
+
+        def pp_pad():
+            L.uamd_set_tuning(1, 8)
+            U.GEMM256_MODE, U.LARGE_KERNEL = "on", "pp"
+            return U.lora_linear_forward(Xp, [(Wp, None, None, None, None)])[0]
+        cands["pp_pad"] = pp_pad
+        cands["torch_pad"] = lambda: Xp @ Wp.t()
+        if os.environ.get("GEMM_AB_ALL"):
+            cands["fr"] = mk("fr", None, 8)
+            cands["w4v2"] = mk("w4", 2, 8)
         for name, f in cands.items():
             y = f()
             err = float((y.float() - ref.float()).abs().max())

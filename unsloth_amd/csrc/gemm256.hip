@@ -6,9 +6,9 @@
 // every operand byte crosses the VGPR->LDS store path (ds_write_b128 = 13 cycles / KiB) -- and tops out near
 // 0.85 PFLOP/s. Here:
 //   * operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4): no VGPR round trip, no ds_write;
-//   * one 1-KiB DMA instruction fills exactly one [16 rows x 32 k] MFMA sub-tile; the bank swizzle
-//     (16-byte slot ^= 2 for rows 8..15, conflict-free for ds_read_b128) is applied on the per-lane SOURCE
-//     address because the DMA destination is lane-linear;
+//   * one 1-KiB DMA instruction fills [8 rows x 64 k] = 8 full 128-byte lines (half of a 16-row MFMA tile, all of
+//     TK); the bank swizzle (16-byte slot ^= (row>>1)&7, conflict-free for ds_read_b128) is applied on the
+//     per-lane SOURCE address because the DMA destination is lane-linear;
 //   * 8 waves = 2 groups of 4 (group = wave>>2 owns 128 rows). The groups run in ANTI-PHASE: in every
 //     barrier-delimited slot one group issues its LDS fragment reads + next tiles' DMA while the other group
 //     owns the matrix pipe for 16 back-to-back MFMAs (two waves share a SIMD: one computes, one loads);
@@ -93,6 +93,25 @@ __device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
         __builtin_amdgcn_s_barrier();           \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
+
+// -DUAMD_G256_TRACE: s_memtime stamps at slot boundaries of K tiles 16 and 17 (tools/gemm_trace.py); never in
+// the shipped library.
+#ifdef UAMD_G256_TRACE
+__device__ unsigned* g_trace256 = nullptr;
+#endif
+#if defined(UAMD_G256_TRACE) && UAMD_G256_TRACE == 1
+#define STAMP(KT, I)                                                                    \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if ((KT) == 16 || (KT) == 17) {                                                 \
+            ts[(((KT) & 1) << 4) + (I)] = (unsigned)__builtin_amdgcn_s_memtime();       \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          \
+        }                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define STAMP(KT, I) do { } while (0)
+#endif
 
 template <typename T>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
@@ -179,34 +198,39 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
             for (int j = 0; j < 4; ++j) acc[i][j] *= s;
     }
 
-    // ---- DMA source pointers. Piece c (0..7) of a tile, issued by wave w, fills sub-tile u = c*8 + w:
-    //      u < 32: A rows rg*16.. (rg = (u>>1)&15), k half kh = u&1 ; u >= 32: B likewise.
-    //      lane -> (row = lane>>2, 16-byte slot = (lane&3) ^ (row>=8 ? 2 : 0)) inside the sub-tile.
-    const int sub_row = lane >> 2;
-    const int sub_slot = (lane & 3) ^ (((lane >> 5) & 1) << 1);
-    const int rg_w = wave >> 1, kh_w = wave & 1;
+    // ---- DMA source pointers. Piece c (0..7) of a tile, issued by wave w, fills sub-tile u = c*8 + w =
+    //      [8 rows x 64 k] = 8 FULL 128-byte lines (u < 32: A rows u*8.., u >= 32: B rows (u-32)*8..). Full lines
+    //      matter: the L2 serves requests, not bytes -- [16 rows x 64 B] half-line pieces deliver 36 B/clk/CU with
+    //      all CUs streaming, full-line pieces 59 (tools/probes/dma_probe.hip, profiles/r01_dma_probe.txt).
+    //      lane -> (row = lane>>3, 16-byte slot position q = lane&7) in LDS (the DMA destination is lane-linear);
+    //      the bank swizzle is applied on the SOURCE: position q of row r holds k-slot q ^ f(r), f = (r16>>1)&7
+    //      with r16 the row inside its 16-row MFMA tile (conflict-free for all four ds_read_b128 lane groups).
+    const int sub_row = lane >> 3;
+    const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
     const T* a_src[4];
     const T* b_src[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int ra = m0 + (c * 4 + rg_w) * 16 + sub_row;
-        int rb = n0 + (c * 4 + rg_w) * 16 + sub_row;
+        int ra = m0 + (c * 8 + wave) * 8 + sub_row;
+        int rb = n0 + (c * 8 + wave) * 8 + sub_row;
         ra = ra < M ? ra : M - 1;          // clamped rows are never stored
         rb = rb < N ? rb : N - 1;
-        a_src[c] = (const T*)p.A + (int64_t)ra * p.lda + kh_w * 32 + sub_slot * 8;
-        b_src[c] = (const T*)g.B + (int64_t)rb * g.ldb + kh_w * 32 + sub_slot * 8;
+        a_src[c] = (const T*)p.A + (int64_t)ra * p.lda + sub_slot * 8;
+        b_src[c] = (const T*)g.B + (int64_t)rb * g.ldb + sub_slot * 8;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
     auto issue = [&](int c, int kt, int stage) {       // c, stage are compile-time at every call site
         const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-        const T* src = (c < 4 ? a_src[c] : b_src[c - 4]) + (int64_t)kt * TK;
+        const T* src = (c < 4 ? a_src[c & 3] : b_src[c & 3]) + (int64_t)kt * TK;
         dma16(src, dst);
     };
 
-    // ---- fragment read offsets (bytes inside a stage)
-    const int frag_off = l15 * 64 + ((l4 ^ ((l15 >> 3) << 1)) << 4);
-    const int a_base = (grp * 8) * 2048 + frag_off;               // A sub-tile (rg, kh) at (rg*2+kh)*1024
-    const int b_base = 32 * 1024 + (wn * 4) * 2048 + frag_off;
+    // ---- fragment read offsets (bytes inside a stage): 16-row tile i of A at i*2 KiB ([16 rows][128 B]),
+    //      B tiles after the 32 KiB of A; lane reads row l15, k-slot (ks*4 + l4) ^ f(l15)
+    const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
+    const int frag_off[2] = {frag_off0, frag_off0 ^ 64};
+    const int a_base = (grp * 8) * 2048;
+    const int b_base = 32 * 1024 + (wn * 4) * 2048;
     frag_t af[4][2], bf[4][2];     // A: 4 m-tiles of the current 64-row half x 2 k-halves; B: 4 n-tiles x 2
     auto read_a = [&](int stage, int mq) {
 #pragma unroll
@@ -214,7 +238,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 union { uint4 r; frag_t f; } u;
-                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + a_base + ((mq * 4 + i) * 2 + ks) * 1024);
+                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + a_base + (mq * 4 + i) * 2048 + frag_off[ks]);
                 af[i][ks] = u.f;
             }
     };
@@ -224,7 +248,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 union { uint4 r; frag_t f; } u;
-                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + b_base + ((nq * 2 + j) * 2 + ks) * 1024);
+                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + b_base + (nq * 2 + j) * 2048 + frag_off[ks]);
                 bf[nq * 2 + j][ks] = u.f;
             }
     };
@@ -239,8 +263,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
                     acc[mq * 4 + i][nq * 2 + j] = Mfma2<T>::run(bf[nq * 2 + j][ks], af[i][ks], acc[mq * 4 + i][nq * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
-
     const int nk = K / TK;     // host guarantees K % 64 == 0
+#ifdef UAMD_G256_TRACE
+    unsigned ts[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) ts[i] = 0;
+    ts[30] = (unsigned)__builtin_amdgcn_s_memtime();      // whole-tile cycles (UAMD_G256_TRACE=2: only these two)
+#endif
     // ---- prologue: tile 0 completely, first 3 pieces of tile 1
 #pragma unroll
     for (int c = 0; c < 8; ++c) issue(c, 0, 0);
@@ -259,19 +288,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         read_a(STAGE, 0); read_b(STAGE, 0);                                              \
         if ((KT) + 1 < nk) { issue(3, (KT) + 1, (STAGE) ^ 1); issue(4, (KT) + 1, (STAGE) ^ 1); issue(5, (KT) + 1, (STAGE) ^ 1); } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-        SLOT_BARRIER();                                                                  \
-        mma(0, 0); SLOT_BARRIER();                                                       \
+        STAMP(KT, 8); SLOT_BARRIER(); STAMP(KT, 0);                                      \
+        mma(0, 0); STAMP(KT, 9); SLOT_BARRIER(); STAMP(KT, 1);                                                       \
         /* L1 */                                                                         \
         read_b(STAGE, 1);                                                                \
         if ((KT) + 1 < nk) { issue(6, (KT) + 1, (STAGE) ^ 1); issue(7, (KT) + 1, (STAGE) ^ 1); } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-        SLOT_BARRIER();                                                                  \
-        mma(0, 1); SLOT_BARRIER();                                                       \
+        STAMP(KT, 10); SLOT_BARRIER(); STAMP(KT, 2);                                     \
+        mma(0, 1); STAMP(KT, 11); SLOT_BARRIER(); STAMP(KT, 3);                                                       \
         /* L2 */                                                                         \
         read_a(STAGE, 1);                                                                \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
-        SLOT_BARRIER();                                                                  \
-        mma(1, 1); SLOT_BARRIER();                                                       \
+        STAMP(KT, 12); SLOT_BARRIER(); STAMP(KT, 4);                                     \
+        mma(1, 1); STAMP(KT, 13); SLOT_BARRIER(); STAMP(KT, 5);                                                       \
         /* L3: this stage is drained by BOTH groups (their last reads ended >= 1 barrier ago) */ \
         if ((KT) + 2 < nk) {                                                             \
             issue(0, (KT) + 2, STAGE); issue(1, (KT) + 2, STAGE); issue(2, (KT) + 2, STAGE); \
@@ -279,8 +308,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         } else {                                                                         \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
         }                                                                                \
-        SLOT_BARRIER();                                                                  \
-        mma(1, 0); SLOT_BARRIER();                                                       \
+        STAMP(KT, 14); SLOT_BARRIER(); STAMP(KT, 6);                                     \
+        mma(1, 0); STAMP(KT, 15); SLOT_BARRIER(); STAMP(KT, 7);                                                       \
     } while (0)
 
     int kt = 0;
@@ -290,7 +319,15 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     }
     if (kt < nk) TILE_BODY(0, kt);
 #undef TILE_BODY
+
     if (grp == 0) SLOT_BARRIER();          // match group 1's extra barrier
+#ifdef UAMD_G256_TRACE
+    ts[31] = (unsigned)__builtin_amdgcn_s_memtime();
+    if (g_trace256 && lane == 0 && blockIdx.x < 1024) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) g_trace256[(blockIdx.x * 8 + wave) * 32 + i] = ts[i];
+    }
+#endif
 
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = ..+4*l4 (operands were passed swapped)
     T* Cg = (T*)g.C;
@@ -342,6 +379,12 @@ int launch256(const G256Args& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef UAMD_G256_TRACE
+extern "C" int uamd_debug_g256_trace(unsigned* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace256), &buf, sizeof(buf));
+}
+#endif
 
 // Same contract as uamd_gemm_nt (dense B), 256x256x64 tiles. Requires K % 64 == 0.
 extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,

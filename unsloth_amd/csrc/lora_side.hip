@@ -483,3 +483,63 @@ extern "C" int uamd_lora_xa2(const void* X, int64_t ldx, const void* W, int64_t 
     if (dtype == UAMD_F16) return xa2_dispatch<f16_t>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
     return UAMD_ERR_DTYPE;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Once per optimizer step: activation-dtype copies of every LoRA factor, row-major AND transposed, in ONE launch.
+// The reference casts at every use (`A.to(dtype)`, `B.to(dtype)`, unsloth/kernels/utils.py:1166-1167,
+// fast_lora.py:138-145), i.e. ~1,400 tiny cast / transpose kernels per step at 7 projections x 32 layers.
+// Descriptor table lives in device memory (built once per model); block -> matrix by binary search over the
+// prefix sum of 32x32 tiles.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256) lora_prepare_kernel(const uamd_lora_prep_desc* __restrict__ d, int n_mats,
+                                                          const int* __restrict__ tile_prefix) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n_mats - 1;                       // last matrix whose first tile <= blockIdx.x
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tile_prefix[mid] <= bid) lo = mid; else hi = mid - 1;
+    }
+    const uamd_lora_prep_desc m = d[lo];
+    const int t = bid - tile_prefix[lo];
+    const int tiles_c = (m.cols + 31) / 32;
+    const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8
+    const float* src = (const float*)m.src;
+    T* rm = (T*)m.dst_rowmajor;
+    T* tr = (T*)m.dst_transposed;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        float v = 0.f;
+        if (r < m.rows && c < m.cols) {
+            v = src[(int64_t)r * m.cols + c];
+            if (rm) rm[(int64_t)r * m.cols + c] = from_f32<T>(v);
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+    if (tr) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + ty + 8 * i, r = r0 + tx;              // transposed: [cols][rows]
+            if (r < m.rows && c < m.cols) tr[(int64_t)c * m.rows + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+        }
+    }
+}
+}  // namespace
+
+extern "C" int uamd_lora_prepare(const uamd_lora_prep_desc* descs_dev, const int* tile_prefix_dev, int n_mats,
+                                 int total_tiles, int dtype, void* stream) {
+    if (!descs_dev || !tile_prefix_dev || n_mats <= 0 || total_tiles < 0) return UAMD_ERR_ARG;
+    if (total_tiles == 0) return UAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == UAMD_BF16)
+        hipLaunchKernelGGL((lora_prepare_kernel<bf16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, descs_dev, n_mats, tile_prefix_dev);
+    else if (dtype == UAMD_F16)
+        hipLaunchKernelGGL((lora_prepare_kernel<f16_t>), dim3((unsigned)total_tiles), dim3(256), 0, st, descs_dev, n_mats, tile_prefix_dev);
+    else
+        return UAMD_ERR_DTYPE;
+    return uamd_launch_status();
+}

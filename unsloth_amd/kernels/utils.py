@@ -185,9 +185,83 @@ except Exception:  # pragma: no cover
     pass
 
 
+class _PreparedFactors:
+    """Per (device, dtype): activation-dtype row-major + transposed copies of every LoRA factor seen so far,
+    refreshed by ONE `uamd_lora_prepare` launch per optimizer step (epoch)."""
+
+    def __init__(self, device, dtype):
+        self.device, self.dtype = device, dtype
+        self.params = {}        # id -> [weakref, rm, tr, version]
+        self.epoch = -1
+        self.table = None       # (ptr signature, descs tensor, prefix tensor, total tiles)
+
+    @staticmethod
+    def _tiles(P):
+        return ((P.shape[0] + 31) // 32) * ((P.shape[1] + 31) // 32)
+
+    def _launch(self, ents):
+        import numpy as np
+        descs = np.zeros(len(ents), dtype=np.dtype([("src", "<u8"), ("rm", "<u8"), ("tr", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+        prefix, tot = np.zeros(len(ents), dtype=np.int32), 0
+        for i, (P, rm, tr) in enumerate(ents):
+            descs[i] = (P.data_ptr(), rm.data_ptr(), tr.data_ptr(), P.shape[0], P.shape[1])
+            prefix[i] = tot
+            tot += self._tiles(P)
+        sig = descs.tobytes()
+        if self.table is None or self.table[0] != sig:
+            d = torch.from_numpy(descs.view(np.uint8).copy()).to(self.device)
+            pf = torch.from_numpy(prefix).to(self.device)
+            tab = (sig, d, pf, tot)
+            if len(ents) > 1:
+                self.table = tab
+        else:
+            tab = self.table
+        any_p = ents[0][0]
+        with _lib.device_ctx(any_p):
+            rc = _lib.lib().uamd_lora_prepare(_lib.ptr(tab[1]), _lib.ptr(tab[2]), len(ents), tab[3],
+                                              _lib.dtype_code(self.dtype), _lib.stream_of(any_p))
+        _lib.check(rc, "uamd_lora_prepare")
+        # the table tensors must outlive the launch: stream-ordered free is fine for torch's caching allocator
+
+    def get(self, P, tag):
+        pid = id(P)
+        ent = self.params.get(pid)
+        epoch = _CAST_EPOCH[0]
+        with torch.no_grad():
+            if ent is None or ent[0]() is not P or ent[1].shape != P.shape:
+                rm = torch.empty(P.shape, dtype=self.dtype, device=self.device)
+                tr = torch.empty((P.shape[1], P.shape[0]), dtype=self.dtype, device=self.device)
+                ent = [weakref.ref(P, lambda _, pid=pid: self.params.pop(pid, None)), rm, tr, -1, -1]
+                self.params[pid] = ent
+            if self.epoch != epoch:
+                live = []
+                for e in list(self.params.values()):
+                    Q = e[0]()
+                    if Q is not None:
+                        live.append((Q, e[1], e[2]))
+                        e[3], e[4] = Q._version, epoch
+                self._launch(live)
+                self.epoch = epoch
+            elif ent[4] != epoch or ent[3] != P._version:       # registered (or modified in place) mid-epoch
+                self._launch([(P, ent[1], ent[2])])
+                ent[3], ent[4] = P._version, epoch
+        return ent[1] if tag == "rowmajor" else ent[2]
+
+
+_PREPARED = {}
+LORA_PREPARE = os.environ.get("UNSLOTH_AMD_LORA_PREPARE", "1") != "0"
+
+
 def _cached_cast(P, tag, dtype, build):
     if not isinstance(P, torch.nn.Parameter):
         return build()
+    if (LORA_PREPARE and tag in ("rowmajor", "T") and P.is_cuda and P.dtype == torch.float32 and P.dim() == 2
+            and P.is_contiguous() and dtype in (torch.bfloat16, torch.float16)):
+        key = (P.device, dtype)
+        g = _PREPARED.get(key)
+        if g is None:
+            g = _PREPARED[key] = _PreparedFactors(P.device, dtype)
+        return g.get(P, tag)
     pid = id(P)
     ent = _CAST_CACHE.get(pid)
     if (ent is None or ent[0]() is not P or ent[1] != P._version or ent[2] != P.data_ptr()
@@ -215,11 +289,21 @@ def lora_xa(X2d, A_list):
         A0 = A_list[0]
         Acat = _cached_cast(A0, "rowmajor", dtype, lambda: A0.to(dtype).contiguous())   # A.to(dtype), utils.py:1166
     else:
-        Acat = torch.zeros((sum(Rp), K), dtype=dtype, device=X2d.device)
-        o = 0
-        for A, r, rp in zip(A_list, Rs, Rp):
-            Acat[o:o + r] = A
-            o += rp
+        def _cat():
+            if Rs == Rp:
+                return torch.cat([cast_lora(A, dtype) for A in A_list], dim=0)
+            buf = torch.zeros((sum(Rp), K), dtype=dtype, device=X2d.device)
+            o = 0
+            for A, r, rp in zip(A_list, Rs, Rp):
+                buf[o:o + r] = A
+                o += rp
+            return buf
+        if all(isinstance(A, torch.nn.Parameter) for A in A_list):
+            # keyed on the first factor, tagged with the identity + version of the others
+            tag = ("cat",) + tuple((id(A), A._version, A.data_ptr()) for A in A_list[1:])
+            Acat = _cached_cast(A_list[0], tag, dtype, _cat)
+        else:
+            Acat = _cat()
     Rt = Acat.shape[0]
     if Rt > 192:
         raise NotImplementedError(f"sum of LoRA ranks sharing one input = {Rt} > 192")
