@@ -226,13 +226,18 @@ int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* w
  * LSE [B,Hq,lse_stride] fp32 (natural log-sum-exp of the scaled scores, saved for the backward; lse_stride =
  * T rounded up to a multiple of 32, pad zero-filled by the caller). Hq/Hk in {1,2,4,8}.
  * uamd_attn_bwd: two launches (dQ + Delta = rowsum(dO*O), then dK/dV), deterministic, no atomics. `strides` has
- * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [B,Hq,lse_stride] fp32 scratch. */
+ * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [B,Hq,lse_stride] fp32 scratch.
+ * Band (packed documents / sliding window; block-diagonal causal mask of utils/packing.py:650-693, window rule
+ * `q - key < W`): query q attends keys lo[q] <= key <= q, equivalently key is seen by queries key <= q <= hi[key].
+ * lo, hi: int32 [B, T], non-decreasing along T, lo[q] <= q <= hi[q]; NULL (both) = plain causal. Tiles outside
+ * the band are skipped, not just masked. */
 int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE, const int64_t* strides,
-                  int B, int T, int Hq, int Hk, int D, int lse_stride, float scale, int causal, int dtype,
-                  void* stream);
+                  int B, int T, int Hq, int Hk, int D, int lse_stride, float scale, int causal, const int* lo,
+                  int dtype, void* stream);
 int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* LSE,
                   void* dQ, void* dK, void* dV, float* Delta, const int64_t* strides, int B, int T, int Hq, int Hk,
-                  int D, int lse_stride, float scale, int causal, int dtype, void* stream);
+                  int D, int lse_stride, float scale, int causal, const int* lo, const int* hi, int dtype,
+                  void* stream);
 
 /* uamd_lora_xa2: same contract as uamd_lora_xa for R <= 64, streaming version (csrc/lora_side.hip): 32 rows per
  * block, K split over 4 waves, X and W through a per-wave LDS-DMA ring, fixed-order reduction. */

@@ -13,15 +13,15 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-def ref_attention(q, k, v, scale):
+def ref_attention(q, k, v, scale, allowed=None):
     """q [B,T,Hq,D], k/v [B,T,Hk,D] fp32 -> (o [B,T,Hq,D], lse [B,Hq,T]); P rounded like the kernel is NOT modelled
-    (the tolerance covers it)."""
+    (the tolerance covers it). `allowed` [T,T] bool overrides the plain causal mask."""
     B, T, Hq, D = q.shape
     G = Hq // k.shape[2]
     kk = k.repeat_interleave(G, dim=2)
     vv = v.repeat_interleave(G, dim=2)
     s = torch.einsum("bthd,bshd->bhts", q, kk) * scale
-    mask = torch.ones(T, T, dtype=torch.bool).tril()
+    mask = torch.ones(T, T, dtype=torch.bool).tril() if allowed is None else allowed
     s = s.masked_fill(~mask, float("-inf"))
     lse = torch.logsumexp(s, dim=-1)
     p = torch.softmax(s, dim=-1)
@@ -81,3 +81,73 @@ def test_attn_backward_matches_fp32_autograd(dtype, B, T, Hq, Hk):
         assert err <= tol, (name, err, ref)
     dq2, dk2, dv2 = attn_backward(do.to(DEV), q, k, v, o, lse, scale)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
+
+
+def packed_mask(T, lengths, window):
+    """dense allowed[q, key] of the reference's block-diagonal causal mask (utils/packing.py:650-693)."""
+    allowed = torch.zeros(T, T, dtype=torch.bool)
+    off = 0
+    for n in list(lengths) + [T - sum(lengths)]:
+        if n <= 0:
+            continue
+        blk = torch.ones(n, n, dtype=torch.bool).tril()
+        if window is not None:
+            idx = torch.arange(n)
+            blk &= (idx[:, None] - idx[None, :]) < window
+        allowed[off:off + n, off:off + n] = blk
+        off += n
+    return allowed
+
+
+BAND_CASES = [  # T, Hq, Hk, packed lengths (None = one sequence), window
+    (256, 4, 1, [100, 60, 96], None),
+    (512, 8, 2, [1, 2, 3, 250, 64, 63, 129], None),       # document boundaries inside / on tile edges
+    (384, 4, 4, None, 64),
+    (777, 8, 2, None, 100),
+    (1024, 8, 2, [300, 724], 128),
+    (200, 2, 1, [33, 33, 33], 16),                          # trailing tokens form one more document
+    (2048, 8, 2, [512, 1024, 512], None),
+]
+
+
+@pytest.mark.parametrize("T,Hq,Hk,lengths,window", BAND_CASES)
+def test_attn_band_forward_backward(T, Hq, Hk, lengths, window):
+    """packed documents / sliding window: the kernels skip and mask by the (lo, hi) band; oracle = dense mask."""
+    from unsloth_amd.kernels.attention import attention_band, attn_backward, attn_forward
+    dtype, B, D = torch.bfloat16, 1, 128
+    qkv = torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(5)).to(dtype)
+    do = torch.randn(B, T, Hq, D, generator=g(6)).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    allowed = packed_mask(T, lengths or [T], window)
+    qr = qkv[..., :Hq * D].view(B, T, Hq, D).float().requires_grad_(True)
+    kr = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D).float().requires_grad_(True)
+    vr = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D).float().requires_grad_(True)
+    o_ref, lse_ref = ref_attention(qr, kr, vr, scale, allowed)
+    o_ref.backward(do.float())
+    band = attention_band(T, batch=B, seq_lengths=lengths, sliding_window=window, device=DEV)
+    qd = qkv.to(DEV)
+    q = qd[..., :Hq * D].view(B, T, Hq, D)
+    k = qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qd[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    o, lse = attn_forward(q, k, v, scale, band)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), rtol=1e-4, atol=2e-3)
+    err = (o.float().cpu() - o_ref.detach()).abs().max().item()
+    assert err <= 2e-2, err
+    dq, dk, dv = attn_backward(do.to(DEV), q, k, v, o, lse, scale, band)
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        e = (got.float().cpu() - want).abs().max().item()
+        ref = want.abs().max().item()
+        assert e <= 3e-2 * max(ref, 1.0), (name, e, ref)
+        assert torch.isfinite(got).all()
+
+
+def test_attn_band_batch_window():
+    """B > 1 with a sliding window (Mistral, mistral.py:116-120): same band for every row of the batch."""
+    from unsloth_amd.kernels.attention import attention_band, flash_attention
+    B, T, Hq, Hk, D, W = 2, 320, 4, 2, 128, 96
+    q = torch.randn(B, T, Hq, D, generator=g(7)).to(torch.bfloat16)
+    k = torch.randn(B, T, Hk, D, generator=g(8)).to(torch.bfloat16)
+    v = torch.randn(B, T, Hk, D, generator=g(9)).to(torch.bfloat16)
+    o_ref, _ = ref_attention(q.float(), k.float(), v.float(), 1.0 / math.sqrt(D), packed_mask(T, [T], W))
+    o = flash_attention(q.to(DEV), k.to(DEV), v.to(DEV), None, attention_band(T, batch=B, sliding_window=W, device=DEV))
+    assert (o.float().cpu() - o_ref).abs().max().item() <= 2e-2

@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda", 0)
 
 
-def _tiny(load_in_4bit=True, gc=True, r=8, layers=2, seed=3407):
+def _tiny(load_in_4bit=True, gc=True, r=8, layers=2, seed=3407, head_dim=32):
     from transformers import LlamaConfig
     from unsloth_amd import FastLanguageModel
-    cfg = LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=layers, num_attention_heads=8,
-                      num_key_value_heads=2, head_dim=32, vocab_size=1000, rms_norm_eps=1e-5,
+    heads = 8 if head_dim == 32 else 4            # head_dim 128: the hand-written flash-attention kernels run
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=layers, num_attention_heads=heads,
+                      num_key_value_heads=2, head_dim=head_dim, vocab_size=1000, rms_norm_eps=1e-5,
                       max_position_embeddings=512, rope_parameters={"rope_type": "default", "rope_theta": 5e5},
                       tie_word_embeddings=False)
     model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=256, load_in_4bit=load_in_4bit,
@@ -44,10 +45,10 @@ def _grads(model):
             for n, p in model.named_parameters() if p.requires_grad}
 
 
-@pytest.mark.parametrize("load_in_4bit", [True, False])
-def test_loss_and_lora_grads_match_hf_oracle(load_in_4bit):
+@pytest.mark.parametrize("load_in_4bit,head_dim", [(True, 32), (False, 32), (True, 128)])
+def test_loss_and_lora_grads_match_hf_oracle(load_in_4bit, head_dim):
     from oracle.ref_model import hf_reference_loss_and_lora_grads
-    model = _tiny(load_in_4bit)
+    model = _tiny(load_in_4bit, head_dim=head_dim)
     assert model.get_base_model()._unsloth_amd_patched == (2, 2, 2), "fast hooks not installed on every layer"
     ids, labels, pos = _batch()
     out = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
@@ -96,18 +97,25 @@ def test_return_logits_branch_and_n_items():
     assert abs(float(out2.loss) * 1000 / n - float(ref_loss)) <= 1e-2 * abs(float(ref_loss))
 
 
-def test_padding_free_packed_batch_equals_per_document_oracle():
+@pytest.mark.parametrize("head_dim", [32, 128])
+def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypatch):
     """position ids restart per document (indexed RoPE), attention is block-diagonal, boundary targets are
-    masked: the packed row must equal the documents run separately."""
+    masked: the packed row must equal the documents run separately. head_dim 128 = the band (lo, hi) path of the
+    flash kernels, 32 = SDPA with the dense packed mask."""
     from oracle.ref_model import hf_reference_loss_and_lora_grads
+    from unsloth_amd.kernels import attention as flash
     from unsloth_amd.utils.packing import enable_padding_free_metadata
-    model = _tiny()
+    bands = []
+    real = flash.flash_attention
+    monkeypatch.setattr(flash, "flash_attention", lambda q, k, v, s=None, band=None: (bands.append(band), real(q, k, v, s, band))[1])
+    model = _tiny(head_dim=head_dim)
     g = torch.Generator().manual_seed(5)
     docs = [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (40, 17, 64)]
     batch = enable_padding_free_metadata(docs, device=DEV)
     out = model(**batch)
     out.loss.backward()
     got = _grads(model)
+    assert (len(bands) > 0 and all(b is not None for b in bands)) == (head_dim == 128)
     # oracle: each document alone; sum of token losses / total targets
     tot, n_tot, ref = 0.0, 0, None
     for d in docs:

@@ -100,3 +100,33 @@ def test_sdpa_packed_mask_is_block_causal():                          # packing.
     w = build_sdpa_packed_attention_mask((torch.tensor([4]), None, 4), dtype=torch.float32,
                                          device=torch.device("cpu"), sliding_window=2)
     assert (w[0, 0] == 0).int().tolist() == [[1, 0, 0, 0], [1, 1, 0, 0], [0, 1, 1, 0], [0, 0, 1, 1]]
+
+
+def test_attention_band_matches_dense_packed_mask():
+    """(lo, hi) band == the finite entries of build_sdpa_packed_attention_mask (reference utils/packing.py:650-693),
+    both ways round: lo[q] <= key <= q  <=>  key <= q <= hi[key]. Integer, exact."""
+    import torch
+    from unsloth_amd.kernels.attention import attention_band
+    from unsloth_amd.utils.packing import build_sdpa_packed_attention_mask
+    gen = torch.Generator().manual_seed(0)
+    for trial in range(20):
+        n_docs = int(torch.randint(1, 7, (1,), generator=gen))
+        lens = torch.randint(1, 40, (n_docs,), generator=gen).to(torch.int32)
+        T = int(lens.sum())
+        window = [None, 1, 5, 17, 1000][trial % 5]
+        dense = build_sdpa_packed_attention_mask((lens, None, int(lens.max())), dtype=torch.float32, device="cpu",
+                                                 sliding_window=window)[0, 0]
+        allowed = torch.isfinite(dense) & (dense == 0)
+        lo, hi = attention_band(T, seq_lengths=lens, sliding_window=window)
+        assert lo.dtype == torch.int32 and lo.shape == (1, T)
+        pos = torch.arange(T)
+        by_lo = (pos[None, :] >= lo[0][:, None]) & (pos[None, :] <= pos[:, None])
+        by_hi = (pos[:, None] <= hi[0][None, :]) & (pos[None, :] <= pos[:, None])
+        assert torch.equal(by_lo, allowed) and torch.equal(by_hi, allowed)
+        assert bool((lo[0][1:] >= lo[0][:-1]).all()) and bool((hi[0][1:] >= hi[0][:-1]).all())
+    # no packing, window only, batch of 3
+    lo, hi = attention_band(10, batch=3, sliding_window=4)
+    assert lo.shape == (3, 10) and lo[1].tolist() == [0, 0, 0, 0, 1, 2, 3, 4, 5, 6] and hi[2].tolist() == [3, 4, 5, 6, 7, 8, 9, 9, 9, 9]
+    # tokens past the packed documents form one more document
+    lo, hi = attention_band(8, seq_lengths=[3, 2])
+    assert lo[0].tolist() == [0, 0, 0, 3, 3, 5, 5, 5] and hi[0].tolist() == [2, 2, 2, 4, 4, 7, 7, 7]

@@ -90,9 +90,9 @@ SIGNATURES = {
     "uamd_lora_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int,
-                              c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p]),
+                              c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     "uamd_attn_bwd": (c_int, [c_void_p] * 10 + [ctypes.POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int,
-                                               c_float, c_int, c_int, c_void_p]),
+                                               c_float, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "uamd_debug_mfma_probe": (c_int, [c_void_p, c_void_p]),
 }
 

@@ -60,6 +60,7 @@ typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O; float* LSE;
+    const int* lo;                       // [B, T] first key each query may attend (NULL: 0), non-decreasing in t
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
     int B, T, Hq, Hk, G, nsub;          // G = Hq / Hk, nsub = 8 / G q-subtiles of 32 rows per block
     int nqt;                             // number of q tiles
@@ -112,6 +113,11 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const int qs = qtile * QT + (wave / G) * 32;                      // first q position of this wave
     const int q_pos = qs + l31;
     const int q_ld = q_pos < T_ ? q_pos : T_ - 1;
+    // band lower edge (packed documents / sliding window): per-lane, and -- lo being non-decreasing -- lane 0 /
+    // lane 31 give the wave's min / max, the block's first row the block's min
+    const int lo_q = p.lo ? p.lo[(int64_t)b * T_ + q_ld] : 0;
+    const int lo_w0 = __builtin_amdgcn_readfirstlane(lo_q), lo_w1 = __builtin_amdgcn_readlane(lo_q, 31);
+    const int t_first = (p.lo ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] : 0) / KT;
 
     // ---- Q^T operand fragments (B operand: lane -> q = l31, 8 d at 16 ks + 8 lh), kept for the whole tile loop
     frag_t qf[8];
@@ -181,18 +187,21 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     float m_run = -INFINITY, l_run = 0.f;      // running max (log2 domain, both lane halves agree) / partial sum
 
     // ---- prologue
-    issue(0, 0);
-    if (nkv_blk > 1) issue(1, 1);
+    const int nt = nkv_blk - t_first;
+    issue(t_first, 0);
+    if (nt > 1) issue(t_first + 1, 1);
 
     const int last_tile_wave = min(qs + 31, T_ - 1) / KT;            // tiles beyond are fully masked for this wave
-    for (int t = 0; t < nkv_blk; ++t) {
-        if (t + 1 < nkv_blk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int first_tile_wave = lo_w0 / KT;                          // ... and tiles before
+    for (int ti = 0; ti < nt; ++ti) {
+        const int t = t_first + ti;
+        if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < nkv_blk) issue(t + 2, (t + 2) % NST);           // its stage was last read before this barrier
-        if (t > last_tile_wave) continue;                            // wave-uniform: nothing to add
-        const unsigned char* sk = smem + (t % NST) * STAGE_B;
+        if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);              // its stage was last read before this barrier
+        if (t > last_tile_wave || t < first_tile_wave) continue;     // wave-uniform: nothing to add
+        const unsigned char* sk = smem + (ti % NST) * STAGE_B;
         const unsigned char* sv = sk + TILE_B;
 
         // ---- S^T[key][q] = K Q^T : 2 key tiles x 8 k-steps
@@ -210,7 +219,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         }
         // ---- online softmax, log2 domain. lane: q = q_pos; register r of tile kt: key below
         const int k0 = t * KT;
-        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_);
+        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_) || (k0 < lo_w1);
         float mt = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -219,21 +228,23 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
                 float s = st[kt][r] * p.scale_log2;
                 if (need_mask) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key > q_pos || key >= T_) s = -INFINITY;
+                    if (key > q_pos || key >= T_ || key < lo_q) s = -INFINITY;
                 }
                 st[kt][r] = s;
                 mt = fmaxf(mt, s);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                    // first tile: exp2(-inf) = 0
+        // a row whose band starts after this tile has seen only masked keys so far: keep the exponent finite
+        const float m_ref = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);                    // first tile: exp2(-inf) = 0
         m_run = m_new;
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(st[kt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(st[kt][r] - m_ref);
                 st[kt][r] = e;
                 ls += e;
             }
@@ -291,6 +302,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 struct AttnBwdArgs {
     const void* Q; const void* K; const void* V; const void* O; const void* dO; const float* LSE;
     void* dQ; void* dK; void* dV; float* Delta;
+    const int* lo; const int* hi;        // band: query q attends keys lo[q] <= key <= q  <=>  q <= hi[key]
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh;
     int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
     int B, T, Hq, Hk, G, nsub, lse_st, nqt;
@@ -339,6 +351,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
     if (lh == 0 && q_pos < T_) p.Delta[stat_idx] = delta;
     const float lse2 = p.LSE[stat_idx] * 1.4426950408889634f;
+    const int lo_q = p.lo ? p.lo[(int64_t)b * T_ + q_ld] : 0;
+    const int lo_w0 = __builtin_amdgcn_readfirstlane(lo_q), lo_w1 = __builtin_amdgcn_readlane(lo_q, 31);
+    const int t_first = (p.lo ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] : 0) / KT;
 
     const int nkv_blk = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);
     int drow[2], dsw[2];
@@ -387,20 +402,23 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
 
-    issue(0, 0);
-    if (nkv_blk > 1) issue(1, 1);
+    const int nt = nkv_blk - t_first;
+    issue(t_first, 0);
+    if (nt > 1) issue(t_first + 1, 1);
     const int last_tile_wave = min(qs + 31, T_ - 1) / KT;
-    for (int t = 0; t < nkv_blk; ++t) {
-        if (t + 1 < nkv_blk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const int first_tile_wave = lo_w0 / KT;
+    for (int ti = 0; ti < nt; ++ti) {
+        const int t = t_first + ti;
+        if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < nkv_blk) issue(t + 2, (t + 2) % NST);
-        if (t > last_tile_wave) continue;
-        const unsigned char* sk = smem + (t % NST) * STAGE_B;
+        if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);
+        if (t > last_tile_wave || t < first_tile_wave) continue;
+        const unsigned char* sk = smem + (ti % NST) * STAGE_B;
         const unsigned char* sv = sk + TILE_B;
         const int k0 = t * KT;
-        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_);
+        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_) || (k0 < lo_w1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             f32x16_t st, dp;
@@ -420,7 +438,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 float pv = __builtin_amdgcn_exp2f(st[r] * p.scale_log2 - lse2);
                 if (need_mask) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key > q_pos || key >= T_) pv = 0.f;
+                    if (key > q_pos || key >= T_ || key < lo_q) pv = 0.f;
                 }
                 st[r] = pv * (dp[r] - delta) * p.scale;
             }
@@ -525,6 +543,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     const int key = k0 + kh * 32 + l31;               // this lane's key (C-layout column)
     const int key_ld = key < T_ ? key : T_ - 1;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    // band upper edge: last query that attends this lane's key (non-decreasing in key)
+    const int hi_k = p.hi ? p.hi[(int64_t)b * T_ + key_ld] : T_ - 1;
+    const int hi_w0 = __builtin_amdgcn_readfirstlane(hi_k), hi_w1 = __builtin_amdgcn_readlane(hi_k, 31);
+    const int hi_blk = p.hi ? p.hi[(int64_t)b * T_ + min(k0 + KT - 1, T_ - 1)] : T_ - 1;
 
     // ---- K^T operand (lane -> key, 8 d at 16 ks + 8 lh): 8 KiB per wave. Keeping it in VGPRs next to the 128
     //      accumulator registers spills, and the LDS is full (2 x 65 KiB stages + V), so it is re-read from L2 at
@@ -551,7 +573,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     const unsigned tstep = (unsigned)(t_st * 8);                       // 4 rows in bytes
     const int nq32 = (T_ + 31) / 32;
     const int q32_first = k0 / 32;
-    const int nsteps = (nq32 - q32_first + nslice - 1) / nslice;
+    const int nsteps = (min(nq32, hi_blk / 32 + 1) - q32_first + nslice - 1) / nslice;
 
     // per-lane LDS read addresses inside a tile (swizzle C)
     const int r_lane = l31 * 256 + ((swz_c(l31 & 15) ^ lh) << 4);
@@ -626,7 +648,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             const int q0 = q0_of(step, slice);
-            if (q0 >= T_ || q0 + 31 < k0 + kh * 32) continue;              // idle / entirely above the diagonal
+            if (q0 >= T_ || q0 + 31 < k0 + kh * 32 || q0 > hi_w1) continue;   // idle / above the diagonal / below the band
             const unsigned char* sq = smem + stage * KD_STG + unit * 16384;
             const unsigned char* sdo = sq + 8192;
             const unsigned char* sv = smem + KD_V_OFF + kh * 32 * 256;
@@ -651,7 +673,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
                 vb.r = *reinterpret_cast<const uint4*>(sv + (r_lane ^ (ks * 32)));
                 dp = MfmaA<T>::run(da.f, vb.f, dp);
             }
-            const bool need_mask = (q0 < k0 + kh * 32 + 31) || (q0 + 32 > T_) || (k0 + KT > T_);
+            const bool need_mask = (q0 < k0 + kh * 32 + 31) || (q0 + 32 > T_) || (k0 + KT > T_) || (q0 + 31 > hi_w0);
             auto soft = [&](auto masked) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -666,7 +688,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
                         float ds = pv * (dp[r] - dl) * p.scale;
                         if (decltype(masked)::value) {
                             const int q = q0 + 8 * a + 4 * lh + j;
-                            if (key > q || q >= T_ || key >= T_) { pv = 0.f; ds = 0.f; }
+                            if (key > q || q >= T_ || key >= T_ || q > hi_k) { pv = 0.f; ds = 0.f; }
                         }
                         sc[r] = pv;
                         dp[r] = ds;
@@ -674,12 +696,6 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
                 }
             };
             if (need_mask) soft(std::true_type{}); else soft(std::false_type{});
-#ifdef UAMD_ATTN_DEBUG
-            if (wave == 0 && step == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-                float* dbg = p.Delta + (int64_t)p.B * p.Hq * p.lse_st;
-                for (int r = 0; r < 16; ++r) { dbg[lane * 32 + r] = sc[r]; dbg[lane * 32 + 16 + r] = dp[r]; }
-            }
-#endif
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 union { uint32_t w[4]; frag_t f; } pb, sb;
@@ -761,7 +777,8 @@ int set_lds_attr(K_ kernel, int bytes, bool* done) {
 extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO,
                              const float* LSE, void* dQ, void* dK, void* dV, float* Delta,
                              const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
-                             float scale, int causal, int dtype, void* stream) {
+                             float scale, int causal, const int* lo, const int* hi, int dtype, void* stream) {
+    if ((lo == nullptr) != (hi == nullptr)) return UAMD_ERR_ARG;
     if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !Delta || !strides) return UAMD_ERR_ARG;
     if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;
@@ -777,6 +794,7 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
         return UAMD_ERR_ARG;
     AttnBwdArgs a;
     a.Q = Q; a.K = K; a.V = V; a.O = O; a.dO = dO; a.LSE = LSE; a.dQ = dQ; a.dK = dK; a.dV = dV; a.Delta = Delta;
+    a.lo = lo; a.hi = hi;
     a.q_sb = strides[0]; a.q_st = strides[1]; a.q_sh = strides[2];
     a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
     a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];
@@ -816,7 +834,7 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
 
 extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
                              const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
-                             float scale, int causal, int dtype, void* stream) {
+                             float scale, int causal, const int* lo, int dtype, void* stream) {
     if (!Q || !K || !V || !O || !LSE || !strides || B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;
     if (D != AD || !causal || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
@@ -828,7 +846,7 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     // 32-bit per-lane byte offsets inside a 64-key tile
     if (strides[4] > (1 << 22) || strides[7] > (1 << 22)) return UAMD_ERR_ARG;
     AttnArgs a;
-    a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE; a.lo = lo;
     a.q_sb = strides[0]; a.q_st = strides[1]; a.q_sh = strides[2];
     a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
     a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];

@@ -34,8 +34,47 @@ def _pad32(T):
     return (T + 31) // 32 * 32
 
 
-def attn_forward(q, k, v, scale=None):
-    """q [B,T,Hq,128], k/v [B,T,Hk,128] (strided views are fine) -> (o [B,T,Hq,128] contiguous, lse [B,Hq,T] fp32)."""
+def attention_band(T, batch=1, seq_lengths=None, sliding_window=None, device="cpu"):
+    """Band of the block-diagonal causal mask as two int32 [batch, T] arrays (lo, hi): query q attends keys
+    lo[q] <= key <= q, i.e. key is seen by queries key <= q <= hi[key].
+    `seq_lengths`: lengths of the documents packed back to back into ONE row of T tokens (the reference's
+    `packed_seq_lengths`, utils/packing.py:586-606; tokens past sum(lengths) form one more document);
+    `sliding_window` W: additionally q - key < W (packing.py:679-683, attention_dispatch.py:292).
+    Integer work, done with torch ops on `device`; exact."""
+    pos = torch.arange(T, dtype=torch.int64, device=device)
+    if seq_lengths is not None:
+        if batch != 1:
+            raise ValueError("packed sequences are one row of tokens (batch 1)")
+        lens = torch.as_tensor(seq_lengths, dtype=torch.int64, device=device).flatten()
+        lens = lens[lens > 0]
+        ends = torch.cumsum(lens, 0).clamp_(max=T)                 # exclusive end of every document
+        doc = torch.searchsorted(ends, pos, right=True)            # document of every token
+        ends = torch.cat([ends, ends.new_full((1,), T)])           # trailing (padding) tokens: one more document
+        starts = torch.cat([ends.new_zeros(1), ends[:-1]])
+        lo, hi = starts[doc], ends[doc] - 1
+    else:
+        lo, hi = torch.zeros_like(pos), torch.full_like(pos, T - 1)
+    if sliding_window is not None and sliding_window > 0:
+        lo = torch.maximum(lo, pos - (sliding_window - 1))
+        hi = torch.minimum(hi, pos + (sliding_window - 1))
+    lo = lo.to(torch.int32)[None].expand(batch, T).contiguous()
+    hi = hi.to(torch.int32)[None].expand(batch, T).contiguous()
+    return lo, hi
+
+
+def _band_ptrs(band, B, T, dev):
+    if band is None:
+        return None, None
+    lo, hi = band
+    for x in (lo, hi):
+        assert x.dtype == torch.int32 and x.shape == (B, T) and x.is_contiguous() and x.device == dev, \
+            "band = (lo, hi): contiguous int32 [B, T] on the activations' device"
+    return _lib.ptr(lo), _lib.ptr(hi)
+
+
+def attn_forward(q, k, v, scale=None, band=None):
+    """q [B,T,Hq,128], k/v [B,T,Hk,128] (strided views are fine) -> (o [B,T,Hq,128] contiguous, lse [B,Hq,T] fp32).
+    `band` = (lo, hi) from attention_band() restricts the causal mask to packed documents / a sliding window."""
     _lib.require_gpu(q, k, v)
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
@@ -44,15 +83,16 @@ def attn_forward(q, k, v, scale=None):
     o = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
     Tp = _pad32(T)
     lse = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
+    lo, _ = _band_ptrs(band, B, T, q.device)
     with _lib.device_ctx(q):
         rc = _lib.lib().uamd_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(lse),
-                                      _strides(q, k, v, o), B, T, Hq, Hk, D, Tp, float(scale), 1,
+                                      _strides(q, k, v, o), B, T, Hq, Hk, D, Tp, float(scale), 1, lo,
                                       _lib.dtype_code(q.dtype), _lib.stream_of(q))
     _lib.check(rc, "uamd_attn_fwd")
     return o, lse[:, :, :T]
 
 
-def attn_backward(do, q, k, v, o, lse, scale=None):
+def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
     """Gradients of attn_forward: (dq [B,T,Hq,D], dk, dv [B,T,Hk,D]), contiguous, in q's dtype. `lse` is the view
     attn_forward returned (its storage is padded to a multiple of 32 positions). Two launches, deterministic."""
     _lib.require_gpu(do, q, k, v, o)
@@ -68,11 +108,12 @@ def attn_backward(do, q, k, v, o, lse, scale=None):
     dk = torch.empty((B, T, Hk, D), dtype=q.dtype, device=q.device)
     dv = torch.empty((B, T, Hk, D), dtype=q.dtype, device=q.device)
     delta = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
+    lo, hi = _band_ptrs(band, B, T, q.device)
     with _lib.device_ctx(q):
         rc = _lib.lib().uamd_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do),
                                       _lib.ptr(lse), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(delta),
                                       _strides(q, k, v, o, do, dq, dk, dv), B, T, Hq, Hk, D, Tp, float(scale), 1,
-                                      _lib.dtype_code(q.dtype), _lib.stream_of(q))
+                                      lo, hi, _lib.dtype_code(q.dtype), _lib.stream_of(q))
     _lib.check(rc, "uamd_attn_bwd")
     return dq, dk, dv
 
@@ -81,18 +122,18 @@ class FlashAttention(torch.autograd.Function):
     """o = causal_attention(q, k, v) on [B,T,H,128] views; saves (q, k, v, o, lse) like flash-attention."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
-        o, lse = attn_forward(q, k, v, scale)
+    def forward(ctx, q, k, v, scale, band):
+        o, lse = attn_forward(q, k, v, scale, band)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale = scale
+        ctx.scale, ctx.band = scale, band
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale)
-        return dq, dk, dv, None
+        dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band)
+        return dq, dk, dv, None, None
 
 
-def flash_attention(q, k, v, scale=None):
-    return FlashAttention.apply(q, k, v, scale)
+def flash_attention(q, k, v, scale=None, band=None):
+    return FlashAttention.apply(q, k, v, scale, band)

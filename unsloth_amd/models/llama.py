@@ -125,19 +125,37 @@ def original_apply_o(self, X):
     return self.o_proj(X)
 
 
+_BAND_CACHE = {}     # device -> (seq_lengths tensor, (B, T, window), band): one band per batch, reused by all layers
+
+
+def _attention_band(seq_info, B, T, window, device):
+    """(lo, hi) int32 band of the packed / windowed causal mask, built once per batch like the reference's
+    _SDPA_MASK_CACHE (utils/packing.py:657-693) -- but 8 bytes per token instead of a dense T x T mask."""
+    seq_lengths = seq_info[0] if seq_info is not None else None
+    ent = _BAND_CACHE.get(device)
+    if ent is not None and ent[0] is seq_lengths and ent[1] == (B, T, window):
+        return ent[2]
+    band = _flash.attention_band(T, batch=B, seq_lengths=seq_lengths, sliding_window=window, device=device)
+    _BAND_CACHE[device] = (seq_lengths, (B, T, window), band)
+    return band
+
+
 def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
     """causal (GQA, packed, windowed) attention. Q [B,Hq,T,D], K/V [B,Hk,T,D] (strided views of the [B,T,H,D]
     projection outputs) -> [B, T, Hq*D].
-    Plain causal batches with head_dim 128 take the hand-written CDNA4 kernels (kernels/attention.py), which read
-    the [B,T,H,D] memory directly and write the o_proj input layout: no transposes, no copies. Packed /
-    masked / windowed batches use torch SDPA with an explicit mask (run_attention's SDPA branch,
-    attention_dispatch.py:560-617)."""
+    Causal batches with head_dim 128 -- plain, packed (block-diagonal over `seq_info` documents) or
+    sliding-window -- take the hand-written CDNA4 kernels (kernels/attention.py), which read the [B,T,H,D]
+    memory directly and write the o_proj input layout: no transposes, no copies, no dense mask. Batches with a
+    key-padding `attention_mask` (and other head dims) use torch SDPA with an explicit mask (run_attention's
+    SDPA branch, attention_dispatch.py:560-617)."""
     B, Hq, T, D = Q.shape
-    window = sliding_window if (sliding_window is not None and T > sliding_window) else None   # mistral.py:116-120
-    if seq_info is None and attention_mask is None and window is None:
+    window = sliding_window if (sliding_window is not None and 0 < sliding_window < T) else None   # mistral.py:116-120
+    if attention_mask is None and _USE_FLASH:
         q, k, v = Q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2)          # [B,T,H,D] views
-        if _USE_FLASH and _flash.supported(q, k, v):
-            return _flash.flash_attention(q, k, v).reshape(B, T, Hq * D)
+        if _flash.supported(q, k, v) and (seq_info is None or B == 1):
+            band = None if (seq_info is None and window is None) else _attention_band(seq_info, B, T, window, Q.device)
+            return _flash.flash_attention(q, k, v, None, band).reshape(B, T, Hq * D)
+    if seq_info is None and attention_mask is None and window is None:
         A = F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
         return A.transpose(1, 2).reshape(B, T, Hq * D)
     if seq_info is not None:
