@@ -114,9 +114,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("UNSLOTH_AMD_DP_FORCE", "0") == "1"     # 1-rank RCCL group: exercises the DP path on one GPU
+    if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
+        if force_dp and world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29512")
+            dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
@@ -140,7 +146,7 @@ def main():
             if "lora_B" in n:           # non-zero B so every LoRA gradient is exercised with real numbers
                 p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
     opt = make_optimizer(model, lr=2e-4)
-    arena = LoRAGradArena(model) if world > 1 else None
+    arena = LoRAGradArena(model) if (world > 1 or force_dp) else None
     B, T, V = a.batch, a.seq, cfg.vocab_size
     gi = torch.Generator(device="cpu").manual_seed(rank)       # different data per rank
     batches = []
@@ -209,7 +215,7 @@ def main():
                                            share_of_step=round(v["total_ms"] / (dt * 1e3), 3))
                                    for k, v in gs.items() if k != dom_name})
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the other ranks must not wait on it)
             from oracle.cpu_baseline import time_layer
             cpu = time_layer(n_layers=a.layers, budget_s=a.cpu_budget)
             cpu["value"] = round(cpu["value"], 2)
@@ -229,7 +235,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }
         print(json.dumps(rec), flush=True)
-    if world > 1:
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

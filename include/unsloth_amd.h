@@ -203,7 +203,8 @@ int uamd_lora_xa(const void* X, int64_t ldx, const void* A, int64_t lda, float* 
  *     out = scale * P[M, R]^T @ Z[M, N]          (R <= 16; split wider ranks into 16-column problems)
  * P is fp32 (an uamd_lora_xa result) and is rounded to `dtype` on load, where the reference holds a tensor of
  * the activation dtype; Z is [M, N] in `dtype`; out is fp32, [R, N] (out_nr = 0, lora_A.grad layout) or
- * [N, R] (out_nr = 1, lora_B.grad layout). Deterministic: fixed-order two-stage reduction over M through
+ * [N, R] (out_nr bit 0 set, lora_B.grad layout); out_nr bit 1 set: out += product (gradient accumulation
+ * straight into the data-parallel arena) instead of out = product. Deterministic: fixed-order two-stage reduction over M through
  * `workspace` (fp32, >= sum_i ceil(M/128) * 16 * ceil(N_i/128)*128 floats always suffices). N % 8 == 0, ldz % 8 == 0, ldp % 4 == 0. */
 typedef struct {
     const float* P;

@@ -144,3 +144,86 @@ def test_training_reduces_loss_and_adapters_round_trip(tmp_path):
     from safetensors.torch import load_file
     sd = load_file(os.path.join(str(tmp_path), "adapter_model.safetensors"))
     assert any(k.endswith("q_proj.lora_A.weight") for k in sd) and len(sd) == 2 * 7 * 2
+
+
+def test_bnb4bit_checkpoint_round_trip_and_merge(tmp_path):
+    """the frozen NF4 base written in the bitsandbytes safetensors layout loads back through
+    FastLanguageModel.from_pretrained WITHOUT re-quantisation (same bytes -> bit-identical loss), and
+    save_pretrained_merged folds the adapters like save.py:_merge_lora (checked against dequant + s*B@A in fp32
+    and by running the merged 16-bit model in stock transformers)."""
+    from transformers import AutoModelForCausalLM
+    from unsloth_amd import FastLanguageModel, checkpoint as ck
+    from unsloth_amd import nf4
+    model = _tiny()
+    ids, labels, pos = _batch(B=1, T=64, seed=7)
+    kw = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    with torch.no_grad():
+        loss0 = float(model(**kw).loss)
+    d4, d16 = str(tmp_path / "b4"), str(tmp_path / "m16")
+    model.save_pretrained_merged(d4, save_method="base_4bit")
+    model.save_pretrained(d4)
+    # ---- reload: NF4 bytes must be taken as they are
+    m2, _ = FastLanguageModel.from_pretrained(d4, max_seq_length=256, load_in_4bit=True, device=DEV)
+    lin0, lin2 = model.get_base_model().model.layers[1].mlp.gate_proj.base_layer, m2.model.layers[1].mlp.gate_proj
+    assert isinstance(lin2, nf4.Linear4bit) and torch.equal(lin0.weight.data, lin2.weight.data)
+    assert torch.equal(lin0.weight.quant_state.absmax, lin2.weight.quant_state.absmax)
+    m2 = FastLanguageModel.get_peft_model(m2, r=8, lora_alpha=16)
+    from safetensors.torch import load_file
+    sd = load_file(os.path.join(d4, "adapter_model.safetensors"))
+    own = dict(m2.named_parameters())
+    for k, v in sd.items():
+        name = k.replace(".lora_A.weight", ".lora_A.default.weight").replace(".lora_B.weight", ".lora_B.default.weight")
+        own[name].data.copy_(v.to(DEV))
+    with torch.no_grad():
+        loss2 = float(m2(**kw).loss)
+    assert loss2 == loss0, (loss0, loss2)
+    # ---- merge
+    proj = model.get_base_model().model.layers[0].self_attn.q_proj
+    Wm, _ = ck.merge_lora_weight(proj, "q_proj")
+    W = nf4.dequantize_nf4(proj.base_layer.weight.data, proj.base_layer.weight.quant_state).float()
+    A, B = proj.lora_A["default"].weight.float(), proj.lora_B["default"].weight.float()
+    want = (W + proj.scaling["default"] * (B @ A)).to(torch.bfloat16)
+    assert (Wm.float() - want.float()).abs().max().item() <= 2 ** -8 * want.float().abs().max().item()
+    model.save_pretrained_merged(d16, save_method="merged_16bit")
+    from unsloth_amd.kernels.rms_layernorm import patch_rms_layernorm, unpatch_rms_layernorm
+    unpatch_rms_layernorm()                      # stock transformers classes for the independent check (CPU, fp32)
+    try:
+        hf = AutoModelForCausalLM.from_pretrained(d16, dtype=torch.float32)
+        with torch.no_grad():
+            logits = hf(input_ids=ids).logits.float()
+    finally:
+        patch_rms_layernorm()
+    ref_loss = torch.nn.functional.cross_entropy(logits[0, :-1], labels[0, 1:], ignore_index=-100)
+    assert abs(float(ref_loss) - loss0) <= 1e-2 * abs(loss0), (float(ref_loss), loss0)
+
+
+def test_grad_arena_direct_accumulation_matches_autograd():
+    """dp.LoRAGradArena registers gradient sinks: the fused LoRA-gradient kernel adds straight into the arena
+    (no AccumulateGrad per parameter). Same numbers as the autograd path, bit for bit; two micro-steps accumulate."""
+    from unsloth_amd.dp import LoRAGradArena
+    from unsloth_amd.kernels.utils import GRAD_SINKS
+    model = _tiny(gc=False)
+    ids, labels, pos = _batch(B=2, T=64, seed=11)
+    kw = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    model(**kw).loss.backward()
+    ref = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    for p in model.parameters():
+        p.grad = None
+    arena = LoRAGradArena(model)
+    try:
+        assert len(GRAD_SINKS) == len(ref)
+        arena.zero_grad()
+        model(**kw).loss.backward()
+        arena.finish()
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                assert p.grad.data_ptr() == arena._views[id(p)].data_ptr(), n
+                assert torch.equal(p.grad, ref[n]), n
+        model(**kw).loss.backward()                    # second micro-step accumulates
+        arena.finish()
+        worst = max(float((p.grad - 2 * ref[n]).abs().max() / (ref[n].abs().max() + 1e-12))
+                    for n, p in model.named_parameters() if p.requires_grad)
+        assert worst <= 1e-6, worst
+    finally:
+        arena.close()
+    assert not GRAD_SINKS

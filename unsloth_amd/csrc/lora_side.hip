@@ -211,8 +211,8 @@ __global__ void __launch_bounds__(256) lora_tn_reduce_kernel(TnArgs a) {
     float v = 0.f;
     for (int s = 0; s < a.S; ++s) v += part[(int64_t)s * TN_R * npad];
     v *= pr.scale;
-    if (pr.out_nr) pr.out[(int64_t)n * pr.ldo + r] = v;
-    else pr.out[(int64_t)r * pr.ldo + n] = v;
+    float* o = (pr.out_nr & 1) ? pr.out + (int64_t)n * pr.ldo + r : pr.out + (int64_t)r * pr.ldo + n;
+    *o = (pr.out_nr & 2) ? *o + v : v;                 // bit 1: accumulate into `out` (gradient arena)
 }
 
 // ------------------------------------------------------------------------------------------------------------

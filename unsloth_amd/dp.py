@@ -17,6 +17,7 @@ MI355X-first version of that exchange:
   * deterministic: fixed bucket order, fp32 sum.
 Works unchanged on gloo/CPU (tests/test_dp_gloo.py, world_size 2).
 """
+import os
 import re
 from contextlib import contextmanager
 
@@ -30,7 +31,9 @@ def _layer_index(name):
 
 
 class LoRAGradArena:
-    def __init__(self, model, process_group=None, bucket_bytes=4 << 20, overlap=True):
+    def __init__(self, model, process_group=None, bucket_bytes=None, overlap=True, direct=True):
+        if bucket_bytes is None:
+            bucket_bytes = int(float(os.environ.get("UNSLOTH_AMD_DP_BUCKET_MB", "64")) * (1 << 20))
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("no trainable parameters")
@@ -44,6 +47,8 @@ class LoRAGradArena:
         self.group = process_group
         self.overlap = overlap
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # UNSLOTH_AMD_DP_FORCE=1: issue the collectives even in a 1-rank group (exercises RCCL + hooks on one GPU)
+        self._force = os.environ.get("UNSLOTH_AMD_DP_FORCE", "0") == "1" and dist.is_initialized()
         self.buckets = []          # (start, end, n_params)
         self._bucket_of = {}
         off, b_start, b_count = 0, 0, 0
@@ -65,6 +70,32 @@ class LoRAGradArena:
         self._handles = []
         self._sync = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        # the fused LoRA-gradient kernel adds straight into the arena (kernels/utils.py GRAD_SINKS): no
+        # AccumulateGrad kernel per parameter; .ready() does the bucket bookkeeping the autograd hook would do
+        self._views = {}
+        if direct and self.arena.is_cuda:
+            from .kernels.utils import GRAD_SINKS
+            for p in self.params:
+                self._views[id(p)] = p.grad
+                GRAD_SINKS[id(p)] = self
+
+    def grad_view(self, p):
+        v = self._views[id(p)]
+        if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+            p.grad = v                                   # e.g. after optimizer.zero_grad(set_to_none=True)
+        return v
+
+    def ready(self, p):
+        self._hook(p)
+
+    def close(self):
+        from .kernels.utils import GRAD_SINKS
+        for p in self.params:
+            if GRAD_SINKS.get(id(p)) is self:
+                del GRAD_SINKS[id(p)]
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     # ------------------------------------------------------------------------------------------
     def _hook(self, p):
@@ -72,7 +103,7 @@ class LoRAGradArena:
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
             self._pending[b] = 0
-            if self._sync and self.overlap and self.world_size > 1:
+            if self._sync and self.overlap and (self.world_size > 1 or self._force):
                 self._launch(b)
 
     def _launch(self, b):
@@ -82,7 +113,7 @@ class LoRAGradArena:
 
     def finish(self):
         """Call after backward, before optimizer.step(): launches anything not overlapped and waits."""
-        if self.world_size > 1 and self._sync:
+        if (self.world_size > 1 or self._force) and self._sync:
             if not self.overlap:
                 for b in range(len(self.buckets)):
                     self._launch(b)

@@ -17,6 +17,7 @@ GEMM (torch.matmul/addmm_), as in the reference (:172-189): they are tiny and la
 import torch
 
 from .utils import (
+    GRAD_SINKS,
     cast_lora,
     get_lora_parameters,
     lora_dx_terms,
@@ -60,7 +61,7 @@ def _lora_grads_fused(items):
     """items: [(X2d, dY2d, A, B, s, XA, P)] with XA = X @ A^T (fp32, saved by the forward) and P = dY @ B (fp32,
     shared with the dX GEMM). Returns [(dA, dB)] in fp32, all products of the block in ONE launch per 8:
         dA = s * P^T @ X   [r, in]          dB = s * dY^T @ XA   [out, r]          (fast_lora.py:172-189)"""
-    probs, slots = [], []
+    probs, slots, targets, sinks = [], [], [], []
     for (X2d, dY2d, A, B, s, XA, P) in items:
         if A is None:
             slots.append(None)
@@ -69,7 +70,15 @@ def _lora_grads_fused(items):
         slots.append(len(probs))
         probs.append((P, X2d, r, False, s))
         probs.append((XA, dY2d, r, True, s))
-    outs = lora_tn(probs)
+        for prm in (A, B):
+            sink = GRAD_SINKS.get(id(prm)) if GRAD_SINKS else None
+            sinks.append((sink, prm))
+            targets.append(sink.grad_view(prm) if sink is not None else None)
+    outs = lora_tn(probs, targets if any(t is not None for t in targets) else None)
+    for sink, prm in sinks:
+        if sink is not None:
+            sink.ready(prm)               # the gradient is in the arena: autograd gets None for it
+    outs = [None if sk[0] is not None else o for o, sk in zip(outs, sinks)]
     return [(None, None) if k is None else (outs[k], outs[k + 1]) for k in slots]
 
 

@@ -454,9 +454,17 @@ def lora_tn_supported(Zs):
     return all(Z.is_cuda and Z.dtype in (torch.bfloat16, torch.float16) and Z.shape[-1] % 8 == 0 for Z in Zs)
 
 
-def lora_tn(problems):
+# Gradient sinks: id(parameter) -> object with .grad_view(p) (contiguous fp32 tensor of p's shape that ACCUMULATES
+# the gradient, e.g. a slice of dp.LoRAGradArena) and .ready(p) (called once the kernel that adds into it has been
+# enqueued). With a sink the fused LoRA-gradient kernel adds straight into the arena: no per-parameter
+# AccumulateGrad kernel, no temporary.
+GRAD_SINKS = {}
+
+
+def lora_tn(problems, targets=None):
     """problems: [(P fp32 [M, >=R] with unit column stride, Z [M, N], R, out_nr, scale)].
     Returns the fp32 products, [R, N] (out_nr False: lora_A.grad layout) or [N, R] (True: lora_B.grad layout).
+    `targets[i]` (optional): contiguous fp32 tensor of that shape to ACCUMULATE into instead of allocating.
     One launch per 8 sixteen-rank problems; deterministic."""
     if not problems:
         return []
@@ -464,11 +472,17 @@ def lora_tn(problems):
     dev = problems[0][1].device
     dtype = problems[0][1].dtype
     outs, descs, keep = [], [], []
-    for (P, Z, R, out_nr, scale) in problems:
+    for pi, (P, Z, R, out_nr, scale) in enumerate(problems):
         Z2 = _rows2d(Z)
         assert Z2.shape[0] == M and P.shape[0] == M and P.dtype == torch.float32 and P.stride(1) == 1
         N = Z2.shape[1]
-        out = torch.empty((N, R) if out_nr else (R, N), dtype=torch.float32, device=dev)
+        tgt = targets[pi] if targets is not None else None
+        if tgt is not None:
+            assert (tgt.dtype == torch.float32 and tgt.is_contiguous() and tgt.device == dev
+                    and tuple(tgt.shape) == ((N, R) if out_nr else (R, N)))
+            out = tgt
+        else:
+            out = torch.empty((N, R) if out_nr else (R, N), dtype=torch.float32, device=dev)
         outs.append(out)
         keep.append(Z2)
         for r0 in range(0, R, 16):
@@ -476,7 +490,8 @@ def lora_tn(problems):
             optr = out.data_ptr() + (4 * r0 if out_nr else 4 * r0 * N)
             descs.append(_lib.LoraTnProblem(P=P.data_ptr() + 4 * r0, Z=Z2.data_ptr(), out=optr, ldp=P.stride(0),
                                             ldz=Z2.stride(0), ldo=(R if out_nr else N), N=N, R=rc,
-                                            out_nr=int(bool(out_nr)), scale=float(scale)))
+                                            out_nr=int(bool(out_nr)) | (2 if tgt is not None else 0),
+                                            scale=float(scale)))
     S = (M + 127) // 128            # upper bound on the row chunks the kernel may choose
     L = _lib.lib()
     for i in range(0, len(descs), 8):

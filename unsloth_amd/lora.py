@@ -209,5 +209,25 @@ class PeftModelForCausalLM(nn.Module):
             json.dump(cfg, f, indent=2, default=str)
 
 
+def _save_pretrained_merged(self, save_directory, tokenizer=None, save_method="merged_16bit", **kwargs):
+    """`model.save_pretrained_merged` of the reference (save.py): "lora" = adapters only, "merged_16bit" = dense
+    16-bit safetensors with the adapters folded in, "merged_4bit"/"4bit" is the frozen NF4 base as it sits in HBM."""
+    from . import checkpoint as _ckpt
+    if save_method == "lora":
+        self.save_pretrained(save_directory)
+    elif save_method in ("merged_16bit", "16bit"):
+        _ckpt.save_pretrained_merged(self, save_directory)
+    elif save_method in ("base_4bit", "4bit"):
+        _ckpt.save_pretrained_4bit(self, save_directory)
+    else:
+        raise NotImplementedError(f"save_method={save_method!r}: 'lora', 'merged_16bit', 'base_4bit' (GGUF and "
+                                  "re-quantised merged_4bit exports are outside the hot path)")
+    if tokenizer is not None:
+        tokenizer.save_pretrained(save_directory)
+
+
+PeftModelForCausalLM.save_pretrained_merged = _save_pretrained_merged
+
+
 def get_peft_model(model, peft_config, adapter_name="default"):
     return PeftModelForCausalLM(model, peft_config, adapter_name)

@@ -70,9 +70,28 @@ class FastLanguageModel:
         if rope_scaling is not None:
             config.rope_scaling = rope_scaling
         FastLlamaModel.pre_patch()
+        prequantized = False
         if model_name is not None and os.path.isdir(str(model_name)):
-            model = AutoModelForCausalLM.from_pretrained(model_name, config=config, dtype=dtype)
-            model.to(device)
+            from .. import checkpoint as _ckpt
+            if _ckpt.is_prequantized(config):
+                # `*-bnb-4bit` checkpoint: transformers would need bitsandbytes to deserialise it (llama.py:2615-2626);
+                # build the module tree without storage and fill it from the safetensors directly, NF4 bytes unchanged
+                import copy
+                cfg16 = copy.deepcopy(config)
+                if hasattr(cfg16, "quantization_config"):
+                    del cfg16.quantization_config
+                with torch.device("meta"):
+                    model = AutoModelForCausalLM.from_config(cfg16, dtype=dtype)
+                model.to_empty(device=device)
+                missing, unexpected = _ckpt.load_prequantized_(model, str(model_name), device, dtype)
+                still = [m for m in missing if "rotary" not in m]
+                if still:
+                    raise RuntimeError(f"{model_name}: checkpoint has no tensors for {still[:8]} ...")
+                model.config.quantization_config = _ckpt.bnb_quantization_config(dtype)
+                prequantized = True
+            else:
+                model = AutoModelForCausalLM.from_pretrained(model_name, config=config, dtype=dtype)
+                model.to(device)
             try:
                 from transformers import AutoTokenizer
                 tokenizer = AutoTokenizer.from_pretrained(model_name)
@@ -90,7 +109,7 @@ class FastLanguageModel:
             model.to(dtype)
         for p in model.parameters():
             p.requires_grad_(False)
-        if load_in_4bit and not load_in_16bit:
+        if load_in_4bit and not load_in_16bit and not prequantized:
             quantize_model_nf4_(model)
             torch.cuda.empty_cache()
         model.config.dtype = dtype
