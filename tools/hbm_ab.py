@@ -28,6 +28,9 @@ def run(fn, iters=10):
 
 
 def ab(out, name, nbytes, cands, rounds=5):
+    only = os.environ.get("HBM_AB_ONLY")          # substring filter on the kernel label
+    if only and only not in name:
+        return
     for f in cands.values():
         f()
     torch.cuda.synchronize()
@@ -45,6 +48,7 @@ def ab(out, name, nbytes, cands, rounds=5):
 
 def main():
     out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    only = os.environ.get("HBM_AB_ONLY")          # substring filter on the kernel label
     bf = torch.bfloat16
     T, H, I = 8192, 4096, 14336
     X = torch.randn(T, H, device=DEV, dtype=bf)
@@ -79,8 +83,28 @@ def main():
             L.uamd_set_tuning(3, knob)
             return dequantize_nf4(packed, qs, transpose=True, use_global_buffer=True)
         return f
-    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t64": dq(0), "t256": dq(1),
+    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t64": dq(0), "t256": dq(1), 
                                                    "plain": lambda: dequantize_nf4(packed, qs, use_global_buffer=True)})
+    Wd2 = (torch.randn(H, I, device=DEV) * 0.02).to(bf)
+    packed2, qs2 = quantize_nf4(Wd2)
+
+    def dq2(knob):
+        def f():
+            L.uamd_set_tuning(3, knob)
+            return dequantize_nf4(packed2, qs2, transpose=True, use_global_buffer=True)
+        return f
+    ab(out, "nf4_dequant_T down", I * H * 2.516, {"t256": dq2(1), 
+                                                   "plain": lambda: dequantize_nf4(packed2, qs2, use_global_buffer=True)})
+    Wd3 = (torch.randn(H, H, device=DEV) * 0.02).to(bf)
+    packed3, qs3 = quantize_nf4(Wd3)
+
+    def dq3(knob):
+        def f():
+            L.uamd_set_tuning(3, knob)
+            return dequantize_nf4(packed3, qs3, transpose=True, use_global_buffer=True)
+        return f
+    ab(out, "nf4_dequant_T o", H * H * 2.516, {"t256": dq3(1), 
+                                               "plain": lambda: dequantize_nf4(packed3, qs3, use_global_buffer=True)})
     L.uamd_set_tuning(3, 1)
     # lora_xa / lora_tn
     A3 = [torch.nn.Parameter(torch.randn(16, H, device=DEV) * 0.02) for _ in range(3)]

@@ -174,6 +174,11 @@ nf4_dequant_t_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const flo
 //   * transposed write: 8 consecutive lanes cover 128 B of one output row (16 B per lane from one
 //     ds_read_b128; the XOR only permutes the four words inside it, undone with register selects).
 // 2.5 B/param of HBM traffic, both sides moved in >= 128-byte contiguous segments.
+// Measured (profiles/r01_dequant_t_variants.jsonl): this kernel, a version that transposes with
+// ds_read_b64_tr_b16, a persistent software-pipelined version and a barrier-free wave-private version (32x128
+// tiles, +- non-temporal stores) ALL take the row-major kernel's time plus the same 15-25 us per launch, whatever
+// the matrix size (4096x4096 and 14336x4096 alike): the cost is in how the transposed output leaves the chip
+// (scattered 128-byte lines written back at the end of the kernel), not in the kernel body. The simplest one stays.
 template <typename T>
 __global__ void __launch_bounds__(256)
 nf4_dequant_t2_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const float* __restrict__ lut_g,
@@ -306,7 +311,8 @@ int launch_dequant(const uint8_t* packed, const AbsmaxSrc& am, const float* lut,
                            am, lut, (T*)out, n, blocksize);
     } else {
         if (sizeof(T) != 2 || (cols & 7)) return UAMD_ERR_ARG;
-        if ((blocksize & 7) == 0 && uamd_tuning_get(UAMD_TUNE_DEQUANT_T) != 0) {
+        const int tv = uamd_tuning_get(UAMD_TUNE_DEQUANT_T);
+        if ((blocksize & 7) == 0 && tv != 0) {
             dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + 63) / 64));
             hipLaunchKernelGGL((nf4_dequant_t2_kernel<T>), grid, dim3(256), 0, st, packed, am, lut,
                                (T*)out, (int)rows, (int)cols, ld_out, blocksize);
