@@ -64,10 +64,13 @@ class GemmTimer:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flops = 2.0 * X2d.shape[0] * X2d.shape[1] * sum(g.N for g in groups)
             flops += sum(2.0 * X2d.shape[0] * g.R * g.N for g in groups if g.lora_xa)
+            # algorithmic bytes: A once, every B once, every C written once (+ read once when accumulating)
+            M_, K_ = X2d.shape
+            nbytes = 2.0 * M_ * K_ + sum(2.0 * g.N * K_ + 2.0 * M_ * g.N * (2 if accumulate else 1) for g in groups)
             s.record()
             name = orig(X2d, groups, nf4, accumulate)
             e.record()
-            recs.setdefault(KERNEL_OF[name], []).append((s, e, flops))
+            recs.setdefault(KERNEL_OF[name], []).append((s, e, flops, nbytes))
             return name
 
         U._launch_gemm = timed
@@ -80,10 +83,11 @@ class GemmTimer:
         for name, recs in self.records.items():
             if not recs:
                 continue
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            fl = sum(r[2] for r in recs)
             out[name] = dict(launches=len(recs), total_ms=ms, avg_us=ms * 1e3 / len(recs), flops=fl,
-                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+                             tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                             alg_bytes=sum(r[3] for r in recs) / len(recs))
         return out
 
 
@@ -207,8 +211,21 @@ def main():
         dom_name = [k for k, v in gs.items() if v is dom][0] if dom else None
         roofline = None
         if dom:
+            # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json,
+            # tools/gpu_pmc_bench.sh): counters cannot be collected inside a timed run
+            traffic, traffic_src = None, None
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
+                    pt = json.load(f)
+                if dom_name in pt:
+                    traffic = pt[dom_name]["traffic_bytes"]
+                    traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = dict(bound="mfma", kernel=dom_name, achieved=round(dom["tflops"], 1), peak=MFMA_PEAK_TFLOPS,
-                            unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), traffic=None,
+                            unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
+                            traffic_unit="bytes per launch (mean)", traffic_source=traffic_src,
+                            algorithmic_bytes_per_launch=round(dom["alg_bytes"]),
                             launches_per_step=dom["launches"] // a.steps, avg_launch_us=round(dom["avg_us"], 1),
                             share_of_step=round(dom["total_ms"] / (dt * 1e3), 3),
                             other={k: dict(tflops=round(v["tflops"], 1), avg_us=round(v["avg_us"], 1),
