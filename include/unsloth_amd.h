@@ -57,6 +57,19 @@ int uamd_rms_layernorm_bwd(const void* dY, void* dX, const void* X, const void* 
                            int64_t dx_row_stride, int64_t x_row_stride, int gemma, int x_dtype,
                            int w_dtype, void* stream);
 
+/* Residual add fused into the norm (llama.py:823-844 runs `residual + x` and the norm as two passes):
+ *   fwd: h = X + Res -> H (one rounding to the activation dtype), Y = rmsnorm(h) * W, r as above. H may alias X / Res.
+ *   bwd: dX = rmsnorm_backward(dY; H, W, r) + dRes (both rounded like the separate ops). dX may alias dY / dRes.
+ * Llama-style norm only; rows up to 64 * 8 16-byte vectors, 16-byte aligned, else UAMD_ERR_ALIGN. */
+int uamd_add_rms_layernorm_fwd(const void* X, const void* Res, const void* W, void* H, void* Y, float* r,
+                               int64_t n_rows, int n_cols, int64_t x_row_stride, int64_t res_row_stride,
+                               int64_t h_row_stride, int64_t y_row_stride, float eps, int x_dtype, int w_dtype,
+                               void* stream);
+int uamd_add_rms_layernorm_bwd(const void* dY, const void* dRes, void* dX, const void* H, const void* W,
+                               const float* r, int64_t n_rows, int n_cols, int64_t dy_row_stride,
+                               int64_t dres_row_stride, int64_t dx_row_stride, int64_t h_row_stride, int x_dtype,
+                               int w_dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * RoPE (rotate-half), IN PLACE.  backward != 0 negates sin (rope_embedding.py:140-142).
  * uamd_rope_embedding    replaces _rope_embedding    (rope_embedding.py:104-166) as launched by

@@ -230,3 +230,37 @@ def test_cross_entropy_golden_and_mean(golden):
     loss.backward()
     torch.testing.assert_close(lg.grad[0, 0, -64:].cpu(), c["dlogits_row0_tail"], rtol=1e-4, atol=1e-7)
     assert torch.all(lg.grad[0, 1] == 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("rows,cols", [(64, 4096), (5, 2048), (33, 1024), (257, 64)])
+def test_add_rms_layernorm_equals_add_then_norm(dtype, rows, cols):
+    """residual add fused into the norm == torch add followed by the (oracle-checked) norm kernels, bit for bit,
+    forward (h and y) and backward (dX with the residual-path gradient added inside the kernel)."""
+    from unsloth_amd.kernels.rms_layernorm import Fast_Add_RMS_Layernorm, Fast_RMS_Layernorm, add_rms_supported
+    if not add_rms_supported(torch.empty(1, cols, dtype=dtype, device=DEV), torch.empty(cols, dtype=dtype, device=DEV)):
+        pytest.skip("row too long for the register-resident kernel: fast_add_rms_layernorm takes the two-op path")
+    g = torch.Generator().manual_seed(cols + rows)
+    x = torch.randn(rows, cols, generator=g).to(dtype).to(DEV)
+    res = torch.randn(rows, cols, generator=g).to(dtype).to(DEV)
+    W = torch.rand(cols, generator=g).to(dtype).to(DEV)
+    dh = torch.randn(rows, cols, generator=g).to(dtype).to(DEV)
+    dy = torch.randn(rows, cols, generator=g).to(dtype).to(DEV)
+    # reference: separate ops
+    x1, r1 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    h1 = r1 + x1
+    y1 = Fast_RMS_Layernorm.apply(h1, W, 1e-5, False)
+    torch.autograd.backward([h1, y1], [dh.clone(), dy.clone()])
+    # fused
+    x2, r2 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    h2, y2 = Fast_Add_RMS_Layernorm.apply(x2, r2, W, 1e-5)
+    assert torch.equal(h2, h1) and torch.equal(y2, y1)
+    torch.autograd.backward([h2, y2], [dh.clone(), dy.clone()])
+    assert torch.equal(x2.grad, x1.grad) and torch.equal(r2.grad, r1.grad)
+    # h unused downstream (last layer): dH is None
+    x3, r3 = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+    _, y3 = Fast_Add_RMS_Layernorm.apply(x3, r3, W, 1e-5)
+    y3.backward(dy.clone())
+    x4 = x.clone().requires_grad_(True)
+    Fast_RMS_Layernorm.apply(res + x4, W, 1e-5, False).backward(dy.clone())
+    assert torch.equal(x3.grad, x4.grad)

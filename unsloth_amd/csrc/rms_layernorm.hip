@@ -14,10 +14,14 @@
 
 namespace {
 
-template <typename T, typename WT, int ITERS, bool GEMMA>
+// ADD: the residual add in front of the norm is fused in -- h = T(x + res) (one rounding, what `residual + x`
+// gives in torch), h is written to Hout (the next residual) and normalised (llama.py:823-844 does add, then norm,
+// as two passes over the activations).
+template <typename T, typename WT, int ITERS, bool GEMMA, bool ADD = false>
 __global__ void __launch_bounds__(256)
 rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ Y,
-             float* __restrict__ R, int64_t n_rows, int n_cols, int64_t xs, int64_t ys, float eps, int mode) {
+             float* __restrict__ R, int64_t n_rows, int n_cols, int64_t xs, int64_t ys, float eps, int mode,
+             const T* __restrict__ Res = nullptr, T* __restrict__ Hout = nullptr, int64_t rs = 0, int64_t hs = 0) {
     constexpr int VEC = Vec16<T>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -30,6 +34,24 @@ rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ 
         const int c = (lane + 64 * i) * VEC;
         if (c < n_cols) xv[i] = ld16_m(x + c, mode);
         else xv[i].raw = make_uint4(0, 0, 0, 0);
+    }
+    if (ADD) {
+        const T* res = Res + row * rs;
+        T* h = Hout + row * hs;
+        Vec16<T> rv[ITERS];
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = (lane + 64 * i) * VEC;
+            if (c < n_cols) rv[i] = ld16_m(res + c, mode);
+            else rv[i].raw = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int c = (lane + 64 * i) * VEC;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) xv[i].e[j] = from_f32<T>(to_f32(xv[i].e[j]) + to_f32(rv[i].e[j]));
+            if (c < n_cols) st16(h + c, xv[i]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < ITERS; ++i)
@@ -61,11 +83,13 @@ rms_fwd_wave(const T* __restrict__ X, const WT* __restrict__ W, T* __restrict__ 
     }
 }
 
-template <typename T, typename WT, int ITERS, bool GEMMA>
+// ADD: dX = T(T(rms_dx) + dRes): the gradient that reaches h = x + res from the residual path is added here
+// instead of by a separate autograd accumulation pass (same two roundings as that pass).
+template <typename T, typename WT, int ITERS, bool GEMMA, bool ADD = false>
 __global__ void __launch_bounds__(256)
 rms_bwd_wave(const T* dY, T* dX, const T* __restrict__ X,
              const WT* __restrict__ W, const float* __restrict__ R, int64_t n_rows, int n_cols,
-             int64_t dys, int64_t dxs, int64_t xs, int mode) {
+             int64_t dys, int64_t dxs, int64_t xs, int mode, const T* dRes = nullptr, int64_t drs = 0) {
     constexpr int VEC = Vec16<T>::N;
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -113,6 +137,11 @@ rms_bwd_wave(const T* dY, T* dX, const T* __restrict__ X,
                 const float normed = to_f32(xv[i].e[j]) * inv;
                 // rms_layernorm.py:112
                 o.e[j] = from_f32<T>(inv / n * (n * dyw - normed * rs));
+            }
+            if (ADD) {
+                const Vec16<T> dr = ld16_m(dRes + row * drs + c, mode);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o.e[j] = from_f32<T>(to_f32(o.e[j]) + to_f32(dr.e[j]));
             }
             st16_m(dx + c, o, mode);
         }
@@ -212,6 +241,40 @@ int launch_bwd(const void* dY, void* dX, const void* X, const void* W, const flo
     return uamd_launch_status();
 }
 
+template <typename T, typename WT, bool GEMMA>
+int launch_add_fwd(const void* X, const void* Res, const void* W, void* H, void* Y, float* R, int64_t n_rows,
+                   int n_cols, int64_t xs, int64_t rs, int64_t hs, int64_t ys, float eps, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool vec_ok = (n_cols % VEC == 0) && (xs % VEC == 0) && (ys % VEC == 0) && (rs % VEC == 0) &&
+                        (hs % VEC == 0) && aligned16(X) && aligned16(Y) && aligned16(W) && aligned16(Res) &&
+                        aligned16(H) && n_cols <= 64 * VEC * 8;
+    if (!vec_ok || GEMMA) return UAMD_ERR_ALIGN;
+    const int iters = (n_cols + 64 * VEC - 1) / (64 * VEC);
+    dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+    const int mode = uamd_tuning_get(UAMD_TUNE_STREAM_NT);
+#define L(I) hipLaunchKernelGGL((rms_fwd_wave<T, WT, I, false, true>), grid, block, 0, st, (const T*)X, (const WT*)W, (T*)Y, R, n_rows, n_cols, xs, ys, eps, mode, (const T*)Res, (T*)H, rs, hs)
+    if (iters <= 1) L(1); else if (iters <= 2) L(2); else if (iters <= 4) L(4); else L(8);
+#undef L
+    return uamd_launch_status();
+}
+
+template <typename T, typename WT, bool GEMMA>
+int launch_add_bwd(const void* dY, const void* dRes, void* dX, const void* X, const void* W, const float* R,
+                   int64_t n_rows, int n_cols, int64_t dys, int64_t drs, int64_t dxs, int64_t xs, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    const bool vec_ok = (n_cols % VEC == 0) && (xs % VEC == 0) && (dys % VEC == 0) && (dxs % VEC == 0) &&
+                        (drs % VEC == 0) && aligned16(X) && aligned16(dY) && aligned16(dX) && aligned16(W) &&
+                        aligned16(dRes) && n_cols <= 64 * VEC * 8;
+    if (!vec_ok || GEMMA) return UAMD_ERR_ALIGN;
+    const int iters = (n_cols + 64 * VEC - 1) / (64 * VEC);
+    dim3 grid((unsigned)((n_rows + 3) / 4)), block(256);
+    const int mode = uamd_tuning_get(UAMD_TUNE_STREAM_NT);
+#define L(I) hipLaunchKernelGGL((rms_bwd_wave<T, WT, I, false, true>), grid, block, 0, st, (const T*)dY, (T*)dX, (const T*)X, (const WT*)W, R, n_rows, n_cols, dys, dxs, xs, mode, (const T*)dRes, drs)
+    if (iters <= 1) L(1); else if (iters <= 2) L(2); else if (iters <= 4) L(4); else L(8);
+#undef L
+    return uamd_launch_status();
+}
+
 }  // namespace
 
 #define RMS_DISPATCH(FN, ...)                                                        \
@@ -248,4 +311,33 @@ extern "C" int uamd_rms_layernorm_bwd(const void* dY, void* dX, const void* X, c
     hipStream_t st = (hipStream_t)stream;
     RMS_DISPATCH(launch_bwd, dY, dX, X, W, r, n_rows, n_cols, dy_row_stride, dx_row_stride,
                  x_row_stride, st)
+}
+
+// h = X + Res (written to H), Y = rmsnorm(h) * W, r = rsqrt(mean h^2 + eps): residual add + norm in ONE pass
+// (the reference runs them as two, llama.py:823-844). Rows up to 64*8 16-byte vectors, 16-byte aligned
+// (otherwise UAMD_ERR_ALIGN: call the two separate ops). H may alias Res or X.
+extern "C" int uamd_add_rms_layernorm_fwd(const void* X, const void* Res, const void* W, void* H, void* Y, float* r,
+                                          int64_t n_rows, int n_cols, int64_t x_row_stride, int64_t res_row_stride,
+                                          int64_t h_row_stride, int64_t y_row_stride, float eps, int x_dtype,
+                                          int w_dtype, void* stream) {
+    if (n_rows < 0 || n_cols <= 0 || !X || !Res || !H || !Y || !W || !r) return UAMD_ERR_ARG;
+    if (n_rows == 0) return UAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int gemma = 0;
+    RMS_DISPATCH(launch_add_fwd, X, Res, W, H, Y, r, n_rows, n_cols, x_row_stride, res_row_stride, h_row_stride,
+                 y_row_stride, eps, st)
+}
+
+// dX = rmsnorm_backward(dY; h, W, r) + dRes, dRes = the gradient arriving at h from the residual path. dX may
+// alias dY (the reference's in-place contract, rms_layernorm.py:218) or dRes.
+extern "C" int uamd_add_rms_layernorm_bwd(const void* dY, const void* dRes, void* dX, const void* H, const void* W,
+                                          const float* r, int64_t n_rows, int n_cols, int64_t dy_row_stride,
+                                          int64_t dres_row_stride, int64_t dx_row_stride, int64_t h_row_stride,
+                                          int x_dtype, int w_dtype, void* stream) {
+    if (n_rows < 0 || n_cols <= 0 || !dY || !dRes || !dX || !H || !W || !r) return UAMD_ERR_ARG;
+    if (n_rows == 0) return UAMD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int gemma = 0;
+    RMS_DISPATCH(launch_add_bwd, dY, dRes, dX, H, W, r, n_rows, n_cols, dy_row_stride, dres_row_stride,
+                 dx_row_stride, h_row_stride, st)
 }

@@ -52,6 +52,82 @@ class Fast_RMS_Layernorm(torch.autograd.Function):
         return dX.view(*shape), None, None, None
 
 
+class Fast_Add_RMS_Layernorm(torch.autograd.Function):
+    """(h, y) = (X + residual, rmsnorm(X + residual) * W) in one pass over the activations; the backward adds the
+    gradient that reaches h from the residual path inside the norm's backward kernel. Same numbers as
+    `h = residual + X; y = Fast_RMS_Layernorm(h)` (llama.py:823-844) with the autograd accumulation of dh."""
+
+    @staticmethod
+    def forward(ctx, X, residual, W, eps):
+        _lib.require_gpu(X, residual, W)
+        shape = X.shape
+        dim = shape[-1]
+        X2 = X.reshape(-1, dim)
+        R2 = residual.reshape(-1, dim)
+        if X2.stride(1) != 1:
+            X2 = X2.contiguous()
+        if R2.stride(1) != 1:
+            R2 = R2.contiguous()
+        n_rows = X2.shape[0]
+        H = torch.empty((n_rows, dim), dtype=X.dtype, device=X.device)
+        Y = torch.empty((n_rows, dim), dtype=X.dtype, device=X.device)
+        r = torch.empty(n_rows, dtype=torch.float32, device=X.device)
+        W = W.contiguous()
+        with _lib.device_ctx(X):
+            rc = _lib.lib().uamd_add_rms_layernorm_fwd(
+                _lib.ptr(X2), _lib.ptr(R2), _lib.ptr(W), _lib.ptr(H), _lib.ptr(Y), _lib.ptr(r), n_rows, dim,
+                X2.stride(0), R2.stride(0), H.stride(0), Y.stride(0), float(eps), _lib.dtype_code(X.dtype),
+                _lib.dtype_code(W.dtype), _lib.stream_of(X))
+        _lib.check(rc, "uamd_add_rms_layernorm_fwd")
+        ctx.save_for_backward(H, W, r)
+        return H.view(*shape), Y.view(*shape)
+
+    @staticmethod
+    def backward(ctx, dH, dY):
+        H, W, r = ctx.saved_tensors
+        shape = dY.shape
+        dim = shape[-1]
+        dY = dY.reshape(-1, dim)
+        if dY.stride(1) != 1:
+            dY = dY.contiguous()
+        n_rows = dY.shape[0]
+        with _lib.device_ctx(dY):
+            if dH is None:
+                rc = _lib.lib().uamd_rms_layernorm_bwd(
+                    _lib.ptr(dY), _lib.ptr(dY), _lib.ptr(H), _lib.ptr(W), _lib.ptr(r), n_rows, dim, dY.stride(0),
+                    dY.stride(0), H.stride(0), 0, _lib.dtype_code(dY.dtype), _lib.dtype_code(W.dtype),
+                    _lib.stream_of(dY))
+            else:
+                dH = dH.reshape(-1, dim)
+                if dH.stride(1) != 1:
+                    dH = dH.contiguous()
+                rc = _lib.lib().uamd_add_rms_layernorm_bwd(
+                    _lib.ptr(dY), _lib.ptr(dH), _lib.ptr(dY), _lib.ptr(H), _lib.ptr(W), _lib.ptr(r), n_rows, dim,
+                    dY.stride(0), dH.stride(0), dY.stride(0), H.stride(0), _lib.dtype_code(dY.dtype),
+                    _lib.dtype_code(W.dtype), _lib.stream_of(dY))
+        _lib.check(rc, "uamd_add_rms_layernorm_bwd")
+        dX = dY.view(*shape)                       # written over dY, like rms_layernorm.py:218
+        return dX, dX, None, None
+
+
+def add_rms_supported(X, W):
+    """shapes the fused kernel takes (otherwise: torch add + fast_rms_layernorm)."""
+    vec = 16 // X.element_size()
+    return (X.is_cuda and X.dtype in (torch.bfloat16, torch.float16, torch.float32) and X.shape[-1] % vec == 0
+            and X.shape[-1] <= 64 * vec * 8 and W.dtype in (X.dtype, torch.float32))
+
+
+@torch.compiler.disable
+def fast_add_rms_layernorm(layernorm, X, residual):
+    """(residual + X, layernorm(residual + X)) -- the add of llama.py:833/:840 fused into the following norm."""
+    W = layernorm.weight
+    eps = layernorm.variance_epsilon if hasattr(layernorm, "variance_epsilon") else layernorm.eps
+    if not add_rms_supported(X, W):
+        h = residual + X
+        return h, Fast_RMS_Layernorm.apply(h, W, eps, False)
+    return Fast_Add_RMS_Layernorm.apply(X, residual, W, eps)
+
+
 @torch.compiler.disable
 def fast_rms_layernorm(layernorm, X, gemma=False):
     """rms_layernorm.py:244-255."""

@@ -36,6 +36,7 @@ from ..kernels import (
     unsloth_fused_ce_loss,
 )
 from ..kernels.utils import invalidate_cast_cache, lora_linear_forward
+from ..kernels.rms_layernorm import fast_add_rms_layernorm
 from ..utils.packing import (
     build_sdpa_packed_attention_mask,
     get_packed_info_from_kwargs,
@@ -47,6 +48,7 @@ from .. import nf4 as _nf4
 from ..kernels import attention as _flash
 
 _USE_FLASH = os.environ.get("UNSLOTH_AMD_FLASH_ATTENTION", "1") == "1"
+_FUSED_RESIDUAL = os.environ.get("UNSLOTH_AMD_FUSED_RESIDUAL", "1") == "1"
 
 __version__ = "0.1.0"
 
@@ -196,12 +198,30 @@ def LlamaDecoderLayer_fast_forward(self, hidden_states, cos, sin, rope_position_
     hidden_states = fast_rms_layernorm(self.input_layernorm, hidden_states)
     hidden_states = LlamaAttention_fast_forward(self.self_attn, hidden_states, cos, sin, rope_position_ids,
                                                 seq_info, attention_mask)
-    hidden_states = residual + hidden_states
-    residual = hidden_states
-    hidden_states = fast_rms_layernorm(self.post_attention_layernorm, hidden_states)
+    if _FUSED_RESIDUAL:
+        residual, hidden_states = fast_add_rms_layernorm(self.post_attention_layernorm, hidden_states, residual)
+    else:
+        hidden_states = residual + hidden_states
+        residual = hidden_states
+        hidden_states = fast_rms_layernorm(self.post_attention_layernorm, hidden_states)
     hidden_states = self.mlp(hidden_states)
     hidden_states = residual + hidden_states
     return hidden_states
+
+
+def LlamaDecoderLayer_fused_residual_forward(self, residual, delta, cos, sin, rope_position_ids=None, seq_info=None,
+                                             attention_mask=None):
+    """The same layer with the residual stream carried as (residual, delta): hidden = residual + delta is never
+    formed by a separate pass -- each add is fused into the norm that follows it (kernels/rms_layernorm.py
+    Fast_Add_RMS_Layernorm), also across the layer boundary. Returns (residual', delta') for the next layer."""
+    if delta is None:
+        hidden = residual
+        x = fast_rms_layernorm(self.input_layernorm, hidden)
+    else:
+        hidden, x = fast_add_rms_layernorm(self.input_layernorm, delta, residual)
+    attn = LlamaAttention_fast_forward(self.self_attn, x, cos, sin, rope_position_ids, seq_info, attention_mask)
+    hidden, x = fast_add_rms_layernorm(self.post_attention_layernorm, attn, hidden)
+    return hidden, self.mlp(x)
 
 
 def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_ids=None, inputs_embeds=None,
@@ -232,6 +252,15 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
     gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
     if gc and not hidden_states.requires_grad:
         hidden_states.requires_grad_(True)      # reentrant checkpoint needs an input that requires grad
+    if not gc and _FUSED_RESIDUAL:
+        # residual stream carried as (residual, delta): every `residual + x` is fused into the norm after it
+        residual, delta = hidden_states, None
+        for layer in self.layers:
+            residual, delta = LlamaDecoderLayer_fused_residual_forward(layer, residual, delta, cos, sin,
+                                                                       rope_position_ids, seq_info, attention_mask)
+        if delta is None:
+            return fast_rms_layernorm(self.norm, residual)
+        return fast_add_rms_layernorm(self.norm, delta, residual)[1]                # :1228
     for layer in self.layers:
         if gc:
             # llama.py:1169-1193: reentrant, no RNG state (dropout is 0 on this path)
