@@ -779,9 +779,9 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
                              const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
                              float scale, int causal, const int* lo, const int* hi, int dtype, void* stream) {
     if ((lo == nullptr) != (hi == nullptr)) return UAMD_ERR_ARG;
-    if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !Delta || !strides) return UAMD_ERR_ARG;
     if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
-    if (B == 0 || T == 0) return UAMD_OK;
+    if (B == 0 || T == 0) return UAMD_OK;                     // empty batch: nothing to read (pointers may be null)
+    if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !Delta || !strides) return UAMD_ERR_ARG;
     if (D != AD || !causal || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
     const int G = Hq / Hk;
     if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
@@ -835,8 +835,9 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
 extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
                              const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
                              float scale, int causal, const int* lo, int dtype, void* stream) {
-    if (!Q || !K || !V || !O || !LSE || !strides || B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
-    if (B == 0 || T == 0) return UAMD_OK;
+    if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
+    if (B == 0 || T == 0) return UAMD_OK;                     // empty batch: nothing to read (pointers may be null)
+    if (!Q || !K || !V || !O || !LSE || !strides) return UAMD_ERR_ARG;
     if (D != AD || !causal || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
     const int G = Hq / Hk;
     if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
