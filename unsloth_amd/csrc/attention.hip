@@ -193,14 +193,16 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 
     const int last_tile_wave = min(qs + 31, T_ - 1) / KT;            // tiles beyond are fully masked for this wave
     const int first_tile_wave = lo_w0 / KT;                          // ... and tiles before
-    for (int ti = 0; ti < nt; ++ti) {
+    // One tile step; MASKED is compile-time and the tile range is split by hand (see attn_bwd_dq_kernel).
+    auto step = [&](int ti, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         const int t = t_first + ti;
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);              // its stage was last read before this barrier
-        if (t > last_tile_wave || t < first_tile_wave) continue;     // wave-uniform: nothing to add
+        if (t > last_tile_wave || t < first_tile_wave) return;       // wave-uniform: nothing to add
         const unsigned char* sk = smem + (ti % NST) * STAGE_B;
         const unsigned char* sv = sk + TILE_B;
 
@@ -219,14 +221,13 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         }
         // ---- online softmax, log2 domain. lane: q = q_pos; register r of tile kt: key below
         const int k0 = t * KT;
-        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_) || (k0 < lo_w1);
         float mt = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float s = st[kt][r] * p.scale_log2;
-                if (need_mask) {
+                if (MASKED) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (key > q_pos || key >= T_ || key < lo_q) s = -INFINITY;
                 }
@@ -270,6 +271,15 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
                     o_acc[dt] = MfmaA<T>::run(va.f, pb.f, o_acc[dt]);
                 }
             }
+    };
+    {
+        const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);       // tiles that start below the band edge
+        const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
+        const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
+        int ti = 0;
+        for (; t_first + ti < t_pre_end; ++ti) step(ti, std::true_type{});
+        for (; t_first + ti < t_suf; ++ti) step(ti, std::false_type{});
+        for (; ti < nt; ++ti) step(ti, std::true_type{});
     }
 
     // ---- epilogue: O = O^T / l, LSE = ln2 * (m + log2 l)
@@ -407,18 +417,21 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     if (nt > 1) issue(t_first + 1, 1);
     const int last_tile_wave = min(qs + 31, T_ - 1) / KT;
     const int first_tile_wave = lo_w0 / KT;
-    for (int ti = 0; ti < nt; ++ti) {
+    // One tile step. MASKED is a compile-time flag and the tile range is split by hand into
+    // [band-edge tiles | interior tiles | diagonal / ragged tiles]: with a run-time `need_mask` that depends on
+    // the band the compiler keeps both paths' registers alive in one loop body (+50 VGPRs, spills).
+    auto step = [&](int ti, auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
         const int t = t_first + ti;
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);
-        if (t > last_tile_wave || t < first_tile_wave) continue;
+        if (t > last_tile_wave || t < first_tile_wave) return;
         const unsigned char* sk = smem + (ti % NST) * STAGE_B;
         const unsigned char* sv = sk + TILE_B;
         const int k0 = t * KT;
-        const bool need_mask = (k0 + KT - 1 > qs) || (k0 + KT > T_) || (k0 < lo_w1);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
             f32x16_t st, dp;
@@ -436,7 +449,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pv = __builtin_amdgcn_exp2f(st[r] * p.scale_log2 - lse2);
-                if (need_mask) {
+                if (MASKED) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (key > q_pos || key >= T_ || key < lo_q) pv = 0.f;
                 }
@@ -457,6 +470,17 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 }
             }
         }
+    };
+    {
+        // tiles whose first key lies below the wave's largest band edge: a prefix; tiles that touch the diagonal
+        // or run past T: a suffix
+        const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);
+        const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
+        const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
+        int ti = 0;
+        for (; t_first + ti < t_pre_end; ++ti) step(ti, std::true_type{});
+        for (; t_first + ti < t_suf; ++ti) step(ti, std::false_type{});
+        for (; ti < nt; ++ti) step(ti, std::true_type{});
     }
     if (q_pos < T_) {
         T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)q_pos * p.dq_st + (int64_t)head * p.dq_sh;
