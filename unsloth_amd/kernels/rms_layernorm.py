@@ -79,12 +79,15 @@ class Fast_Add_RMS_Layernorm(torch.autograd.Function):
                 X2.stride(0), R2.stride(0), H.stride(0), Y.stride(0), float(eps), _lib.dtype_code(X.dtype),
                 _lib.dtype_code(W.dtype), _lib.stream_of(X))
         _lib.check(rc, "uamd_add_rms_layernorm_fwd")
+        ctx.set_materialize_grads(False)           # an unused h (last layer) arrives as dH = None, not as a zero tensor
         ctx.save_for_backward(H, W, r)
         return H.view(*shape), Y.view(*shape)
 
     @staticmethod
     def backward(ctx, dH, dY):
         H, W, r = ctx.saved_tensors
+        if dY is None:                             # only the residual stream was used downstream
+            return dH, dH, None, None
         shape = dY.shape
         dim = shape[-1]
         dY = dY.reshape(-1, dim)
