@@ -94,6 +94,23 @@ __device__ __forceinline__ uint32_t pack_pair(float lo, float hi) {
     return v.u;
 }
 
+// -DUAMD_ATTN_TRACE: s_memtime stamps around the phases of forward tiles 8 and 9 (tools/attn_trace.py); never in the
+// shipped library.
+#ifdef UAMD_ATTN_TRACE
+__device__ unsigned* g_attn_trace = nullptr;
+#define ASTAMP(TI, I)                                                                    \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        if ((TI) == 8 || (TI) == 9) {                                                    \
+            ats[(((TI) & 1) << 3) + (I)] = (unsigned)__builtin_amdgcn_s_memtime();       \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           \
+        }                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define ASTAMP(TI, I) do { } while (0)
+#endif
+
 template <typename T>
 __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -186,6 +203,11 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;      // running max (log2 domain, both lane halves agree) / partial sum
 
+#ifdef UAMD_ATTN_TRACE
+    unsigned ats[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ats[i] = 0;
+#endif
     // ---- prologue
     const int nt = nkv_blk - t_first;
     issue(t_first, 0);
@@ -197,11 +219,15 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     auto step = [&](int ti, auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
         const int t = t_first + ti;
+        ASTAMP(ti, 0);
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ASTAMP(ti, 1);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        ASTAMP(ti, 2);
         if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);              // its stage was last read before this barrier
+        ASTAMP(ti, 3);
         if (t > last_tile_wave || t < first_tile_wave) return;       // wave-uniform: nothing to add
         const unsigned char* sk = smem + (ti % NST) * STAGE_B;
         const unsigned char* sv = sk + TILE_B;
@@ -219,6 +245,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
                 st[kt] = MfmaA<T>::run(u.f, qf[ks], st[kt]);
             }
         }
+        ASTAMP(ti, 4);
         // ---- online softmax, log2 domain. lane: q = q_pos; register r of tile kt: key below
         const int k0 = t * KT;
         float mt = -INFINITY;
@@ -253,6 +280,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) o_acc[i] *= alpha;
 
+        ASTAMP(ti, 5);
         // ---- O^T[d][q] += V^T P^T : per (kt, c) one k-step of 16 keys; lane half lh contracts keys
         //      32 kt + 16 c + {4 lh .. 4 lh + 3, 8 + 4 lh .. 8 + 4 lh + 3} = registers 8c .. 8c+7 of st[kt]
 #pragma unroll
@@ -271,6 +299,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
                     o_acc[dt] = MfmaA<T>::run(va.f, pb.f, o_acc[dt]);
                 }
             }
+        ASTAMP(ti, 6);
     };
     {
         const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);       // tiles that start below the band edge
@@ -282,6 +311,12 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         for (; ti < nt; ++ti) step(ti, std::true_type{});
     }
 
+#ifdef UAMD_ATTN_TRACE
+    if (g_attn_trace && lane == 0 && blockIdx.x < 256) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g_attn_trace[(blockIdx.x * 8 + wave) * 16 + i] = ats[i];
+    }
+#endif
     // ---- epilogue: O = O^T / l, LSE = ln2 * (m + log2 l)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -786,6 +821,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 }
 
 }  // namespace
+
+#ifdef UAMD_ATTN_TRACE
+extern "C" int uamd_debug_attn_trace(unsigned* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_trace), &buf, sizeof(buf));
+}
+#endif
 
 template <typename K_>
 int set_lds_attr(K_ kernel, int bytes, bool* done) {
