@@ -86,6 +86,13 @@ __device__ __forceinline__ void dma16x2(const void* base, unsigned v0, unsigned 
         : "memory");
 }
 
+// max over the two lane halves (lanes l and l ^ 32) without touching the LDS pipe: v_permlane32_swap is a VALU
+// op, so the softmax does not wait (lgkmcnt) for operand reads that are in flight for the next MFMA phase.
+__device__ __forceinline__ float max_across_halves(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <typename T>
 __device__ __forceinline__ uint32_t pack_pair(float lo, float hi) {
     union { T h[2]; uint32_t u; } v;
@@ -111,7 +118,8 @@ __device__ unsigned* g_attn_trace = nullptr;
 #define ASTAMP(TI, I) do { } while (0)
 #endif
 
-template <typename T>
+// BAND = false: plain causal attention, the band bookkeeping folds away at compile time (it costs ~50 VGPRs).
+template <typename T, bool BAND>
 __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename MfmaA<T>::frag frag_t;
@@ -132,9 +140,9 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const int q_ld = q_pos < T_ ? q_pos : T_ - 1;
     // band lower edge (packed documents / sliding window): per-lane, and -- lo being non-decreasing -- lane 0 /
     // lane 31 give the wave's min / max, the block's first row the block's min
-    const int lo_q = p.lo ? p.lo[(int64_t)b * T_ + q_ld] : 0;
-    const int lo_w0 = __builtin_amdgcn_readfirstlane(lo_q), lo_w1 = __builtin_amdgcn_readlane(lo_q, 31);
-    const int t_first = (p.lo ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] : 0) / KT;
+    const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
+    const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
+    const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
 
     // ---- Q^T operand fragments (B operand: lane -> q = l31, 8 d at 16 ks + 8 lh), kept for the whole tile loop
     frag_t qf[8];
@@ -216,8 +224,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const int last_tile_wave = min(qs + 31, T_ - 1) / KT;            // tiles beyond are fully masked for this wave
     const int first_tile_wave = lo_w0 / KT;                          // ... and tiles before
     // One tile step; MASKED is compile-time and the tile range is split by hand (see attn_bwd_dq_kernel).
-    auto step = [&](int ti, auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value;
+    auto step = [&](int ti, auto mode_c, bool rt_mask) {       // mode 0: no mask, 1: mask, 2: mask iff rt_mask
+        constexpr int MODE = decltype(mode_c)::value;
         const int t = t_first + ti;
         ASTAMP(ti, 0);
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -246,6 +254,29 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             }
         }
         ASTAMP(ti, 4);
+        // ---- (plain-causal build, which has the registers for it) the V^T operands of the first two 16-key steps
+        //      are fetched NOW: the transposing reads do not depend on P and the softmax below is pure VALU --
+        //      otherwise each of the 16 PV MFMAs waits for its own two ds_read_b64_tr_b16 (tools/attn_trace.py:
+        //      2,500 cycles for 16 MFMAs; 1,600 with the operands two steps ahead). The tile period only moves from
+        //      6,200 to 5,800 cycles: with 8 waves per CU the LDS read stream itself (256 KB per tile step, half of
+        //      it 8-byte transposing reads that need >= 4 waves per SIMD for full rate) is the next limit.
+        constexpr bool PREFETCH = !BAND;
+        auto load_v = [&](int u, frag_t* dst) {                       // u = 2 kt + c: keys 16 u .. 16 u + 15
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int a0 = (u * 16) * 256 + (v_lane ^ (dt << 6));
+                union { s16x4_t h[2]; frag_t f; } va;
+                va.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0));
+                va.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0 + 8 * 256));
+                dst[dt] = va.f;
+            }
+        };
+        frag_t va0[4], va1[4], va2[4];
+        if (PREFETCH) {
+            load_v(0, va0);
+            load_v(1, va1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- online softmax, log2 domain. lane: q = q_pos; register r of tile kt: key below
         const int k0 = t * KT;
         float mt = -INFINITY;
@@ -254,14 +285,14 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float s = st[kt][r] * p.scale_log2;
-                if (MASKED) {
+                if (MODE == 1 || (MODE == 2 && rt_mask)) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (key > q_pos || key >= T_ || key < lo_q) s = -INFINITY;
                 }
                 st[kt][r] = s;
                 mt = fmaxf(mt, s);
             }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = max_across_halves(mt);
         const float m_new = fmaxf(m_run, mt);
         // a row whose band starts after this tile has seen only masked keys so far: keep the exponent finite
         const float m_ref = m_new == -INFINITY ? 0.f : m_new;
@@ -281,34 +312,49 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         for (int i = 0; i < 4; ++i) o_acc[i] *= alpha;
 
         ASTAMP(ti, 5);
-        // ---- O^T[d][q] += V^T P^T : per (kt, c) one k-step of 16 keys; lane half lh contracts keys
-        //      32 kt + 16 c + {4 lh .. 4 lh + 3, 8 + 4 lh .. 8 + 4 lh + 3} = registers 8c .. 8c+7 of st[kt]
+        // ---- O^T[d][q] += V^T P^T : per 16-key step u = 2 kt + c; lane half lh contracts keys
+        //      16 u + {4 lh .. 4 lh + 3, 8 + 4 lh .. 8 + 4 lh + 3} = registers 8c .. 8c+7 of st[kt]
+        auto pv = [&](int u, const frag_t* vsrc) {
+            const int kt = u >> 1, c = u & 1;
+            union { uint32_t w[4]; frag_t f; } pb;
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int j = 0; j < 4; ++j) pb.w[j] = pack_pair<T>(st[kt][8 * c + 2 * j], st[kt][8 * c + 2 * j + 1]);
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                union { uint32_t w[4]; frag_t f; } pb;
+            for (int dt = 0; dt < 4; ++dt) o_acc[dt] = MfmaA<T>::run(vsrc[dt], pb.f, o_acc[dt]);
+        };
+        if (PREFETCH) {                                               // operand fetch two steps ahead, 3 buffers
+            load_v(2, va2);
+            __builtin_amdgcn_sched_barrier(0);
+            pv(0, va0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(3, va0);
+            __builtin_amdgcn_sched_barrier(0);
+            pv(1, va1);
+            pv(2, va2);
+            pv(3, va0);
+        } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pb.w[j] = pack_pair<T>(st[kt][8 * c + 2 * j], st[kt][8 * c + 2 * j + 1]);
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
-                    const int a0 = (kt * 32 + c * 16) * 256 + (v_lane ^ (dt << 6));
-                    union { s16x4_t h[2]; frag_t f; } va;
-                    va.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0));
-                    va.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0 + 8 * 256));
-                    o_acc[dt] = MfmaA<T>::run(va.f, pb.f, o_acc[dt]);
-                }
+            for (int u = 0; u < 4; ++u) {
+                load_v(u, va0);
+                pv(u, va0);
             }
+        }
         ASTAMP(ti, 6);
     };
     {
         const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);       // tiles that start below the band edge
         const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
         const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
-        int ti = 0;
-        for (; t_first + ti < t_pre_end; ++ti) step(ti, std::true_type{});
-        for (; t_first + ti < t_suf; ++ti) step(ti, std::false_type{});
-        for (; ti < nt; ++ti) step(ti, std::true_type{});
+        if constexpr (BAND) {
+            int ti = 0;
+            for (; t_first + ti < t_pre_end; ++ti) step(ti, std::integral_constant<int, 1>{}, true);
+            for (; t_first + ti < t_suf; ++ti) step(ti, std::integral_constant<int, 0>{}, false);
+            for (; ti < nt; ++ti) step(ti, std::integral_constant<int, 1>{}, true);
+        } else {
+            // plain causal: ONE loop with the (monotone) mask test around the masking statement only -- hipcc
+            // splits the range itself and needs far fewer registers than with the hand-split loops
+            for (int ti = 0; ti < nt; ++ti) step(ti, std::integral_constant<int, 2>{}, ti >= t_suf);
+        }
     }
 
 #ifdef UAMD_ATTN_TRACE
@@ -356,7 +402,7 @@ struct AttnBwdArgs {
 
 __device__ __forceinline__ int swz_c(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <typename T>
+template <typename T, bool BAND>
 __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename MfmaA<T>::frag frag_t;
@@ -396,9 +442,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
     if (lh == 0 && q_pos < T_) p.Delta[stat_idx] = delta;
     const float lse2 = p.LSE[stat_idx] * 1.4426950408889634f;
-    const int lo_q = p.lo ? p.lo[(int64_t)b * T_ + q_ld] : 0;
-    const int lo_w0 = __builtin_amdgcn_readfirstlane(lo_q), lo_w1 = __builtin_amdgcn_readlane(lo_q, 31);
-    const int t_first = (p.lo ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] : 0) / KT;
+    const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
+    const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
+    const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
 
     const int nkv_blk = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);
     int drow[2], dsw[2];
@@ -455,8 +501,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     // One tile step. MASKED is a compile-time flag and the tile range is split by hand into
     // [band-edge tiles | interior tiles | diagonal / ragged tiles]: with a run-time `need_mask` that depends on
     // the band the compiler keeps both paths' registers alive in one loop body (+50 VGPRs, spills).
-    auto step = [&](int ti, auto masked_c) {
-        constexpr bool MASKED = decltype(masked_c)::value;
+    auto step = [&](int ti, auto mode_c, bool rt_mask) {       // mode 0: no mask, 1: mask, 2: mask iff rt_mask
+        constexpr int MODE = decltype(mode_c)::value;
         const int t = t_first + ti;
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,7 +530,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pv = __builtin_amdgcn_exp2f(st[r] * p.scale_log2 - lse2);
-                if (MASKED) {
+                if (MODE == 1 || (MODE == 2 && rt_mask)) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (key > q_pos || key >= T_ || key < lo_q) pv = 0.f;
                 }
@@ -512,10 +558,16 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);
         const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
         const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
-        int ti = 0;
-        for (; t_first + ti < t_pre_end; ++ti) step(ti, std::true_type{});
-        for (; t_first + ti < t_suf; ++ti) step(ti, std::false_type{});
-        for (; ti < nt; ++ti) step(ti, std::true_type{});
+        if constexpr (BAND) {
+            int ti = 0;
+            for (; t_first + ti < t_pre_end; ++ti) step(ti, std::integral_constant<int, 1>{}, true);
+            for (; t_first + ti < t_suf; ++ti) step(ti, std::integral_constant<int, 0>{}, false);
+            for (; ti < nt; ++ti) step(ti, std::integral_constant<int, 1>{}, true);
+        } else {
+            // plain causal: ONE loop with the (monotone) mask test around the masking statement only -- hipcc
+            // splits the range itself and needs far fewer registers than with the hand-split loops
+            for (int ti = 0; ti < nt; ++ti) step(ti, std::integral_constant<int, 2>{}, ti >= t_suf);
+        }
     }
     if (q_pos < T_) {
         T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)q_pos * p.dq_st + (int64_t)head * p.dq_sh;
@@ -875,20 +927,30 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     dim3 grid_q((unsigned)(a.nqt * Hk * B));
     dim3 grid_k((unsigned)(((T + KT - 1) / KT) * Hk * B));
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set[4][64] = {{false}};
+    static bool attr_set[6][64] = {{false}};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     int rc;
     if (dtype == UAMD_BF16) {
-        if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t>, ATTN_LDS, &attr_set[0][dev]))) return rc;
         if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<bf16_t>, KD_LDS, &attr_set[1][dev]))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t>), grid_q, dim3(512), ATTN_LDS, st, a);
+        if (lo) {
+            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t, true>, ATTN_LDS, &attr_set[0][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, true>), grid_q, dim3(512), ATTN_LDS, st, a);
+        } else {
+            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t, false>, ATTN_LDS, &attr_set[4][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, false>), grid_q, dim3(512), ATTN_LDS, st, a);
+        }
         if ((rc = uamd_launch_status())) return rc;
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), grid_k, dim3(512), KD_LDS, st, a);
     } else if (dtype == UAMD_F16) {
-        if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t>, ATTN_LDS, &attr_set[2][dev]))) return rc;
         if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<f16_t>, KD_LDS, &attr_set[3][dev]))) return rc;
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t>), grid_q, dim3(512), ATTN_LDS, st, a);
+        if (lo) {
+            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t, true>, ATTN_LDS, &attr_set[2][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, true>), grid_q, dim3(512), ATTN_LDS, st, a);
+        } else {
+            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t, false>, ATTN_LDS, &attr_set[5][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false>), grid_q, dim3(512), ATTN_LDS, st, a);
+        }
         if ((rc = uamd_launch_status())) return rc;
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), grid_k, dim3(512), KD_LDS, st, a);
     } else {
@@ -923,25 +985,26 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     a.nqt = (T + QT - 1) / QT;
     dim3 grid((unsigned)(a.nqt * Hk * B));
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set[2][64] = {{false}};
+    static bool attr_set[4][64] = {{false}};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int rc;
     if (dtype == UAMD_BF16) {
-        if (!attr_set[0][dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<bf16_t>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
-            if (e != hipSuccess) return (int)e;
-            attr_set[0][dev] = true;
+        if (lo) {
+            if ((rc = set_lds_attr(&attn_fwd_kernel<bf16_t, true>, ATTN_LDS, &attr_set[0][dev]))) return rc;
+            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true>), grid, dim3(512), ATTN_LDS, st, a);
+        } else {
+            if ((rc = set_lds_attr(&attn_fwd_kernel<bf16_t, false>, ATTN_LDS, &attr_set[1][dev]))) return rc;
+            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false>), grid, dim3(512), ATTN_LDS, st, a);
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), grid, dim3(512), ATTN_LDS, st, a);
     } else if (dtype == UAMD_F16) {
-        if (!attr_set[1][dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<f16_t>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, ATTN_LDS);
-            if (e != hipSuccess) return (int)e;
-            attr_set[1][dev] = true;
+        if (lo) {
+            if ((rc = set_lds_attr(&attn_fwd_kernel<f16_t, true>, ATTN_LDS, &attr_set[2][dev]))) return rc;
+            hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true>), grid, dim3(512), ATTN_LDS, st, a);
+        } else {
+            if ((rc = set_lds_attr(&attn_fwd_kernel<f16_t, false>, ATTN_LDS, &attr_set[3][dev]))) return rc;
+            hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false>), grid, dim3(512), ATTN_LDS, st, a);
         }
-        hipLaunchKernelGGL((attn_fwd_kernel<f16_t>), grid, dim3(512), ATTN_LDS, st, a);
     } else {
         return UAMD_ERR_DTYPE;
     }
