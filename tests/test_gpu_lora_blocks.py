@@ -91,6 +91,36 @@ def test_lora_qkv_and_o(quant):
     assert rel_fro(Xg2.grad, dx) < 1e-2 and rel_fro(o["A"].grad, dA) < 2e-2 and rel_fro(o["B"].grad, dB) < 2e-2
 
 
+def test_lora_qkv_backward_merged_gemm(monkeypatch):
+    """dQ | dK | dV arriving as column blocks of ONE buffer (what the flash-attention backward produces): dX runs as a
+    single K-concatenated GEMM with the three rank-r terms side by side. Same oracle, same tolerances; the merged
+    path must actually be taken (one GEMM launch for dX instead of three)."""
+    from unsloth_amd.kernels import utils as U
+    from unsloth_amd.kernels.fast_lora import LoRA_QKV
+    H, Hkv, r, Bz, T = 512, 128, 16, 2, 96
+    q, k, v = _mk(H, H, r, 32, True), _mk(Hkv, H, r, 42, True), _mk(Hkv, H, r, 52, True)
+    X = (torch.randn(Bz, T, H, generator=g(17)) * 0.5).to(torch.bfloat16)
+    Xg = X.to(DEV).requires_grad_(True)
+    Q, Kk, V = LoRA_QKV.apply(Xg * 1.0, q["dev"][0], q["dev"][1], q["A"], q["B"], q["s"],
+                              k["dev"][0], k["dev"][1], k["A"], k["B"], k["s"],
+                              v["dev"][0], v["dev"][1], v["A"], v["B"], v["s"], True)
+    d = torch.randn(Bz, T, H + 2 * Hkv, generator=g(18)).to(torch.bfloat16)
+    dd = d.to(DEV)
+    launches = []
+    orig = U._launch_gemm
+    monkeypatch.setattr(U, "_launch_gemm", lambda X2d, groups, nf4, accumulate=False: (
+        launches.append((tuple(X2d.shape), accumulate)), orig(X2d, groups, nf4, accumulate))[1])
+    torch.autograd.backward([Q, Kk, V], [dd[..., :H], dd[..., H:H + Hkv], dd[..., H + Hkv:]])
+    assert launches == [((Bz * T, H + 2 * Hkv), False)], launches
+    dX = 0
+    for p, dy in ((q, d[..., :H]), (k, d[..., H:H + Hkv]), (v, d[..., H + Hkv:])):
+        W, A, B, s = p["cpu"]
+        dx, dA, dB = R.lora_linear_grads(X, dy, W, A, B, s)
+        dX = dX + dx
+        assert rel_fro(p["A"].grad, dA) < 2e-2 and rel_fro(p["B"].grad, dB) < 2e-2
+    assert rel_fro(Xg.grad, dX) < 1e-2, rel_fro(Xg.grad, dX)
+
+
 def test_matmul_lora_reference_signature():
     """matmul_lora(X, W, W_quant, A, B, s) incl. the transposed-weight call of the backward
     (fast_lora.py:156: matmul_lora(dY, W.t(), q, B.t(), A.t(), s) == dY @ W + s (dY B) A)."""

@@ -93,7 +93,7 @@ def attn_forward(q, k, v, scale=None, band=None):
 
 
 def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
-    """Gradients of attn_forward: (dq [B,T,Hq,D], dk, dv [B,T,Hk,D]), contiguous, in q's dtype. `lse` is the view
+    """Gradients of attn_forward: (dq [B,T,Hq,D], dk, dv [B,T,Hk,D]) in q's dtype, column blocks of one buffer. `lse` is the view
     attn_forward returned (its storage is padded to a multiple of 32 positions). Two launches, deterministic."""
     _lib.require_gpu(do, q, k, v, o)
     B, T, Hq, D = q.shape
@@ -104,9 +104,12 @@ def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
     assert lse.stride(1) == Tp and lse.stride(2) == 1, "pass the LSE returned by attn_forward"
     if do.stride(3) != 1:
         do = do.contiguous()
-    dq = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
-    dk = torch.empty((B, T, Hk, D), dtype=q.dtype, device=q.device)
-    dv = torch.empty((B, T, Hk, D), dtype=q.dtype, device=q.device)
+    # dQ | dK | dV side by side in ONE [B, T, (Hq + 2 Hk) D] buffer, the layout of a fused QKV projection output:
+    # the q/k/v projections' backward can then run dX as a single K-concatenated GEMM (kernels/utils.py)
+    dqkv = torch.empty((B, T, (Hq + 2 * Hk) * D), dtype=q.dtype, device=q.device)
+    dq = dqkv[..., :Hq * D].view(B, T, Hq, D)
+    dk = dqkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    dv = dqkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
     delta = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
     lo, hi = _band_ptrs(band, B, T, q.device)
     with _lib.device_ctx(q):

@@ -278,9 +278,10 @@ def _cached_cast(P, tag, dtype, build):
     return out
 
 
-def lora_xa(X2d, A_list):
+def lora_xa(X2d, A_list, out=None):
     """XA_g = X @ A_g^T for every projection sharing X, ONE launch. fp32, each block of columns
-    padded to a multiple of 8. Returns (buffer, [(col_offset, R_padded)])."""
+    padded to a multiple of 8. Returns (buffer, [(col_offset, R_padded)]). `out`: optional fp32 [M, sum Rp]
+    destination with unit column stride (e.g. a column slice of a wider buffer)."""
     dtype = X2d.dtype
     Rs = [A.shape[0] for A in A_list]
     Rp = [(r + 7) // 8 * 8 for r in Rs]
@@ -307,7 +308,11 @@ def lora_xa(X2d, A_list):
     Rt = Acat.shape[0]
     if Rt > 192:
         raise NotImplementedError(f"sum of LoRA ranks sharing one input = {Rt} > 192")
-    out = torch.empty((X2d.shape[0], Rt), dtype=torch.float32, device=X2d.device)
+    if out is None:
+        out = torch.empty((X2d.shape[0], Rt), dtype=torch.float32, device=X2d.device)
+    else:
+        assert out.dtype == torch.float32 and tuple(out.shape) == (X2d.shape[0], Rt) and out.stride(1) == 1 \
+            and out.stride(0) % 4 == 0
     L = _lib.lib()
     fn, name = (L.uamd_lora_xa2, "uamd_lora_xa2") if (LORA_XA_V2 and Rt <= 64 and K >= 8) else (L.uamd_lora_xa, "uamd_lora_xa")
     with _lib.device_ctx(X2d):
@@ -402,6 +407,13 @@ def lora_dx_terms(dYs, projs):
     """P_g = dY_g @ B_g (fp32 [M, Rp]) for every projection with an adapter (None otherwise): the rank-r factor
     shared by dX += s (dY B) A and by d_A = s (dY B)^T X (fast_lora.py:172-189)."""
     terms = []
+    ranks = [None if A is None else A.shape[0] for (_, _, A, _, _) in projs]
+    # all P_g side by side in ONE [M, sum r] buffer when possible: lora_linear_dx can then hand the whole rank
+    # block to a single K-concatenated GEMM
+    shared, col = None, 0
+    if len(projs) > 1 and all(r is not None and r % 8 == 0 for r in ranks):
+        M = _rows2d(dYs[0]).shape[0]
+        shared = torch.empty((M, sum(ranks)), dtype=torch.float32, device=dYs[0].device)
     for dY, (W, W_quant, A, B, s) in zip(dYs, projs):
         if A is None:
             terms.append(None)
@@ -409,9 +421,72 @@ def lora_dx_terms(dYs, projs):
         dY2d = _rows2d(dY)
         dtype = dY2d.dtype
         Bt = _cached_cast(B, "T", dtype, lambda B=B, dtype=dtype: B.to(dtype).t().contiguous())        # [r, N]
-        xa, offs = lora_xa(dY2d, [Bt])                              # dY @ B
+        if shared is not None:
+            r = A.shape[0]
+            xa, offs = lora_xa(dY2d, [Bt], out=shared[:, col:col + r])
+            col += r
+        else:
+            xa, offs = lora_xa(dY2d, [Bt])                          # dY @ B
         terms.append(xa[:, :offs[0][1]])
     return terms
+
+
+MERGE_DX = os.environ.get("UNSLOTH_AMD_MERGE_DX", "1") != "0"
+
+
+def _adjacent_columns(ts):
+    """The 2-D views `ts` are consecutive column blocks of one row-major buffer -> the [M, sum N] view, else None."""
+    t0 = ts[0]
+    off = 0
+    for t in ts:
+        if (t.dim() != 2 or t.stride(1) != 1 or t.stride(0) != t0.stride(0) or t.shape[0] != t0.shape[0]
+                or t.dtype != t0.dtype or t.device != t0.device
+                or t.data_ptr() != t0.data_ptr() + off * t0.element_size()):
+            return None
+        off += t.shape[1]
+    if off > t0.stride(0):
+        return None
+    return torch.as_strided(t0, (t0.shape[0], off), (t0.stride(0), 1))
+
+
+def _lora_linear_dx_merged(dYs, projs, out, terms):
+    """dX = [dY_1 | dY_2 | ...] @ [W_1; W_2; ...] + s [P_1 | P_2 | ...] @ [A_1; A_2; ...] as ONE GEMM when the
+    incoming gradients are column blocks of one buffer (the attention backward writes dQ, dK, dV that way): the
+    contraction simply runs over the concatenated output features. Saves the read-modify-write of dX per extra
+    projection and the short-K launches (k_proj / v_proj: K = 1024). Returns None when the shapes do not allow it."""
+    if len(dYs) < 2 or any(q is None for (_, q, _, _, _) in projs):
+        return None
+    if any(A is None for (_, _, A, _, _) in projs) or any(t is None for t in terms):
+        return None
+    scales = {float(s) for (_, _, _, _, s) in projs}
+    if len(scales) != 1:
+        return None
+    dY2 = [_rows2d(dY) for dY in dYs]
+    dYcat = _adjacent_columns(dY2)
+    Pcat = _adjacent_columns(list(terms))
+    if dYcat is None or Pcat is None or dYcat.shape[1] % 64 or dYcat.stride(0) % 8:
+        return None
+    dtype = dYcat.dtype
+    Kin = projs[0][1].shape[1]
+    if any(q.shape[1] != Kin or q.dtype != dtype for (_, q, _, _, _) in projs):
+        return None
+    M, Ntot = dYcat.shape
+    Wt = _nf4.scratch(dYcat.device, Kin * Ntot, dtype, slot=2).view(Kin, Ntot)
+    col = 0
+    for (W, q, _, _, _) in projs:
+        n = q.shape[0]
+        _nf4.dequantize_nf4(W, q, out=Wt[:, col:col + n], transpose=True)          # [Kin, n] at column `col`
+        col += n
+    A_list = [A for (_, _, A, _, _) in projs]
+    tag = ("catT",) + tuple((id(A), A._version, A.data_ptr()) for A in A_list[1:])
+    lb = _cached_cast(A_list[0], tag, dtype,
+                      lambda: torch.cat([_cached_cast(A, "T", dtype, lambda A=A: A.to(dtype).t().contiguous())
+                                         for A in A_list], dim=1).contiguous())
+    if out is None:
+        out = torch.empty((M, Kin), dtype=dtype, device=dYcat.device)
+    g = _group(Wt, out, Kin, Wt.stride(0), xa=Pcat, ld_xa=Pcat.stride(0), lb=lb, R=Pcat.shape[1], scale=scales.pop())
+    _launch_gemm(dYcat, [g], nf4=False, accumulate=False)
+    return out
 
 
 def lora_linear_dx(dYs, projs, out=None, terms=None):
@@ -422,6 +497,9 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
     dtype = dYs[0].dtype
     if terms is None:
         terms = lora_dx_terms(dYs, projs)
+    merged = _lora_linear_dx_merged(dYs, projs, out, terms) if MERGE_DX else None
+    if merged is not None:
+        return merged
     first = True
     for dY, (W, W_quant, A, B, s), xa in zip(dYs, projs, terms):
         dY2d = _rows2d(dY)

@@ -218,7 +218,9 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
         else:
             out = torch.empty(shape, dtype=dtype, device=packed.device)
     else:
-        assert tuple(out.shape) == tuple(shape) and out.dtype == dtype and out.is_contiguous()
+        assert tuple(out.shape) == tuple(shape) and out.dtype == dtype and out.stride(1) == 1
+        assert transpose or out.is_contiguous(), "a strided destination is only supported by the transposing kernel"
+    ld_out = out.stride(0)
     lut = qs.code
     with _lib.device_ctx(packed):
         if qs.nested and not cache_absmax:
@@ -227,12 +229,12 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
             rc = _lib.lib().uamd_nf4_dequantize(
                 _lib.ptr(packed), None, _lib.ptr(qs.absmax), _lib.ptr(qs.state2.code),
                 _lib.ptr(qs.state2.absmax), qs._offset_f, qs.state2.blocksize, _lib.ptr(lut),
-                _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), rows,
+                _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), ld_out,
                 _lib.stream_of(packed))
         else:
             rc = _lib.lib().uamd_nf4_dequantize(
                 _lib.ptr(packed), _lib.ptr(absmax_f32(qs)), None, None, None, 0.0, 0, _lib.ptr(lut),
-                _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), rows,
+                _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), ld_out,
                 _lib.stream_of(packed))
     _lib.check(rc, "uamd_nf4_dequantize")
     return out
