@@ -97,35 +97,53 @@ def main():
     nparam = I * H
     emit(out, "nf4_dequant", timeit(lambda: dequantize_nf4(packed, qs, use_global_buffer=True)), nparam * 2.516, params=nparam)
     emit(out, "nf4_dequant_T", timeit(lambda: dequantize_nf4(packed, qs, transpose=True, use_global_buffer=True)), nparam * 2.516, params=nparam)
+    # fused residual add + norm
+    T = a.tokens[-1]
+    from unsloth_amd.kernels.rms_layernorm import Fast_Add_RMS_Layernorm
+    X = torch.randn(T, H, device=DEV, dtype=bf)
+    Rr = torch.randn(T, H, device=DEV, dtype=bf)
+    Wn = torch.rand(H, device=DEV, dtype=bf)
+    emit(out, "add_rms_fwd", timeit(lambda: Fast_Add_RMS_Layernorm.apply(X, Rr, Wn, 1e-5)), 4 * T * H * 2 + H * 2 + T * 4, T=T)
+    # attention (causal GQA 32:8, d 128), B x 2048
+    from unsloth_amd.kernels import attention as A_
+    Bq, S = T // 2048, 2048
+    qkv = torch.randn(Bq, S, (Hq + 2 * Hk) * D, device=DEV, dtype=bf)
+    q = qkv[..., :Hq * D].view(Bq, S, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hk) * D].view(Bq, S, Hk, D)
+    v = qkv[..., (Hq + Hk) * D:].view(Bq, S, Hk, D)
+    o, lse = A_.attn_forward(q, k, v)
+    do = torch.randn_like(o)
+    fl = 4.0 * Bq * Hq * S * S * D / 2
+    emit(out, "attn_fwd", timeit(lambda: A_.attn_forward(q, k, v)), flops=fl, T=T)
+    emit(out, "attn_bwd(dq+dkdv)", timeit(lambda: A_.attn_backward(do, q, k, v, o, lse)), flops=2.5 * fl, T=T)
+    # LoRA side products
+    A3 = [torch.nn.Parameter(torch.randn(16, H, device=DEV) * 0.02) for _ in range(3)]
+    emit(out, "lora_xa2 q|k|v (R=48)", timeit(lambda: U.lora_xa(X, A3)), T * H * 2, T=T)
+    emit(out, "lora_xa2 (R=16, K=4096)", timeit(lambda: U.lora_xa(X, A3[:1])), T * H * 2, T=T)
+    Xi = torch.randn(T, I, device=DEV, dtype=bf)
+    Ad = [torch.nn.Parameter(torch.randn(16, I, device=DEV) * 0.02)]
+    emit(out, "lora_xa2 (R=16, K=14336)", timeit(lambda: U.lora_xa(Xi, Ad)), T * I * 2, T=T)
+    P = torch.randn(T, 16, device=DEV)
+    emit(out, "lora_tn 6 problems (MLP block)", timeit(lambda: U.lora_tn([(P, Xi, 16, False, 1.0), (P, X, 16, True, 1.0),
+                                                                          (P, X, 16, False, 1.0), (P, Xi, 16, True, 1.0),
+                                                                          (P, X, 16, False, 1.0), (P, Xi, 16, True, 1.0)])),
+         (3 * T * I + 3 * T * H) * 2, T=T)
+    del Xi
     if a.skip_gemm:
         return
-    # GEMMs
-    for T in a.tokens:
+    # GEMMs: the step's shapes on the shipped kernel, hipBLASLt beside it
+    for T in a.tokens[-1:]:
         X = torch.randn(T, H, device=DEV, dtype=bf)
-        for (N, Kd, tag) in ((H, H, "o_proj"), (I, H, "gate_proj"), (H, I, "down_proj")):
+        for (N, Kd, tag) in ((H, H, "o_proj"), (I, H, "gate_proj"), (H, I, "down_proj"), (H, H + 2 * Hk * D, "qkv_dx_merged")):
             Xin = X if Kd == H else torch.randn(T, Kd, device=DEV, dtype=bf)
             Wf = (torch.randn(N, Kd, device=DEV) * 0.02).to(bf)
-            p, q = quantize_nf4(Wf)
             fl = 2.0 * T * N * Kd
             emit(out, f"torch_matmul_{tag}", timeit(lambda: Xin @ Wf.t()), flops=fl, T=T)
-            U.GEMM256_MODE = "off"
-            emit(out, f"gemm_dense128_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
-            U.GEMM256_MODE = "on"
-            emit(out, f"gemm_dense256_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
-            U.GEMM256_MODE = "auto"
-            U.FUSED_NF4, U.FUSED_NF4_MAX_M = True, 1 << 30
-            emit(out, f"gemm_nf4_fused_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(p, q, None, None, None)])), flops=fl, T=T)
-            U.FUSED_NF4 = False
-            emit(out, f"gemm_nf4_unfused_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(p, q, None, None, None)])), flops=fl, T=T)
-            U.FUSED_NF4 = True
-            A = torch.randn(16, Kd, device=DEV) * 0.02
-            B = torch.randn(N, 16, device=DEV) * 0.02
-            emit(out, f"gemm_nf4_fused_lora_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(p, q, A, B, 1.0)])), flops=fl, T=T)
-            dYo = torch.randn(T, N, device=DEV, dtype=bf)
-            emit(out, f"dx_nf4_lora_{tag}", timeit(lambda: U.lora_linear_dx([dYo], [(p, q, A, B, 1.0)])), flops=fl, T=T)
-            del Wf, p, q
-        A3 = [torch.randn(16, H, device=DEV) * 0.02 for _ in range(3)]
-        emit(out, "lora_xa_qkv", timeit(lambda: U.lora_xa(X, A3)), T * H * 2, T=T)
+            emit(out, f"gemm_nt256_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
+            Aa = torch.nn.Parameter(torch.randn(16, Kd, device=DEV) * 0.02)
+            Bb = torch.nn.Parameter(torch.randn(N, 16, device=DEV) * 0.02)
+            emit(out, f"gemm_nt256+lora_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, Aa, Bb, 1.0)])), flops=fl, T=T)
+            del Wf
 
 
 if __name__ == "__main__":

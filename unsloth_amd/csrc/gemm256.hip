@@ -158,46 +158,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    // ---- LoRA term first (same as gemm.hip): acc = s * (T(XA) @ LB^T)
-    if (g.lora_xa != nullptr) {
-        const int R = g.R;
-        for (int k0 = 0; k0 < R; k0 += 32) {
-            const int k = k0 + l4 * 8;
-            frag_t lb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + l15;
-                uint4 raw = make_uint4(0, 0, 0, 0);
-                if (n < N && k < R)
-                    raw = *reinterpret_cast<const uint4*>((const T*)g.lora_b + (int64_t)n * g.ld_lb + k);
-                union { uint4 r; frag_t f; } u; u.r = raw; lb[j] = u.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int m = m0 + grp * 128 + i * 16 + l15;
-                Vec16<T> v;
-                v.raw = make_uint4(0, 0, 0, 0);
-                if (m < M && k < R) {
-                    const float* src = g.lora_xa + (int64_t)m * g.ld_xa + k;
-                    const float4 f0 = *reinterpret_cast<const float4*>(src);
-                    const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
-                    v.e[0] = from_f32<T>(f0.x); v.e[1] = from_f32<T>(f0.y);
-                    v.e[2] = from_f32<T>(f0.z); v.e[3] = from_f32<T>(f0.w);
-                    v.e[4] = from_f32<T>(f1.x); v.e[5] = from_f32<T>(f1.y);
-                    v.e[6] = from_f32<T>(f1.z); v.e[7] = from_f32<T>(f1.w);
-                }
-                union { uint4 r; frag_t f; } u; u.r = v.raw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma2<T>::run(lb[j], u.f, acc[i][j]);
-            }
-        }
-        const float s = g.lora_scale;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] *= s;
-    }
-
     // ---- DMA source pointers. Piece c (0..7) of a tile, issued by wave w, fills sub-tile u = c*8 + w =
     //      [8 rows x 64 k] = 8 FULL 128-byte lines (u < 32: A rows u*8.., u >= 32: B rows (u-32)*8..). Full lines
     //      matter: the L2 serves requests, not bytes -- [16 rows x 64 B] half-line pieces deliver 36 B/clk/CU with
@@ -273,12 +233,55 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     // ---- prologue: tile 0 completely, first 3 pieces of tile 1
 #pragma unroll
     for (int c = 0; c < 8; ++c) issue(c, 0, 0);
-    if (nk > 1) {
-        issue(0, 1, 1); issue(1, 1, 1); issue(2, 1, 1);
-        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nk > 1) { issue(0, 1, 1); issue(1, 1, 1); issue(2, 1, 1); }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- LoRA term: acc = s * (T(XA) @ LB^T). Computed AFTER the first tiles' LDS-DMA has been issued, so its
+    //      global loads (fp32 XA rows, LB rows) and 32 MFMAs sit under the DMA's flight time. (The term costs
+    //      ~4 us per tile either way -- 4 % of a 8192x14336x4096 launch, tools/microbench.py -- so its latency was
+    //      not the expensive part; open.)
+    if (g.lora_xa != nullptr) {
+        const int R = g.R;
+        for (int k0 = 0; k0 < R; k0 += 32) {
+            const int k = k0 + l4 * 8;
+            frag_t lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l15;
+                uint4 raw = make_uint4(0, 0, 0, 0);
+                if (n < N && k < R)
+                    raw = *reinterpret_cast<const uint4*>((const T*)g.lora_b + (int64_t)n * g.ld_lb + k);
+                union { uint4 r; frag_t f; } u; u.r = raw; lb[j] = u.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + grp * 128 + i * 16 + l15;
+                Vec16<T> v;
+                v.raw = make_uint4(0, 0, 0, 0);
+                if (m < M && k < R) {
+                    const float* src = g.lora_xa + (int64_t)m * g.ld_xa + k;
+                    const float4 f0 = *reinterpret_cast<const float4*>(src);
+                    const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
+                    v.e[0] = from_f32<T>(f0.x); v.e[1] = from_f32<T>(f0.y);
+                    v.e[2] = from_f32<T>(f0.z); v.e[3] = from_f32<T>(f0.w);
+                    v.e[4] = from_f32<T>(f1.x); v.e[5] = from_f32<T>(f1.y);
+                    v.e[6] = from_f32<T>(f1.z); v.e[7] = from_f32<T>(f1.w);
+                }
+                union { uint4 r; frag_t f; } u; u.r = v.raw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma2<T>::run(lb[j], u.f, acc[i][j]);
+            }
+        }
+        const float s = g.lora_scale;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] *= s;
     }
+
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SLOT_BARRIER();
     if (grp == 1) SLOT_BARRIER();          // anti-phase: group 1 runs one slot behind
 
