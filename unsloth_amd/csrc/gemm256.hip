@@ -237,36 +237,50 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- LoRA term: acc = s * (T(XA) @ LB^T). Computed AFTER the first tiles' LDS-DMA has been issued, so its
-    //      global loads (fp32 XA rows, LB rows) and 32 MFMAs sit under the DMA's flight time. (The term costs
-    //      ~4 us per tile either way -- 4 % of a 8192x14336x4096 launch, tools/microbench.py -- so its latency was
-    //      not the expensive part; open.)
+    //      global loads (fp32 XA rows, LB rows) and 32 MFMAs sit under the DMA's flight time, and with every load
+    //      of the step issued before the first use: ~1 us per tile instead of ~4 (31 -> 8 us of a
+    //      8192x14336x4096 launch, tools/microbench.py).
     if (g.lora_xa != nullptr) {
         const int R = g.R;
         for (int k0 = 0; k0 < R; k0 += 32) {
             const int k = k0 + l4 * 8;
-            frag_t lb[4];
+            const bool kin = k < R;                       // lanes past the rank contribute zeros
+            const int kc = kin ? k : 0;
+            // ALL loads of the step first (rows / columns past the edge are clamped: their products are never
+            // stored), then the conversions and MFMAs: with the bounds tests around each load hipcc emitted eight
+            // load -> s_waitcnt vmcnt(0) -> 4 MFMAs rounds, ~0.5 us of L2 latency each, per tile.
+            uint4 lbr[4];
+            float4 xr[8][2];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + l15;
-                uint4 raw = make_uint4(0, 0, 0, 0);
-                if (n < N && k < R)
-                    raw = *reinterpret_cast<const uint4*>((const T*)g.lora_b + (int64_t)n * g.ld_lb + k);
-                union { uint4 r; frag_t f; } u; u.r = raw; lb[j] = u.f;
+                int n = n0 + wn * 64 + j * 16 + l15;
+                n = n < N ? n : N - 1;
+                lbr[j] = *reinterpret_cast<const uint4*>((const T*)g.lora_b + (int64_t)n * g.ld_lb + kc);
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int m = m0 + grp * 128 + i * 16 + l15;
+                int m = m0 + grp * 128 + i * 16 + l15;
+                m = m < M ? m : M - 1;
+                const float* src = g.lora_xa + (int64_t)m * g.ld_xa + kc;
+                xr[i][0] = *reinterpret_cast<const float4*>(src);
+                xr[i][1] = *reinterpret_cast<const float4*>(src + 4);
+            }
+            frag_t lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                union { uint4 r; frag_t f; } u;
+                u.r = kin ? lbr[j] : make_uint4(0, 0, 0, 0);
+                lb[j] = u.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
                 Vec16<T> v;
-                v.raw = make_uint4(0, 0, 0, 0);
-                if (m < M && k < R) {
-                    const float* src = g.lora_xa + (int64_t)m * g.ld_xa + k;
-                    const float4 f0 = *reinterpret_cast<const float4*>(src);
-                    const float4 f1 = *reinterpret_cast<const float4*>(src + 4);
-                    v.e[0] = from_f32<T>(f0.x); v.e[1] = from_f32<T>(f0.y);
-                    v.e[2] = from_f32<T>(f0.z); v.e[3] = from_f32<T>(f0.w);
-                    v.e[4] = from_f32<T>(f1.x); v.e[5] = from_f32<T>(f1.y);
-                    v.e[6] = from_f32<T>(f1.z); v.e[7] = from_f32<T>(f1.w);
-                }
+                const float4 f0 = xr[i][0], f1 = xr[i][1];
+                v.e[0] = from_f32<T>(f0.x); v.e[1] = from_f32<T>(f0.y);
+                v.e[2] = from_f32<T>(f0.z); v.e[3] = from_f32<T>(f0.w);
+                v.e[4] = from_f32<T>(f1.x); v.e[5] = from_f32<T>(f1.y);
+                v.e[6] = from_f32<T>(f1.z); v.e[7] = from_f32<T>(f1.w);
+                if (!kin) v.raw = make_uint4(0, 0, 0, 0);
                 union { uint4 r; frag_t f; } u; u.r = v.raw;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = Mfma2<T>::run(lb[j], u.f, acc[i][j]);
