@@ -208,8 +208,18 @@ __global__ void __launch_bounds__(256) lora_tn_reduce_kernel(TnArgs a) {
     if (idx >= (int64_t)R * N) return;
     const int r = (int)(idx / N), n = (int)(idx - (int64_t)r * N);
     const float* part = a.ws + a.ws_off[pi] + (int64_t)r * npad + n;
+    // same summation order as a plain loop, but 8 loads in flight per round instead of one load -> wait -> add
     float v = 0.f;
-    for (int s = 0; s < a.S; ++s) v += part[(int64_t)s * TN_R * npad];
+    const int64_t sstride = (int64_t)TN_R * npad;
+    int s = 0;
+    for (; s + 8 <= a.S; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = part[(int64_t)(s + u) * sstride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < a.S; ++s) v += part[(int64_t)s * sstride];
     v *= pr.scale;
     float* o = (pr.out_nr & 1) ? pr.out + (int64_t)n * pr.ldo + r : pr.out + (int64_t)r * pr.ldo + n;
     *o = (pr.out_nr & 2) ? *o + v : v;                 // bit 1: accumulate into `out` (gradient arena)
