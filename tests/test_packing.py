@@ -130,3 +130,23 @@ def test_attention_band_matches_dense_packed_mask():
     # tokens past the packed documents form one more document
     lo, hi = attention_band(8, seq_lengths=[3, 2])
     assert lo[0].tolist() == [0, 0, 0, 3, 3, 5, 5, 5] and hi[0].tolist() == [2, 2, 2, 4, 4, 7, 7, 7]
+
+
+def test_adjacent_columns_detection():
+    """kernels/utils._adjacent_columns: the q/k/v gradients are merged into one K-concatenated GEMM only when they
+    really are consecutive column blocks of one row-major buffer."""
+    import torch
+    from unsloth_amd.kernels.utils import _adjacent_columns
+    buf = torch.arange(6 * 20, dtype=torch.float32).view(6, 20)
+    a, b, c = buf[:, :8], buf[:, 8:12], buf[:, 12:20]
+    cat = _adjacent_columns([a, b, c])
+    assert cat is not None and cat.shape == (6, 20) and torch.equal(cat, buf) and cat.data_ptr() == buf.data_ptr()
+    assert _adjacent_columns([a, c]) is None                       # gap
+    assert _adjacent_columns([b, a]) is None                       # wrong order
+    assert _adjacent_columns([a, b.clone()]) is None               # different storage
+    assert _adjacent_columns([a, buf[:5, 8:12]]) is None           # different row count
+    assert _adjacent_columns([a.double(), b.double()]) is None     # copies, not views
+    part = _adjacent_columns([b, c])                                # a sub-range is fine: starts at column 8
+    assert part is not None and part.shape == (6, 12) and torch.equal(part, buf[:, 8:])
+    three_d = buf.view(2, 3, 20)[..., :8].reshape(-1, 8)            # the [B, T, H] -> [B*T, H] view autograd hands over
+    assert _adjacent_columns([three_d, buf.view(2, 3, 20)[..., 8:12].reshape(-1, 4)]) is not None
