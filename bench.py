@@ -40,7 +40,7 @@ def llama3_8b_config(n_layers=32, vocab=128256):
         attention_bias=False, mlp_bias=False)
 
 
-KERNEL_OF = {"uamd_gemm_nt_fr": "gemm_nt_fr_kernel<bf16>", "uamd_gemm_nt_w4": "gemm_nt_w4_kernel<bf16>", "uamd_gemm_nt_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nt": "gemm_nt_kernel<bf16,dense>",
+KERNEL_OF = {"uamd_gemm_nt_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nt": "gemm_nt_kernel<bf16,dense>",
              "uamd_gemm_nt_nf4": "gemm_nt_kernel<bf16,NF4>"}
 
 

@@ -178,6 +178,16 @@ typedef struct {
     int R;
     float lora_scale;
     int _pad;
+    /* Rank block as EXTRA K TILES (uamd_gemm_nt_256 only; takes precedence over lora_xa/lora_b there):
+     *   C_g += XK[M, Rk] @ BK_g[N_g, Rk]^T   contracted in the same LDS-DMA pipeline as A @ B_g^T,
+     * with XK = T(X A^T) (uamd_lora_xa2k: the reference's rounding point, utils.py:1166-1168), zero-padded to Rk
+     * columns, and BK_g = T(lora_scale_g * LB_g) placed at its rank columns of a zero [N_g, Rk] buffer
+     * (uamd_lora_prepare dst_pad). Rk % 64 == 0; NULL lora_xk = no rank block. */
+    const void* lora_xk;
+    const void* lora_bk;
+    int64_t ld_xk, ld_bk;
+    int Rk;
+    int _pad2;
 } uamd_gemm_group;
 
 int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
@@ -186,25 +196,17 @@ int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group
  * groups in anti-phase (csrc/gemm256.hip); for large M. Requires K % 64 == 0. */
 int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
-/* uamd_gemm_nt_w4: same contract as uamd_gemm_nt with 256x256x32 tiles, FOUR waves (one per SIMD, 128x128 each,
- * v_mfma_f32_32x32x16), 4-stage LDS-DMA ring with two tiles in flight across the single barrier per K tile
- * (csrc/gemm_w4.hip); the large-M kernel. Requires K % 32 == 0, lda/ldb <= 2^22 elements. */
-int uamd_gemm_nt_w4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
-                    int n_groups, int accumulate, int dtype, void* stream);
-/* uamd_gemm_nt_fr: same contract, 256x256x64 tiles, 8 free-running waves (128x64 each, v_mfma_f32_32x32x16,
- * software-pipelined fragment reads, ONE barrier per K tile; csrc/gemm_fr.hip). Requires K % 64 == 0. */
-int uamd_gemm_nt_fr(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
-                    int n_groups, int accumulate, int dtype, void* stream);
 /* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
- *   UAMD_TUNE_W4_VARIANT  (UAMD_W4_VARIANT)   instruction-schedule variant of the w4 K-tile body: 0 free,
- *                                             1 chunk-pinned, 2 MFMA/ds_read alternating 1:1
- *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernels (L2 reuse) */
-#define UAMD_TUNE_W4_VARIANT 0
+ *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernel (L2 reuse) */
+#define UAMD_TUNE_GLU_VAR 0     /* (UAMD_GLU_VAR) gated-MLP activation kernels: 0 = 2048-block grid-stride, 1 = uncapped grid,
+                                 * one 16-byte vector per thread, 2 = uncapped grid, two vectors per thread */
 #define UAMD_TUNE_GROUP_M 1
 #define UAMD_TUNE_STREAM_NT 2   /* (UAMD_STREAM_NT) streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
 #define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64 */
 #define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention dK/dV kernel: 1 = four waves x 512 registers, 0 = eight waves */
-#define UAMD_TUNE_COUNT 5
+#define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
+                                 * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
+#define UAMD_TUNE_COUNT 6
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
@@ -257,6 +259,12 @@ int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
  * block, K split over 4 waves, X and W through a per-wave LDS-DMA ring, fixed-order reduction. */
 int uamd_lora_xa2(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,
                   int64_t ld_out, int M, int K, int R, int out_cols, int dtype, void* stream);
+/* uamd_lora_xa2k: uamd_lora_xa2 that ALSO writes out_k[M, k_cols] = T(X A^T) in the activation dtype (columns
+ * >= R zero): the rank block uamd_gemm_nt_256 consumes as extra K tiles (uamd_gemm_group.lora_xk). k_cols % 8 == 0,
+ * k_cols >= R, ld_k % 8 == 0. out (fp32) may be NULL when only the rank block is wanted. */
+int uamd_lora_xa2k(const void* X, int64_t ldx, const void* A, int64_t lda, float* out, int64_t ld_out,
+                   void* out_k, int64_t ld_k, int k_cols, int M, int K, int R, int out_cols, int dtype,
+                   void* stream);
 
 /* Activation-dtype copies of fp32 LoRA factors, row-major and transposed, for ALL matrices in one launch (the
  * reference casts per use: utils.py:1166-1167, fast_lora.py:138-145). `descs_dev` / `tile_prefix_dev` are DEVICE
@@ -267,6 +275,13 @@ typedef struct {
     void* dst_rowmajor;       /* dtype [rows, cols] or NULL */
     void* dst_transposed;     /* dtype [cols, rows] or NULL */
     int rows, cols;
+    /* optional third copy: pad_scale * src (pad_transposed == 0: element (r, c) at dst_pad[r * pad_ld + c]) or its
+     * transpose (pad_transposed != 0: at dst_pad[c * pad_ld + r]) -- the zero-padded BK operand of
+     * uamd_gemm_group.lora_bk (the caller zero-fills the buffer once; only the rank columns are written) */
+    void* dst_pad;
+    int64_t pad_ld;
+    float pad_scale;
+    int pad_transposed;
 } uamd_lora_prep_desc;
 int uamd_lora_prepare(const uamd_lora_prep_desc* descs_dev, const int* tile_prefix_dev, int n_mats,
                       int total_tiles, int dtype, void* stream);

@@ -36,11 +36,38 @@ def test_library_exports_every_declared_symbol():
     assert L.uamd_version() >= 1
 
 
-def test_gemm_group_struct_layout():
+def test_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct of include/unsloth_amd.h as gcc sees them == the ctypes / numpy mirrors."""
     import ctypes
-    from unsloth_amd._lib import GemmGroup
-    assert ctypes.sizeof(GemmGroup) == 5 * 8 + 4 * 8 + 4 * 4
-    assert GemmGroup.N.offset == 72 and GemmGroup.lora_scale.offset == 80
+    import subprocess
+    import numpy as np
+    from unsloth_amd._lib import GemmGroup, LoraTnProblem
+    from unsloth_amd.kernels.utils import _PreparedFactors
+    fields = {"uamd_gemm_group": [f[0] for f in GemmGroup._fields_],
+              "uamd_lora_tn_problem": [f[0] for f in LoraTnProblem._fields_],
+              "uamd_lora_prep_desc": ["src", "dst_rowmajor", "dst_transposed", "rows", "cols", "dst_pad", "pad_ld",
+                                      "pad_scale", "pad_transposed"]}
+    src = ["#include <stdio.h>", "#include <stddef.h>", '#include "unsloth_amd.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append(f'printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            src.append(f'printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src += ["return 0; }"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    assert int(got["uamd_gemm_group"]) == ctypes.sizeof(GemmGroup)
+    for f in fields["uamd_gemm_group"]:
+        assert int(got[f"uamd_gemm_group.{f}"]) == getattr(GemmGroup, f).offset, f
+    assert int(got["uamd_lora_tn_problem"]) == ctypes.sizeof(LoraTnProblem)
+    for f in fields["uamd_lora_tn_problem"]:
+        assert int(got[f"uamd_lora_tn_problem.{f}"]) == getattr(LoraTnProblem, f).offset, f
+    dt = np.dtype(_PreparedFactors._DESC)
+    assert int(got["uamd_lora_prep_desc"]) == dt.itemsize
+    for cname, (npname, _) in zip(fields["uamd_lora_prep_desc"], _PreparedFactors._DESC):
+        assert int(got[f"uamd_lora_prep_desc.{cname}"]) == dt.fields[npname][1], cname
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")

@@ -234,14 +234,14 @@ def test_lora_xa(M, K, Rs):
 
 
 # ---------------------------------------------------------------- 256x256 LDS-DMA ping-pong kernel
-@pytest.fixture(params=["w4", "pp", "fr"])
-def force256(request):
-    """Force a 256x256 kernel for every shape: "w4" = csrc/gemm_w4.hip, "pp" = csrc/gemm256.hip."""
+@pytest.fixture
+def force256():
+    """Force the 256x256 kernel (csrc/gemm256.hip) for every shape."""
     from unsloth_amd.kernels import utils as U
-    old = (U.GEMM256_MODE, U.LARGE_KERNEL)
-    U.GEMM256_MODE, U.LARGE_KERNEL = "on", request.param
-    yield request.param
-    U.GEMM256_MODE, U.LARGE_KERNEL = old
+    old = U.GEMM256_MODE
+    U.GEMM256_MODE = "on"
+    yield "pp"
+    U.GEMM256_MODE = old
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -249,8 +249,8 @@ def force256(request):
                                    (4096, 4096, 4096), (1000, 1024, 14336), (260, 516, 32), (256, 256, 96),
                                    (777, 333, 160)])
 def test_gemm256_dense(force256, dtype, M, N, K):
-    if force256 in ("pp", "fr") and K % 64:
-        pytest.skip("gemm256.hip / gemm_fr.hip need K % 64 == 0")
+    if K % 64:
+        pytest.skip("gemm256.hip needs K % 64 == 0 (the dispatcher routes other K to the 128x128 kernel)")
     from unsloth_amd.kernels.utils import lora_linear_forward
     X = torch.randn(M, K, generator=g(105)).to(dtype)
     W = (torch.randn(N, K, generator=g(106)) * 0.05).to(dtype)
@@ -291,6 +291,21 @@ def test_gemm256_groups_lora_accumulate(force256):
     outs = lora_linear_forward(X.to(DEV), projs)
     for o, ref, N in zip(outs, refs, Ns):
         _check_gemm(o, ref, dtype, K, f"gemm256 grouped lora N={N}")
+    # the same with the factors as fp32 Parameters: the rank block's BK operand then comes from the persistent,
+    # once-per-step uamd_lora_prepare buffers (zero-padded, scale folded in) instead of per-call torch ops
+    pprojs = [(W, q, torch.nn.Parameter(A), torch.nn.Parameter(B), s) for (W, q, A, B, s) in projs]
+    outs_p = lora_linear_forward(X.to(DEV), pprojs)
+    for o, o2 in zip(outs, outs_p):
+        assert torch.equal(o, o2)
+    with torch.no_grad():
+        pprojs[1][3].mul_(2.0)                     # in-place update of one B: the prepared copy must follow
+    from unsloth_amd.kernels.utils import invalidate_cast_cache
+    invalidate_cast_cache()
+    outs_q = lora_linear_forward(X.to(DEV), pprojs)
+    assert torch.equal(outs_q[0], outs[0]) and torch.equal(outs_q[2], outs[2])
+    xa1 = (X.float() @ projs[1][2].cpu().to(dtype).float().t()).to(dtype).float()
+    _check_gemm(outs_q[1], _ref_mm(X, projs[1][0].cpu()) + 0.5 * xa1 @ pprojs[1][3].detach().cpu().to(dtype).float().t(),
+                dtype, K, "gemm256 grouped lora after in-place update")
     # accumulate: C += A @ B^T
     C0 = torch.randn(M, Ns[0], generator=g(140)).to(dtype)
     C = C0.clone().to(DEV)

@@ -15,13 +15,9 @@ X = torch.randn(M, K, device="cuda", dtype=bf)
 W = (torch.randn(N, K, device="cuda") * 0.02).to(bf)
 L = _lib.lib()
 U.GEMM256_MODE = "on"
-for kern, var in (("pp", None), ("fr", None)):
-    U.LARGE_KERNEL = kern
-    if var is not None:
-        L.uamd_set_tuning(0, var)
-    for _ in range(3):
-        U.lora_linear_forward(X, [(W, None, None, None, None)])
-    torch.cuda.synchronize()
+for _ in range(3):
+    U.lora_linear_forward(X, [(W, None, None, None, None)])
+torch.cuda.synchronize()
 for _ in range(3):
     X @ W.t()
 torch.cuda.synchronize()

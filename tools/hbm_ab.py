@@ -65,14 +65,47 @@ def main():
     def rms_b():
         L.uamd_rms_layernorm_bwd(_lib.ptr(dY), _lib.ptr(dY), _lib.ptr(X), _lib.ptr(W), _lib.ptr(r), T, H, H, H, H, 0, 2, 2,
                                  _lib.stream_of(X))
-    ab(out, "rms_fwd", 2 * T * H * 2 + H * 2 + T * 4,
-       {f"nt{m}": nt(m, lambda: K.Fast_RMS_Layernorm.apply(X, W, 1e-5, False)) for m in (0, 1, 2, 3)})
-    ab(out, "rms_bwd", 3 * T * H * 2 + H * 2 + T * 4, {f"nt{m}": nt(m, rms_b) for m in (0, 1, 2, 3)})
+    def var(knob, v, f, m=0):
+        def g():
+            L.uamd_set_tuning(knob, v)
+            L.uamd_set_tuning(2, m)
+            return f()
+        return g
+
+    Rs = torch.randn(T, H, device=DEV, dtype=bf)
+    Hb = torch.empty(T, H, device=DEV, dtype=bf)
+    Yb = torch.empty(T, H, device=DEV, dtype=bf)
+
+    def add_f():
+        L.uamd_add_rms_layernorm_fwd(_lib.ptr(X), _lib.ptr(Rs), _lib.ptr(W), _lib.ptr(Hb), _lib.ptr(Yb), _lib.ptr(r), T, H,
+                                     H, H, H, H, 1e-5, 2, 2, _lib.stream_of(X))
+
+    def add_b():
+        L.uamd_add_rms_layernorm_bwd(_lib.ptr(dY), _lib.ptr(Rs), _lib.ptr(dY), _lib.ptr(X), _lib.ptr(W), _lib.ptr(r), T, H,
+                                     H, H, H, H, 2, 2, _lib.stream_of(X))
+    rf = lambda: K.Fast_RMS_Layernorm.apply(X, W, 1e-5, False)
+    for T_ in (T,):
+        ab(out, "rms_fwd", 2 * T * H * 2 + H * 2 + T * 4,
+           {"wave": var(5, 0, rf), "wave_nt1": var(5, 0, rf, 1), "rowblock": var(5, 1, rf), "rowblock_nt1": var(5, 1, rf, 1),
+            "rowblock_nt3": var(5, 1, rf, 3)})
+        ab(out, "rms_bwd", 3 * T * H * 2 + H * 2 + T * 4,
+           {"wave": var(5, 0, rms_b), "wave_nt1": var(5, 0, rms_b, 1), "rowblock": var(5, 1, rms_b),
+            "rowblock_nt1": var(5, 1, rms_b, 1), "rowblock_nt3": var(5, 1, rms_b, 3)})
+        ab(out, "add_rms_fwd", 4 * T * H * 2 + H * 2 + T * 4,
+           {"wave": var(5, 0, add_f), "rowblock": var(5, 1, add_f), "rowblock_nt1": var(5, 1, add_f, 1)})
+        ab(out, "add_rms_bwd", 4 * T * H * 2 + H * 2 + T * 4,
+           {"wave": var(5, 0, add_b), "rowblock": var(5, 1, add_b), "rowblock_nt1": var(5, 1, add_b, 1)})
+    L.uamd_set_tuning(5, 0)
+    L.uamd_set_tuning(2, 0)
     e = torch.randn(T, I, device=DEV, dtype=bf)
     g_ = torch.randn(T, I, device=DEV, dtype=bf)
     DW = torch.randn(T, I, device=DEV, dtype=bf)
-    ab(out, "swiglu_fwd", 3 * T * I * 2, {f"nt{m}": nt(m, lambda: K.swiglu_fg_kernel(e, g_)) for m in (0, 1, 2, 3)})
-    ab(out, "swiglu_bwd", 6 * T * I * 2, {f"nt{m}": nt(m, lambda: K.swiglu_DWf_DW_dfg_kernel(DW, e, g_)) for m in (0, 1, 2, 3)})
+    sf = lambda: K.swiglu_fg_kernel(e, g_)
+    sb = lambda: K.swiglu_DWf_DW_dfg_kernel(DW, e, g_)
+    # note: the forward launcher flips bit0 of the nt mode (default = non-temporal loads)
+    ab(out, "swiglu_fwd", 3 * T * I * 2, {f"v{v}_nt{m}": var(0, v, sf, m) for v in (0, 1, 2) for m in (0, 1, 2)})
+    ab(out, "swiglu_bwd", 6 * T * I * 2, {f"v{v}_nt{m}": var(0, v, sb, m) for v in (0, 1, 2) for m in (0, 1, 3)})
+    L.uamd_set_tuning(0, 0)
     L.uamd_set_tuning(2, 0)
     # transposing dequant
     Wd = (torch.randn(I, H, device=DEV) * 0.02).to(bf)
@@ -83,7 +116,16 @@ def main():
             L.uamd_set_tuning(3, knob)
             return dequantize_nf4(packed, qs, transpose=True, use_global_buffer=True)
         return f
-    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t64": dq(0), "t256": dq(1), 
+    def dq_pad(pk, q, pad):
+        rows, cols = q.shape
+        buf = torch.empty(cols, rows + pad, device=DEV, dtype=bf)
+
+        def f():
+            L.uamd_set_tuning(3, 1)
+            return dequantize_nf4(pk, q, out=buf[:, :rows], transpose=True)
+        return f
+    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t64": dq(0), "t256": dq(1), "t256_pad64": dq_pad(packed, qs, 64),
+                                                   "t256_pad192": dq_pad(packed, qs, 192), "t256_pad1088": dq_pad(packed, qs, 1088),
                                                    "plain": lambda: dequantize_nf4(packed, qs, use_global_buffer=True)})
     Wd2 = (torch.randn(H, I, device=DEV) * 0.02).to(bf)
     packed2, qs2 = quantize_nf4(Wd2)
@@ -93,7 +135,8 @@ def main():
             L.uamd_set_tuning(3, knob)
             return dequantize_nf4(packed2, qs2, transpose=True, use_global_buffer=True)
         return f
-    ab(out, "nf4_dequant_T down", I * H * 2.516, {"t256": dq2(1), 
+    ab(out, "nf4_dequant_T down", I * H * 2.516, {"t256": dq2(1), "t256_pad64": dq_pad(packed2, qs2, 64),
+                                                   "t256_pad192": dq_pad(packed2, qs2, 192), 
                                                    "plain": lambda: dequantize_nf4(packed2, qs2, use_global_buffer=True)})
     Wd3 = (torch.randn(H, H, device=DEV) * 0.02).to(bf)
     packed3, qs3 = quantize_nf4(Wd3)
@@ -103,7 +146,8 @@ def main():
             L.uamd_set_tuning(3, knob)
             return dequantize_nf4(packed3, qs3, transpose=True, use_global_buffer=True)
         return f
-    ab(out, "nf4_dequant_T o", H * H * 2.516, {"t256": dq3(1), 
+    ab(out, "nf4_dequant_T o", H * H * 2.516, {"t256": dq3(1), "t256_pad64": dq_pad(packed3, qs3, 64),
+                                               "t256_pad192": dq_pad(packed3, qs3, 192), 
                                                "plain": lambda: dequantize_nf4(packed3, qs3, use_global_buffer=True)})
     L.uamd_set_tuning(3, 1)
     # lora_xa / lora_tn

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--tokens", type=int, nargs="+", default=[2048, 8192])
     ap.add_argument("--skip-gemm", action="store_true")
     ap.add_argument("--only-gemm", action="store_true")
+    ap.add_argument("--gemm-tokens", type=int, nargs="+", default=None)
     a = ap.parse_args()
     out = open(a.out, "w") if a.out else None
     bf = torch.bfloat16
@@ -132,17 +133,23 @@ def main():
     if a.skip_gemm:
         return
     # GEMMs: the step's shapes on the shipped kernel, hipBLASLt beside it
-    for T in a.tokens[-1:]:
+    for T in (a.gemm_tokens or a.tokens[-1:]):
         X = torch.randn(T, H, device=DEV, dtype=bf)
         for (N, Kd, tag) in ((H, H, "o_proj"), (I, H, "gate_proj"), (H, I, "down_proj"), (H, H + 2 * Hk * D, "qkv_dx_merged")):
             Xin = X if Kd == H else torch.randn(T, Kd, device=DEV, dtype=bf)
             Wf = (torch.randn(N, Kd, device=DEV) * 0.02).to(bf)
             fl = 2.0 * T * N * Kd
             emit(out, f"torch_matmul_{tag}", timeit(lambda: Xin @ Wf.t()), flops=fl, T=T)
-            emit(out, f"gemm_nt256_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T)
+            emit(out, f"gemm_nt_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, None, None, None)])), flops=fl, T=T,
+                 kernel_used=U._launch_gemm.__name__ if False else ("256" if U._use_gemm256(T, Kd, [N]) else "128"))
             Aa = torch.nn.Parameter(torch.randn(16, Kd, device=DEV) * 0.02)
             Bb = torch.nn.Parameter(torch.randn(N, 16, device=DEV) * 0.02)
-            emit(out, f"gemm_nt256+lora_{tag}", timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, Aa, Bb, 1.0)])), flops=fl, T=T)
+            t_all = timeit(lambda: U.lora_linear_forward(Xin, [(Wf, None, Aa, Bb, 1.0)]))
+            emit(out, f"gemm_nt+lora_{tag} (X A^T launch + GEMM with the rank block)", t_all, flops=fl, T=T)
+            use256 = U._use_gemm256(T, Kd, [N])
+            t_xa = timeit(lambda: U._xa_and_rank_block(Xin, [Aa], use256))
+            emit(out, f"gemm_nt+lora_{tag} (GEMM alone = above minus the X A^T launch)", max(t_all - t_xa, 1e-9), flops=fl, T=T,
+                 xa_us=round(t_xa * 1e6, 2))
             del Wf
 
 

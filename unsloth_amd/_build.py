@@ -25,8 +25,6 @@ SOURCES = [
     "nf4.hip",
     "gemm.hip",
     "gemm256.hip",
-    "gemm_w4.hip",
-    "gemm_fr.hip",
     "lora_side.hip",
     "attention.hip",
 ]

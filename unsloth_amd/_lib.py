@@ -30,6 +30,8 @@ class GemmGroup(ctypes.Structure):
         ("B", c_void_p), ("C", c_void_p), ("absmax", c_void_p), ("lora_xa", c_void_p),
         ("lora_b", c_void_p), ("ldb", c_int64), ("ldc", c_int64), ("ld_xa", c_int64),
         ("ld_lb", c_int64), ("N", c_int), ("R", c_int), ("lora_scale", c_float), ("_pad", c_int),
+        ("lora_xk", c_void_p), ("lora_bk", c_void_p), ("ld_xk", c_int64), ("ld_bk", c_int64), ("Rk", c_int),
+        ("_pad2", c_int),
     ]
 
 
@@ -76,10 +78,6 @@ SIGNATURES = {
                              c_int, c_void_p]),
     "uamd_gemm_nt_256": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
                                  c_int, c_void_p]),
-    "uamd_gemm_nt_fr": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
-                                c_int, c_void_p]),
-    "uamd_gemm_nt_w4": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
-                                c_int, c_void_p]),
     "uamd_set_tuning": (c_int, [c_int, c_int]),
     "uamd_gemm_nt_nf4": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int,
                                  c_int, c_int, c_void_p]),
@@ -87,6 +85,8 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_void_p]),
     "uamd_lora_xa2": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                               c_int, c_int, c_int, c_void_p]),
+    "uamd_lora_xa2k": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int,
+                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "uamd_add_rms_layernorm_fwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_float,
                                                              c_int, c_int, c_void_p]),
     "uamd_add_rms_layernorm_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_int,

@@ -24,6 +24,10 @@
 //   M2: 16 MFMA (1,1)                                                                               | barrier
 //   L3: DMA pieces 0,1,2 of tile t+2 (buffer of tile t is drained) | vmcnt(3): tile t+1 landed      | barrier
 //   M3: 16 MFMA (1,0)                                                                               | barrier
+// The LoRA term s*(X A^T) B^T is NOT a separate prologue: the rank block rides the same pipeline as Rk/64 EXTRA K
+// TILES whose DMA sources are XK = T(X A^T) [M, Rk] and BK = T(s B) [N, Rk] (zero-padded to 64 columns, see
+// uamd_gemm_group.lora_xk). One extra tile per output tile costs 64/K of the launch (1.6 % at K = 4096, 0.4 % at
+// K = 14336); the round-1 register prologue (fp32 XA loads + conversions + 32 MFMAs before the loop) cost 4-8 %.
 #include <stdlib.h>
 
 #include "common.h"
@@ -179,10 +183,22 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         b_src[c] = (const T*)g.B + (int64_t)rb * g.ldb + sub_slot * 8;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
+    const int nk_main = K / TK;                        // host guarantees K % 64 == 0
+    const int nk = nk_main + (g.lora_xk != nullptr ? g.Rk / TK : 0);
     auto issue = [&](int c, int kt, int stage) {       // c, stage are compile-time at every call site
         const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-        const T* src = (c < 4 ? a_src[c & 3] : b_src[c & 3]) + (int64_t)kt * TK;
-        dma16(src, dst);
+        if (kt < nk_main) {                            // scalar branch (kt is uniform)
+            dma16((c < 4 ? a_src[c & 3] : b_src[c & 3]) + (int64_t)kt * TK, dst);
+        } else {
+            // rank-block tile: same piece geometry, sources are XK / BK rows (addresses rebuilt here: no
+            // registers are held for them during the main loop)
+            int row = (c < 4 ? m0 : n0) + ((c & 3) * 8 + wave) * 8 + sub_row;
+            const int last = (c < 4 ? M : N) - 1;
+            row = row < last ? row : last;
+            const T* base = c < 4 ? (const T*)g.lora_xk : (const T*)g.lora_bk;
+            const int64_t ld = c < 4 ? g.ld_xk : g.ld_bk;
+            dma16(base + (int64_t)row * ld + (kt - nk_main) * TK + sub_slot * 8, dst);
+        }
     };
 
     // ---- fragment read offsets (bytes inside a stage): 16-row tile i of A at i*2 KiB ([16 rows][128 B]),
@@ -223,7 +239,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
                     acc[mq * 4 + i][nq * 2 + j] = Mfma2<T>::run(bf[nq * 2 + j][ks], af[i][ks], acc[mq * 4 + i][nq * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
     };
-    const int nk = K / TK;     // host guarantees K % 64 == 0
 #ifdef UAMD_G256_TRACE
     unsigned ts[32];
 #pragma unroll
@@ -235,63 +250,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     for (int c = 0; c < 8; ++c) issue(c, 0, 0);
     if (nk > 1) { issue(0, 1, 1); issue(1, 1, 1); issue(2, 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
-
-    // ---- LoRA term: acc = s * (T(XA) @ LB^T). Computed AFTER the first tiles' LDS-DMA has been issued, so its
-    //      global loads (fp32 XA rows, LB rows) and 32 MFMAs sit under the DMA's flight time, and with every load
-    //      of the step issued before the first use: ~1 us per tile instead of ~4 (31 -> 8 us of a
-    //      8192x14336x4096 launch, tools/microbench.py).
-    if (g.lora_xa != nullptr) {
-        const int R = g.R;
-        for (int k0 = 0; k0 < R; k0 += 32) {
-            const int k = k0 + l4 * 8;
-            const bool kin = k < R;                       // lanes past the rank contribute zeros
-            const int kc = kin ? k : 0;
-            // ALL loads of the step first (rows / columns past the edge are clamped: their products are never
-            // stored), then the conversions and MFMAs: with the bounds tests around each load hipcc emitted eight
-            // load -> s_waitcnt vmcnt(0) -> 4 MFMAs rounds, ~0.5 us of L2 latency each, per tile.
-            uint4 lbr[4];
-            float4 xr[8][2];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int n = n0 + wn * 64 + j * 16 + l15;
-                n = n < N ? n : N - 1;
-                lbr[j] = *reinterpret_cast<const uint4*>((const T*)g.lora_b + (int64_t)n * g.ld_lb + kc);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                int m = m0 + grp * 128 + i * 16 + l15;
-                m = m < M ? m : M - 1;
-                const float* src = g.lora_xa + (int64_t)m * g.ld_xa + kc;
-                xr[i][0] = *reinterpret_cast<const float4*>(src);
-                xr[i][1] = *reinterpret_cast<const float4*>(src + 4);
-            }
-            frag_t lb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                union { uint4 r; frag_t f; } u;
-                u.r = kin ? lbr[j] : make_uint4(0, 0, 0, 0);
-                lb[j] = u.f;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                Vec16<T> v;
-                const float4 f0 = xr[i][0], f1 = xr[i][1];
-                v.e[0] = from_f32<T>(f0.x); v.e[1] = from_f32<T>(f0.y);
-                v.e[2] = from_f32<T>(f0.z); v.e[3] = from_f32<T>(f0.w);
-                v.e[4] = from_f32<T>(f1.x); v.e[5] = from_f32<T>(f1.y);
-                v.e[6] = from_f32<T>(f1.z); v.e[7] = from_f32<T>(f1.w);
-                if (!kin) v.raw = make_uint4(0, 0, 0, 0);
-                union { uint4 r; frag_t f; } u; u.r = v.raw;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = Mfma2<T>::run(lb[j], u.f, acc[i][j]);
-            }
-        }
-        const float s = g.lora_scale;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] *= s;
-    }
 
     __builtin_amdgcn_sched_barrier(0);
     if (nk > 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
@@ -403,7 +361,8 @@ extern "C" int uamd_debug_g256_trace(unsigned* buf) {
 }
 #endif
 
-// Same contract as uamd_gemm_nt (dense B), 256x256x64 tiles. Requires K % 64 == 0.
+// Same contract as uamd_gemm_nt (dense B), 256x256x64 tiles. Requires K % 64 == 0. The LoRA term comes as the
+// rank block lora_xk / lora_bk (extra K tiles); a group that only carries lora_xa / lora_b is rejected.
 extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                                 int n_groups, int accumulate, int dtype, void* stream) {
     if (M < 0 || K <= 0 || n_groups < 1 || n_groups > UAMD_G256_MAX_GROUPS || !groups) return UAMD_ERR_ARG;
@@ -419,9 +378,10 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
             const uamd_gemm_group& g = groups[i];
             if (g.N <= 0 || !g.B || !g.C) return UAMD_ERR_ARG;
             if ((g.ldb & 7) || !aligned16(g.B)) return UAMD_ERR_ALIGN;
-            if (g.lora_xa) {
-                if (!g.lora_b || g.R <= 0 || (g.R & 7) || (g.ld_xa & 3) || (g.ld_lb & 7) ||
-                    !aligned16(g.lora_xa) || !aligned16(g.lora_b))
+            if (g.lora_xa && !g.lora_xk) return UAMD_ERR_ARG;     // this kernel takes the rank block as K tiles
+            if (g.lora_xk) {
+                if (!g.lora_bk || g.Rk <= 0) return UAMD_ERR_ARG;
+                if ((g.Rk & 63) || (g.ld_xk & 7) || (g.ld_bk & 7) || !aligned16(g.lora_xk) || !aligned16(g.lora_bk))
                     return UAMD_ERR_ALIGN;
             }
             a.g[i] = g;

@@ -130,25 +130,113 @@ __global__ void __launch_bounds__(256) glu_bwd_kernel(T* DW, T* E, T* G, int64_t
     }
 }
 
-inline unsigned grid_for(int64_t nvec) {
+// Two vectors per thread, both tensors' loads of both vectors in flight before the first use; one pass per block
+// (no grid-stride loop: the hardware dispatcher streams 256-thread blocks, which is how the reference's Triton
+// kernel reaches 6.0 TB/s on this shape).
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256) glu_bwd2_kernel(T* DW, T* E, T* G, int64_t n, int mode) {
+    constexpr int VEC = Vec16<T>::N;
+    const int64_t nvec = n / VEC;
+    const int64_t i0 = (int64_t)blockIdx.x * 512 + threadIdx.x, i1 = i0 + 256;
+    if (i1 < nvec) {
+        Vec16<T> dw0 = ld16_m(DW + i0 * VEC, mode), e0 = ld16_m(E + i0 * VEC, mode), g0 = ld16_m(G + i0 * VEC, mode);
+        Vec16<T> dw1 = ld16_m(DW + i1 * VEC, mode), e1 = ld16_m(E + i1 * VEC, mode), g1 = ld16_m(G + i1 * VEC, mode);
+        Vec16<T> h, df, de;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bwd_one<T, ACT>(dw0.e[j], e0.e[j], g0.e[j], h.e[j], df.e[j], de.e[j]);
+        st16_m(DW + i0 * VEC, h, mode);
+        st16_m(E + i0 * VEC, df, mode);
+        st16_m(G + i0 * VEC, de, mode);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bwd_one<T, ACT>(dw1.e[j], e1.e[j], g1.e[j], h.e[j], df.e[j], de.e[j]);
+        st16_m(DW + i1 * VEC, h, mode);
+        st16_m(E + i1 * VEC, df, mode);
+        st16_m(G + i1 * VEC, de, mode);
+    } else if (i0 < nvec) {
+        Vec16<T> dw = ld16_m(DW + i0 * VEC, mode), e = ld16_m(E + i0 * VEC, mode), g = ld16_m(G + i0 * VEC, mode);
+        Vec16<T> h, df, de;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) bwd_one<T, ACT>(dw.e[j], e.e[j], g.e[j], h.e[j], df.e[j], de.e[j]);
+        st16_m(DW + i0 * VEC, h, mode);
+        st16_m(E + i0 * VEC, df, mode);
+        st16_m(G + i0 * VEC, de, mode);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t k = nvec * VEC + threadIdx.x; k < n; k += 256) {
+            T h, df, de;
+            bwd_one<T, ACT>(DW[k], E[k], G[k], h, df, de);
+            DW[k] = h; E[k] = df; G[k] = de;
+        }
+    }
+}
+
+template <typename T, int ACT>
+__global__ void __launch_bounds__(256)
+glu_fwd2_kernel(const T* __restrict__ E, const T* __restrict__ G, T* __restrict__ H, int64_t n, int mode) {
+    constexpr int VEC = Vec16<T>::N;
+    const int64_t nvec = n / VEC;
+    const int64_t i0 = (int64_t)blockIdx.x * 512 + threadIdx.x, i1 = i0 + 256;
+    auto one = [&](const Vec16<T>& e, const Vec16<T>& g, int64_t i) {
+        Vec16<T> h;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float f;
+            act_fwd<ACT>(to_f32(e.e[j]), f);
+            h.e[j] = from_f32<T>(round_to<T>(f) * to_f32(g.e[j]));
+        }
+        st16_m(H + i * VEC, h, mode);
+    };
+    if (i1 < nvec) {
+        Vec16<T> e0 = ld16_m(E + i0 * VEC, mode), g0 = ld16_m(G + i0 * VEC, mode);
+        Vec16<T> e1 = ld16_m(E + i1 * VEC, mode), g1 = ld16_m(G + i1 * VEC, mode);
+        one(e0, g0, i0);
+        one(e1, g1, i1);
+    } else if (i0 < nvec) {
+        Vec16<T> e0 = ld16_m(E + i0 * VEC, mode), g0 = ld16_m(G + i0 * VEC, mode);
+        one(e0, g0, i0);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t k = nvec * VEC + threadIdx.x; k < n; k += 256) {
+            float f;
+            act_fwd<ACT>(to_f32(E[k]), f);
+            H[k] = from_f32<T>(round_to<T>(f) * to_f32(G[k]));
+        }
+    }
+}
+
+// UAMD_TUNE_GLU_VAR: 0 = 2048-block grid-stride kernels, 1 = the same kernels with one vector per thread and an
+// uncapped grid, 2 = two vectors per thread, uncapped grid
+inline unsigned grid_for(int64_t nvec, int var) {
     int64_t blocks = (nvec + 255) / 256;
     if (blocks < 1) blocks = 1;
-    const int64_t cap = 256 * 8;  // 256 CUs x 8 resident 256-thread blocks
+    const int64_t cap = var == 0 ? 256 * 8 : 0x7fffffffLL;  // 256 CUs x 8 resident 256-thread blocks
     return (unsigned)(blocks < cap ? blocks : cap);
 }
 
 template <typename T, int ACT>
 int launch_fwd(const void* e, const void* g, void* h, int64_t n, hipStream_t st) {
     if (!aligned16(e) || !aligned16(g) || !aligned16(h)) return UAMD_ERR_ALIGN;
-    hipLaunchKernelGGL((glu_fwd_kernel<T, ACT>), dim3(grid_for(n / Vec16<T>::N)), dim3(256), 0, st,
-                       (const T*)e, (const T*)g, (T*)h, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT) ^ 1);
+    const int var = uamd_tuning_get(UAMD_TUNE_GLU_VAR);
+    const int64_t nvec = n / Vec16<T>::N;
+    if (var == 2 && (nvec + 511) / 512 < 0x7fffffffLL)
+        hipLaunchKernelGGL((glu_fwd2_kernel<T, ACT>), dim3((unsigned)((nvec + 511) / 512 > 0 ? (nvec + 511) / 512 : 1)),
+                           dim3(256), 0, st, (const T*)e, (const T*)g, (T*)h, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT) ^ 1);
+    else
+        hipLaunchKernelGGL((glu_fwd_kernel<T, ACT>), dim3(grid_for(nvec, var)), dim3(256), 0, st,
+                           (const T*)e, (const T*)g, (T*)h, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT) ^ 1);
     return uamd_launch_status();
 }
 template <typename T, int ACT>
 int launch_bwd(void* dw, void* e, void* g, int64_t n, hipStream_t st) {
     if (!aligned16(dw) || !aligned16(e) || !aligned16(g)) return UAMD_ERR_ALIGN;
-    hipLaunchKernelGGL((glu_bwd_kernel<T, ACT>), dim3(grid_for(n / Vec16<T>::N)), dim3(256), 0, st,
-                       (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
+    const int var = uamd_tuning_get(UAMD_TUNE_GLU_VAR);
+    const int64_t nvec = n / Vec16<T>::N;
+    if (var == 2 && (nvec + 511) / 512 < 0x7fffffffLL)
+        hipLaunchKernelGGL((glu_bwd2_kernel<T, ACT>), dim3((unsigned)((nvec + 511) / 512 > 0 ? (nvec + 511) / 512 : 1)),
+                           dim3(256), 0, st, (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
+    else
+        hipLaunchKernelGGL((glu_bwd_kernel<T, ACT>), dim3(grid_for(nvec, var)), dim3(256), 0, st,
+                           (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
     return uamd_launch_status();
 }
 

@@ -249,6 +249,7 @@ template <typename T, int NT>
 __global__ void __launch_bounds__(256) lora_xa2_kernel(const T* __restrict__ X, int64_t ldx,
                                                        const T* __restrict__ W, int64_t ldw,
                                                        float* __restrict__ out, int64_t ld_out,
+                                                       T* __restrict__ out_k, int64_t ld_k, int k_cols,
                                                        int M, int K, int R, int out_cols) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma16<T>::frag frag_t;
@@ -368,22 +369,46 @@ __global__ void __launch_bounds__(256) lora_xa2_kernel(const T* __restrict__ X, 
             for (int r = 0; r < 4; ++r)
                 red[(wave * 32 + i * 16 + 4 * g4 + r) * (NT * 16) + j * 16 + l15] = acc[i][j][r];
     __syncthreads();
-    for (int idx = tid; idx < 32 * out_cols; idx += 256) {
-        const int mm = idx / out_cols, c = idx - mm * out_cols;
-        if (m0 + mm < M) {
-            float v = 0.f;
-            if (c < R) {
-                const float* q = red + mm * (NT * 16) + c;
-                v = ((q[0] + q[32 * NT * 16]) + q[2 * 32 * NT * 16]) + q[3 * 32 * NT * 16];
+    if (out != nullptr) {
+        for (int idx = tid; idx < 32 * out_cols; idx += 256) {
+            const int mm = idx / out_cols, c = idx - mm * out_cols;
+            if (m0 + mm < M) {
+                float v = 0.f;
+                if (c < R) {
+                    const float* q = red + mm * (NT * 16) + c;
+                    v = ((q[0] + q[32 * NT * 16]) + q[2 * 32 * NT * 16]) + q[3 * 32 * NT * 16];
+                }
+                out[(int64_t)(m0 + mm) * ld_out + c] = v;          // columns R..out_cols-1 are zero padding
             }
-            out[(int64_t)(m0 + mm) * ld_out + c] = v;          // columns R..out_cols-1 are zero padding
+        }
+    }
+    // the same sums rounded to the activation dtype (where the reference holds `X @ A.to(dtype)`, utils.py:1166),
+    // zero-padded to k_cols: the rank block the 256x256 GEMM contracts as extra K tiles. 8 columns per thread.
+    if (out_k != nullptr) {
+        const int vec_per_row = k_cols >> 3;
+        for (int idx = tid; idx < 32 * vec_per_row; idx += 256) {
+            const int mm = idx / vec_per_row, c0 = (idx - mm * vec_per_row) * 8;
+            if (m0 + mm < M) {
+                Vec16<T> v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + j;
+                    float x = 0.f;
+                    if (c < R) {
+                        const float* q = red + mm * (NT * 16) + c;
+                        x = ((q[0] + q[32 * NT * 16]) + q[2 * 32 * NT * 16]) + q[3 * 32 * NT * 16];
+                    }
+                    v.e[j] = from_f32<T>(x);
+                }
+                st16(out_k + (int64_t)(m0 + mm) * ld_k + c0, v);
+            }
         }
     }
 }
 
 template <typename T, int NT>
-int launch_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out, int M, int K,
-               int R, int out_cols, hipStream_t st) {
+int launch_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out, void* out_k,
+               int64_t ld_k, int k_cols, int M, int K, int R, int out_cols, hipStream_t st) {
     static bool done[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -394,18 +419,18 @@ int launch_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* ou
         done[dev] = true;
     }
     hipLaunchKernelGGL((lora_xa2_kernel<T, NT>), dim3((unsigned)((M + 31) / 32)), dim3(256), XaCfg<NT>::LDS, st,
-                       (const T*)X, ldx, (const T*)W, ldw, out, ld_out, M, K, R, out_cols);
+                       (const T*)X, ldx, (const T*)W, ldw, out, ld_out, (T*)out_k, ld_k, k_cols, M, K, R, out_cols);
     return uamd_launch_status();
 }
 
 template <typename T>
-int xa2_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out, int M, int K,
-                 int R, int out_cols, hipStream_t st) {
+int xa2_dispatch(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out, void* out_k,
+                 int64_t ld_k, int k_cols, int M, int K, int R, int out_cols, hipStream_t st) {
     const int nt = (R + 15) / 16;
-    if (nt <= 1) return launch_xa2<T, 1>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
-    if (nt <= 2) return launch_xa2<T, 2>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
-    if (nt <= 3) return launch_xa2<T, 3>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
-    if (nt <= 4) return launch_xa2<T, 4>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    if (nt <= 1) return launch_xa2<T, 1>(X, ldx, W, ldw, out, ld_out, out_k, ld_k, k_cols, M, K, R, out_cols, st);
+    if (nt <= 2) return launch_xa2<T, 2>(X, ldx, W, ldw, out, ld_out, out_k, ld_k, k_cols, M, K, R, out_cols, st);
+    if (nt <= 3) return launch_xa2<T, 3>(X, ldx, W, ldw, out, ld_out, out_k, ld_k, k_cols, M, K, R, out_cols, st);
+    if (nt <= 4) return launch_xa2<T, 4>(X, ldx, W, ldw, out, ld_out, out_k, ld_k, k_cols, M, K, R, out_cols, st);
     return UAMD_ERR_ARG;
 }
 
@@ -483,15 +508,28 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
 }
 
 // XA[M, out_cols] = X[M, K] @ W[R, K]^T in fp32 (columns >= R zero-filled), streaming version for R <= 64.
-extern "C" int uamd_lora_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out,
-                             int M, int K, int R, int out_cols, int dtype, void* stream) {
-    if (M < 0 || K < 8 || R <= 0 || out_cols < R || R > 64 || out_cols > 256) return UAMD_ERR_ARG;
+extern "C" int uamd_lora_xa2k(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out,
+                              void* out_k, int64_t ld_k, int k_cols, int M, int K, int R, int out_cols, int dtype,
+                              void* stream) {
+    if (M < 0 || K < 8 || R <= 0 || R > 64) return UAMD_ERR_ARG;
+    if (!out && !out_k) return UAMD_ERR_ARG;
+    if (out && (out_cols < R || out_cols > 256)) return UAMD_ERR_ARG;
+    if (out_k && (k_cols < R || k_cols > 256)) return UAMD_ERR_ARG;
     if (M == 0) return UAMD_OK;
     if ((K & 7) || (ldx & 7) || (ldw & 7) || !aligned16(X) || !aligned16(W)) return UAMD_ERR_ALIGN;
+    if (out_k && ((k_cols & 7) || (ld_k & 7) || !aligned16(out_k))) return UAMD_ERR_ALIGN;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == UAMD_BF16) return xa2_dispatch<bf16_t>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
-    if (dtype == UAMD_F16) return xa2_dispatch<f16_t>(X, ldx, W, ldw, out, ld_out, M, K, R, out_cols, st);
+    if (dtype == UAMD_BF16)
+        return xa2_dispatch<bf16_t>(X, ldx, W, ldw, out, ld_out, out_k, ld_k, k_cols, M, K, R, out_cols, st);
+    if (dtype == UAMD_F16)
+        return xa2_dispatch<f16_t>(X, ldx, W, ldw, out, ld_out, out_k, ld_k, k_cols, M, K, R, out_cols, st);
     return UAMD_ERR_DTYPE;
+}
+
+extern "C" int uamd_lora_xa2(const void* X, int64_t ldx, const void* W, int64_t ldw, float* out, int64_t ld_out,
+                             int M, int K, int R, int out_cols, int dtype, void* stream) {
+    if (!out) return UAMD_ERR_ARG;
+    return uamd_lora_xa2k(X, ldx, W, ldw, out, ld_out, nullptr, 0, 0, M, K, R, out_cols, dtype, stream);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -519,6 +557,8 @@ __global__ void __launch_bounds__(256) lora_prepare_kernel(const uamd_lora_prep_
     const float* src = (const float*)m.src;
     T* rm = (T*)m.dst_rowmajor;
     T* tr = (T*)m.dst_transposed;
+    T* pad = (T*)m.dst_pad;                                          // scaled copy with its own leading dimension
+    const bool pad_t = m.pad_transposed != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
@@ -526,15 +566,20 @@ __global__ void __launch_bounds__(256) lora_prepare_kernel(const uamd_lora_prep_
         if (r < m.rows && c < m.cols) {
             v = src[(int64_t)r * m.cols + c];
             if (rm) rm[(int64_t)r * m.cols + c] = from_f32<T>(v);
+            if (pad && !pad_t) pad[(int64_t)r * m.pad_ld + c] = from_f32<T>(m.pad_scale * v);
         }
         tile[ty + 8 * i][tx] = v;
     }
     __syncthreads();
-    if (tr) {
+    if (tr || (pad && pad_t)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = c0 + ty + 8 * i, r = r0 + tx;              // transposed: [cols][rows]
-            if (r < m.rows && c < m.cols) tr[(int64_t)c * m.rows + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+            if (r < m.rows && c < m.cols) {
+                const float v = tile[tx][ty + 8 * i];
+                if (tr) tr[(int64_t)c * m.rows + r] = from_f32<T>(v);
+                if (pad && pad_t) pad[(int64_t)c * m.pad_ld + r] = from_f32<T>(m.pad_scale * v);
+            }
         }
     }
 }

@@ -30,13 +30,11 @@ next_power_of_2 = lambda n: 1 << (max(int(n), 1) - 1).bit_length()
 # ~3 % of the GEMM time at 8192 tokens) and the dense 256x256 LDS-DMA kernel runs at ~2x the fused rate.
 FUSED_NF4 = os.environ.get("UNSLOTH_AMD_FUSED_NF4", "1") == "1"
 FUSED_NF4_MAX_M = int(os.environ.get("UNSLOTH_AMD_FUSED_NF4_MAX_M", "512"))
-# dense GEMM kernel selection: "auto" = a 256x256 tile kernel once the launch has enough 256x256 tiles to fill the
-# 256 CUs (GEMM256_MIN_TILES), else the 128x128 register-staged kernel (csrc/gemm.hip); "on"/"off" force it.
-# Which 256x256 kernel: LARGE_KERNEL = "w4" (csrc/gemm_w4.hip: 4 waves, 32x32x16 MFMA, 4-stage DMA ring) or
-# "pp" (csrc/gemm256.hip: 8 waves in two anti-phase groups) or "fr" (csrc/gemm_fr.hip: 8 free-running waves).
+# dense GEMM kernel selection: "auto" = the 256x256 ping-pong kernel (csrc/gemm256.hip: LDS-DMA, 8 waves in two
+# anti-phase groups) once the launch has enough 256x256 tiles to fill the 256 CUs (GEMM256_MIN_TILES), else the
+# 128x128 register-staged kernel (csrc/gemm.hip); "on"/"off" force it.
 GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
 GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "192"))
-LARGE_KERNEL = os.environ.get("UNSLOTH_AMD_LARGE_GEMM", "pp")
 # X @ A^T / dY @ B: streaming LDS-DMA kernel (csrc/lora_side.hip) for total rank <= 64, else the first version
 LORA_XA_V2 = os.environ.get("UNSLOTH_AMD_LORA_XA_V2", "1") == "1"
 
@@ -116,22 +114,27 @@ def fast_dequantize(W, quant_state=None, out=None, use_global_buffer=False):
 
 # ------------------------------------------------------------------------------------------------
 # GEMM plumbing
-def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0):
+def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0, xk=None, bk=None):
+    """One uamd_gemm_group. The LoRA term comes either as (xa fp32, lb, scale) -- the register prologue of the
+    128x128 kernels -- or as the rank block (xk, bk) the 256x256 kernel contracts as extra K tiles; `xa` and `R` are
+    kept in both cases (the benchmark's flop accounting reads them)."""
     return GemmGroup(
         B=B.data_ptr(), C=C.data_ptr(), absmax=absmax.data_ptr() if absmax is not None else None,
         lora_xa=xa.data_ptr() if xa is not None else None, lora_b=lb.data_ptr() if lb is not None else None,
         ldb=ldb, ldc=C.stride(0), ld_xa=ld_xa, ld_lb=lb.stride(0) if lb is not None else 0,
-        N=N, R=R, lora_scale=float(scale), _pad=0)
+        N=N, R=R, lora_scale=float(scale), _pad=0,
+        lora_xk=xk.data_ptr() if xk is not None else None, lora_bk=bk.data_ptr() if bk is not None else None,
+        ld_xk=xk.stride(0) if xk is not None else 0, ld_bk=bk.stride(0) if bk is not None else 0,
+        Rk=xk.shape[1] if xk is not None else 0, _pad2=0)
 
 
-def _use_gemm256(M, K, groups):
-    if GEMM256_MODE == "off" or K % (32 if LARGE_KERNEL == "w4" else 64):
-        return False
-    if LARGE_KERNEL in ("w4", "fr") and max([g.ldb for g in groups]) > (1 << 22):
+def _use_gemm256(M, K, Ns):
+    """`Ns`: output widths of the groups of one launch."""
+    if GEMM256_MODE == "off" or K % 64:
         return False
     if GEMM256_MODE == "on":
         return True
-    tiles = ((M + 255) // 256) * sum((g.N + 255) // 256 for g in groups)
+    tiles = ((M + 255) // 256) * sum((n + 255) // 256 for n in Ns)
     return tiles >= GEMM256_MIN_TILES
 
 
@@ -141,13 +144,8 @@ def _launch_gemm(X2d, groups, nf4, accumulate=False):
     M, K = X2d.shape
     if nf4:
         fn, name = L.uamd_gemm_nt_nf4, "uamd_gemm_nt_nf4"
-    elif _use_gemm256(M, K, groups):
-        if LARGE_KERNEL == "w4":
-            fn, name = L.uamd_gemm_nt_w4, "uamd_gemm_nt_w4"
-        elif LARGE_KERNEL == "fr":
-            fn, name = L.uamd_gemm_nt_fr, "uamd_gemm_nt_fr"
-        else:
-            fn, name = L.uamd_gemm_nt_256, "uamd_gemm_nt_256"
+    elif _use_gemm256(M, K, [g.N for g in groups]):
+        fn, name = L.uamd_gemm_nt_256, "uamd_gemm_nt_256"
     else:
         fn, name = L.uamd_gemm_nt, "uamd_gemm_nt"
     with _lib.device_ctx(X2d):
@@ -191,7 +189,8 @@ class _PreparedFactors:
 
     def __init__(self, device, dtype):
         self.device, self.dtype = device, dtype
-        self.params = {}        # id -> [weakref, rm, tr, version]
+        self.params = {}        # id -> [weakref, rm, tr, version, epoch, padspec]
+        self.pad_bufs = {}      # key -> zero-initialised [rows, width] buffer (rank-block BK operands of the GEMM)
         self.epoch = -1
         self.table = None       # (ptr signature, descs tensor, prefix tensor, total tiles)
 
@@ -199,12 +198,21 @@ class _PreparedFactors:
     def _tiles(P):
         return ((P.shape[0] + 31) // 32) * ((P.shape[1] + 31) // 32)
 
+    _DESC = [("src", "<u8"), ("rm", "<u8"), ("tr", "<u8"), ("rows", "<i4"), ("cols", "<i4"), ("pad", "<u8"),
+             ("pad_ld", "<i8"), ("pad_scale", "<f4"), ("pad_t", "<i4")]          # uamd_lora_prep_desc
+
     def _launch(self, ents):
         import numpy as np
-        descs = np.zeros(len(ents), dtype=np.dtype([("src", "<u8"), ("rm", "<u8"), ("tr", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+        descs = np.zeros(len(ents), dtype=np.dtype(self._DESC))
+        assert descs.dtype.itemsize == 56
         prefix, tot = np.zeros(len(ents), dtype=np.int32), 0
-        for i, (P, rm, tr) in enumerate(ents):
-            descs[i] = (P.data_ptr(), rm.data_ptr(), tr.data_ptr(), P.shape[0], P.shape[1])
+        for i, (P, rm, tr, pad) in enumerate(ents):
+            if pad is None:
+                descs[i] = (P.data_ptr(), rm.data_ptr(), tr.data_ptr(), P.shape[0], P.shape[1], 0, 0, 0.0, 0)
+            else:
+                buf, col, scale, transposed = pad
+                descs[i] = (P.data_ptr(), rm.data_ptr(), tr.data_ptr(), P.shape[0], P.shape[1],
+                            buf.data_ptr() + col * buf.element_size(), buf.stride(0), scale, int(transposed))
             prefix[i] = tot
             tot += self._tiles(P)
         sig = descs.tobytes()
@@ -223,7 +231,13 @@ class _PreparedFactors:
         _lib.check(rc, "uamd_lora_prepare")
         # the table tensors must outlive the launch: stream-ordered free is fine for torch's caching allocator
 
-    def get(self, P, tag):
+    def _forget(self, pid):
+        self.params.pop(pid, None)
+        for k in [k for k in self.pad_bufs if pid in k[0]]:
+            self.pad_bufs.pop(k, None)
+
+    def _entry(self, P, padspec=None):
+        """Registers P (and, optionally, its padded/scaled third copy) and makes every copy current."""
         pid = id(P)
         ent = self.params.get(pid)
         epoch = _CAST_EPOCH[0]
@@ -231,21 +245,42 @@ class _PreparedFactors:
             if ent is None or ent[0]() is not P or ent[1].shape != P.shape:
                 rm = torch.empty(P.shape, dtype=self.dtype, device=self.device)
                 tr = torch.empty((P.shape[1], P.shape[0]), dtype=self.dtype, device=self.device)
-                ent = [weakref.ref(P, lambda _, pid=pid: self.params.pop(pid, None)), rm, tr, -1, -1]
+                ent = [weakref.ref(P, lambda _, pid=pid: self._forget(pid)), rm, tr, -1, -1, None]
                 self.params[pid] = ent
+            if padspec is not None:
+                old = ent[5]
+                if old is None or old[0] is not padspec[0] or old[1:] != padspec[1:]:
+                    ent[5] = padspec
+                    ent[4] = -1                                # this entry must be (re)written
             if self.epoch != epoch:
                 live = []
                 for e in list(self.params.values()):
                     Q = e[0]()
                     if Q is not None:
-                        live.append((Q, e[1], e[2]))
+                        live.append((Q, e[1], e[2], e[5]))
                         e[3], e[4] = Q._version, epoch
                 self._launch(live)
                 self.epoch = epoch
             elif ent[4] != epoch or ent[3] != P._version:       # registered (or modified in place) mid-epoch
-                self._launch([(P, ent[1], ent[2])])
+                self._launch([(P, ent[1], ent[2], ent[5])])
                 ent[3], ent[4] = P._version, epoch
+        return ent
+
+    def get(self, P, tag):
+        ent = self._entry(P)
         return ent[1] if tag == "rowmajor" else ent[2]
+
+    def get_pad(self, members, rows, width, transposed):
+        """members: [(P, col_off, scale)] written side by side into ONE zero-initialised [rows, width] buffer:
+        scale * P (transposed=False, P is [rows, r]) or scale * P^T (transposed=True, P is [r, rows]) at columns
+        col_off..col_off+r. Returns the buffer: the BK operand of the GEMM's rank-block K tiles."""
+        key = (tuple(id(P) for P, _, _ in members), rows, width, bool(transposed))
+        buf = self.pad_bufs.get(key)
+        if buf is None:
+            buf = self.pad_bufs[key] = torch.zeros((rows, width), dtype=self.dtype, device=self.device)
+        for P, col, scale in members:
+            self._entry(P, (buf, int(col), float(scale), bool(transposed)))
+        return buf
 
 
 _PREPARED = {}
@@ -278,10 +313,35 @@ def _cached_cast(P, tag, dtype, build):
     return out
 
 
-def lora_xa(X2d, A_list, out=None):
+def rank_block_bk(members, rows, width, transposed, dtype):
+    """BK operand of the GEMM's rank-block K tiles: a zero [rows, width] buffer with scale * P (or scale * P^T when
+    `transposed`) at columns col_off.. for every member (P, col_off, scale). When the factors are fp32 CUDA
+    Parameters (the training case) the buffer is persistent and kept current by the once-per-step
+    uamd_lora_prepare launch; otherwise it is built here."""
+    prepared = LORA_PREPARE and dtype in (torch.bfloat16, torch.float16) and all(
+        isinstance(P, torch.nn.Parameter) and P.is_cuda and P.dtype == torch.float32 and P.dim() == 2
+        and P.is_contiguous() for P, _, _ in members)
+    if not prepared:
+        # plain tensors (tests, ad-hoc calls of matmul_lora): built per call with torch ops
+        with torch.no_grad():
+            buf = torch.zeros((rows, width), dtype=dtype, device=members[0][0].device)
+            for P, col, scale in members:
+                src = P.detach().t() if transposed else P.detach()
+                buf[:, col:col + src.shape[1]] = (src.float() * float(scale)).to(dtype)
+        return buf
+    key = (members[0][0].device, dtype)
+    g = _PREPARED.get(key)
+    if g is None:
+        g = _PREPARED[key] = _PreparedFactors(members[0][0].device, dtype)
+    return g.get_pad(members, rows, width, transposed)
+
+
+def lora_xa(X2d, A_list, out=None, out_k=None, k_cols=0):
     """XA_g = X @ A_g^T for every projection sharing X, ONE launch. fp32, each block of columns
     padded to a multiple of 8. Returns (buffer, [(col_offset, R_padded)]). `out`: optional fp32 [M, sum Rp]
-    destination with unit column stride (e.g. a column slice of a wider buffer)."""
+    destination with unit column stride (e.g. a column slice of a wider buffer). `out_k` (activation dtype, unit
+    column stride) additionally receives the sums rounded to the activation dtype, zero-filled up to `k_cols`
+    columns: the XK operand of the GEMM's rank-block K tiles."""
     dtype = X2d.dtype
     Rs = [A.shape[0] for A in A_list]
     Rp = [(r + 7) // 8 * 8 for r in Rs]
@@ -314,11 +374,19 @@ def lora_xa(X2d, A_list, out=None):
         assert out.dtype == torch.float32 and tuple(out.shape) == (X2d.shape[0], Rt) and out.stride(1) == 1 \
             and out.stride(0) % 4 == 0
     L = _lib.lib()
-    fn, name = (L.uamd_lora_xa2, "uamd_lora_xa2") if (LORA_XA_V2 and Rt <= 64 and K >= 8) else (L.uamd_lora_xa, "uamd_lora_xa")
-    with _lib.device_ctx(X2d):
-        rc = fn(_lib.ptr(X2d), X2d.stride(0), _lib.ptr(Acat), Acat.stride(0), _lib.ptr(out), out.stride(0),
-                X2d.shape[0], K, Rt, Rt, _lib.dtype_code(dtype), _lib.stream_of(X2d))
-    _lib.check(rc, name)
+    if out_k is not None:
+        assert Rt <= 64 and out_k.dtype == dtype and out_k.stride(1) == 1 and k_cols >= Rt
+        with _lib.device_ctx(X2d):
+            rc = L.uamd_lora_xa2k(_lib.ptr(X2d), X2d.stride(0), _lib.ptr(Acat), Acat.stride(0), _lib.ptr(out),
+                                  out.stride(0), _lib.ptr(out_k), out_k.stride(0), k_cols, X2d.shape[0], K, Rt, Rt,
+                                  _lib.dtype_code(dtype), _lib.stream_of(X2d))
+        _lib.check(rc, "uamd_lora_xa2k")
+    else:
+        fn, name = (L.uamd_lora_xa2, "uamd_lora_xa2") if (LORA_XA_V2 and Rt <= 64 and K >= 8) else (L.uamd_lora_xa, "uamd_lora_xa")
+        with _lib.device_ctx(X2d):
+            rc = fn(_lib.ptr(X2d), X2d.stride(0), _lib.ptr(Acat), Acat.stride(0), _lib.ptr(out), out.stride(0),
+                    X2d.shape[0], K, Rt, Rt, _lib.dtype_code(dtype), _lib.stream_of(X2d))
+        _lib.check(rc, name)
     offs, o = [], 0
     for rp in Rp:
         offs.append((o, rp))
@@ -341,6 +409,29 @@ def _pad_rank(B, Rp, dtype):
     return out
 
 
+def _rank_width(r):
+    return (r + 63) // 64 * 64
+
+
+def _xa_and_rank_block(X2d, A_list, want_k, out=None):
+    """(xa fp32 [M, sum Rp], offsets, xk): X @ A_g^T for the projections sharing X and, when `want_k`, the same sums
+    in the activation dtype zero-padded to a multiple of 64 columns (XK, the GEMM's rank-block operand)."""
+    Rt = sum((A.shape[0] + 7) // 8 * 8 for A in A_list)
+    if not want_k:
+        xa, offs = lora_xa(X2d, A_list, out=out)
+        return xa, offs, None
+    M = X2d.shape[0]
+    width = _rank_width(Rt)
+    if Rt <= 64 and LORA_XA_V2 and X2d.shape[1] >= 8:
+        xk = torch.empty((M, width), dtype=X2d.dtype, device=X2d.device)
+        xa, offs = lora_xa(X2d, A_list, out=out, out_k=xk, k_cols=width)
+    else:                                   # total rank > 64: first-version kernel, then a padded cast
+        xa, offs = lora_xa(X2d, A_list, out=out)
+        xk = torch.zeros((M, width), dtype=X2d.dtype, device=X2d.device)
+        xk[:, :Rt] = xa
+    return xa, offs, xk
+
+
 def lora_linear_forward(X, projs, outs=None, return_xa=False):
     """Y_g = X @ W_g^T + s_g * (X @ A_g^T) @ B_g^T for projections `projs` = [(W, W_quant, A, B, s)]
     that share X. Returns a list of [.., N_g] tensors. This is matmul_lora (utils.py:1128-1170)
@@ -353,32 +444,45 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
     M, K = X2d.shape
     lead = X.shape[:-1]
     with_lora = [p for p in projs if p[2] is not None]
-    xa, offs = (None, [])
+    Ns = [(q.shape[0] if q is not None else W.shape[0]) for (W, q, _, _, _) in projs]
+    fused_nf4 = [q is not None and FUSED_NF4 and M < FUSED_NF4_MAX_M and q.blocksize == 64 and K % 64 == 0
+                 for (_, q, _, _, _) in projs]
+    # the dense groups go to the 256x256 kernel when the launch is large enough: there the LoRA term rides along as
+    # extra K tiles (XK = T(X A^T) zero-padded to 64 columns, BK_g = T(s_g B_g) at its rank columns)
+    dense_Ns = [n for n, f in zip(Ns, fused_nf4) if not f]
+    use256 = bool(dense_Ns) and _use_gemm256(M, K, dense_Ns)
+    xa, offs, xk = None, [], None
     if with_lora:
-        xa, offs = lora_xa(X2d, [p[2] for p in with_lora])
+        xa, offs, xk = _xa_and_rank_block(X2d, [p[2] for p in with_lora], use256)
     results, dense_groups, nf4_groups, keep = [], [], [], []
     li = 0
     for gi, (W, W_quant, A, B, s) in enumerate(projs):
         if W_quant is not None:
-            N = W_quant.shape[0]
             assert W_quant.shape[1] == K, "weight/in_features mismatch"
-        else:
-            N = W.shape[0]
+        N = Ns[gi]
         C = outs[gi] if outs is not None else torch.empty((M, N), dtype=dtype, device=X.device)
         kw = {}
         if A is not None:
             o, rp = offs[li]
             li += 1
-            lb = _pad_rank(B, rp, dtype)
-            keep.append(lb)
-            kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
-        if W_quant is not None and FUSED_NF4 and M < FUSED_NF4_MAX_M and W_quant.blocksize == 64 and K % 64 == 0:
+            if xk is not None and not fused_nf4[gi]:
+                bk = rank_block_bk([(B, o, s)], N, xk.shape[1], False, dtype)
+                keep.append(bk)
+                kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), R=rp, scale=s, xk=xk, bk=bk)
+            else:
+                lb = _pad_rank(B, rp, dtype)
+                keep.append(lb)
+                kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
+        if fused_nf4[gi]:
             nf4_groups.append(_group(W, C, N, 0, absmax=_nf4.absmax_f32(W_quant), **kw))
         else:
             Wd = W
             if W_quant is not None:
                 # one scratch slot per group member: the grouped launch reads all of them
                 Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=True, slot=8 + gi)
+                if Wd.dtype != dtype:
+                    raise TypeError(f"quant_state.dtype {Wd.dtype} != activation dtype {dtype}: the dequantised "
+                                    "weight would be misread by the GEMM (set quant_state.dtype to the compute dtype)")
             elif Wd.dtype != dtype or Wd.stride(1) != 1 or Wd.stride(0) % 8:
                 Wd = Wd.to(dtype).contiguous()
             keep.append(Wd)
@@ -405,29 +509,54 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
 
 def lora_dx_terms(dYs, projs):
     """P_g = dY_g @ B_g (fp32 [M, Rp]) for every projection with an adapter (None otherwise): the rank-r factor
-    shared by dX += s (dY B) A and by d_A = s (dY B)^T X (fast_lora.py:172-189)."""
+    shared by dX += s (dY B) A and by d_A = s (dY B)^T X (fast_lora.py:172-189).
+    When the dX GEMM will run on the 256x256 kernel, each launch also writes T(P_g) into a shared zero-padded
+    [M, 64k] rank block (attached to the returned tensor as `_uamd_xk = (xk, col_off)`): the XK operand of that
+    GEMM's extra K tiles."""
     terms = []
     ranks = [None if A is None else A.shape[0] for (_, _, A, _, _) in projs]
+    dY2 = [_rows2d(dY) for dY in dYs]
+    M = dY2[0].shape[0]
+    dev, dtype = dY2[0].device, dY2[0].dtype
+    Kin = [(q.shape[1] if q is not None else W.shape[1]) for (W, q, _, _, _) in projs]
+    want_k = (dtype in (torch.bfloat16, torch.float16) and LORA_XA_V2
+              and all(_use_gemm256(M, 64, [k]) for k in Kin))
     # all P_g side by side in ONE [M, sum r] buffer when possible: lora_linear_dx can then hand the whole rank
     # block to a single K-concatenated GEMM
     shared, col = None, 0
-    if len(projs) > 1 and all(r is not None and r % 8 == 0 for r in ranks):
-        M = _rows2d(dYs[0]).shape[0]
-        shared = torch.empty((M, sum(ranks)), dtype=torch.float32, device=dYs[0].device)
-    for dY, (W, W_quant, A, B, s) in zip(dYs, projs):
+    with_lora = [r for r in ranks if r is not None]
+    if len(projs) > 1 and len(with_lora) == len(projs) and all(r % 8 == 0 for r in ranks):
+        shared = torch.empty((M, sum(ranks)), dtype=torch.float32, device=dev)
+    Rt = sum((r + 7) // 8 * 8 for r in with_lora)
+    xk = None
+    if want_k and with_lora and Rt <= 64 and (shared is not None or len(with_lora) == 1):
+        xk = torch.empty((M, _rank_width(Rt)), dtype=dtype, device=dev)
+    n_left = len(with_lora)
+    for dY2d, (W, W_quant, A, B, s) in zip(dY2, projs):
         if A is None:
             terms.append(None)
             continue
-        dY2d = _rows2d(dY)
-        dtype = dY2d.dtype
+        n_left -= 1
         Bt = _cached_cast(B, "T", dtype, lambda B=B, dtype=dtype: B.to(dtype).t().contiguous())        # [r, N]
+        r = A.shape[0]
+        rp = (r + 7) // 8 * 8
+        kw = {}
+        if xk is not None:
+            # the last launch also zero-fills the padding columns up to the 64-multiple
+            kw = dict(out_k=xk[:, col:], k_cols=(xk.shape[1] - col) if n_left == 0 else rp)
         if shared is not None:
-            r = A.shape[0]
-            xa, offs = lora_xa(dY2d, [Bt], out=shared[:, col:col + r])
-            col += r
+            xa, offs = lora_xa(dY2d, [Bt], out=shared[:, col:col + r], **kw)
         else:
-            xa, offs = lora_xa(dY2d, [Bt])                          # dY @ B
-        terms.append(xa[:, :offs[0][1]])
+            xa, offs = lora_xa(dY2d, [Bt], **kw)                    # dY @ B
+        t = xa[:, :offs[0][1]]
+        if xk is not None:
+            t._uamd_xk = (xk, col)
+        elif want_k:                            # odd ranks / total rank > 64: padded cast with torch ops
+            own = torch.zeros((M, _rank_width(t.shape[1])), dtype=dtype, device=dev)
+            own[:, :t.shape[1]] = t
+            t._uamd_xk = (own, 0)
+        col += rp
+        terms.append(t)
     return terms
 
 
@@ -458,9 +587,6 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
         return None
     if any(A is None for (_, _, A, _, _) in projs) or any(t is None for t in terms):
         return None
-    scales = {float(s) for (_, _, _, _, s) in projs}
-    if len(scales) != 1:
-        return None
     dY2 = [_rows2d(dY) for dY in dYs]
     dYcat = _adjacent_columns(dY2)
     Pcat = _adjacent_columns(list(terms))
@@ -478,13 +604,24 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
         _nf4.dequantize_nf4(W, q, out=Wt[:, col:col + n], transpose=True)          # [Kin, n] at column `col`
         col += n
     A_list = [A for (_, _, A, _, _) in projs]
-    tag = ("catT",) + tuple((id(A), A._version, A.data_ptr()) for A in A_list[1:])
-    lb = _cached_cast(A_list[0], tag, dtype,
-                      lambda: torch.cat([_cached_cast(A, "T", dtype, lambda A=A: A.to(dtype).t().contiguous())
-                                         for A in A_list], dim=1).contiguous())
     if out is None:
         out = torch.empty((M, Kin), dtype=dtype, device=dYcat.device)
-    g = _group(Wt, out, Kin, Wt.stride(0), xa=Pcat, ld_xa=Pcat.stride(0), lb=lb, R=Pcat.shape[1], scale=scales.pop())
+    xks = [getattr(t, "_uamd_xk", None) for t in terms]
+    if _use_gemm256(M, Ntot, [Kin]) and all(x is not None and x[0] is xks[0][0] for x in xks):
+        # rank block as extra K tiles: XK = [T(P_q) | T(P_k) | T(P_v) | 0], BK = [s_q A_q^T | s_k A_k^T | s_v A_v^T | 0]
+        xk = xks[0][0]
+        bk = rank_block_bk([(A, x[1], s) for (_, _, A, _, s), x in zip(projs, xks)], Kin, xk.shape[1], True, dtype)
+        g = _group(Wt, out, Kin, Wt.stride(0), xa=Pcat, ld_xa=Pcat.stride(0), R=Pcat.shape[1], scale=1.0, xk=xk, bk=bk)
+    else:
+        scales = {float(s) for (_, _, _, _, s) in projs}
+        if len(scales) != 1:
+            return None
+        tag = ("catT",) + tuple((id(A), A._version, A.data_ptr()) for A in A_list[1:])
+        lb = _cached_cast(A_list[0], tag, dtype,
+                          lambda: torch.cat([_cached_cast(A, "T", dtype, lambda A=A: A.to(dtype).t().contiguous())
+                                             for A in A_list], dim=1).contiguous())
+        g = _group(Wt, out, Kin, Wt.stride(0), xa=Pcat, ld_xa=Pcat.stride(0), lb=lb, R=Pcat.shape[1],
+                   scale=scales.pop())
     _launch_gemm(dYcat, [g], nf4=False, accumulate=False)
     return out
 
@@ -512,14 +649,22 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
             Wt = W.to(dtype).t().contiguous()
         if out is None:
             out = torch.empty((M, Kin), dtype=dtype, device=dY.device)
+        if Wt.dtype != dtype:
+            raise TypeError(f"quant_state.dtype {Wt.dtype} != activation dtype {dtype}: the dequantised weight "
+                            "would be misread by the GEMM (set quant_state.dtype to the compute dtype)")
         kw = {}
         if A is not None:
             rp = xa.shape[1]
-            if A.shape[0] == rp:
-                lb = _cached_cast(A, "T", dtype, lambda A=A, dtype=dtype: A.to(dtype).t().contiguous())    # A^T [Kin, r]
+            xk = getattr(xa, "_uamd_xk", None)
+            if xk is not None and _use_gemm256(M, N, [Kin]):
+                bk = rank_block_bk([(A, xk[1], s)], Kin, xk[0].shape[1], True, dtype)     # s A^T at its rank columns
+                kw = dict(xa=xa, ld_xa=xa.stride(0), R=rp, scale=s, xk=xk[0], bk=bk)
             else:
-                lb = _pad_rank(A.to(dtype).t(), rp, dtype)
-            kw = dict(xa=xa, ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
+                if A.shape[0] == rp:
+                    lb = _cached_cast(A, "T", dtype, lambda A=A, dtype=dtype: A.to(dtype).t().contiguous())    # A^T [Kin, r]
+                else:
+                    lb = _pad_rank(A.to(dtype).t(), rp, dtype)
+                kw = dict(xa=xa, ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
         g = _group(Wt, out, Kin, Wt.stride(0), **kw)
         _launch_gemm(dY2d, [g], nf4=False, accumulate=not first)
         first = False
