@@ -154,22 +154,22 @@ def main():
     # ------------------------------------------------------------------ cross entropy
     for tag, V, kw in (("plain", 1000, {}), ("softcap", 500, dict(logit_softcapping=30.0)),
                        ("scale", 500, dict(logit_scaling=0.125)), ("v32000", 32000, {}), ("v128256", 128256, {}),
-                       ("v128256_softcap", 128256, dict(logit_softcapping=30.0))):
+                       ("v70000_softcap", 70000, dict(logit_softcapping=30.0))):
         @case(f"ce_{tag}")
         def _():
-            Bc, Tc = (2, 4) if V <= 1000 else ((1, 4) if V <= 32000 else (1, 3))
+            Bc, Tc = (2, 4) if V <= 1000 else ((1, 4) if V <= 32000 else (1, 3 if V < 100000 else 2))
             logits = rnd(Bc, Tc, V, scale=4.0)
             labels = torch.randint(0, V, (Bc, Tc), generator=gen)
-            labels[0, 1] = -100
+            labels[0, 0 if Tc == 2 else 1] = -100
             if V > 1000:
-                labels[0, 2] = V - 1
+                labels[0, Tc - 1] = V - 1
             lg = logits.to(dev).requires_grad_(True)
             loss = ce.fast_cross_entropy_loss(lg * 1.0, labels.to(dev), **kw)
             loss.backward()
             return dict(logits=logits, labels=labels, loss=cpu(loss), dlogits=cpu(lg.grad), **kw)
 
     # ------------------------------------------------------------------ manual-autograd LoRA blocks (dense bf16 W)
-    for tag, Hd, I, Hkv, r, Bz, T in (("small", 64, 128, 32, 8, 2, 5), ("mid", 256, 768, 64, 16, 2, 64)):
+    for tag, Hd, I, Hkv, r, Bz, T in (("small", 64, 128, 32, 8, 2, 5), ("mid", 256, 512, 64, 16, 2, 64)):
         mk = lambda o, i: (rnd(o, i, scale=0.05), rnd(r, i, dtype=torch.float32, scale=0.05),
                            rnd(o, r, dtype=torch.float32, scale=0.05), 2.0)
 

@@ -88,7 +88,7 @@ def test_bnb4bit_round_trip_is_byte_exact(tmp_path, tie, shard):
         fresh = AutoModelForCausalLM.from_config(cfg16, dtype=torch.bfloat16)
     fresh.to_empty(device="cpu")
     missing, unexpected = ck.load_prequantized_(fresh, str(tmp_path), "cpu", torch.bfloat16)
-    assert not unexpected and not [m for m in missing if "rotary" not in m]
+    assert not unexpected and not missing
     a, b = ck.state_dict_4bit(model), ck.state_dict_4bit(fresh)
     assert set(a) == set(b)
     for k in a:
@@ -120,3 +120,49 @@ def test_dequantised_checkpoint_matches_oracle_values(tmp_path):
     got = nf4_dequantize_state(packed, qs)
     assert torch.equal(got, want)
     assert np.isfinite(got.float().numpy()).all()
+
+
+def test_load_reconciles_stamped_dtype_detects_missing_tensors_and_rebuilds_rotary(tmp_path):
+    """(a) a checkpoint stamped float16 loaded for bf16 compute must end with quant_state.dtype == bf16
+    (the GEMM reads the decode scratch as the activation dtype); (b) a tensor the checkpoint lacks is reported as
+    missing even though nothing is on the meta device after to_empty(); (c) non-persistent rotary buffers are
+    recomputed from the config instead of staying uninitialised."""
+    import copy
+    from safetensors.torch import load_file, save_file
+    from transformers import AutoConfig, AutoModelForCausalLM
+    from unsloth_amd import checkpoint as ck
+    from unsloth_amd import nf4
+    model = _quantized_tiny()
+    for m in model.modules():
+        if isinstance(m, nf4.Linear4bit):
+            m.weight.quant_state.dtype = torch.float16          # how many *-bnb-4bit repos are stamped
+    ck.save_pretrained_4bit(model, str(tmp_path))
+    cfg = AutoConfig.from_pretrained(str(tmp_path))
+    cfg16 = copy.deepcopy(cfg)
+    del cfg16.quantization_config
+
+    def fresh():
+        with torch.device("meta"):
+            m = AutoModelForCausalLM.from_config(cfg16, dtype=torch.bfloat16)
+        m.to_empty(device="cpu")
+        return m
+    f1 = fresh()
+    rot = [m for m in f1.modules() if "inv_freq" in getattr(m, "_buffers", {})]
+    for m in rot:
+        m._buffers["inv_freq"].fill_(float("nan"))             # what uninitialised memory may well hold
+    missing, unexpected = ck.load_prequantized_(f1, str(tmp_path), "cpu", torch.bfloat16)
+    assert not missing and not unexpected
+    qs = f1.model.layers[0].mlp.gate_proj.weight.quant_state
+    assert qs.dtype == torch.bfloat16
+    want = AutoModelForCausalLM.from_config(cfg16)
+    for m, w in zip(rot, [m for m in want.modules() if "inv_freq" in getattr(m, "_buffers", {})]):
+        assert torch.equal(m.inv_freq, w.inv_freq)
+    # drop one dense tensor from the file: it must come back as missing
+    fn = os.path.join(str(tmp_path), ck.checkpoint_files(str(tmp_path))[0])
+    sd = load_file(fn)
+    victim = "model.layers.1.input_layernorm.weight"
+    assert victim in sd
+    del sd[victim]
+    save_file(sd, fn, metadata={"format": "pt"})
+    missing, _ = ck.load_prequantized_(fresh(), str(tmp_path), "cpu", torch.bfloat16)
+    assert missing == [victim]

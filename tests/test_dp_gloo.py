@@ -23,9 +23,9 @@ class Tiny(torch.nn.Module):
             blk.frozen.weight.requires_grad_(False)
             self.model.layers.append(blk)
 
-    def forward(self, x):
-        for blk in self.model.layers:
-            x = blk.frozen(x) + blk.lora_B(blk.lora_A(x))
+    def forward(self, x, skip_lora_of=None):
+        for i, blk in enumerate(self.model.layers):
+            x = blk.frozen(x) if i == skip_lora_of else blk.frozen(x) + blk.lora_B(blk.lora_A(x))
         return x
 
 
@@ -71,7 +71,31 @@ def _worker(rank, world, port, overlap, q):
         m(x).square().sum().backward()
         arena.finish()
     unsynced = any(not torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(arena.params, want))
-    q.put((rank, ok, int(n), unsynced))
+    # optimizer.zero_grad(set_to_none=True) (PyTorch's default) detaches the arena views; the next
+    # backward must still end with the REDUCED sum in the arena and in p.grad, not stale or un-reduced values
+    for p in arena.params:
+        p.grad = None
+    m(x).square().sum().backward()
+    arena.finish()
+    ok_none = all(p.grad is not None and p.grad.data_ptr() == arena._views[id(p)].data_ptr()
+                  and torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(arena.params, want))
+    # a trainable parameter that receives NO gradient this step (block 1 bypassed): its bucket's count
+    # never fills, finish() must still reduce it on every rank (no hang, no divergence)
+    arena.zero_grad()
+    m(x, skip_lora_of=1).square().sum().backward()
+    arena.finish()
+    want2 = [torch.zeros_like(p) for p in arena.params]
+    for r in range(world):
+        m2 = Tiny()
+        m2.load_state_dict(m.state_dict())
+        xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + r))
+        m2(xr, skip_lora_of=1).square().sum().backward()
+        named = dict(m2.named_parameters())
+        for w, name in zip(want2, arena.names):
+            if named[name].grad is not None:
+                w += named[name].grad
+    ok_skip = all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(arena.params, want2))
+    q.put((rank, ok and ok_none and ok_skip, int(n), unsynced))
     dist.destroy_process_group()
 
 

@@ -138,7 +138,8 @@ def test_matmul_lora_reference_signature():
     assert dx.shape == (120, 256) and rel_fro(dx, want) < 1e-2
 
 
-@pytest.mark.parametrize("V,softcap", [(1000, 0.0), (32000, 0.0), (128256, 0.0), (5003 * 8, 30.0)])
+@pytest.mark.parametrize("V,softcap", [(1000, 0.0), (32000, 0.0), (128256, 0.0), (5003 * 8, 30.0),
+                                       (32001, 0.0), (1003, 30.0)])       # vocab % 8 != 0: one added pad token
 def test_fused_linear_ce(V, softcap):
     from unsloth_amd.kernels import unsloth_fused_ce_loss
     B, T, H = 2, 96, 256
@@ -151,11 +152,22 @@ def test_fused_linear_ce(V, softcap):
     hg = hidden.to(DEV).requires_grad_(True)
     loss = unsloth_fused_ce_loss(None, hg * 1.0, Wt.to(DEV), None, labels.to(DEV), logit_softcapping=softcap,
                                  chunk_rows=64)
-    torch.testing.assert_close(loss.cpu().float(), want.float(), rtol=2e-3, atol=2e-3)   # north star: 1e-3 bf16
-    (loss * 3.0).backward()
-    assert rel_fro(hg.grad, 3.0 * dh_want.float()) < 2e-2, rel_fro(hg.grad, 3.0 * dh_want.float())
+    torch.testing.assert_close(loss.cpu().float(), want.float(), rtol=1e-3, atol=1e-3)   # north star: 1e-3 bf16
+    (loss / 3.0).backward()      # an upstream scale that is NOT a bf16 number: applied in fp32, rounded once
+    assert rel_fro(hg.grad, dh_want.float() / 3.0) < 2e-2, rel_fro(hg.grad, dh_want.float() / 3.0)
     # n_items given (global token count under DP) only rescales
     loss2 = unsloth_fused_ce_loss(None, hidden.to(DEV), Wt.to(DEV), None, labels.to(DEV), n_items=1000,
                                   logit_softcapping=softcap)
     n = torch.count_nonzero(R.shift_labels(labels) != -100)
-    torch.testing.assert_close(loss2.cpu().float() * 1000 / n, want.float(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(loss2.cpu().float() * 1000 / n, want.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_fused_ce_chunk_rows_policy():
+    """chunk sizing (f3): `target_gb` bounds the transient [rows, V] logits chunk, multiples of 256 rows, 4096 max."""
+    from unsloth_amd.kernels.cross_entropy_loss import fused_ce_chunk_rows
+    dev = torch.device(DEV)
+    assert fused_ce_chunk_rows(8192, 128256, 2, dev, target_gb=1.0) == 4096          # 1.05 GB chunk > 1 GiB? 4096*128256*2 = 0.98 GiB
+    assert fused_ce_chunk_rows(8192, 128256, 2, dev, target_gb=0.25) == 1024
+    assert fused_ce_chunk_rows(8192, 128256, 2, dev, target_gb=0.01) == 256
+    assert fused_ce_chunk_rows(300, 32000, 2, dev, target_gb=4.0) == 512             # never more rows than the batch has
+    assert fused_ce_chunk_rows(8192, 128256, 2, dev) in range(256, 4097, 256)

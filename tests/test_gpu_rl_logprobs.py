@@ -27,6 +27,7 @@ def ref_logprobs(h, W, idx, mult=0.0, div=0.0, cap=0.0, temp=1.0):
     (3, 65, 256, 5000, dict(logit_scale_multiply=0.5, logit_scale_divide=2.0)),
     (2, 64, 256, 70000, dict(logit_softcapping=30.0)),             # vocab > 65536: the CE kernel has no chunk limit
     (1, 513, 256, 1000, dict(chunks=3, temperature=1.3)),
+    (2, 40, 256, 32001, {}),                                        # vocab % 8 != 0
 ])
 def test_hidden_states_logprobs_forward_backward(B, L, H, V, kw):
     from unsloth_amd.models.rl_replacements import chunked_hidden_states_selective_log_softmax as f

@@ -124,8 +124,7 @@ def main():
             L.uamd_set_tuning(3, 1)
             return dequantize_nf4(pk, q, out=buf[:, :rows], transpose=True)
         return f
-    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t64": dq(0), "t256": dq(1), "t256_pad64": dq_pad(packed, qs, 64),
-                                                   "t256_pad192": dq_pad(packed, qs, 192), "t256_pad1088": dq_pad(packed, qs, 1088),
+    ab(out, "nf4_dequant_T gate", I * H * 2.516, {"t256": dq(1), "t256_rowfast": dq(2),
                                                    "plain": lambda: dequantize_nf4(packed, qs, use_global_buffer=True)})
     Wd2 = (torch.randn(H, I, device=DEV) * 0.02).to(bf)
     packed2, qs2 = quantize_nf4(Wd2)
@@ -135,8 +134,7 @@ def main():
             L.uamd_set_tuning(3, knob)
             return dequantize_nf4(packed2, qs2, transpose=True, use_global_buffer=True)
         return f
-    ab(out, "nf4_dequant_T down", I * H * 2.516, {"t256": dq2(1), "t256_pad64": dq_pad(packed2, qs2, 64),
-                                                   "t256_pad192": dq_pad(packed2, qs2, 192), 
+    ab(out, "nf4_dequant_T down", I * H * 2.516, {"t256": dq2(1), "t256_rowfast": dq2(2), 
                                                    "plain": lambda: dequantize_nf4(packed2, qs2, use_global_buffer=True)})
     Wd3 = (torch.randn(H, H, device=DEV) * 0.02).to(bf)
     packed3, qs3 = quantize_nf4(Wd3)
@@ -146,8 +144,7 @@ def main():
             L.uamd_set_tuning(3, knob)
             return dequantize_nf4(packed3, qs3, transpose=True, use_global_buffer=True)
         return f
-    ab(out, "nf4_dequant_T o", H * H * 2.516, {"t256": dq3(1), "t256_pad64": dq_pad(packed3, qs3, 64),
-                                               "t256_pad192": dq_pad(packed3, qs3, 192), 
+    ab(out, "nf4_dequant_T o", H * H * 2.516, {"t256": dq3(1), "t256_rowfast": dq3(2), 
                                                "plain": lambda: dequantize_nf4(packed3, qs3, use_global_buffer=True)})
     L.uamd_set_tuning(3, 1)
     # lora_xa / lora_tn

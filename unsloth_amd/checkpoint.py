@@ -201,6 +201,11 @@ def load_prequantized_(model, directory, device, dtype=None):
         qs = _nf4.QuantState.from_dict(side, device)
         if qs.quant_type != "nf4":
             raise NotImplementedError(f"{wkey}: quant_type {qs.quant_type!r}")
+        if dtype is not None:
+            # bnb-4bit repos are often stamped float16 whatever the training dtype: the stamp only says what the
+            # decode WRITES, and the GEMM reads the scratch as the activation dtype. The reference overwrites it
+            # with the model dtype after load (models/granite.py:586-596); so do we.
+            qs.dtype = dtype
         out_f, in_f = qs.shape
         if packed.numel() * 2 != out_f * in_f:
             raise ValueError(f"{wkey}: {packed.numel()} packed bytes for shape {tuple(qs.shape)}")
@@ -239,8 +244,44 @@ def load_prequantized_(model, directory, device, dtype=None):
         if emb is not None and head is not None:
             head.weight = emb.weight
             loaded.add("lm_head.weight")
-    missing = [n for n, p in model.named_parameters() if n not in loaded and p.device.type == "meta"]
+    # every parameter the module tree still holds must have come from the checkpoint (after `to_empty` nothing is on
+    # the meta device any more, so the device cannot be the test: a tensor the checkpoint lacks would otherwise stay
+    # uninitialised HBM). Persistent buffers likewise; non-persistent ones (rotary inv_freq) are rebuilt below.
+    missing = [n for n, _ in model.named_parameters() if n not in loaded]
+    non_persistent = {f"{mn}.{bn}" if mn else bn for mn, m in model.named_modules()
+                      for bn in getattr(m, "_non_persistent_buffers_set", ())}
+    missing += [n for n, _ in model.named_buffers() if n not in loaded and n not in non_persistent]
+    reinit_rotary_buffers_(model, device)
     return missing, unexpected
+
+
+def reinit_rotary_buffers_(model, device):
+    """Non-persistent rotary buffers (`inv_freq`, `original_inv_freq`) never travel in a checkpoint; after
+    `to_empty` they are uninitialised memory, and HF's own forward (which the decode / generation path uses) reads
+    them. Recompute them from the config exactly as the module's constructor does."""
+    cfg = getattr(model, "config", None)
+    for m in model.modules():
+        if "inv_freq" not in getattr(m, "_buffers", {}):
+            continue
+        init = getattr(m, "rope_init_fn", None)
+        mcfg = getattr(m, "config", None) or cfg
+        inv = None
+        try:
+            if init is not None:
+                inv, scaling = init(mcfg, device)
+                if hasattr(m, "attention_scaling"):
+                    m.attention_scaling = scaling
+        except Exception:
+            inv = None
+        if inv is None:
+            from .models.llama import compute_inv_freq
+            inv, scaling, _ = compute_inv_freq(mcfg)
+            if hasattr(m, "attention_scaling"):
+                m.attention_scaling = scaling
+        inv = inv.to(device=device, dtype=torch.float32)
+        m._buffers["inv_freq"] = inv
+        if "original_inv_freq" in m._buffers:
+            m._buffers["original_inv_freq"] = inv.clone()
 
 
 # ------------------------------------------------------------------------------------------------

@@ -183,15 +183,23 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         b_src[c] = (const T*)g.B + (int64_t)rb * g.ldb + sub_slot * 8;
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
-    const int nk_main = K / TK;                        // host guarantees K % 64 == 0
-    const int nk = nk_main + (g.lora_xk != nullptr ? g.Rk / TK : 0);
-    auto issue = [&](int c, int kt, int stage) {       // c, stage are compile-time at every call site
+    // K tiles: nk_main of the operands proper, then the rank block's. Both counts are wave-uniform by construction;
+    // readfirstlane tells the compiler so (loop bounds and branches on them stay on the scalar unit).
+    const int nk_main = __builtin_amdgcn_readfirstlane(K / TK);      // host guarantees K % 64 == 0
+    const int nk = __builtin_amdgcn_readfirstlane(nk_main + (g.lora_xk != nullptr ? g.Rk / TK : 0));
+    // issue_main: the hot path, branch-free (tiles of A / B proper). c, stage are compile-time at every call site.
+    auto issue_main = [&](int c, int kt, int stage) {
         const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-        if (kt < nk_main) {                            // scalar branch (kt is uniform)
-            dma16((c < 4 ? a_src[c & 3] : b_src[c & 3]) + (int64_t)kt * TK, dst);
+        dma16((c < 4 ? a_src[c & 3] : b_src[c & 3]) + (int64_t)kt * TK, dst);
+    };
+    // issue_any: used only by the prologue and the last few tiles, where the tile being fetched may belong to the
+    // rank block: same piece geometry, sources are XK / BK rows (addresses rebuilt here: no registers are held
+    // for them during the main loop)
+    auto issue_any = [&](int c, int kt, int stage) {
+        if (kt < nk_main) {
+            issue_main(c, kt, stage);
         } else {
-            // rank-block tile: same piece geometry, sources are XK / BK rows (addresses rebuilt here: no
-            // registers are held for them during the main loop)
+            const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
             int row = (c < 4 ? m0 : n0) + ((c & 3) * 8 + wave) * 8 + sub_row;
             const int last = (c < 4 ? M : N) - 1;
             row = row < last ? row : last;
@@ -247,8 +255,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
 #endif
     // ---- prologue: tile 0 completely, first 3 pieces of tile 1
 #pragma unroll
-    for (int c = 0; c < 8; ++c) issue(c, 0, 0);
-    if (nk > 1) { issue(0, 1, 1); issue(1, 1, 1); issue(2, 1, 1); }
+    for (int c = 0; c < 8; ++c) issue_main(c, 0, 0);
+    if (nk > 1) { issue_any(0, 1, 1); issue_any(1, 1, 1); issue_any(2, 1, 1); }
     __builtin_amdgcn_sched_barrier(0);
 
     __builtin_amdgcn_sched_barrier(0);
@@ -257,17 +265,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     SLOT_BARRIER();
     if (grp == 1) SLOT_BARRIER();          // anti-phase: group 1 runs one slot behind
 
-#define TILE_BODY(STAGE, KT)                                                             \
+// ISSUE: issue_main (fast loop: every tile it prefetches is a tile of A / B proper and exists, CHECK = 0) or
+// issue_any (last tiles: the prefetched tile may be a rank-block tile or past the end, CHECK = 1)
+#define TILE_BODY(STAGE, KT, ISSUE, CHECK)                                                \
     do {                                                                                 \
         /* L0 */                                                                         \
         read_a(STAGE, 0); read_b(STAGE, 0);                                              \
-        if ((KT) + 1 < nk) { issue(3, (KT) + 1, (STAGE) ^ 1); issue(4, (KT) + 1, (STAGE) ^ 1); issue(5, (KT) + 1, (STAGE) ^ 1); } \
+        if (!(CHECK) || (KT) + 1 < nk) { ISSUE(3, (KT) + 1, (STAGE) ^ 1); ISSUE(4, (KT) + 1, (STAGE) ^ 1); ISSUE(5, (KT) + 1, (STAGE) ^ 1); } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
         STAMP(KT, 8); SLOT_BARRIER(); STAMP(KT, 0);                                      \
         mma(0, 0); STAMP(KT, 9); SLOT_BARRIER(); STAMP(KT, 1);                                                       \
         /* L1 */                                                                         \
         read_b(STAGE, 1);                                                                \
-        if ((KT) + 1 < nk) { issue(6, (KT) + 1, (STAGE) ^ 1); issue(7, (KT) + 1, (STAGE) ^ 1); } \
+        if (!(CHECK) || (KT) + 1 < nk) { ISSUE(6, (KT) + 1, (STAGE) ^ 1); ISSUE(7, (KT) + 1, (STAGE) ^ 1); } \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
         STAMP(KT, 10); SLOT_BARRIER(); STAMP(KT, 2);                                     \
         mma(0, 1); STAMP(KT, 11); SLOT_BARRIER(); STAMP(KT, 3);                                                       \
@@ -277,8 +287,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         STAMP(KT, 12); SLOT_BARRIER(); STAMP(KT, 4);                                     \
         mma(1, 1); STAMP(KT, 13); SLOT_BARRIER(); STAMP(KT, 5);                                                       \
         /* L3: this stage is drained by BOTH groups (their last reads ended >= 1 barrier ago) */ \
-        if ((KT) + 2 < nk) {                                                             \
-            issue(0, (KT) + 2, STAGE); issue(1, (KT) + 2, STAGE); issue(2, (KT) + 2, STAGE); \
+        if (!(CHECK) || (KT) + 2 < nk) {                                                 \
+            ISSUE(0, (KT) + 2, STAGE); ISSUE(1, (KT) + 2, STAGE); ISSUE(2, (KT) + 2, STAGE); \
             asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                             \
         } else {                                                                         \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
@@ -288,11 +298,17 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     } while (0)
 
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        TILE_BODY(0, kt);
-        TILE_BODY(1, kt + 1);
+    // fast loop: tiles kt <= nk_main - 3 prefetch only tiles kt + 1, kt + 2 <= nk_main - 1
+    for (; kt + 1 < nk_main - 2; kt += 2) {
+        TILE_BODY(0, kt, issue_main, 0);
+        TILE_BODY(1, kt + 1, issue_main, 0);
     }
-    if (kt < nk) TILE_BODY(0, kt);
+    // the last two or three tiles of A / B and the rank block's tiles (kt is even here)
+    for (; kt + 1 < nk; kt += 2) {
+        TILE_BODY(0, kt, issue_any, 1);
+        TILE_BODY(1, kt + 1, issue_any, 1);
+    }
+    if (kt < nk) TILE_BODY(0, kt, issue_any, 1);
 #undef TILE_BODY
 
     if (grp == 0) SLOT_BARRIER();          // match group 1's extra barrier

@@ -9,11 +9,13 @@
 //   unsloth/kernels/geglu.py:142-167   _approx_forward_kernel
 //   unsloth/kernels/geglu.py:188-244   _approx_backward_kernel
 //
-// HBM-bound streaming kernels: 16-byte vectors per lane, 2 vectors in flight per lane, the forward's inputs
-// (read exactly once, 2 x 235 MB at 8192 tokens: larger than the 256 MiB Infinity Cache) are loaded
-// non-temporally (+17 % measured: 4.9 -> 5.7 TB/s; profiles/r01_hbm_ab.jsonl),
-// grid capped at 256 CUs x 8 blocks with a grid-stride loop, 64-bit indexing always
-// (the reference switches to int64 only above 2^31 elements, swiglu.py:20-24).
+// HBM-bound streaming kernels: 16-byte vectors per lane, two vectors per thread with every load of both issued
+// before the first use, one pass per 256-thread block over an UNCAPPED grid (the hardware dispatcher streams the
+// blocks; the round-1 version ran 2048 persistent blocks with a grid-stride loop: 5.85 -> 6.7 TB/s forward,
+// 5.04 -> 5.66 TB/s backward at 8192 tokens, profiles/r02_hbm_ab.jsonl; the reference's Triton kernels on the same
+// box: 5.5 / 6.0 TB/s, profiles/r02_ref_triton_microbench.jsonl). Inputs are read exactly once (2-3 x 235 MB at
+// 8192 tokens: larger than the 256 MiB Infinity Cache) and loaded non-temporally. 64-bit indexing always (the
+// reference switches to int64 only above 2^31 elements, swiglu.py:20-24).
 //
 // Rounding points follow the reference exactly: f is rounded to the activation dtype before
 // it is multiplied by g; h/df/dg are products IN the activation dtype; de is computed in
@@ -233,10 +235,10 @@ int launch_bwd(void* dw, void* e, void* g, int64_t n, hipStream_t st) {
     const int64_t nvec = n / Vec16<T>::N;
     if (var == 2 && (nvec + 511) / 512 < 0x7fffffffLL)
         hipLaunchKernelGGL((glu_bwd2_kernel<T, ACT>), dim3((unsigned)((nvec + 511) / 512 > 0 ? (nvec + 511) / 512 : 1)),
-                           dim3(256), 0, st, (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
+                           dim3(256), 0, st, (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT) ^ 1);
     else
         hipLaunchKernelGGL((glu_bwd_kernel<T, ACT>), dim3(grid_for(nvec, var)), dim3(256), 0, st,
-                           (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT));
+                           (T*)dw, (T*)e, (T*)g, n, uamd_tuning_get(UAMD_TUNE_STREAM_NT) ^ 1);
     return uamd_launch_status();
 }
 

@@ -182,7 +182,7 @@ nf4_dequant_t_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const flo
 template <typename T>
 __global__ void __launch_bounds__(256)
 nf4_dequant_t2_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const float* __restrict__ lut_g,
-                      T* __restrict__ out, int rows, int cols, int64_t ld_out, int blocksize) {
+                      T* __restrict__ out, int rows, int cols, int64_t ld_out, int blocksize, int row_fastest) {
     __shared__ float lut[16];
     __shared__ float code2[256];
     __shared__ __attribute__((aligned(16))) uint32_t tile[256 * 32];        // 32 KiB
@@ -190,7 +190,10 @@ nf4_dequant_t2_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const fl
     if (tid < 16) lut[tid] = lut_g ? lut_g[tid] : kNF4[tid];
     if (am.u8) code2[tid] = am.code2[tid];
     __syncthreads();
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 256;
+    // row_fastest: consecutive blocks take consecutive 64-row tiles of W = ADJACENT 128-byte segments of the same 256
+    // output rows, so that within a short window whole DRAM pages of the transposed output get written (with the
+    // column tile fastest, neighbouring segments of an output row are written by blocks far apart in time)
+    const int r0 = (row_fastest ? blockIdx.x : blockIdx.y) * 64, c0 = (row_fastest ? blockIdx.y : blockIdx.x) * 256;
     const int cg = lane & 31;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -313,9 +316,11 @@ int launch_dequant(const uint8_t* packed, const AbsmaxSrc& am, const float* lut,
         if (sizeof(T) != 2 || (cols & 7)) return UAMD_ERR_ARG;
         const int tv = uamd_tuning_get(UAMD_TUNE_DEQUANT_T);
         if ((blocksize & 7) == 0 && tv != 0) {
+            const int rf = tv == 2;
             dim3 grid((unsigned)((cols + 255) / 256), (unsigned)((rows + 63) / 64));
+            if (rf) grid = dim3((unsigned)((rows + 63) / 64), (unsigned)((cols + 255) / 256));
             hipLaunchKernelGGL((nf4_dequant_t2_kernel<T>), grid, dim3(256), 0, st, packed, am, lut,
-                               (T*)out, (int)rows, (int)cols, ld_out, blocksize);
+                               (T*)out, (int)rows, (int)cols, ld_out, blocksize, rf);
         } else {
             dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
             hipLaunchKernelGGL((nf4_dequant_t_kernel<T>), grid, dim3(256), 0, st, packed, am, lut,

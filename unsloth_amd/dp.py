@@ -67,22 +67,29 @@ class LoRAGradArena:
             last_layer = layer
         self.buckets.append([b_start, off, b_count])
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)      # per step: which buckets already have a collective in flight
         self._handles = []
         self._sync = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self._views = {id(p): p.grad for p in self.params}
         # the fused LoRA-gradient kernel adds straight into the arena (kernels/utils.py GRAD_SINKS): no
         # AccumulateGrad kernel per parameter; .ready() does the bucket bookkeeping the autograd hook would do
-        self._views = {}
         if direct and self.arena.is_cuda:
             from .kernels.utils import GRAD_SINKS
             for p in self.params:
-                self._views[id(p)] = p.grad
                 GRAD_SINKS[id(p)] = self
 
     def grad_view(self, p):
+        """Arena slice the fused gradient kernel ADDS into. If the optimizer dropped the gradient
+        (`zero_grad(set_to_none=True)`, PyTorch's default) the slice still holds the previous step's reduced
+        values: zero it before re-attaching, so the add starts from nothing."""
         v = self._views[id(p)]
-        if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-            p.grad = v                                   # e.g. after optimizer.zero_grad(set_to_none=True)
+        if p.grad is None:
+            v.zero_()
+            p.grad = v
+        elif p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)                              # a gradient accumulated outside the arena so far
+            p.grad = v
         return v
 
     def ready(self, p):
@@ -99,6 +106,12 @@ class LoRAGradArena:
 
     # ------------------------------------------------------------------------------------------
     def _hook(self, p):
+        v = self._views[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+            # autograd's AccumulateGrad built a fresh p.grad (the view had been dropped by
+            # zero_grad(set_to_none=True)): move it into the arena, which is what gets reduced and stepped on
+            v.copy_(p.grad)
+            p.grad = v
         b = self._bucket_of[id(p)]
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
@@ -110,17 +123,22 @@ class LoRAGradArena:
         s, e, _ = self.buckets[b]
         h = dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append(h)
+        self._launched[b] = True
 
     def finish(self):
-        """Call after backward, before optimizer.step(): launches anything not overlapped and waits."""
+        """Call after backward, before optimizer.step(): launches every bucket that has no collective in flight
+        yet -- all of them without overlap, and with overlap the ones whose count never filled because some
+        trainable parameter received no gradient this step (every rank must still reduce the SAME buckets, or
+        the replicas diverge) -- then waits."""
         if (self.world_size > 1 or self._force) and self._sync:
-            if not self.overlap:
-                for b in range(len(self.buckets)):
+            for b in range(len(self.buckets)):
+                if not self._launched[b]:
                     self._launch(b)
             for h in self._handles:
                 h.wait()
         self._handles = []
         self._pending = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
     @contextmanager
     def no_sync(self):
@@ -134,15 +152,10 @@ class LoRAGradArena:
     def zero_grad(self):
         """Keeps the views: the arena is zeroed in one memset instead of N small ones."""
         self.arena.zero_()
-        for p, (s, n) in zip(self.params, self._offsets()):
-            if p.grad is None or p.grad.data_ptr() != self.arena.data_ptr() + 4 * s:
-                p.grad = self.arena[s:s + n].view_as(p)
-
-    def _offsets(self):
-        off = 0
         for p in self.params:
-            yield off, p.numel()
-            off += p.numel()
+            v = self._views[id(p)]
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
 
     def grad_norm(self):
         return self.arena.norm()

@@ -17,7 +17,6 @@ from .rope_embedding import (
     inplace_rope_embedding,
     Fast_RoPE_Embedding,
     Fast_RoPE_Embedding_QK,
-    Slow_RoPE_Embedding,
 )
 from .swiglu import swiglu_fg_kernel, swiglu_DWf_DW_dfg_kernel
 from .geglu import (

@@ -112,6 +112,41 @@ def patch_loss_functions(torch_compile=True):
 
 
 # ------------------------------------------------------------------------------------------------
+def _padded_vocab(V):
+    return (V + 7) // 8 * 8
+
+
+def _logits_chunk(rows, V, dtype, device):
+    """[rows, Vp] buffer, Vp = V rounded up to a multiple of 8 (the MFMA GEMM wants 16-byte aligned rows and a
+    contraction length that is a multiple of 8: a vocabulary like 32001 -- one added pad token -- must not make
+    every training step raise). The GEMM and the CE kernels work on the [:, :V] view; the padding columns are zero
+    and stay zero, so the full view is a valid A operand for d(hidden) = dlogits @ W (with W^T zero-padded alike)."""
+    Vp = _padded_vocab(V)
+    buf = torch.empty((rows, Vp), dtype=dtype, device=device)
+    if Vp != V:
+        buf[:, V:].zero_()
+    return buf
+
+
+def fused_ce_chunk_rows(T, V, itemsize, device, target_gb=None):
+    """Rows of hidden states per logits chunk. The reference (unsloth_zoo.loss_utils, called with `target_gb` from
+    models/llama.py:1497-1509) sizes its chunks from the free VRAM / an explicit `target_gb`; same policy here:
+    the transient [rows, V] logits chunk takes at most `target_gb` GiB when given, else at most 1/8 of the memory
+    that is free right now, and never more than 4096 rows (1.05 GB at vocab 128256 in bf16: beyond that the GEMM
+    gains nothing). Multiples of 256 rows (one GEMM tile), at least 256."""
+    per_row = _padded_vocab(V) * itemsize
+    if target_gb is not None and target_gb > 0:
+        budget = float(target_gb) * (1 << 30)
+    else:
+        try:
+            free, _ = torch.cuda.mem_get_info(device)
+        except Exception:
+            free = 8 << 30
+        budget = free / 8
+    rows = int(budget // per_row) // 256 * 256
+    return max(256, min(4096, rows, (T + 255) // 256 * 256))
+
+
 class _FusedLinearCE(torch.autograd.Function):
     """loss = sum_rows CE(hidden @ W^T) / n_items without ever holding [T, V] logits.
 
@@ -133,7 +168,8 @@ class _FusedLinearCE(torch.autograd.Function):
         for r0 in range(0, T, chunk_rows):
             r1 = min(T, r0 + chunk_rows)
             h = hidden2d[r0:r1]
-            logits = torch.empty((r1 - r0, V), dtype=hidden2d.dtype, device=dev)
+            chunk = _logits_chunk(r1 - r0, V, hidden2d.dtype, dev)
+            logits = chunk[:, :V]
             _u._launch_gemm(h, [_u._group(weight, logits, V, weight.stride(0))], nf4=False)
             lab = labels[r0:r1]
             losses, lse = _ce_forward(logits, lab, softcap, scale)
@@ -141,8 +177,8 @@ class _FusedLinearCE(torch.autograd.Function):
             if need_grad:
                 dl = torch.ones(r1 - r0, dtype=torch.float32, device=dev) * inv_n
                 _ce_backward_(logits, dl, lse, lab, softcap, scale)        # logits <- dlogits
-                # dh = dlogits @ W : contraction over V -> NT GEMM against W^T [H, V]
-                _u._launch_gemm(logits, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
+                # dh = dlogits @ W : contraction over V -> NT GEMM against W^T [H, Vp]
+                _u._launch_gemm(chunk, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
         ctx.save_for_backward(dh)
         return loss_sum * inv_n
 
@@ -150,7 +186,10 @@ class _FusedLinearCE(torch.autograd.Function):
     def backward(ctx, dloss):
         (dh,) = ctx.saved_tensors
         if dh is not None:
-            dh = dh * dloss.to(dh.dtype)
+            # the upstream scale (1/accumulation steps, a GradScaler factor, ...) is applied in fp32 and the
+            # product rounded once: casting the scalar to bf16 first would put 2^-9 of relative error on every
+            # gradient of the step
+            dh = (dh.to(torch.float32) * dloss.to(torch.float32)).to(dh.dtype)
         return dh, None, None, None, None, None, None, None
 
 
@@ -158,13 +197,21 @@ _WT_CACHE = {}
 
 
 def _transposed_weight(weight):
-    """W^T [H, V] of the frozen lm_head, built once per weight version (288 GB HBM: 1 GB is cheap,
-    and it turns the d(hidden) product into the same K-contiguous NT GEMM as everything else)."""
+    """W^T [H, Vp] of the frozen lm_head (vocabulary zero-padded to a multiple of 8), built once per weight
+    version (288 GB HBM: 1 GB is cheap, and it turns the d(hidden) product into the same K-contiguous NT GEMM
+    as everything else)."""
     key = weight.data_ptr()
+    V, H = weight.shape
+    Vp = _padded_vocab(V)
     ent = _WT_CACHE.get(key)
-    if ent is None or ent[0] != weight._version or ent[1].shape != (weight.shape[1], weight.shape[0]):
+    if ent is None or ent[0] != weight._version or ent[1].shape != (H, Vp):
         _WT_CACHE.clear()
-        ent = (weight._version, weight.detach().t().contiguous())
+        if Vp == V:
+            wt = weight.detach().t().contiguous()
+        else:
+            wt = torch.zeros((H, Vp), dtype=weight.dtype, device=weight.device)
+            wt[:, :V] = weight.detach().t()
+        ent = (weight._version, wt)
         _WT_CACHE[key] = ent
     return ent[1]
 
@@ -194,7 +241,7 @@ def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, 
         W = W.to(h2d.dtype)
     Wt = _transposed_weight(W)
     if chunk_rows is None:
-        chunk_rows = 4096           # 4096 x 128256 bf16 = 1.05 GB transient per chunk
+        chunk_rows = fused_ce_chunk_rows(h2d.shape[0], W.shape[0], h2d.element_size(), h2d.device, target_gb)
     loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
                                 int(chunk_rows))
     if scaling is not None:

@@ -4,7 +4,9 @@
   Fast_RoPE_Embedding_QK  (:283-399)  Q,K as [B,H,T,D] (possibly strided views), optional int32
                                       per-token gather indices, one launch for Q and K
   fast_rope_embedding     (:265-280)  dispatch on rope_embedding_indices
-  Slow_RoPE_Embedding / inplace_rope_embedding (:402-439) torch formulation, kept as the reference has it
+  inplace_rope_embedding  (:435-439)  explicit positions -> the same kernel with gather indices (the reference's
+                                      torch formulation Slow_RoPE_Embedding :402-432 has no counterpart here: the
+                                      oracle restates it, oracle/ref_ops.py)
 
 MI355X difference: the kernel takes element strides, so `fast_rope_embedding` without indices
 does NOT pay the reference's `Q.transpose(1,2).contiguous()` copies (:276-277): it rotates the
@@ -109,34 +111,15 @@ def fast_rope_embedding(Q, K, cos, sin, rope_embedding_indices=None):
     return Fast_RoPE_Embedding_QK.apply(Q, K, cos, sin, rope_embedding_indices)
 
 
-class Slow_RoPE_Embedding(torch.autograd.Function):
-    """Torch formulation, verbatim semantics of rope_embedding.py:402-432 (in place on Q)."""
-
-    @staticmethod
-    def forward(ctx, Q, cos, sin, position_ids):
-        if position_ids is not None:
-            cos = cos.squeeze(1).squeeze(0)
-            sin = sin.squeeze(1).squeeze(0)
-            cos = cos[position_ids].unsqueeze(2)
-            sin = sin[position_ids].unsqueeze(2)
-        half = Q.shape[-1] // 2
-        RH_Q = torch.cat((-Q[..., half:], Q[..., :half]), dim=-1)
-        Q *= cos
-        Q.addcmul_(RH_Q, sin)
-        ctx.save_for_backward(cos, sin)
-        return Q
-
-    @staticmethod
-    def backward(ctx, dY):
-        cos, sin = ctx.saved_tensors
-        half = dY.shape[-1] // 2
-        RH_dY = torch.cat((dY[..., half:], -dY[..., :half]), dim=-1)
-        dY *= cos
-        dY.addcmul_(RH_dY, sin)
-        return dY, None, None, None
-
-
 def inplace_rope_embedding(Q, K, cos, sin, position_ids):
-    Q = Slow_RoPE_Embedding.apply(Q, cos, sin, position_ids)
-    K = Slow_RoPE_Embedding.apply(K, cos, sin, position_ids)
-    return Q, K
+    """rope_embedding.py:435-439 (the reference's decode-time entry: rotate Q and K [B,H,T,D] in place at explicit
+    `position_ids`). Here it is the SAME HIP kernel as training, with the positions as its per-token gather
+    indices; there is no torch-op formulation of RoPE anywhere on the product path."""
+    if position_ids is None:
+        return fast_rope_embedding(Q, K, cos, sin, None)
+    bsz, q_len = Q.shape[0], Q.shape[2]
+    idx = position_ids.to(device=Q.device, dtype=torch.int32)
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(0)
+    idx = idx.expand(bsz, q_len).reshape(-1)
+    return fast_rope_embedding(Q, K, cos, sin, idx)

@@ -66,41 +66,51 @@ def _rope_params(config):
 
 
 def compute_inv_freq(config):
-    """fp32 inv_freq as llama.py:1851-1855 (int64 arange -> float), then the config's scaling."""
+    """(inv_freq fp32 [dim/2], attention_scaling, time_divisor) of the config's RoPE variant.
+
+    default : theta^(-2i/dim) from an int64 arange cast to float (llama.py:1851-1855).
+    llama3  : Llama-3.1's three frequency bands (llama.py:1688-1717; transformers ROPE_INIT_FUNCTIONS["llama3"]):
+              wavelengths shorter than original_ctx/high_freq_factor keep their frequency, longer than
+              original_ctx/low_freq_factor are slowed down by `factor`, and the band in between is interpolated.
+              Written as ONE blend with a clamped weight -- w = 1 keeps, w = 0 divides -- which is bit-identical to
+              the reference's select-of-three (0*x + 1*y == y and the band edges give w exactly 0 or 1).
+    linear  : positions are DIVIDED by `factor` when the table is built (llama.py:1917-1945: `t / scaling_factor`,
+              not inv_freq / factor as transformers does: the two round differently).
+    Anything else (yarn / longrope / dynamic) is outside the hot-path scope and raises."""
     theta, kind, p = _rope_params(config)
     dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
     dim = int(dim * getattr(config, "partial_rotary_factor", 1.0))
     inv_freq = 1.0 / (theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
-    attention_scaling, time_scale = 1.0, 1.0
-    if kind == "llama3":                                            # llama.py:1688-1717
+    attention_scaling, time_divisor = 1.0, 1.0
+    if kind == "llama3":
         factor = p.get("factor", 8.0)
         low, high = p.get("low_freq_factor", 1.0), p.get("high_freq_factor", 4.0)
-        old = p.get("original_max_position_embeddings", 8192)
-        low_wl, high_wl = old / low, old / high
-        wavelen = 2 * math.pi / inv_freq
-        scaled = torch.where(wavelen > low_wl, inv_freq / factor, inv_freq)
-        smooth = (old / wavelen - low) / (high - low)
-        smoothed = (1 - smooth) * inv_freq / factor + smooth * inv_freq
-        is_medium = (wavelen >= high_wl) & (wavelen <= low_wl)
-        inv_freq = torch.where(is_medium, smoothed, scaled)
-    elif kind == "linear":                                          # llama.py:1917-1945
-        time_scale = 1.0 / p.get("factor", 1.0)
+        ctx = p.get("original_max_position_embeddings", 8192)
+        if low == high:
+            raise ValueError("llama3 rope scaling needs low_freq_factor != high_freq_factor")
+        periods_in_ctx = ctx / (2 * math.pi / inv_freq)            # how often the component wraps inside the old context
+        w = ((periods_in_ctx - low) / (high - low)).clamp_(0.0, 1.0)
+        inv_freq = (1 - w) * inv_freq / factor + w * inv_freq
+    elif kind == "linear":
+        time_divisor = float(p.get("factor", 1.0))
     elif kind not in ("default", None):
         raise NotImplementedError(f"rope_type {kind!r} (yarn/longrope/dynamic) is outside the hot path scope")
-    return inv_freq, attention_scaling, time_scale
+    return inv_freq, attention_scaling, time_divisor
 
 
 class RopeTables:
     """cos/sin cache shared by all layers (llama.py:3002-3006), one per device."""
 
     def __init__(self, config):
-        self.inv_freq, self.attention_scaling, self.time_scale = compute_inv_freq(config)
+        self.inv_freq, self.attention_scaling, self.time_divisor = compute_inv_freq(config)
         self.max_position_embeddings = getattr(config, "max_position_embeddings", 4096)
         self.current_rope_size = 0
         self._cache = {}
 
     def _build(self, seq_len, device, dtype):
-        t = torch.arange(seq_len, dtype=torch.int64).float() * self.time_scale
+        t = torch.arange(seq_len, dtype=torch.int64).float()
+        if self.time_divisor != 1.0:
+            t = t / self.time_divisor                           # linear scaling (llama.py:1941-1943)
         freqs = torch.outer(t, self.inv_freq)
         emb = torch.cat((freqs, freqs), dim=-1)
         cos = (emb.cos() * self.attention_scaling).to(dtype=dtype, device=device)
@@ -410,6 +420,12 @@ class FastLlamaModel:
         inner = model.model
         inner._unsloth_amd_dtype = dtype
         inner._unsloth_amd_rope = RopeTables(model.config)
+        for m in model.modules():
+            # the decode writes quant_state.dtype and the GEMM reads it as the activation dtype: keep them equal,
+            # whatever the checkpoint was stamped with (the reference does the same after load, granite.py:586-596)
+            if isinstance(m, _nf4.Linear4bit) and dtype is not None:
+                m.weight.quant_state.dtype = dtype
+                m.compute_dtype = dtype
         for layer in inner.layers:
             layer.self_attn.apply_qkv = original_apply_qkv
             layer.self_attn.apply_o = original_apply_o

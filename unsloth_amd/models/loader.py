@@ -84,9 +84,8 @@ class FastLanguageModel:
                     model = AutoModelForCausalLM.from_config(cfg16, dtype=dtype)
                 model.to_empty(device=device)
                 missing, unexpected = _ckpt.load_prequantized_(model, str(model_name), device, dtype)
-                still = [m for m in missing if "rotary" not in m]
-                if still:
-                    raise RuntimeError(f"{model_name}: checkpoint has no tensors for {still[:8]} ...")
+                if missing:
+                    raise RuntimeError(f"{model_name}: checkpoint has no tensors for {missing[:8]} ...")
                 model.config.quantization_config = _ckpt.bnb_quantization_config(dtype)
                 prequantized = True
             else:

@@ -16,7 +16,8 @@ import torch
 
 from .. import _lib
 from ..kernels import utils as _u
-from ..kernels.cross_entropy_loss import Fast_CrossEntropyLoss, _ce_backward_, _ce_forward, _transposed_weight
+from ..kernels.cross_entropy_loss import (Fast_CrossEntropyLoss, _ce_backward_, _ce_forward, _logits_chunk,
+                                          _transposed_weight)
 
 
 class _ChunkedLogProbs(torch.autograd.Function):
@@ -30,7 +31,8 @@ class _ChunkedLogProbs(torch.autograd.Function):
         dh = torch.empty_like(hidden2d) if need_grad else None
         for r0 in range(0, T, chunk_rows):
             r1 = min(T, r0 + chunk_rows)
-            logits = torch.empty((r1 - r0, V), dtype=hidden2d.dtype, device=dev)
+            chunk = _logits_chunk(r1 - r0, V, hidden2d.dtype, dev)       # row stride padded to a multiple of 8
+            logits = chunk[:, :V]
             _u._launch_gemm(hidden2d[r0:r1], [_u._group(weight, logits, V, weight.stride(0))], nf4=False)
             idx = index[r0:r1]
             losses, lse = _ce_forward(logits, idx, softcap, scale)
@@ -38,7 +40,7 @@ class _ChunkedLogProbs(torch.autograd.Function):
             if need_grad:
                 dl = torch.full((r1 - r0,), -1.0, dtype=torch.float32, device=dev)      # d(logprob) = -d(loss)
                 _ce_backward_(logits, dl, lse, idx, softcap, scale)                     # logits <- d logprob / d logits
-                _u._launch_gemm(logits, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
+                _u._launch_gemm(chunk, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
         ctx.save_for_backward(dh)
         return out
 
@@ -47,7 +49,8 @@ class _ChunkedLogProbs(torch.autograd.Function):
         (dh,) = ctx.saved_tensors
         if dh is None:
             return None, None, None, None, None, None, None
-        return dh * g.to(dh.dtype).unsqueeze(1), None, None, None, None, None, None
+        # row-wise upstream scale applied in fp32, one rounding (not g rounded to bf16 first)
+        return (dh.to(torch.float32) * g.to(torch.float32).unsqueeze(1)).to(dh.dtype), None, None, None, None, None, None
 
 
 def _effective_scale(mult, div, softcap, temperature):

@@ -20,28 +20,38 @@ _PACKED_INFO_CACHE = {}
 _SDPA_MASK_CACHE = {}
 
 
-def get_packed_info_from_kwargs(kwargs: dict, device) -> Optional[Tuple[torch.Tensor, torch.Tensor, int]]:
-    seq_lengths = kwargs.get("packed_seq_lengths")
+def _document_ends(seq_lengths, device):
+    """Exclusive end offset of every packed document (int64 running sum of the lengths) or None when there are
+    no documents. Accepts a tensor or any sequence; any shape is read as a flat list."""
     if seq_lengths is None:
         return None
-    entry = _PACKED_INFO_CACHE.get(device)
-    if entry is not None and entry["seq_lengths"] is seq_lengths:
-        return entry["result"]
-    lengths = seq_lengths.to(device=device, dtype=torch.int32, non_blocking=True)
-    cu_seqlens = torch.zeros(lengths.numel() + 1, dtype=torch.int32, device=device)
-    torch.cumsum(lengths, dim=0, dtype=torch.int32, out=cu_seqlens[1:])
-    max_seqlen = int(lengths.max().item())
-    result = (lengths, cu_seqlens, max_seqlen)
-    _PACKED_INFO_CACHE[device] = {"seq_lengths": seq_lengths, "result": result}
-    return result
+    ends = torch.as_tensor(seq_lengths, device=device).to(torch.int64).reshape(-1).cumsum(0)
+    return ends if ends.numel() else None
+
+
+def get_packed_info_from_kwargs(kwargs: dict, device) -> Optional[Tuple[torch.Tensor, torch.Tensor, int]]:
+    """(lengths int32, cu_seqlens int32 = [0, running sum], max_seqlen) of the batch's `packed_seq_lengths`, or
+    None for an unpacked batch. One entry per device is remembered for the tensor object last seen, so the 32
+    layers of a forward (and the recompute of a checkpointed backward) share it."""
+    src = kwargs.get("packed_seq_lengths")
+    if src is None:
+        return None
+    hit = _PACKED_INFO_CACHE.get(device)
+    if hit is not None and hit[0] is src:
+        return hit[1]
+    lengths = src.to(device=device, dtype=torch.int32, non_blocking=True)
+    cu_seqlens = torch.nn.functional.pad(lengths.cumsum(0, dtype=torch.int32), (1, 0))
+    info = (lengths, cu_seqlens, int(lengths.max()))
+    _PACKED_INFO_CACHE[device] = (src, info)
+    return info
 
 
 def build_sdpa_packed_attention_mask(seq_info, *, dtype, device, sliding_window=None):
     seq_lengths, _, _ = seq_info
     params = (dtype, sliding_window)
-    entry = _SDPA_MASK_CACHE.get(device)
-    if entry is not None and entry["seq_lengths"] is seq_lengths and entry["params"] == params:
-        return entry["mask"]
+    hit = _SDPA_MASK_CACHE.get(device)
+    if hit is not None and hit[0] is seq_lengths and hit[1] == params:
+        return hit[2]
     lengths = seq_lengths.to("cpu", torch.int64)
     total = int(lengths.sum().item())
     # vectorised form of the reference's per-document loop: same document AND causal (AND window)
@@ -53,62 +63,42 @@ def build_sdpa_packed_attention_mask(seq_info, *, dtype, device, sliding_window=
     mask = torch.full((total, total), float("-inf"), dtype=dtype, device=device)
     mask.masked_fill_(allowed, 0.0)
     result = mask.unsqueeze(0).unsqueeze(0)
-    _SDPA_MASK_CACHE[device] = {"seq_lengths": seq_lengths, "params": params, "mask": result}
+    _SDPA_MASK_CACHE[device] = (seq_lengths, params, result)
     return result
 
 
-def _normalize_packed_lengths(seq_lengths: Any, *, device) -> Optional[torch.Tensor]:
-    if seq_lengths is None:
-        return None
-    if isinstance(seq_lengths, torch.Tensor):
-        lengths = seq_lengths.to(device=device, dtype=torch.int64)
-    else:
-        lengths = torch.tensor(seq_lengths, device=device, dtype=torch.int64)
-    if lengths.ndim != 1:
-        lengths = lengths.reshape(-1)
-    if lengths.numel() == 0:
-        return None
-    return lengths
-
-
 def mask_packed_sequence_boundaries(shift_labels, seq_lengths, *, ignore_index: int = -100) -> bool:
-    """Mark the final token of every packed sample in ALREADY SHIFTED labels (in place)."""
-    lengths = _normalize_packed_lengths(seq_lengths, device=shift_labels.device)
-    if lengths is None:
+    """ALREADY SHIFTED labels, in place: the last position of every document predicts the first token of the next
+    one, so flat[end - 1] = ignore_index for every document end that lies inside the tensor (packing.py:710-730).
+    Returns whether anything was written."""
+    ends = _document_ends(seq_lengths, shift_labels.device)
+    if ends is None:
         return False
     flat = shift_labels.reshape(-1)
-    total_tokens = flat.shape[0]
-    boundary_positions = torch.cumsum(lengths, dim=0) - 1
-    valid = boundary_positions < total_tokens
-    if not torch.all(valid):
-        boundary_positions = boundary_positions[valid]
-    if boundary_positions.numel() == 0:
+    last = ends[ends <= flat.numel()] - 1
+    if last.numel() == 0:
         return False
-    flat[boundary_positions] = ignore_index
+    flat.index_fill_(0, last, ignore_index)
     return True
 
 
 def mask_packed_boundary_labels(labels, seq_lengths, *, ignore_index: int = -100):
-    """Same guard on RAW labels, out of place, for the fused CE that shifts internally:
-    masks labels[cumsum(lengths)]; out-of-range positions are redirected to index 0 (which the
-    shift discards)."""
-    if labels is None or not isinstance(labels, torch.Tensor):
+    """RAW labels for the fused cross entropy, which shifts internally: the label at flat[end] (the first token of the
+    following document) must not be predicted from the previous one. OUT OF PLACE -- the caller's batch is never
+    touched (tests/utils/test_packing.py:1488-1524). An end at or past the tensor's size is redirected to flat
+    index 0, which the shift drops anyway (packing.py:733-772)."""
+    if not isinstance(labels, torch.Tensor) or labels.numel() == 0:
         return labels
-    lengths = _normalize_packed_lengths(seq_lengths, device=labels.device)
-    if lengths is None:
+    ends = _document_ends(seq_lengths, labels.device)
+    if ends is None:
         return labels
-    total_tokens = labels.numel()
-    if total_tokens == 0:
-        return labels
-    positions = torch.cumsum(lengths, dim=0)
-    positions = torch.where(positions < total_tokens, positions, torch.zeros_like(positions))
-    flat = labels.reshape(-1).index_fill(0, positions, ignore_index)
-    return flat.view(labels.shape)
+    first_of_next = ends.masked_fill(ends >= labels.numel(), 0)
+    return labels.reshape(-1).index_fill(0, first_of_next, ignore_index).view_as(labels)
 
 
 def packed_position_ids(seq_lengths, device=None) -> torch.Tensor:
     """positions == concat(arange(len)) (tests/utils/test_packing.py:1095-1117), int32 like TRL's."""
-    lengths = _normalize_packed_lengths(seq_lengths, device=device or "cpu")
+    lengths = torch.as_tensor(seq_lengths, device=device or "cpu").to(torch.int64).reshape(-1)
     starts = torch.cumsum(lengths, 0) - lengths
     total = int(lengths.sum())
     return (torch.arange(total, device=lengths.device) - torch.repeat_interleave(starts, lengths)).to(torch.int32)
