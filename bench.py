@@ -27,6 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+GC_MODE = {"on": True, "off": False, "unsloth": "unsloth", "unsloth:min": "unsloth:min", "unsloth:all": "unsloth:all"}
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 HBM_PEAK_GBPS = 8000.0
 
@@ -100,12 +101,14 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--gc", choices=["on", "off"], default=os.environ.get("BENCH_GC", "off"),
+    ap.add_argument("--gc", choices=["on", "off", "unsloth", "unsloth:min", "unsloth:all"],
+                    default=os.environ.get("BENCH_GC", "off"),
                     help="gradient checkpointing for the primary number. off: activations stay in the 288 GB HBM "
-                         "(no recompute); on: the reference default use_gradient_checkpointing='unsloth' semantics "
-                         "(layer inputs only, one extra forward per layer)")
+                         "(no recompute); on: torch's reentrant per-layer checkpoint (layer inputs only, one extra "
+                         "forward per layer); unsloth[:policy]: selective recompute (models/fast_layer.py)")
     ap.add_argument("--alt-steps", type=int, default=int(os.environ.get("BENCH_ALT_STEPS", 3)),
-                    help="also time this many steps in the OTHER checkpointing mode (reported under 'alt'); 0 = skip")
+                    help="also time this many steps in the other checkpointing modes and at batch 1 / 2 "
+                         "(reported under 'alt'); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
@@ -138,10 +141,10 @@ def main():
     t_setup = time.time()
     model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
                                                  load_in_4bit=True, device=dev, random_state=3407,
-                                                 use_gradient_checkpointing=(a.gc == "on"))
+                                                 use_gradient_checkpointing=GC_MODE[a.gc])
     # NOTE: for_training() below re-applies the checkpointing mode per measurement
     model = FastLanguageModel.get_peft_model(model, r=a.rank, lora_alpha=a.rank, lora_dropout=0.0, bias="none",
-                                             use_gradient_checkpointing=(a.gc == "on"), random_state=3407)
+                                             use_gradient_checkpointing=GC_MODE[a.gc], random_state=3407)
     g = torch.Generator(device="cpu").manual_seed(3407)
     n_train = 0
     for n, p in model.named_parameters():
@@ -153,12 +156,15 @@ def main():
     arena = LoRAGradArena(model) if (world > 1 or force_dp) else None
     B, T, V = a.batch, a.seq, cfg.vocab_size
     gi = torch.Generator(device="cpu").manual_seed(rank)       # different data per rank
-    batches = []
-    for _ in range(2):
-        ids = torch.randint(0, V, (B, T), generator=gi).to(dev)
-        pos = torch.arange(T, dtype=torch.int32, device=dev).unsqueeze(0).expand(B, T).contiguous()
-        batches.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
-    n_items = torch.tensor((T - 1) * B * world, device=dev)      # global non-ignored targets per step
+
+    def make_batches(bs):
+        out = []
+        for _ in range(2):
+            ids = torch.randint(0, V, (bs, T), generator=gi).to(dev)
+            pos = torch.arange(T, dtype=torch.int32, device=dev).unsqueeze(0).expand(bs, T).contiguous()
+            out.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
+        return out, torch.tensor((T - 1) * bs * world, device=dev)      # global non-ignored targets per step
+    batches, n_items = make_batches(B)
     timer = GemmTimer()
     timer.install()
     setup_s = time.time() - t_setup
@@ -168,19 +174,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(gc_on, steps, warmup):
+    def measure(gc_mode, steps, warmup, data=None):
         """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
-        model.for_training(use_gradient_checkpointing=gc_on)
+        bt, ni = data if data is not None else (batches, n_items)
+        model.for_training(use_gradient_checkpointing=gc_mode)
         losses = []
         for i in range(warmup):
-            losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
+            losses.append(training_step(model, bt[i % 2], opt, arena, ni))
         sync()
         torch.cuda.reset_peak_memory_stats()
         timer.reset()
         timer.enabled = True
         t0 = time.perf_counter()
         for i in range(steps):
-            losses.append(training_step(model, batches[i % 2], opt, arena, n_items))
+            losses.append(training_step(model, bt[i % 2], opt, arena, ni))
         sync()
         dt = time.perf_counter() - t0
         timer.enabled = False
@@ -194,16 +201,37 @@ def main():
             peak = int(pk)
         return dt, peak, [float(l) for l in losses], timer.summary()
 
-    gc_primary = a.gc == "on"
     alt = None
     if a.alt_steps > 0:
-        # the other checkpointing mode, short, BEFORE the primary run (so the primary's timers/peak stand last)
-        adt, apeak, _, _ = measure(not gc_primary, a.alt_steps, 1)
-        alt = {"gradient_checkpointing": not gc_primary, "value": round(B * T * a.alt_steps * world / adt, 1),
-               "ms_per_step": round(adt / a.alt_steps * 1e3, 2), "peak_vram_gb": round(apeak / 2**30, 2),
-               "steps": a.alt_steps}
-        torch.cuda.empty_cache()
-    dt, peak, loss_vals, gs = measure(gc_primary, a.steps, a.warmup)
+        # the other operating points, short, BEFORE the primary run (so the primary's timers / peak stand last):
+        # the other checkpointing modes at the primary batch, then batch 1 and 2 without checkpointing
+        alt = {}
+
+        def alt_point(tag, gc_mode, bs):
+            data = None if bs == B else make_batches(bs)
+            adt, apeak, _, ags = measure(gc_mode, a.alt_steps, 1, data)
+            dom_ = max(ags.values(), key=lambda r: r["total_ms"]) if ags else None
+            alt[tag] = {"gradient_checkpointing": gc_mode, "batch": bs, "steps": a.alt_steps,
+                        "value": round(bs * T * a.alt_steps * world / adt, 1),
+                        "ms_per_step": round(adt / a.alt_steps * 1e3, 2), "peak_vram_gb": round(apeak / 2**30, 2),
+                        "gemm_tflops": round(dom_["tflops"], 1) if dom_ else None,
+                        "gemm_frac_of_mfma_peak": round(dom_["tflops"] / MFMA_PEAK_TFLOPS, 4) if dom_ else None}
+            del data
+            torch.cuda.empty_cache()
+        for tag, mode in (("gc_torch_reentrant (reference's True)", True),
+                          ("gc_unsloth_selective_recompute (keep attention block, re-run gate/up)", "unsloth"),
+                          ("gc_unsloth_min (keep layer inputs only)", "unsloth:min"), ("gc_off", False)):
+            if mode != GC_MODE[a.gc]:
+                alt_point(tag, mode, B)
+        for bs in (1, 2):
+            if bs != B:
+                alt_point(f"batch_{bs}_gc_off", False, bs)
+    dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
+    rccl_ranks = None
+    if dist.is_initialized():
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                       # an actual collective over the group: counts the ranks that took part
+        rccl_ranks = int(one.item())
 
     if rank == 0:
         tokens = B * T * a.steps * world
@@ -245,9 +273,9 @@ def main():
             "config": {"workload": "Llama-3-8B QLoRA NF4 r=16 (q,k,v,o,gate,up,down) seq2048 bf16, fwd+bwd+AdamW",
                        "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
-                       "gradient_checkpointing": a.gc == "on", "trainable_params": n_train,
+                       "gradient_checkpointing": GC_MODE[a.gc], "trainable_params": n_train,
                        "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": "AdamW(fused) fp32 on LoRA params"},
-            "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T,
+            "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T, "rccl_ranks": rccl_ranks,
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }

@@ -55,7 +55,8 @@ def test_loss_and_lora_grads_match_hf_oracle(load_in_4bit, head_dim):
     assert repr(out.logits) == "EMPTY_LOGITS"                       # fused CE never materialises logits
     out.loss.backward()
     ref_loss, ref_grads = hf_reference_loss_and_lora_grads(model, ids, labels, pos)
-    assert abs(float(out.loss) - float(ref_loss)) <= 1e-2 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    # north_star: loss within 1e-3 (bf16) of the reference path; the fp32 HF oracle is stricter than that
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
     got = _grads(model)
     assert set(got) == set(ref_grads)
     worst = max(rel_fro(got[k], ref_grads[k]) for k in got)
@@ -77,6 +78,66 @@ def test_gradient_checkpointing_is_bitwise_neutral_and_run_to_run_deterministic(
         assert torch.equal(res[0][0], other[0])
         for k in res[0][1]:
             assert torch.equal(res[0][1][k], other[1][k]), k
+
+
+@pytest.mark.parametrize("policy", ["unsloth:min", "unsloth", "unsloth:all", "unsloth:qkv+eg"])
+def test_selective_recompute_layer_function_is_bitwise_equal_to_no_checkpointing(policy):
+    """use_gradient_checkpointing="unsloth" (models/fast_layer.py: one manual-autograd Function per decoder layer,
+    keep-or-recompute per tensor): loss and every LoRA gradient are BITWISE those of the keep-everything autograd
+    composition, for every policy, with packed documents too; and the whole-layer path is really taken."""
+    from unsloth_amd.models import fast_layer
+    from unsloth_amd.utils.packing import enable_padding_free_metadata
+    ids, labels, pos = _batch(seed=3)
+    plain = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    g = torch.Generator().manual_seed(6)
+    packed = enable_padding_free_metadata([torch.randint(0, 1000, (n,), generator=g).tolist() for n in (50, 23, 71)],
+                                          device=DEV)
+    for batch in (plain, packed):
+        ref_model = _tiny(gc=False, head_dim=128, layers=3)
+        out = ref_model(**batch)
+        out.loss.backward()
+        want_loss, want = out.loss.detach().clone(), _grads(ref_model)
+        model = _tiny(gc=policy, head_dim=128, layers=3)
+        calls = []
+        real = fast_layer.DecoderLayerFunction.apply
+        fast_layer.DecoderLayerFunction.apply = staticmethod(lambda *a: (calls.append(1), real(*a))[1])
+        try:
+            out = model(**batch)
+        finally:
+            fast_layer.DecoderLayerFunction.apply = real
+        assert len(calls) == 3, "the whole-layer Function was not used"
+        out.loss.backward()
+        assert torch.equal(out.loss.detach(), want_loss)
+        got = _grads(model)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (policy, k)
+        # a second step on the same model (saved buffers were overwritten in place by the first backward)
+        for p_ in model.parameters():
+            p_.grad = None
+        out = model(**batch)
+        out.loss.backward()
+        got = _grads(model)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (policy, "second step", k)
+
+
+def test_selective_recompute_saves_memory_in_the_expected_order():
+    """peak memory: min < attn < all, and "all" ~ no checkpointing."""
+    ids, labels, pos = _batch(B=4, T=256, seed=4)
+    batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    peaks = {}
+    for mode in ("unsloth:min", "unsloth", "unsloth:all", False):
+        model = _tiny(gc=mode, head_dim=128, layers=4)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = model(**batch)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        peaks[mode] = torch.cuda.max_memory_allocated() - base
+        del model, out
+    assert peaks["unsloth:min"] < peaks["unsloth"] < peaks["unsloth:all"], peaks
+    assert peaks["unsloth:all"] <= 1.1 * peaks[False], peaks
 
 
 def test_return_logits_branch_and_n_items():

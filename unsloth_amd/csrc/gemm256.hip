@@ -91,6 +91,22 @@ __device__ __forceinline__ void dma16(const void* gptr, unsigned lds_addr) {
         : "memory");
 }
 
+// The same with the address split as SGPR base (64-bit, wave-uniform: matrix base + K-tile offset, advanced on the
+// scalar unit) + per-lane 32-bit byte offset (row * ld + swizzled slot, fixed for the whole kernel): no 64-bit
+// VALU add per piece and half the address registers.
+__device__ __forceinline__ void dma16s(unsigned voff, uint64_t sbase, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_addr)
+        : "memory");
+}
+
 #define SLOT_BARRIER()                          \
     do {                                        \
         __builtin_amdgcn_sched_barrier(0);      \
@@ -171,16 +187,21 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     //      with r16 the row inside its 16-row MFMA tile (conflict-free for all four ds_read_b128 lane groups).
     const int sub_row = lane >> 3;
     const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
-    const T* a_src[4];
-    const T* b_src[4];
+    auto sgpr64 = [](const void* q) {               // a wave-uniform pointer as a value the compiler keeps in SGPRs
+        const uint64_t u = (uint64_t)(uintptr_t)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t a_gbase = sgpr64(p.A), b_gbase = sgpr64(g.B);
+    unsigned a_off[4], b_off[4];                    // byte offsets of this lane's row / slot (host: < 4 GiB)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         int ra = m0 + (c * 8 + wave) * 8 + sub_row;
         int rb = n0 + (c * 8 + wave) * 8 + sub_row;
         ra = ra < M ? ra : M - 1;          // clamped rows are never stored
         rb = rb < N ? rb : N - 1;
-        a_src[c] = (const T*)p.A + (int64_t)ra * p.lda + sub_slot * 8;
-        b_src[c] = (const T*)g.B + (int64_t)rb * g.ldb + sub_slot * 8;
+        a_off[c] = (unsigned)(((int64_t)ra * p.lda + sub_slot * 8) * (int64_t)sizeof(T));
+        b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
     }
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
     // K tiles: nk_main of the operands proper, then the rank block's. Both counts are wave-uniform by construction;
@@ -190,11 +211,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     // issue_main: the hot path, branch-free (tiles of A / B proper). c, stage are compile-time at every call site.
     auto issue_main = [&](int c, int kt, int stage) {
         const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-        dma16((c < 4 ? a_src[c & 3] : b_src[c & 3]) + (int64_t)kt * TK, dst);
+        dma16s(c < 4 ? a_off[c & 3] : b_off[c & 3], (c < 4 ? a_gbase : b_gbase) + (uint64_t)kt * (TK * sizeof(T)), dst);
     };
     // issue_any: used only by the prologue and the last few tiles, where the tile being fetched may belong to the
     // rank block: same piece geometry, sources are XK / BK rows (addresses rebuilt here: no registers are held
     // for them during the main loop)
+    // The rank block's base pointers / strides are pulled into SGPRs HERE, once (readfirstlane makes them computed
+    // values, not re-loadable kernel arguments: with plain reads the compiler sank an s_load + s_waitcnt lgkmcnt(0)
+    // pair -- which also drains every LDS read in flight -- into each of the 11 rank-tile DMA sites of a tile).
+    const uint64_t xk_base = sgpr64(g.lora_xk), bk_base = sgpr64(g.lora_bk);
+    const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
     auto issue_any = [&](int c, int kt, int stage) {
         if (kt < nk_main) {
             issue_main(c, kt, stage);
@@ -203,9 +229,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
             int row = (c < 4 ? m0 : n0) + ((c & 3) * 8 + wave) * 8 + sub_row;
             const int last = (c < 4 ? M : N) - 1;
             row = row < last ? row : last;
-            const T* base = c < 4 ? (const T*)g.lora_xk : (const T*)g.lora_bk;
-            const int64_t ld = c < 4 ? g.ld_xk : g.ld_bk;
-            dma16(base + (int64_t)row * ld + (kt - nk_main) * TK + sub_slot * 8, dst);
+            const int ld = c < 4 ? ld_xk : ld_bk;
+            const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
+            dma16s(off, (c < 4 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
         }
     };
 
@@ -384,6 +410,9 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
     if (M < 0 || K <= 0 || n_groups < 1 || n_groups > UAMD_G256_MAX_GROUPS || !groups) return UAMD_ERR_ARG;
     if (M == 0) return UAMD_OK;
     if ((K & 63) || (lda & 7) || !aligned16(A)) return UAMD_ERR_ALIGN;
+    // per-lane addresses are 32-bit byte offsets from the matrix base: every operand must span < 4 GiB
+    const int64_t kSpan = (int64_t)1 << 32;
+    if ((int64_t)M * lda * 2 >= kSpan) return UAMD_ERR_ARG;
     G256Args a;
     a.A = A; a.lda = lda; a.M = M; a.K = K; a.n_groups = n_groups; a.accumulate = accumulate;
     a.tiles_m = (M + TM - 1) / TM;
@@ -394,11 +423,13 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
             const uamd_gemm_group& g = groups[i];
             if (g.N <= 0 || !g.B || !g.C) return UAMD_ERR_ARG;
             if ((g.ldb & 7) || !aligned16(g.B)) return UAMD_ERR_ALIGN;
+            if ((int64_t)g.N * g.ldb * 2 >= kSpan) return UAMD_ERR_ARG;
             if (g.lora_xa && !g.lora_xk) return UAMD_ERR_ARG;     // this kernel takes the rank block as K tiles
             if (g.lora_xk) {
                 if (!g.lora_bk || g.Rk <= 0) return UAMD_ERR_ARG;
                 if ((g.Rk & 63) || (g.ld_xk & 7) || (g.ld_bk & 7) || !aligned16(g.lora_xk) || !aligned16(g.lora_bk))
                     return UAMD_ERR_ALIGN;
+                if ((int64_t)M * g.ld_xk * 2 >= kSpan || (int64_t)g.N * g.ld_bk * 2 >= kSpan) return UAMD_ERR_ARG;
             }
             a.g[i] = g;
             tn += (g.N + TN - 1) / TN;

@@ -9,10 +9,13 @@
 Same saved tensors, same in-place contracts (the activation backward overwrites DW/e/g; dX is
 written into the saved X buffer when inplace=True, :193-204, :497-517), same gradient formulas:
     dA = s * (dY B)^T X      dB = s * dY^T (X A^T)      dX = dY W + s (dY B) A
-What changes is the launch structure (kernels/utils.py): gate+up and q+k+v are one grouped MFMA
-GEMM with NF4 decode + LoRA term fused; each dX contribution is one transposing-dequant launch +
-one GEMM with the LoRA term fused. The six rank-r gradient products per block stay on the library
-GEMM (torch.matmul/addmm_), as in the reference (:172-189): they are tiny and latency-bound.
+What changes is the launch structure (kernels/utils.py): gate+up and q+k+v are one grouped MFMA GEMM
+launch each, the LoRA term rides in that launch as extra K tiles (rank block), every dX is one
+transposing-dequant launch + one GEMM (q/k/v: ONE K-concatenated GEMM), and all rank-r gradient
+products of a block are ONE `uamd_lora_tn` launch (csrc/lora_side.hip) that can add straight into
+the data-parallel gradient arena. Each block also exists as a pair of plain functions
+(`mlp_forward` / `mlp_backward`, ...) for the whole-layer Function with selective recompute
+(models/fast_layer.py).
 """
 import torch
 
@@ -82,20 +85,113 @@ def _lora_grads_fused(items):
     return [(None, None) if k is None else (outs[k], outs[k + 1]) for k in slots]
 
 
+# ---- the blocks as plain functions (forward returns what the backward needs; nothing here touches autograd), used by
+#      the autograd.Function wrappers below AND by the whole-layer Function of models/fast_layer.py, which decides
+#      per tensor whether to keep it or to recompute it in the backward.
+def mlp_forward(X, gate, up, down, act_fwd):
+    """gate/up/down = (W, W_quant, A, B, s). Returns (out, e, g, (xa_gate, xa_up, xa_down)); fast_lora.py:93-96."""
+    (e, g), xa_gu = lora_linear_forward(X, [gate, up], return_xa=True)
+    h = act_fwd(e, g)
+    (out,), xa_d = lora_linear_forward(h, [down], return_xa=True)
+    return out, e, g, (xa_gu[0], xa_gu[1], xa_d[0])
+
+
+def mlp_gate_up_forward(X, gate, up):
+    """The recomputable half of mlp_forward: (e, g) only (the backward rebuilds h = act(e) * g itself)."""
+    return lora_linear_forward(X, [gate, up])
+
+
+def mlp_backward(dY, X, e, g, xas, gate, up, down, act_bwd, inplace=True):
+    """fast_lora.py:127-229. OVERWRITES e and g (the activation backward works in place) and, when `inplace`, writes dX
+    into X's buffer. Returns (dX [same shape as X], (d_gateA, d_gateB, d_upA, d_upB, d_downA, d_downB))."""
+    xa_g, xa_u, xa_d = xas
+    shape = X.shape
+    dY = dY.reshape(-1, dY.shape[-1])
+    X2 = X.reshape(-1, X.shape[-1])
+    e = e.view(-1, e.shape[-1])
+    g = g.view(-1, g.shape[-1])
+    dtype = X2.dtype
+    # DW = dY @ W_down (+ LoRA)                                     fast_lora.py:156
+    (p_d,) = lora_dx_terms([dY], [down])
+    DW = lora_linear_dx([dY], [down], terms=[p_d])
+    DW, e, g = act_bwd(DW, e, g)                                   # in place (:157)
+    h, df, de = DW, e, g
+    p_u, p_g = lora_dx_terms([df, de], [up, gate])
+    if lora_tn_supported([h, dY, X2, df, de]):
+        (d_downA, d_downB), (d_upA, d_upB), (d_gateA, d_gateB) = _lora_grads_fused([
+            (h, dY, down[2], down[3], down[4], xa_d, p_d), (X2, df, up[2], up[3], up[4], xa_u, p_u),
+            (X2, de, gate[2], gate[3], gate[4], xa_g, p_g)])
+    else:
+        d_downA, d_downB = _lora_grads(h, dY, down[2], down[3], down[4], dtype)
+        d_upA, d_upB = _lora_grads(X2, df, up[2], up[3], up[4], dtype)
+        d_gateA, d_gateB = _lora_grads(X2, de, gate[2], gate[3], gate[4], dtype)
+    # dX = df @ W_up + de @ W_gate (+ LoRA terms), into X's buffer when inplace (:193-204)
+    dX = lora_linear_dx([df, de], [up, gate], out=X2 if (inplace and X2.is_contiguous()) else None, terms=[p_u, p_g])
+    return dX.view(shape), (d_gateA, d_gateB, d_upA, d_upB, d_downA, d_downB)
+
+
+def qkv_forward(X, q, k, v):
+    """Returns (Q, K, V, (xa_q, xa_k, xa_v)); fast_lora.py:393-405."""
+    (Q, K, V), xa = lora_linear_forward(X, [q, k, v], return_xa=True)
+    return Q, K, V, tuple(xa)
+
+
+def qkv_backward(dQ, dK, dV, X, xas, q, k, v, inplace=True):
+    """fast_lora.py:425-540. Returns (dX, (d_QA, d_QB, d_KA, d_KB, d_VA, d_VB)); dX lands in X's buffer when `inplace`."""
+    xa_q, xa_k, xa_v = xas
+    shape = X.shape
+    dQ = dQ.reshape(-1, dQ.shape[-1])
+    dK = dK.reshape(-1, dK.shape[-1])
+    dV = dV.reshape(-1, dV.shape[-1])
+    X2 = X.reshape(-1, X.shape[-1])
+    projs = [q, k, v]
+    p_q, p_k, p_v = lora_dx_terms([dQ, dK, dV], projs)
+    if lora_tn_supported([X2, dQ, dK, dV]):
+        (d_QA, d_QB), (d_KA, d_KB), (d_VA, d_VB) = _lora_grads_fused([
+            (X2, dQ, q[2], q[3], q[4], xa_q, p_q), (X2, dK, k[2], k[3], k[4], xa_k, p_k),
+            (X2, dV, v[2], v[3], v[4], xa_v, p_v)])
+    else:
+        d_QA, d_QB = _lora_grads(X2, dQ, q[2], q[3], q[4], X2.dtype)
+        d_KA, d_KB = _lora_grads(X2, dK, k[2], k[3], k[4], X2.dtype)
+        d_VA, d_VB = _lora_grads(X2, dV, v[2], v[3], v[4], X2.dtype)
+    # dX accumulated over q, k, v; overwrites X when inplace (fast_lora.py:497-517)
+    dX = lora_linear_dx([dQ, dK, dV], projs, out=X2 if (inplace and X2.is_contiguous()) else None,
+                        terms=[p_q, p_k, p_v])
+    return dX.view(shape), (d_QA, d_QB, d_KA, d_KB, d_VA, d_VB)
+
+
+def w_forward(X, proj):
+    """Returns (out, xa); fast_lora.py:600-611."""
+    (XW,), xa = lora_linear_forward(X, [proj], return_xa=True)
+    return XW, xa[0]
+
+
+def w_backward(dY, X, xa, proj):
+    """fast_lora.py:613-650. Returns (dX, (d_A, d_B))."""
+    shape = X.shape
+    dY = dY.reshape(-1, dY.shape[-1])
+    X2 = X.reshape(-1, X.shape[-1])
+    (p,) = lora_dx_terms([dY], [proj])
+    if lora_tn_supported([X2, dY]):
+        ((d_A, d_B),) = _lora_grads_fused([(X2, dY, proj[2], proj[3], proj[4], xa, p)])
+    else:
+        d_A, d_B = _lora_grads(X2, dY, proj[2], proj[3], proj[4], X2.dtype)
+    dX = lora_linear_dx([dY], [proj], terms=[p])
+    return dX.view(shape), (d_A, d_B)
+
+
 class LoRA_MLP(torch.autograd.Function):
     @staticmethod
     @_custom_fwd
     def forward(ctx, X, gateW, gateW_quant, gateA, gateB, gateS, upW, upW_quant, upA, upB, upS,
                 downW, downW_quant, downA, downB, downS, _forward_function, _backward_function,
                 inplace=True):
-        (e, g), xa_gu = lora_linear_forward(X, [(gateW, gateW_quant, gateA, gateB, gateS),
-                                                (upW, upW_quant, upA, upB, upS)], return_xa=True)
-        h = _forward_function(e, g)
-        (i,), xa_d = lora_linear_forward(h, [(downW, downW_quant, downA, downB, downS)], return_xa=True)
+        i, e, g, xas = mlp_forward(X, (gateW, gateW_quant, gateA, gateB, gateS), (upW, upW_quant, upA, upB, upS),
+                                   (downW, downW_quant, downA, downB, downS), _forward_function)
         ctx.custom_saved_tensors = (gateW, gateW_quant, gateS, upW, upW_quant, upS, downW,
                                     downW_quant, downS, _backward_function)
         ctx.save_for_backward(gateA, gateB, upA, upB, downA, downB, X, e, g)
-        ctx.xa = (xa_gu[0], xa_gu[1], xa_d[0])      # X A_g^T, X A_u^T, h A_d^T (fp32 [M, r]): tiny, no grad
+        ctx.xa = xas                                # X A_g^T, X A_u^T, h A_d^T (fp32 [M, r]): tiny, no grad
         ctx.inplace = inplace
         return i
 
@@ -105,37 +201,10 @@ class LoRA_MLP(torch.autograd.Function):
         (gateW, gateW_quant, gateS, upW, upW_quant, upS, downW, downW_quant, downS,
          _backward_function) = ctx.custom_saved_tensors
         gateA, gateB, upA, upB, downA, downB, X, e, g = ctx.saved_tensors
-        xa_g, xa_u, xa_d = ctx.xa
-        shape = X.shape
-        dY = dY.reshape(-1, dY.shape[-1])
-        X2 = X.reshape(-1, X.shape[-1])
-        e = e.view(-1, e.shape[-1])
-        g = g.view(-1, g.shape[-1])
-        dtype = X2.dtype
-        down = (downW, downW_quant, downA, downB, downS)
-        up = (upW, upW_quant, upA, upB, upS)
-        gate = (gateW, gateW_quant, gateA, gateB, gateS)
-
-        # DW = dY @ W_down (+ LoRA)                                     fast_lora.py:156
-        (p_d,) = lora_dx_terms([dY], [down])
-        DW = lora_linear_dx([dY], [down], terms=[p_d])
-        DW, e, g = _backward_function(DW, e, g)                        # in place (:157)
-        h, df, de = DW, e, g
-
-        p_u, p_g = lora_dx_terms([df, de], [up, gate])
-        if lora_tn_supported([h, dY, X2, df, de]):
-            (d_downA, d_downB), (d_upA, d_upB), (d_gateA, d_gateB) = _lora_grads_fused([
-                (h, dY, downA, downB, downS, xa_d, p_d), (X2, df, upA, upB, upS, xa_u, p_u),
-                (X2, de, gateA, gateB, gateS, xa_g, p_g)])
-        else:
-            d_downA, d_downB = _lora_grads(h, dY, downA, downB, downS, dtype)
-            d_upA, d_upB = _lora_grads(X2, df, upA, upB, upS, dtype)
-            d_gateA, d_gateB = _lora_grads(X2, de, gateA, gateB, gateS, dtype)
-
-        # dX = df @ W_up + de @ W_gate (+ LoRA terms), into X's buffer when inplace (:193-204)
-        dX = lora_linear_dx([df, de], [up, gate], out=X2 if (ctx.inplace and X2.is_contiguous()) else None,
-                            terms=[p_u, p_g])
-        return (dX.view(shape), None, None, d_gateA, d_gateB, None, None, None, d_upA, d_upB, None,
+        dX, (d_gateA, d_gateB, d_upA, d_upB, d_downA, d_downB) = mlp_backward(
+            dY, X, e, g, ctx.xa, (gateW, gateW_quant, gateA, gateB, gateS), (upW, upW_quant, upA, upB, upS),
+            (downW, downW_quant, downA, downB, downS), _backward_function, ctx.inplace)
+        return (dX, None, None, d_gateA, d_gateB, None, None, None, d_upA, d_upB, None,
                 None, None, d_downA, d_downB, None, None, None, None)
 
 
@@ -164,11 +233,10 @@ class LoRA_QKV(torch.autograd.Function):
     @_custom_fwd
     def forward(ctx, X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB, VS,
                 inplace=True):
-        (Q, K, V), xa = lora_linear_forward(X, [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS),
-                                                (VW, VW_quant, VA, VB, VS)], return_xa=True)
+        Q, K, V, xa = qkv_forward(X, (QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS))
         ctx.custom_saved_tensors = (QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS)
         ctx.save_for_backward(X, QA, QB, KA, KB, VA, VB)
-        ctx.xa = tuple(xa)
+        ctx.xa = xa
         ctx.inplace = inplace
         return Q, K, V
 
@@ -177,26 +245,10 @@ class LoRA_QKV(torch.autograd.Function):
     def backward(ctx, dQ, dK, dV):
         QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS = ctx.custom_saved_tensors
         X, QA, QB, KA, KB, VA, VB = ctx.saved_tensors
-        xa_q, xa_k, xa_v = ctx.xa
-        shape = X.shape
-        dQ = dQ.reshape(-1, dQ.shape[-1])
-        dK = dK.reshape(-1, dK.shape[-1])
-        dV = dV.reshape(-1, dV.shape[-1])
-        X2 = X.reshape(-1, X.shape[-1])
-        dtype = X2.dtype
-        projs = [(QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS)]
-        p_q, p_k, p_v = lora_dx_terms([dQ, dK, dV], projs)
-        if lora_tn_supported([X2, dQ, dK, dV]):
-            (d_QA, d_QB), (d_KA, d_KB), (d_VA, d_VB) = _lora_grads_fused([
-                (X2, dQ, QA, QB, QS, xa_q, p_q), (X2, dK, KA, KB, KS, xa_k, p_k), (X2, dV, VA, VB, VS, xa_v, p_v)])
-        else:
-            d_QA, d_QB = _lora_grads(X2, dQ, QA, QB, QS, dtype)
-            d_KA, d_KB = _lora_grads(X2, dK, KA, KB, KS, dtype)
-            d_VA, d_VB = _lora_grads(X2, dV, VA, VB, VS, dtype)
-        # dX accumulated over q, k, v; overwrites X when inplace (fast_lora.py:497-517)
-        dX = lora_linear_dx([dQ, dK, dV], projs, out=X2 if (ctx.inplace and X2.is_contiguous()) else None,
-                            terms=[p_q, p_k, p_v])
-        return (dX.view(shape), None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None,
+        dX, (d_QA, d_QB, d_KA, d_KB, d_VA, d_VB) = qkv_backward(
+            dQ, dK, dV, X, ctx.xa, (QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS),
+            ctx.inplace)
+        return (dX, None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None,
                 d_VA, d_VB, None, None)
 
 
@@ -212,10 +264,10 @@ class LoRA_W(torch.autograd.Function):
     @staticmethod
     @_custom_fwd
     def forward(ctx, X, W, W_quant, A, B, S):
-        (XW,), xa = lora_linear_forward(X, [(W, W_quant, A, B, S)], return_xa=True)
+        XW, xa = w_forward(X, (W, W_quant, A, B, S))
         ctx.custom_saved_tensors = (W, W_quant, S)
         ctx.save_for_backward(A, B, X)
-        ctx.xa = xa[0]
+        ctx.xa = xa
         return XW
 
     @staticmethod
@@ -223,16 +275,8 @@ class LoRA_W(torch.autograd.Function):
     def backward(ctx, dY):
         W, W_quant, S = ctx.custom_saved_tensors
         A, B, X = ctx.saved_tensors
-        shape = X.shape
-        dY = dY.reshape(-1, dY.shape[-1])
-        X2 = X.reshape(-1, X.shape[-1])
-        (p,) = lora_dx_terms([dY], [(W, W_quant, A, B, S)])
-        if lora_tn_supported([X2, dY]):
-            ((d_A, d_B),) = _lora_grads_fused([(X2, dY, A, B, S, ctx.xa, p)])
-        else:
-            d_A, d_B = _lora_grads(X2, dY, A, B, S, X2.dtype)
-        dX = lora_linear_dx([dY], [(W, W_quant, A, B, S)], terms=[p])
-        return dX.view(shape), None, None, d_A, d_B, None
+        dX, (d_A, d_B) = w_backward(dY, X, ctx.xa, (W, W_quant, A, B, S))
+        return dX, None, None, d_A, d_B, None
 
 
 def apply_lora_o(self, X):

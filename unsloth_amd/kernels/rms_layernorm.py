@@ -9,6 +9,69 @@ import torch
 from .. import _lib
 
 
+# ---- plain launchers (no autograd), shared by the Functions below and by models/fast_layer.py ---------------------
+def _rows(X):
+    X2 = X.reshape(-1, X.shape[-1])
+    return X2 if X2.stride(1) == 1 else X2.contiguous()
+
+
+def rms_fwd(X, W, eps, gemma=False):
+    """(Y, r) for X [..., dim]; Y [rows, dim]."""
+    _lib.require_gpu(X, W)
+    X2 = _rows(X)
+    n_rows, n_cols = X2.shape
+    Y = torch.empty((n_rows, n_cols), dtype=X2.dtype, device=X2.device)
+    r = torch.empty(n_rows, dtype=torch.float32, device=X2.device)
+    W = W.contiguous()
+    with _lib.device_ctx(X2):
+        rc = _lib.lib().uamd_rms_layernorm_fwd(
+            _lib.ptr(X2), _lib.ptr(W), _lib.ptr(Y), _lib.ptr(r), n_rows, n_cols, X2.stride(0), Y.stride(0),
+            float(eps), int(bool(gemma)), _lib.dtype_code(X2.dtype), _lib.dtype_code(W.dtype), _lib.stream_of(X2))
+    _lib.check(rc, "uamd_rms_layernorm_fwd")
+    return Y, r
+
+
+def add_rms_fwd(X, residual, W, eps):
+    """(H, Y, r): H = X + residual, Y = rmsnorm(H) * W."""
+    _lib.require_gpu(X, residual, W)
+    X2, R2 = _rows(X), _rows(residual)
+    n_rows, dim = X2.shape
+    H = torch.empty((n_rows, dim), dtype=X2.dtype, device=X2.device)
+    Y = torch.empty((n_rows, dim), dtype=X2.dtype, device=X2.device)
+    r = torch.empty(n_rows, dtype=torch.float32, device=X2.device)
+    W = W.contiguous()
+    with _lib.device_ctx(X2):
+        rc = _lib.lib().uamd_add_rms_layernorm_fwd(
+            _lib.ptr(X2), _lib.ptr(R2), _lib.ptr(W), _lib.ptr(H), _lib.ptr(Y), _lib.ptr(r), n_rows, dim,
+            X2.stride(0), R2.stride(0), H.stride(0), Y.stride(0), float(eps), _lib.dtype_code(X2.dtype),
+            _lib.dtype_code(W.dtype), _lib.stream_of(X2))
+    _lib.check(rc, "uamd_add_rms_layernorm_fwd")
+    return H, Y, r
+
+
+def rms_bwd_(dY, H, W, r, dH=None):
+    """dX = rmsnorm_backward(dY; H, W, r) (+ dH, the gradient reaching H from the residual path), written IN PLACE
+    over dY (rms_layernorm.py:218) and returned. Llama-style norm."""
+    dY2 = _rows(dY)
+    n_rows, dim = dY2.shape
+    H2 = _rows(H)
+    with _lib.device_ctx(dY2):
+        if dH is None:
+            rc = _lib.lib().uamd_rms_layernorm_bwd(
+                _lib.ptr(dY2), _lib.ptr(dY2), _lib.ptr(H2), _lib.ptr(W), _lib.ptr(r), n_rows, dim, dY2.stride(0),
+                dY2.stride(0), H2.stride(0), 0, _lib.dtype_code(dY2.dtype), _lib.dtype_code(W.dtype),
+                _lib.stream_of(dY2))
+            _lib.check(rc, "uamd_rms_layernorm_bwd")
+        else:
+            dH2 = _rows(dH)
+            rc = _lib.lib().uamd_add_rms_layernorm_bwd(
+                _lib.ptr(dY2), _lib.ptr(dH2), _lib.ptr(dY2), _lib.ptr(H2), _lib.ptr(W), _lib.ptr(r), n_rows, dim,
+                dY2.stride(0), dH2.stride(0), dY2.stride(0), H2.stride(0), _lib.dtype_code(dY2.dtype),
+                _lib.dtype_code(W.dtype), _lib.stream_of(dY2))
+            _lib.check(rc, "uamd_add_rms_layernorm_bwd")
+    return dY2
+
+
 class Fast_RMS_Layernorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, W, eps, gemma=False):

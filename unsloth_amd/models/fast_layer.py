@@ -1,0 +1,213 @@
+"""One decoder layer as ONE manual-autograd Function with selective recompute: the MI355X answer to the reference's
+`use_gradient_checkpointing="unsloth"` (hook site unsloth/models/llama.py:1169-1193, mode selection
+models/_utils.py:360-386).
+
+The reference's "unsloth" mode wraps every decoder layer in unsloth_zoo's offloaded checkpoint: keep only the layer
+input (copied to host RAM), re-run the WHOLE layer in the backward. On a 288 GB part neither the PCIe round trip
+nor most of that recompute is needed. This Function runs the layer's forward without building an autograd graph,
+keeps per layer only what a policy names, and in the backward recomputes exactly the missing tensors before
+walking the same manual backward chain the per-block Functions use (kernels/fast_lora.py):
+
+  always kept   h0 = residual + delta (the layer input, 2 B/token/hidden -- what any checkpoint keeps), the two rms
+                statistics, the rank-r products X A^T (fp32 [T, r], ~3.6 MB per layer at 8192 tokens), the
+                attention log-sum-exp when Q/K/V are kept
+  "qkv"         post-RoPE Q, K, V and the attention output          else: norm1 -> q/k/v GEMM -> RoPE -> flash fwd again
+  "h1"          the residual stream after attention                  else: o_proj GEMM again
+  "eg"          the gate / up projections e, g (the 2 x 14336-wide tensors: 57 % of a layer's activations)
+                                                                     else: norm2 -> gate/up GEMM again
+  never needed  the SwiGLU output h and the down projection: the activation backward rebuilds h from (e, g) in
+                place and nothing in the backward reads the layer's own output -- a reentrant checkpoint
+                recomputes both anyway (27 % of a layer's GEMM flops + two streaming passes).
+
+Recomputed tensors come from the same deterministic kernels on the same inputs, so every policy gives BITWISE the
+gradients of the keep-everything path (tests/test_gpu_model.py).
+
+Policies: "min" = {} (memory of plain checkpointing, ~30 % less recompute), "attn" = {qkv, h1} (re-runs only
+norm2 + gate/up), "all" = everything (no recompute; equals use_gradient_checkpointing=False).
+"""
+import torch
+
+from ..kernels import attention as _flash
+from ..kernels.fast_lora import (
+    get_lora_parameters, mlp_backward, mlp_forward, mlp_gate_up_forward, qkv_backward, qkv_forward, w_backward,
+    w_forward,
+)
+from ..kernels.rms_layernorm import add_rms_fwd, rms_bwd_, rms_fwd
+from ..kernels.utils import lora_linear_forward
+from ..kernels.rope_embedding import _launch_qk, _tables
+from ..kernels.swiglu import swiglu_DWf_DW_dfg_kernel, swiglu_fg_kernel
+
+POLICIES = {"min": frozenset(), "attn": frozenset({"qkv", "h1"}), "all": frozenset({"x1", "qkv", "h1", "x2", "eg"})}
+_PROJ = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+def resolve_policy(policy):
+    if isinstance(policy, str):
+        return POLICIES[policy]
+    return frozenset(policy)
+
+
+def layer_supported(layer, hidden, attention_mask):
+    """The whole-layer Function covers what the fused hooks cover: LoRA (or plain frozen) projections without bias /
+    dropout / DoRA, SwiGLU MLP, head_dim 128 flash attention, no key-padding mask, 16-bit activations."""
+    from ..kernels.fast_lora import apply_lora_mlp_swiglu, apply_lora_o, apply_lora_qkv
+    attn, mlp = layer.self_attn, layer.mlp
+    if attention_mask is not None or hidden.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    if getattr(attn, "apply_qkv", None) is not apply_lora_qkv or getattr(attn, "apply_o", None) is not apply_lora_o:
+        return False
+    if getattr(getattr(mlp, "forward", None), "__func__", None) is not apply_lora_mlp_swiglu:
+        return False
+    return attn.head_dim == 128 and getattr(layer.input_layernorm, "weight", None) is not None
+
+
+def _eps(norm):
+    return norm.variance_epsilon if hasattr(norm, "variance_epsilon") else norm.eps
+
+
+class _Static:
+    """Non-tensor context of one layer call (weights, norm parameters, rope tables, band, shapes)."""
+    __slots__ = ("projs", "w1", "w2", "eps1", "eps2", "cos", "sin", "idx", "band", "n_heads", "n_kv", "head_dim",
+                 "scale", "keep", "shape")
+
+
+class DecoderLayerFunction(torch.autograd.Function):
+    """(residual', delta') = layer(residual, delta): hidden = residual + delta is formed inside the first norm,
+    residual' = hidden + attention block, delta' = MLP output (its add is fused into the NEXT layer's first norm,
+    like models/llama.py LlamaDecoderLayer_fused_residual_forward). `delta` may be None (first layer).
+    `lora` = the 14 LoRA factors (A, B of q, k, v, o, gate, up, down; None where a projection has no adapter): they
+    are inputs so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, st, residual, delta, *lora):
+        keep = st.keep
+        shape = residual.shape
+        st.shape = shape
+        projs = st.projs
+        # ---- attention block
+        if delta is None:
+            h0 = residual.reshape(-1, shape[-1])
+            x1, r1 = rms_fwd(h0, st.w1, st.eps1)
+        else:
+            h0, x1, r1 = add_rms_fwd(delta, residual, st.w1, st.eps1)
+        Q, K, V, xa_qkv = qkv_forward(x1, projs[0], projs[1], projs[2])
+        B_, T_ = shape[0], shape[1]
+        q4 = Q.view(B_, T_, st.n_heads, st.head_dim)
+        k4 = K.view(B_, T_, st.n_kv, st.head_dim)
+        v4 = V.view(B_, T_, st.n_kv, st.head_dim)
+        _launch_qk(q4.transpose(1, 2), k4.transpose(1, 2), st.cos, st.sin, st.idx, False)       # RoPE in place
+        O, lse = _flash.attn_forward(q4, k4, v4, st.scale, st.band)
+        attn = O.view(-1, st.n_heads * st.head_dim)
+        o, xa_o = w_forward(attn, projs[3])
+        h1, x2, r2 = add_rms_fwd(o, h0, st.w2, st.eps2)
+        del o
+        # ---- MLP block
+        out, e, g, xa_mlp = mlp_forward(x2, projs[4], projs[5], projs[6], swiglu_fg_kernel)
+        saved = [h0, r1, r2, *xa_qkv, xa_o, *xa_mlp]
+        ctx.n_fixed = len(saved)
+        if "x1" in keep:
+            saved.append(x1)
+        if "qkv" in keep:
+            saved += [Q, K, V, O, lse]
+        if "h1" in keep:
+            saved.append(h1)
+        if "x2" in keep:
+            saved.append(x2)
+        if "eg" in keep:
+            saved += [e, g]
+        ctx.save_for_backward(*saved, *[t for t in lora if t is not None])
+        ctx.n_saved = len(saved)
+        ctx.lora_mask = [t is not None for t in lora]
+        ctx.st = st
+        ctx.first = delta is None
+        ctx.set_materialize_grads(False)
+        return h1.view(shape), out.view(shape)
+
+    @staticmethod
+    def backward(ctx, d_h1, d_out):
+        st = ctx.st
+        keep = st.keep
+        saved = ctx.saved_tensors
+        h0, r1, r2, xa_q, xa_k, xa_v, xa_o, xa_g, xa_u, xa_d = saved[:ctx.n_fixed]
+        rest = list(saved[ctx.n_fixed:ctx.n_saved])
+        lora_live = list(saved[ctx.n_saved:])
+        lora = [lora_live.pop(0) if m else None for m in ctx.lora_mask]
+        # projections with the adapters as autograd handed them back (same objects as in the forward)
+        projs = [(W, qs, lora[2 * i], lora[2 * i + 1], s) for i, (W, qs, _, _, s) in enumerate(st.projs)]
+        shape = st.shape
+        B_, T_ = shape[0], shape[1]
+        hd, nh, nkv = st.head_dim, st.n_heads, st.n_kv
+        x1 = rest.pop(0) if "x1" in keep else None
+        if "qkv" in keep:
+            Q, K, V, O, lse = rest[:5]
+            del rest[:5]
+        h1 = rest.pop(0) if "h1" in keep else None
+        x2 = rest.pop(0) if "x2" in keep else None
+        if "eg" in keep:
+            e, g = rest[:2]
+        # ---- recompute what the policy did not keep (same kernels, same inputs: bitwise the forward's values)
+        with torch.no_grad():
+            if x1 is None:
+                x1, _ = rms_fwd(h0, st.w1, st.eps1)
+            if "qkv" not in keep:
+                Q, K, V = lora_linear_forward(x1, [projs[0], projs[1], projs[2]])
+                q4 = Q.view(B_, T_, nh, hd)
+                k4 = K.view(B_, T_, nkv, hd)
+                _launch_qk(q4.transpose(1, 2), k4.transpose(1, 2), st.cos, st.sin, st.idx, False)
+                O, lse = _flash.attn_forward(q4, k4, V.view(B_, T_, nkv, hd), st.scale, st.band)
+            attn = O.view(-1, nh * hd)
+            if h1 is None:
+                o, _ = w_forward(attn, projs[3])
+                h1, x2, _ = add_rms_fwd(o, h0, st.w2, st.eps2)
+                del o
+            elif x2 is None:
+                x2, _ = rms_fwd(h1, st.w2, st.eps2)
+            if "eg" not in keep:
+                e, g = mlp_gate_up_forward(x2, projs[4], projs[5])
+            # ---- MLP backward (consumes e, g in place; dX into x2's buffer)
+            if d_out is None:
+                d_out = torch.zeros(shape, dtype=h0.dtype, device=h0.device)
+            # kept e / g / x2 are overwritten by the in-place backward exactly like the reference overwrites its
+            # saved tensors (fast_lora.py:157, :193-204): one backward per forward
+            dx2, g_mlp = mlp_backward(d_out, x2, e, g, (xa_g, xa_u, xa_d), projs[4], projs[5], projs[6],
+                                      swiglu_DWf_DW_dfg_kernel, True)
+            del e, g
+            # ---- norm2 backward + residual gradient: d h1 = rms'(dx2) + d_h1
+            dh1 = rms_bwd_(dx2, h1, st.w2, r2, d_h1)
+            # ---- o_proj backward
+            d_attn, g_o = w_backward(dh1, attn, xa_o, projs[3])
+            # ---- attention backward, RoPE backward (in place), q/k/v backward
+            dq, dk, dv = _flash.attn_backward(d_attn.view(B_, T_, nh, hd), Q.view(B_, T_, nh, hd),
+                                              K.view(B_, T_, nkv, hd), V.view(B_, T_, nkv, hd),
+                                              O.view(B_, T_, nh, hd), lse, st.scale, st.band)
+            _launch_qk(dq.transpose(1, 2), dk.transpose(1, 2), st.cos, st.sin, st.idx, True)
+            dx1, g_qkv = qkv_backward(dq.reshape(-1, nh * hd), dk.reshape(-1, nkv * hd), dv.reshape(-1, nkv * hd), x1,
+                                      (xa_q, xa_k, xa_v), projs[0], projs[1], projs[2], True)
+            # ---- norm1 backward + the residual path: d h0 = rms'(dx1) + d h1
+            need_in = ctx.needs_input_grad[1] or (not ctx.first and ctx.needs_input_grad[2])
+            dh0 = rms_bwd_(dx1, h0, st.w1, r1, dh1).view(shape) if need_in else None
+        grads = [g_qkv[0], g_qkv[1], g_qkv[2], g_qkv[3], g_qkv[4], g_qkv[5], g_o[0], g_o[1],
+                 g_mlp[0], g_mlp[1], g_mlp[2], g_mlp[3], g_mlp[4], g_mlp[5]]
+        grads = [gr if m else None for gr, m in zip(grads, ctx.lora_mask)]
+        return (None, dh0, None if ctx.first else dh0, *grads)
+
+
+def decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids, band, keep):
+    """(residual', delta') through DecoderLayerFunction. `keep`: a resolved policy (frozenset)."""
+    attn = layer.self_attn
+    cfg = attn.config
+    st = _Static()
+    mods = [getattr(attn, n) for n in _PROJ[:4]] + [getattr(layer.mlp, n) for n in _PROJ[4:]]
+    st.projs = [get_lora_parameters(m) for m in mods]
+    st.w1, st.w2 = layer.input_layernorm.weight, layer.post_attention_layernorm.weight
+    st.eps1, st.eps2 = _eps(layer.input_layernorm), _eps(layer.post_attention_layernorm)
+    st.cos, st.sin = _tables(cos, sin)
+    st.idx = rope_position_ids
+    st.band = band
+    st.n_heads, st.n_kv, st.head_dim = cfg.num_attention_heads, cfg.num_key_value_heads, attn.head_dim
+    st.scale = None
+    st.keep = keep
+    lora = []
+    for (_, _, A, B, _) in st.projs:
+        lora += [A, B]
+    return DecoderLayerFunction.apply(st, residual, delta, *lora)

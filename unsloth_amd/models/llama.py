@@ -15,7 +15,8 @@ unsloth/models/llama.py.
 The composition reads HF module ATTRIBUTES (q_proj, input_layernorm.weight, ...) and never calls HF's
 own layer forwards on the training path, so it is insensitive to transformers' internal attention /
 cache / mask API (the installed 5.15 is above the reference's ceiling).
-Attention itself is torch SDPA (flash via AOTriton/CK on ROCm): adjacent component, SURVEY 8(f1).
+Attention is the hand-written causal GQA flash kernel pair of csrc/attention.hip (kernels/attention.py; SURVEY 8(f1));
+torch SDPA only serves key-padding masks and head dims the kernels do not cover.
 """
 import math
 import os
@@ -46,6 +47,7 @@ from ..utils.packing import (
 from .. import lora as _lora
 from .. import nf4 as _nf4
 from ..kernels import attention as _flash
+from . import fast_layer as _fast_layer
 
 _USE_FLASH = os.environ.get("UNSLOTH_AMD_FLASH_ATTENTION", "1") == "1"
 _FUSED_RESIDUAL = os.environ.get("UNSLOTH_AMD_FUSED_RESIDUAL", "1") == "1"
@@ -260,6 +262,20 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
     if rope_position_ids is not None and os.environ.get("UNSLOTH_AMD_CHECK_POSITIONS", "0") == "1":
         assert int(rope_position_ids.max()) < cos.shape[0]
     gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
+    policy = getattr(self, "_unsloth_amd_layer_policy", None)
+    if policy is not None and self.training and torch.is_grad_enabled() and (seq_info is None or bsz == 1) \
+            and all(_fast_layer.layer_supported(l, hidden_states, attention_mask) for l in self.layers):
+        # use_gradient_checkpointing="unsloth": every layer is ONE manual-autograd Function that keeps what the
+        # policy names and recomputes the rest in its backward (models/fast_layer.py)
+        sw = getattr(self.config, "sliding_window", None)
+        window = sw if (sw is not None and 0 < sw < q_len) else None
+        band = None if (seq_info is None and window is None) else \
+            _attention_band(seq_info, bsz, q_len, window, hidden_states.device)
+        residual, delta = hidden_states, None
+        for layer in self.layers:
+            residual, delta = _fast_layer.decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids,
+                                                                band, policy)
+        return fast_add_rms_layernorm(self.norm, delta, residual)[1]
     if gc and not hidden_states.requires_grad:
         hidden_states.requires_grad_(True)      # reentrant checkpoint needs an input that requires grad
     if not gc and _FUSED_RESIDUAL:
@@ -507,11 +523,24 @@ class FastLlamaModel:
 
     @staticmethod
     def for_training(model, use_gradient_checkpointing=True):
-        """llama.py:3824-3885. "unsloth" = offloaded checkpointing in the reference; on 288 GB HBM the
-        layer inputs stay on the device (32 x 16.8 MB at T=2048), so it maps to plain reentrant GC."""
+        """llama.py:3824-3885 + the mode selection of models/_utils.py:360-386.
+          False      : every activation stays in HBM (288 GB), no recompute.
+          True       : torch's reentrant per-layer checkpoint, what the reference gives for `True` (llama.py:1169-1193).
+          "unsloth"  : the reference offloads layer inputs to host RAM and re-runs whole layers; here: selective
+                       recompute (models/fast_layer.py) -- per layer keep the layer input, Q/K/V + attention output
+                       and the post-attention residual, re-run only norm2 + the gate/up GEMM in the backward
+                       (the SwiGLU output and the down projection are never recomputed).
+                       "unsloth:min" keeps only the layer input (the memory of `True`), "unsloth:all" keeps
+                       everything (the speed of `False`); UNSLOTH_AMD_GC_POLICY overrides the default "attn"."""
         base = model.get_base_model() if hasattr(model, "get_base_model") else model
-        gc = bool(use_gradient_checkpointing)
+        policy = None
+        mode = use_gradient_checkpointing
+        if isinstance(mode, str) and mode.split(":")[0] == "unsloth":
+            name = mode.split(":", 1)[1] if ":" in mode else os.environ.get("UNSLOTH_AMD_GC_POLICY", "attn")
+            policy = _fast_layer.resolve_policy(name.split("+") if "+" in name else name)
+        gc = bool(mode)
         base.model.gradient_checkpointing = gc
+        base.model._unsloth_amd_layer_policy = policy
         for m in base.modules():
             if hasattr(m, "gradient_checkpointing"):
                 m.gradient_checkpointing = gc
