@@ -193,6 +193,39 @@ def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypa
     assert total < 4e-2, total
 
 
+@pytest.mark.parametrize("head_dim,gc", [(128, False), (128, "unsloth"), (32, False)])
+def test_packed_batch_of_two_rows_equals_per_document_oracle(head_dim, gc):
+    """sample packing with batch > 1: `packed_seq_lengths` runs over the flattened batch (the reference's cu_seqlens);
+    every row is its own block-diagonal attention problem (flash band path for head_dim 128, band-derived dense mask
+    for the SDPA fallback). Must equal the documents run one by one."""
+    from oracle.ref_model import hf_reference_loss_and_lora_grads
+    model = _tiny(head_dim=head_dim, gc=gc)
+    g = torch.Generator().manual_seed(9)
+    rows = [[40, 24], [17, 30, 17]]
+    docs = [torch.randint(0, 1000, (n,), generator=g).tolist() for r in rows for n in r]
+    ids = torch.tensor([sum(docs[:2], []), sum(docs[2:], [])])
+    pos = torch.tensor([sum([list(range(n)) for n in r], []) for r in rows], dtype=torch.int32)
+    labels = ids.clone()
+    labels[pos == 0] = -100
+    lens = torch.tensor([n for r in rows for n in r], dtype=torch.int32)
+    out = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV), packed_seq_lengths=lens.to(DEV))
+    out.loss.backward()
+    got = _grads(model)
+    tot, n_tot, ref = 0.0, 0, None
+    for d in docs:
+        di = torch.tensor([d])
+        n = len(d) - 1
+        loss, grads = hf_reference_loss_and_lora_grads(model, di, di.clone(), None)
+        tot += float(loss) * n
+        n_tot += n
+        ref = {k: v * n for k, v in grads.items()} if ref is None else {k: ref[k] + grads[k] * n for k in ref}
+    want = tot / n_tot
+    assert abs(float(out.loss) - want) <= 2e-3 * abs(want), (float(out.loss), want)
+    total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]),
+                    torch.cat([(ref[k] / n_tot).flatten() for k in sorted(got)]))
+    assert total < 4e-2, total
+
+
 def test_training_reduces_loss_and_adapters_round_trip(tmp_path):
     from unsloth_amd.trainer import make_optimizer, unsloth_train
     model = _tiny(r=16)

@@ -130,6 +130,24 @@ def test_attention_band_matches_dense_packed_mask():
     # tokens past the packed documents form one more document
     lo, hi = attention_band(8, seq_lengths=[3, 2])
     assert lo[0].tolist() == [0, 0, 0, 3, 3, 5, 5, 5] and hi[0].tolist() == [2, 2, 2, 4, 4, 7, 7, 7]
+    # batch of B packed rows: the lengths run over the FLATTENED batch (the reference's cu_seqlens); every row's band
+    # equals the band of that row packed alone
+    for trial in range(10):
+        B, T = int(torch.randint(2, 5, (1,), generator=gen)), 24
+        rows, flat = [], []
+        for _ in range(B):
+            cuts = sorted(set(torch.randint(1, T, (int(torch.randint(0, 4, (1,), generator=gen)),), generator=gen).tolist()))
+            lens = [b - a for a, b in zip([0] + cuts, cuts + [T])]
+            rows.append(lens)
+            flat += lens
+        window = [None, 3, 9][trial % 3]
+        lo, hi = attention_band(T, batch=B, seq_lengths=flat, sliding_window=window)
+        for b, lens in enumerate(rows):
+            lo1, hi1 = attention_band(T, seq_lengths=lens, sliding_window=window)
+            assert torch.equal(lo[b], lo1[0]) and torch.equal(hi[b], hi1[0])
+    # a document that straddles two rows is cut at the row boundary
+    lo, hi = attention_band(4, batch=2, seq_lengths=[6, 2])
+    assert lo.tolist() == [[0, 0, 0, 0], [0, 0, 2, 2]] and hi.tolist() == [[3, 3, 3, 3], [1, 1, 3, 3]]
 
 
 def test_adjacent_columns_detection():

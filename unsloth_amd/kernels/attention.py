@@ -36,30 +36,32 @@ def _pad32(T):
 
 def attention_band(T, batch=1, seq_lengths=None, sliding_window=None, device="cpu"):
     """Band of the block-diagonal causal mask as two int32 [batch, T] arrays (lo, hi): query q attends keys
-    lo[q] <= key <= q, i.e. key is seen by queries key <= q <= hi[key].
-    `seq_lengths`: lengths of the documents packed back to back into ONE row of T tokens (the reference's
-    `packed_seq_lengths`, utils/packing.py:586-606; tokens past sum(lengths) form one more document);
-    `sliding_window` W: additionally q - key < W (packing.py:679-683, attention_dispatch.py:292).
-    Integer work, done with torch ops on `device`; exact."""
-    pos = torch.arange(T, dtype=torch.int64, device=device)
+    lo[q] <= key <= q, i.e. key is seen by queries key <= q <= hi[key] (positions inside the batch row).
+    `seq_lengths`: lengths of the documents packed back to back over the FLATTENED batch of batch*T tokens (the
+    reference's `packed_seq_lengths`, utils/packing.py:586-606: its varlen attention runs on the flattened rows
+    with cu_seqlens = [0, cumsum(lengths)]); tokens past sum(lengths) form one more document. A batch row is its own
+    attention problem here, so a document that straddles a row boundary is cut there (packing collators end every
+    document inside its row). `sliding_window` W: additionally q - key < W (packing.py:679-683,
+    attention_dispatch.py:292). Integer work, done with torch ops on `device`; exact."""
+    total = batch * T
+    g = torch.arange(total, dtype=torch.int64, device=device)       # flat token index
+    row0 = (g // T) * T                                             # first flat index of the token's batch row
     if seq_lengths is not None:
-        if batch != 1:
-            raise ValueError("packed sequences are one row of tokens (batch 1)")
         lens = torch.as_tensor(seq_lengths, dtype=torch.int64, device=device).flatten()
         lens = lens[lens > 0]
-        ends = torch.cumsum(lens, 0).clamp_(max=T)                 # exclusive end of every document
-        doc = torch.searchsorted(ends, pos, right=True)            # document of every token
-        ends = torch.cat([ends, ends.new_full((1,), T)])           # trailing (padding) tokens: one more document
+        ends = torch.cumsum(lens, 0).clamp_(max=total)             # exclusive end of every document
+        doc = torch.searchsorted(ends, g, right=True)              # document of every token
+        ends = torch.cat([ends, ends.new_full((1,), total)])       # trailing (padding) tokens: one more document
         starts = torch.cat([ends.new_zeros(1), ends[:-1]])
-        lo, hi = starts[doc], ends[doc] - 1
+        lo = torch.maximum(starts[doc], row0) - row0
+        hi = torch.minimum(ends[doc] - 1, row0 + (T - 1)) - row0
     else:
-        lo, hi = torch.zeros_like(pos), torch.full_like(pos, T - 1)
+        lo, hi = torch.zeros_like(g), torch.full_like(g, T - 1)
     if sliding_window is not None and sliding_window > 0:
+        pos = g - row0
         lo = torch.maximum(lo, pos - (sliding_window - 1))
         hi = torch.minimum(hi, pos + (sliding_window - 1))
-    lo = lo.to(torch.int32)[None].expand(batch, T).contiguous()
-    hi = hi.to(torch.int32)[None].expand(batch, T).contiguous()
-    return lo, hi
+    return lo.to(torch.int32).view(batch, T).contiguous(), hi.to(torch.int32).view(batch, T).contiguous()
 
 
 def _band_ptrs(band, B, T, dev):

@@ -39,7 +39,6 @@ from ..kernels import (
 from ..kernels.utils import invalidate_cast_cache, lora_linear_forward
 from ..kernels.rms_layernorm import fast_add_rms_layernorm
 from ..utils.packing import (
-    build_sdpa_packed_attention_mask,
     get_packed_info_from_kwargs,
     mask_packed_boundary_labels,
     mask_packed_sequence_boundaries,
@@ -166,23 +165,22 @@ def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
     window = sliding_window if (sliding_window is not None and 0 < sliding_window < T) else None   # mistral.py:116-120
     if attention_mask is None and _USE_FLASH:
         q, k, v = Q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2)          # [B,T,H,D] views
-        if _flash.supported(q, k, v) and (seq_info is None or B == 1):
+        if _flash.supported(q, k, v):
             band = None if (seq_info is None and window is None) else _attention_band(seq_info, B, T, window, Q.device)
             return _flash.flash_attention(q, k, v, None, band).reshape(B, T, Hq * D)
     if seq_info is None and attention_mask is None and window is None:
         A = F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
         return A.transpose(1, 2).reshape(B, T, Hq * D)
-    if seq_info is not None:
-        mask = build_sdpa_packed_attention_mask(seq_info, dtype=Q.dtype, device=Q.device, sliding_window=window)
-    else:
-        pos = torch.arange(T, device=Q.device)
-        allowed = pos[:, None] >= pos[None, :]
-        if window is not None:
-            allowed = allowed & ((pos[:, None] - pos[None, :]) < window)
-        allowed = allowed[None, None]
-        if attention_mask is not None:
-            allowed = allowed & attention_mask.to(torch.bool)[:, None, None, :]
-        mask = torch.zeros(allowed.shape, dtype=Q.dtype, device=Q.device).masked_fill_(~allowed, float("-inf"))
+    # dense additive mask from the same (lo, hi) band the flash kernels take: one [T, T] block per batch row
+    pos = torch.arange(T, device=Q.device)
+    allowed = (pos[:, None] >= pos[None, :])[None]                              # causal, [1, T(q), T(key)]
+    if seq_info is not None or window is not None:
+        lo, _ = _attention_band(seq_info, B, T, window, Q.device)
+        allowed = allowed & (pos[None, None, :] >= lo[:, :, None])
+    allowed = allowed[:, None]
+    if attention_mask is not None:
+        allowed = allowed & attention_mask.to(torch.bool)[:, None, None, :]
+    mask = torch.zeros(allowed.shape, dtype=Q.dtype, device=Q.device).masked_fill_(~allowed, float("-inf"))
     A = F.scaled_dot_product_attention(Q, K, V, attn_mask=mask, enable_gqa=True)
     return A.transpose(1, 2).reshape(B, T, Hq * D)
 
@@ -263,7 +261,7 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
         assert int(rope_position_ids.max()) < cos.shape[0]
     gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
     policy = getattr(self, "_unsloth_amd_layer_policy", None)
-    if policy is not None and self.training and torch.is_grad_enabled() and (seq_info is None or bsz == 1) \
+    if policy is not None and self.training and torch.is_grad_enabled() \
             and all(_fast_layer.layer_supported(l, hidden_states, attention_mask) for l in self.layers):
         # use_gradient_checkpointing="unsloth": every layer is ONE manual-autograd Function that keeps what the
         # policy names and recomputes the rest in its backward (models/fast_layer.py)
