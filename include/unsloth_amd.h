@@ -192,8 +192,9 @@ typedef struct {
 
 int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                  int n_groups, int accumulate, int dtype, void* stream);
-/* uamd_gemm_nt_256: same contract as uamd_gemm_nt with 256x256x64 tiles, LDS-DMA staging and two wave
- * groups in anti-phase (csrc/gemm256.hip); for large M. Requires K % 64 == 0. */
+/* uamd_gemm_nt_256: same contract as uamd_gemm_nt with 256x256x64 tiles (128x256x64 when the launch is too small to
+ * fill 256 CUs with the big tile), LDS-DMA staging and two wave groups in anti-phase (csrc/gemm256.hip). Requires
+ * K % 64 == 0 and every operand to span less than 4 GiB. */
 int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
 /* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
@@ -207,7 +208,9 @@ int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention dK/dV kernel: 1 = four waves x 512 registers, 0 = eight waves */
 #define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
-#define UAMD_TUNE_COUNT 6
+#define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has
+                                 * fewer than 192 tiles (default), 0 = always 256 rows, 2 = always 128 rows */
+#define UAMD_TUNE_COUNT 7
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

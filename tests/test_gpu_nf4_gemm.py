@@ -262,6 +262,33 @@ def test_gemm256_dense(force256, dtype, M, N, K):
         assert torch.equal(Y, Y2)
 
 
+@pytest.mark.parametrize("half", [0, 2])
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (128, 256, 128), (2048, 4096, 4096), (300, 516, 192), (2048, 1024, 14336),
+                                   (1, 256, 256), (129, 255, 320)])
+def test_gemm256_tile_heights(force256, half, M, N, K):
+    """128 x 256 tiles (three-stage ring, csrc/gemm256.hip gemm_nt256h_kernel) and 256 x 256 tiles give the same
+    fp32-accumulated product; rank block included; run-to-run bitwise deterministic."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    dtype = torch.bfloat16
+    X = torch.randn(M, K, generator=g(151)).to(dtype)
+    W = (torch.randn(N, K, generator=g(152)) * 0.05).to(dtype)
+    A = torch.randn(16, K, generator=g(153)) * 0.05
+    B = torch.randn(N, 16, generator=g(154)) * 0.05
+    L = _lib.lib()
+    try:
+        L.uamd_set_tuning(6, half)
+        (Y,) = lora_linear_forward(X.to(DEV), [(W.to(DEV), None, None, None, None)])
+        _check_gemm(Y, _ref_mm(X, W), dtype, K, f"gemm256 half={half} {M}x{N}x{K}")
+        (Y2,) = lora_linear_forward(X.to(DEV), [(W.to(DEV), None, None, None, None)])
+        assert torch.equal(Y, Y2)
+        (Z,) = lora_linear_forward(X.to(DEV), [(W.to(DEV), None, A.to(DEV), B.to(DEV), 2.0)])
+        xa = (X.float() @ A.to(dtype).float().t()).to(dtype).float()
+        _check_gemm(Z, _ref_mm(X, W) + xa @ (2.0 * B).to(dtype).float().t(), dtype, K, f"gemm256+lora half={half}")
+    finally:
+        L.uamd_set_tuning(6, 1)
+
+
 def test_gemm256_transpose_detecting_and_k_order(force256):
     from unsloth_amd.kernels.utils import lora_linear_forward
     M, N, K = 512, 512, 256

@@ -380,6 +380,234 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Half-height variant: 128 x 256 x 64 tiles, same LDS-DMA ping-pong, for launches whose 256 x 256 tiling would leave
+// CUs idle (M = 2048 tokens: o_proj / down_proj / every dX GEMM have 8 x 16 = 128 such tiles for 256 CUs; the
+// 128-row tiling gives 256). Each wave group owns 64 rows (wave tile 64 x 64, 32 MFMAs per K tile), a K tile is
+// four slots (L0 M0 L1 M1) and the LDS ring has THREE 48 KiB stages: the six DMA pieces of tile t+2 are issued
+// during tile t (3 in L0, 3 in L1, into the stage tile t-1 was read from: both groups finished it one barrier
+// ago), and tile t+1 is waited for with a counted vmcnt(6) at the end of L1 -- one slot before the tile ends,
+// so the group that runs one slot behind has passed its own wait before the other one starts reading.
+constexpr int TMH = 128;
+constexpr int STAGE_H = (TMH + TN) * TK * 2;       // 48 KiB
+constexpr int LDS_H = 3 * STAGE_H;                 // 144 KiB
+
+template <typename T>
+__global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Mfma2<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;      // group owns rows grp*64.., wave owns cols wn*64..
+    const int l15 = lane & 15, l4 = lane >> 4;
+    int tile = blockIdx.x;
+    {
+        const int nt = p.total_tiles, q = nt >> 3, r = nt & 7, x = tile & 7, j = tile >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    int tm, tn_lin;
+    {
+        const int gm = p.group_m, tiles_n = p.tile_start[UAMD_G256_MAX_GROUPS];
+        const int per_group = gm * tiles_n;
+        const int rg = tile / per_group;
+        const int first_m = rg * gm;
+        const int gsz = min(gm, p.tiles_m - first_m);
+        const int rem = tile - rg * per_group;
+        tn_lin = rem / gsz;
+        tm = first_m + (rem - tn_lin * gsz);
+    }
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < UAMD_G256_MAX_GROUPS; ++i)
+        if (i < p.n_groups && tn_lin >= p.tile_start[i]) gi = i;
+    const uamd_gemm_group& g = p.g[gi];
+    const int m0 = tm * TMH, n0 = (tn_lin - p.tile_start[gi]) * TN;
+    const int M = p.M, K = p.K, N = g.N;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // piece c (0..5) of a tile, issued by wave w, fills sub-tile u = c*8 + w: u < 16 -> A rows u*8.., else B rows (u-16)*8..
+    const int sub_row = lane >> 3;
+    const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
+    auto sgpr64 = [](const void* q) {
+        const uint64_t u = (uint64_t)(uintptr_t)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t a_gbase = sgpr64(p.A), b_gbase = sgpr64(g.B);
+    unsigned a_off[2], b_off[4];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int ra = m0 + (c * 8 + wave) * 8 + sub_row;
+        ra = ra < M ? ra : M - 1;
+        a_off[c] = (unsigned)(((int64_t)ra * p.lda + sub_slot * 8) * (int64_t)sizeof(T));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int rb = n0 + (c * 8 + wave) * 8 + sub_row;
+        rb = rb < N ? rb : N - 1;
+        b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    const int nk_main = __builtin_amdgcn_readfirstlane(K / TK);
+    const int nk = __builtin_amdgcn_readfirstlane(nk_main + (g.lora_xk != nullptr ? g.Rk / TK : 0));
+    auto issue_main = [&](int c, int kt, int stage) {       // c, stage compile-time
+        const unsigned dst = lds_base + stage * STAGE_H + (c * 8 + wave) * 1024;
+        dma16s(c < 2 ? a_off[c] : b_off[c - 2], (c < 2 ? a_gbase : b_gbase) + (uint64_t)kt * (TK * sizeof(T)), dst);
+    };
+    const uint64_t xk_base = sgpr64(g.lora_xk), bk_base = sgpr64(g.lora_bk);
+    const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
+    auto issue_any = [&](int c, int kt, int stage) {
+        if (kt < nk_main) {
+            issue_main(c, kt, stage);
+        } else {
+            const unsigned dst = lds_base + stage * STAGE_H + (c * 8 + wave) * 1024;
+            int row = (c < 2 ? m0 + (c * 8 + wave) * 8 : n0 + ((c - 2) * 8 + wave) * 8) + sub_row;
+            const int last = (c < 2 ? M : N) - 1;
+            row = row < last ? row : last;
+            const int ld = c < 2 ? ld_xk : ld_bk;
+            const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
+            dma16s(off, (c < 2 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
+        }
+    };
+    const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
+    const int frag_off[2] = {frag_off0, frag_off0 ^ 64};
+    const int a_lbase = (grp * 4) * 2048;
+    const int b_lbase = 16 * 1024 + (wn * 4) * 2048;
+    frag_t af[4][2], bf[4][2];
+    auto read_a = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { uint4 r; frag_t f; } u;
+                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_H + a_lbase + i * 2048 + frag_off[ks]);
+                af[i][ks] = u.f;
+            }
+    };
+    auto read_b = [&](int stage, int nq) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { uint4 r; frag_t f; } u;
+                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_H + b_lbase + (nq * 2 + j) * 2048 + frag_off[ks]);
+                bf[nq * 2 + j][ks] = u.f;
+            }
+    };
+    auto mma = [&](int nq) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][nq * 2 + j] = Mfma2<T>::run(bf[nq * 2 + j][ks], af[i][ks], acc[i][nq * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // ---- prologue: tiles 0 and 1 completely
+#pragma unroll
+    for (int c = 0; c < 6; ++c) issue_main(c, 0, 0);
+    if (nk > 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) issue_any(c, 1, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SLOT_BARRIER();
+    if (grp == 1) SLOT_BARRIER();          // anti-phase: group 1 runs one slot behind
+
+#define NEXT2(ST) ((ST) == 0 ? 2 : (ST) - 1)     /* stage of tile kt + 2 = (ST + 2) % 3 */
+#define TILE_H(STAGE, KT, ISSUE, CHECK)                                                   \
+    do {                                                                                 \
+        /* L0 */                                                                         \
+        read_a(STAGE); read_b(STAGE, 0);                                                 \
+        if (!(CHECK) || (KT) + 2 < nk) { ISSUE(0, (KT) + 2, NEXT2(STAGE)); ISSUE(1, (KT) + 2, NEXT2(STAGE)); ISSUE(2, (KT) + 2, NEXT2(STAGE)); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(0); SLOT_BARRIER();                                                          \
+        /* L1 */                                                                         \
+        read_b(STAGE, 1);                                                                \
+        if (!(CHECK) || (KT) + 2 < nk) {                                                 \
+            ISSUE(3, (KT) + 2, NEXT2(STAGE)); ISSUE(4, (KT) + 2, NEXT2(STAGE)); ISSUE(5, (KT) + 2, NEXT2(STAGE)); \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(6)" ::: "memory");     \
+        } else {                                                                         \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(0)" ::: "memory");     \
+        }                                                                                \
+        SLOT_BARRIER();                                                                  \
+        mma(1); SLOT_BARRIER();                                                          \
+    } while (0)
+
+    int kt = 0;
+    // fast loop: tiles kt <= nk_main - 3 prefetch tile kt + 2 <= nk_main - 1 (a tile of A / B proper)
+    for (; kt + 2 < nk_main - 2; kt += 3) {
+        TILE_H(0, kt, issue_main, 0);
+        TILE_H(1, kt + 1, issue_main, 0);
+        TILE_H(2, kt + 2, issue_main, 0);
+    }
+    for (; kt < nk; kt += 3) {             // kt is a multiple of 3 here: stage = kt % 3 stays compile-time
+        TILE_H(0, kt, issue_any, 1);
+        if (kt + 1 < nk) TILE_H(1, kt + 1, issue_any, 1);
+        if (kt + 2 < nk) TILE_H(2, kt + 2, issue_any, 1);
+    }
+#undef TILE_H
+#undef NEXT2
+    if (grp == 0) SLOT_BARRIER();          // match group 1's extra barrier
+
+    T* Cg = (T*)g.C;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + grp * 64 + i * 16 + l15;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+            if (n >= N) continue;
+            T* dst = Cg + (int64_t)m * g.ldc + n;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (n + 3 < N && vec_ok) {
+                union { uint2 raw; T e[4]; } o;
+                if (p.accumulate) {
+                    o.raw = *reinterpret_cast<const uint2*>(dst);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
+                *reinterpret_cast<uint2*>(dst) = o.raw;
+            } else {
+                for (int r = 0; r < 4 && n + r < N; ++r) {
+                    float x = v[r];
+                    if (p.accumulate) x += to_f32(dst[r]);
+                    dst[r] = from_f32<T>(x);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch256h(const G256Args& a, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256h_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_nt256h_kernel<T>), dim3((unsigned)a.total_tiles), dim3(512), LDS_H, st, a);
+    return uamd_launch_status();
+}
+
 template <typename T>
 int launch256(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
@@ -415,7 +643,14 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
     if ((int64_t)M * lda * 2 >= kSpan) return UAMD_ERR_ARG;
     G256Args a;
     a.A = A; a.lda = lda; a.M = M; a.K = K; a.n_groups = n_groups; a.accumulate = accumulate;
-    a.tiles_m = (M + TM - 1) / TM;
+    // tile height: 256 rows when that tiling fills the chip, else 128 rows (twice the tiles; UAMD_TUNE_GEMM_HALF:
+    // 0 = never, 1 = when the 256-row tiling has fewer than 192 tiles (default), 2 = always)
+    int tn_all = 0;
+    for (int i = 0; i < n_groups; ++i) tn_all += (groups[i].N + TN - 1) / TN;
+    const int half_mode = uamd_tuning_get(UAMD_TUNE_GEMM_HALF);
+    const bool half = half_mode == 2 || (half_mode == 1 && (int64_t)((M + TM - 1) / TM) * tn_all < 192);
+    const int tile_m = half ? TMH : TM;
+    a.tiles_m = (M + tile_m - 1) / tile_m;
     int tn = 0;
     for (int i = 0; i < UAMD_G256_MAX_GROUPS; ++i) {
         a.tile_start[i] = tn;
@@ -446,6 +681,11 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
         a.group_m = gm < 1 ? 1 : (gm < a.tiles_m ? gm : a.tiles_m);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (half) {
+        if (dtype == UAMD_BF16) return launch256h<bf16_t>(a, st);
+        if (dtype == UAMD_F16) return launch256h<f16_t>(a, st);
+        return UAMD_ERR_DTYPE;
+    }
     if (dtype == UAMD_BF16) return launch256<bf16_t>(a, st);
     if (dtype == UAMD_F16) return launch256<f16_t>(a, st);
     return UAMD_ERR_DTYPE;

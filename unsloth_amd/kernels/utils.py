@@ -134,8 +134,10 @@ def _use_gemm256(M, K, Ns):
         return False
     if GEMM256_MODE == "on":
         return True
-    tiles = ((M + 255) // 256) * sum((n + 255) // 256 for n in Ns)
-    return tiles >= GEMM256_MIN_TILES
+    cols = sum((n + 255) // 256 for n in Ns)
+    # 256 x 256 tiles when they fill the chip, else the same kernel family's 128 x 256 tiles (csrc/gemm256.hip picks
+    # the height); below that the 128 x 128 register-staged kernel
+    return ((M + 255) // 256) * cols >= GEMM256_MIN_TILES or ((M + 127) // 128) * cols >= GEMM256_MIN_TILES
 
 
 def _launch_gemm(X2d, groups, nf4, accumulate=False):
