@@ -92,6 +92,19 @@ int uamd_rope_embedding_qk(void* Q, int64_t q_batch_stride, int64_t q_head_strid
                            int n_heads_k, int head_dim, int backward, int q_dtype,
                            int table_dtype, void* stream);
 
+/* Multimodal RoPE ("mrope", Qwen2-VL text tower; SURVEY 8 f4 / BASELINE config 4). The reference has no kernel for it
+ * (its VLM path is the unsloth_zoo compiler); semantics = transformers' apply_multimodal_rotary_pos_emb:
+ * positions3 = int32 [3, batch*seqlen] (temporal, height, width position per token); rotary pair j uses the temporal
+ * position for j < section_t, the height position for j < section_t + section_h, else the width position.
+ * Everything else as uamd_rope_embedding_qk (in place, strided views, backward != 0 negates sin). */
+int uamd_rope_embedding_qk_mrope(void* Q, int64_t q_batch_stride, int64_t q_head_stride,
+                                 int64_t q_seq_stride, void* K, int64_t k_batch_stride,
+                                 int64_t k_head_stride, int64_t k_seq_stride, const void* cos,
+                                 int64_t cos_row_stride, const void* sin, int64_t sin_row_stride,
+                                 const int32_t* positions3, int section_t, int section_h, int batch,
+                                 int seqlen, int n_heads_q, int n_heads_k, int head_dim, int backward,
+                                 int q_dtype, int table_dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Gated MLP activations over n contiguous elements.
  * forward : h = f(e).to(dtype) * g            swiglu.py:27-47, geglu.py:31-53, :142-167

@@ -1,0 +1,81 @@
+"""-m gpu: multimodal RoPE (Qwen2-VL text tower, BASELINE config 4 / SURVEY 8 f4) on the HIP RoPE kernel against
+transformers' own `apply_multimodal_rotary_pos_emb` + `Qwen2VLRotaryEmbedding` (the implementation the reference's
+VLM path ends up running). Forward and backward; bf16 results must be BIT-identical (both sides multiply and add in
+the activation dtype: three roundings per element), fp32 within 2 ulp."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _hf_tables(pos3, D, theta, dtype):
+    """cos/sin [3, B, T, D] exactly as Qwen2VLRotaryEmbedding.forward builds them (fp32 angles, cast at the end)."""
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    freqs = pos3[..., None].float() * inv                       # [3, B, T, D/2]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def _table(n, D, theta, dtype):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+    fr = torch.outer(torch.arange(n, dtype=torch.int64).float(), inv)
+    emb = torch.cat((fr, fr), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("D,section,Hq,Hk", [(128, (16, 24, 24), 28, 4), (64, (8, 12, 12), 4, 2), (32, (3, 5, 8), 2, 1)])
+def test_mrope_matches_transformers(dtype, D, section, Hq, Hk):
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import apply_multimodal_rotary_pos_emb
+    from unsloth_amd.kernels import fast_mrope_embedding
+    B, T, theta = 2, 37, 1e6
+    g = torch.Generator().manual_seed(D)
+    # text tokens: all three streams equal; an image block: temporal constant, height / width a grid
+    pos3 = torch.arange(T)[None, None, :].repeat(3, B, 1)
+    pos3[0, :, 10:22] = 10
+    pos3[1, :, 10:22] = 10 + torch.arange(12) // 4
+    pos3[2, :, 10:22] = 10 + torch.arange(12) % 4
+    pos3[:, 1] += 5
+    Q = torch.randn(B, Hq, T, D, generator=g).to(dtype)
+    K = torch.randn(B, Hk, T, D, generator=g).to(dtype)
+    cos3, sin3 = _hf_tables(pos3, D, theta, dtype)
+    wantQ, wantK = apply_multimodal_rotary_pos_emb(Q, K, cos3, sin3, list(section))
+    cos, sin = _table(64, D, theta, dtype)
+    # strided [B,T,H,D] storage viewed as [B,H,T,D], like the model's projection outputs
+    Qd = Q.transpose(1, 2).contiguous().to(DEV).transpose(1, 2).requires_grad_(True)
+    Kd = K.transpose(1, 2).contiguous().to(DEV).transpose(1, 2).requires_grad_(True)
+    q, k = fast_mrope_embedding(Qd * 1.0, Kd * 1.0, cos.to(DEV), sin.to(DEV), pos3.to(DEV), section)
+    if dtype == torch.float32:
+        torch.testing.assert_close(q.cpu(), wantQ, rtol=3e-7, atol=3e-7)
+        torch.testing.assert_close(k.cpu(), wantK, rtol=3e-7, atol=3e-7)
+    else:
+        assert torch.equal(q.cpu(), wantQ) and torch.equal(k.cpu(), wantK)
+    # backward = the inverse rotation (sin -> -sin) of the upstream gradient; oracle: autograd through HF's function
+    dQ = torch.randn(B, Hq, T, D, generator=g).to(dtype)
+    dK = torch.randn(B, Hk, T, D, generator=g).to(dtype)
+    Qr, Kr = Q.clone().requires_grad_(True), K.clone().requires_grad_(True)
+    a, b = apply_multimodal_rotary_pos_emb(Qr, Kr, cos3, sin3, list(section))
+    torch.autograd.backward([a, b], [dQ, dK])
+    torch.autograd.backward([q, k], [dQ.to(DEV), dK.to(DEV)])
+    tol = dict(rtol=3e-7, atol=3e-7) if dtype == torch.float32 else dict(rtol=0, atol=0)
+    if dtype == torch.float32:
+        torch.testing.assert_close(Qd.grad.cpu(), Qr.grad, **tol)
+        torch.testing.assert_close(Kd.grad.cpu(), Kr.grad, **tol)
+    else:
+        # autograd's backward of (q*cos + rotate_half(q)*sin) rounds the two products and their sum like the kernel
+        assert torch.equal(Qd.grad.cpu(), Qr.grad) and torch.equal(Kd.grad.cpu(), Kr.grad)
+
+
+def test_mrope_with_equal_streams_is_ordinary_rope():
+    from unsloth_amd.kernels import fast_mrope_embedding, fast_rope_embedding
+    B, H, Hk, T, D = 1, 8, 2, 50, 128
+    g = torch.Generator().manual_seed(1)
+    Q = torch.randn(B, H, T, D, generator=g).to(torch.bfloat16).to(DEV)
+    K = torch.randn(B, Hk, T, D, generator=g).to(torch.bfloat16).to(DEV)
+    cos, sin = _table(128, D, 5e5, torch.bfloat16)
+    idx = torch.randint(0, 128, (B * T,), generator=g).to(torch.int32)
+    q1, k1 = fast_rope_embedding(Q.clone(), K.clone(), cos.to(DEV), sin.to(DEV), idx.to(DEV))
+    q2, k2 = fast_mrope_embedding(Q.clone(), K.clone(), cos.to(DEV), sin.to(DEV), idx.view(1, B, T).repeat(3, 1, 1).to(DEV),
+                                  (16, 24, 24))
+    assert torch.equal(q1, q2) and torch.equal(k1, k2)

@@ -54,6 +54,9 @@ SIGNATURES = {
     "uamd_rope_embedding_qk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                        c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int,
                                        c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "uamd_rope_embedding_qk_mrope": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                             c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int, c_int,
+                                             c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "uamd_swiglu_fg": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_swiglu_DWf_DW_dfg": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_geglu_exact_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

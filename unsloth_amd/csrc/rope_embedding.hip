@@ -27,7 +27,19 @@ struct RopeArgs {
     const int32_t* idx;
     int64_t n_rows;  // batch * seqlen
     int seqlen, n_heads_q, n_heads_k, head_dim, backward;
+    // multimodal RoPE (Qwen2-VL "mrope"): three position streams (temporal, height, width), pos3 = int32 [3, n_rows];
+    // rotary pair j takes its angle from stream 0 for j < sec1, 1 for j < sec2, else 2 (NULL: ordinary RoPE)
+    const int32_t* pos3;
+    int sec1, sec2;
 };
+
+__device__ __forceinline__ int64_t rope_position(const RopeArgs& a, int64_t row, int pair) {
+    if (a.pos3) {
+        const int stream = pair < a.sec1 ? 0 : (pair < a.sec2 ? 1 : 2);
+        return (int64_t)a.pos3[(int64_t)stream * a.n_rows + row];
+    }
+    return a.idx ? (int64_t)a.idx[row] : (row % a.seqlen);            // rope_embedding.py:46-56
+}
 
 template <typename T, bool NATIVE>
 __device__ __forceinline__ void rotate(float q0, float q1, float c, float s, T& o0, T& o1) {
@@ -52,8 +64,7 @@ __global__ void __launch_bounds__(256) rope_vec_kernel(RopeArgs a) {
     const int slot = threadIdx.x / vecs;
     const int nslots = 256 / vecs;
     if (slot >= nslots) return;
-    // rope_embedding.py:46-56 : gather index or row % seqlen
-    const int64_t pos = a.idx ? (int64_t)a.idx[row] : (row % a.seqlen);
+    const int64_t pos = rope_position(a, row, v * VEC);      // section boundaries are multiples of VEC here
     float c[VEC], s[VEC];
     load_w<TT, VEC>((const TT*)a.cos + pos * a.cos_rs + v * VEC, c);
     load_w<TT, VEC>((const TT*)a.sin + pos * a.sin_rs + v * VEC, s);
@@ -81,9 +92,6 @@ template <typename T, typename TT, bool NATIVE>
 __global__ void __launch_bounds__(256) rope_scalar_kernel(RopeArgs a) {
     const int half = a.head_dim >> 1;
     const int64_t row = blockIdx.x;
-    const int64_t pos = a.idx ? (int64_t)a.idx[row] : (row % a.seqlen);
-    const TT* cp = (const TT*)a.cos + pos * a.cos_rs;
-    const TT* sp = (const TT*)a.sin + pos * a.sin_rs;
     const int64_t b = row / a.seqlen, t = row - b * a.seqlen;
     const int total = a.n_heads_q + a.n_heads_k;
     for (int w = threadIdx.x; w < total * half; w += 256) {
@@ -91,8 +99,9 @@ __global__ void __launch_bounds__(256) rope_scalar_kernel(RopeArgs a) {
         T* p = (h < a.n_heads_q)
                    ? (T*)a.Q + b * a.q_bs + (int64_t)h * a.q_hs + t * a.q_ss
                    : (T*)a.K + b * a.k_bs + (int64_t)(h - a.n_heads_q) * a.k_hs + t * a.k_ss;
-        const float c = to_f32(cp[j]);
-        float s = to_f32(sp[j]);
+        const int64_t pos = rope_position(a, row, j);
+        const float c = to_f32(((const TT*)a.cos + pos * a.cos_rs)[j]);
+        float s = to_f32(((const TT*)a.sin + pos * a.sin_rs)[j]);
         if (a.backward) s = -s;
         T o0, o1;
         rotate<T, NATIVE>(to_f32(p[j]), to_f32(p[j + half]), c, s, o0, o1);
@@ -110,6 +119,7 @@ int launch(const RopeArgs& a, hipStream_t st) {
                   (a.cos_rs % VEC == 0) && (a.sin_rs % VEC == 0) &&
                   ((reinterpret_cast<uintptr_t>(a.cos) & 31) == 0) &&
                   ((reinterpret_cast<uintptr_t>(a.sin) & 31) == 0);
+    if (a.pos3) vec_ok = vec_ok && (a.sec1 % VEC == 0) && (a.sec2 % VEC == 0);
     if (a.n_heads_k > 0)
         vec_ok = vec_ok && aligned16(a.K) && (a.k_bs % VEC == 0) && (a.k_hs % VEC == 0) &&
                  (a.k_ss % VEC == 0);
@@ -151,6 +161,7 @@ extern "C" int uamd_rope_embedding(void* Q, int64_t q_row_stride, const void* co
     a.cos = cos; a.cos_rs = cos_row_stride; a.sin = sin; a.sin_rs = sin_row_stride;
     a.idx = nullptr; a.n_rows = n_rows; a.seqlen = seqlen; a.n_heads_q = n_heads;
     a.n_heads_k = 0; a.head_dim = head_dim; a.backward = backward;
+    a.pos3 = nullptr; a.sec1 = a.sec2 = 0;
     return dispatch(a, q_dtype, table_dtype, (hipStream_t)stream);
 }
 
@@ -172,5 +183,31 @@ extern "C" int uamd_rope_embedding_qk(void* Q, int64_t q_batch_stride, int64_t q
     a.idx = rope_indices; a.n_rows = (int64_t)batch * seqlen; a.seqlen = seqlen;
     a.n_heads_q = n_heads_q; a.n_heads_k = K ? n_heads_k : 0; a.head_dim = head_dim;
     a.backward = backward;
+    a.pos3 = nullptr; a.sec1 = a.sec2 = 0;
+    return dispatch(a, q_dtype, table_dtype, (hipStream_t)stream);
+}
+
+// Multimodal RoPE (Qwen2-VL / Qwen2.5-VL "mrope", BASELINE config 4): the reference has no kernel for it (its VLM
+// path goes through the unsloth_zoo compiler); semantics = transformers' apply_multimodal_rotary_pos_emb
+// (models/qwen2_vl/modeling_qwen2_vl.py): positions3 int32 [3, batch*seqlen] = (temporal, height, width) position of
+// every token, mrope_section = (s_t, s_h, s_w) rotary pairs with s_t + s_h + s_w = head_dim / 2: pair j < s_t rotates
+// by the temporal position, s_t <= j < s_t + s_h by the height position, the rest by the width position. Same
+// in-place strided Q/K contract, same cos/sin table ([>= max position, >= head_dim/2]) as uamd_rope_embedding_qk.
+extern "C" int uamd_rope_embedding_qk_mrope(void* Q, int64_t q_batch_stride, int64_t q_head_stride,
+                                            int64_t q_seq_stride, void* K, int64_t k_batch_stride,
+                                            int64_t k_head_stride, int64_t k_seq_stride, const void* cos,
+                                            int64_t cos_row_stride, const void* sin, int64_t sin_row_stride,
+                                            const int32_t* positions3, int section_t, int section_h, int batch,
+                                            int seqlen, int n_heads_q, int n_heads_k, int head_dim, int backward,
+                                            int q_dtype, int table_dtype, void* stream) {
+    if (!positions3 || section_t < 0 || section_h < 0 || section_t + section_h > head_dim / 2) return UAMD_ERR_ARG;
+    RopeArgs a;
+    a.Q = Q; a.q_bs = q_batch_stride; a.q_hs = q_head_stride; a.q_ss = q_seq_stride;
+    a.K = K; a.k_bs = k_batch_stride; a.k_hs = k_head_stride; a.k_ss = k_seq_stride;
+    a.cos = cos; a.cos_rs = cos_row_stride; a.sin = sin; a.sin_rs = sin_row_stride;
+    a.idx = nullptr; a.n_rows = (int64_t)batch * seqlen; a.seqlen = seqlen;
+    a.n_heads_q = n_heads_q; a.n_heads_k = K ? n_heads_k : 0; a.head_dim = head_dim;
+    a.backward = backward;
+    a.pos3 = positions3; a.sec1 = section_t; a.sec2 = section_t + section_h;
     return dispatch(a, q_dtype, table_dtype, (hipStream_t)stream);
 }

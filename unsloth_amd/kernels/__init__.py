@@ -15,6 +15,8 @@ from .rms_layernorm import (
 from .rope_embedding import (
     fast_rope_embedding,
     inplace_rope_embedding,
+    fast_mrope_embedding,
+    Fast_MRoPE_Embedding_QK,
     Fast_RoPE_Embedding,
     Fast_RoPE_Embedding_QK,
 )

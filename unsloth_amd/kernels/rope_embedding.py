@@ -4,6 +4,8 @@
   Fast_RoPE_Embedding_QK  (:283-399)  Q,K as [B,H,T,D] (possibly strided views), optional int32
                                       per-token gather indices, one launch for Q and K
   fast_rope_embedding     (:265-280)  dispatch on rope_embedding_indices
+  fast_mrope_embedding                Qwen2-VL multimodal RoPE (3 position streams) on the same kernel; oracle =
+                                      transformers' apply_multimodal_rotary_pos_emb
   inplace_rope_embedding  (:435-439)  explicit positions -> the same kernel with gather indices (the reference's
                                       torch formulation Slow_RoPE_Embedding :402-432 has no counterpart here: the
                                       oracle restates it, oracle/ref_ops.py)
@@ -109,6 +111,53 @@ class Fast_RoPE_Embedding_QK(torch.autograd.Function):
 def fast_rope_embedding(Q, K, cos, sin, rope_embedding_indices=None):
     """rope_embedding.py:265-280. Q [B,Hq,T,D], K [B,Hk,T,D] -> (Q, K) rotated."""
     return Fast_RoPE_Embedding_QK.apply(Q, K, cos, sin, rope_embedding_indices)
+
+
+class Fast_MRoPE_Embedding_QK(torch.autograd.Function):
+    """Multimodal RoPE (Qwen2-VL text tower): Q [B,Hq,T,D], K [B,Hk,T,D] rotated in place with three
+    position streams. `positions3` int [3, B, T] (temporal, height, width), `mrope_section` = (s_t, s_h, s_w) rotary
+    pairs per stream (Qwen2-VL-7B: 16, 24, 24). cos/sin: the ordinary [max_position, D] table of the text model.
+    Semantics and rounding points = transformers' apply_multimodal_rotary_pos_emb (which the tests use as oracle)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, cos, sin, positions3, mrope_section):
+        _lib.require_gpu(Q, K, cos, sin)
+        cos, sin = _tables(cos, sin)
+        s_t, s_h, s_w = (int(x) for x in mrope_section)
+        assert s_t + s_h + s_w == Q.shape[-1] // 2, "mrope_section must cover head_dim / 2 rotary pairs"
+        Q_out = Q if Q.stride(-1) == 1 else Q.contiguous()
+        K_out = K if K.stride(-1) == 1 else K.contiguous()
+        B, _, T, _ = Q.shape
+        pos3 = positions3.to(device=Q.device, dtype=torch.int32).reshape(3, -1).contiguous()
+        assert pos3.shape[1] == B * T
+        ctx.args = (cos, sin, pos3, s_t, s_h)
+        Fast_MRoPE_Embedding_QK._run(Q_out, K_out, cos, sin, pos3, s_t, s_h, False)
+        return Q_out, K_out
+
+    @staticmethod
+    def _run(Q, K, cos, sin, pos3, s_t, s_h, backward):
+        batch, n_heads_Q, seq_len, head_dim = Q.shape
+        with _lib.device_ctx(Q):
+            rc = _lib.lib().uamd_rope_embedding_qk_mrope(
+                _lib.ptr(Q), Q.stride(0), Q.stride(1), Q.stride(2), _lib.ptr(K), K.stride(0), K.stride(1), K.stride(2),
+                _lib.ptr(cos), cos.stride(0), _lib.ptr(sin), sin.stride(0), _lib.ptr(pos3), s_t, s_h, batch, seq_len,
+                n_heads_Q, K.shape[1], head_dim, int(backward), _lib.dtype_code(Q.dtype), _lib.dtype_code(cos.dtype),
+                _lib.stream_of(Q))
+        _lib.check(rc, "uamd_rope_embedding_qk_mrope")
+
+    @staticmethod
+    def backward(ctx, dQ, dK):
+        cos, sin, pos3, s_t, s_h = ctx.args
+        dQ = dQ if dQ.stride(-1) == 1 else dQ.contiguous()
+        dK = dK if dK.stride(-1) == 1 else dK.contiguous()
+        Fast_MRoPE_Embedding_QK._run(dQ, dK, cos, sin, pos3, s_t, s_h, True)
+        return dQ, dK, None, None, None, None
+
+
+@torch.compiler.disable
+def fast_mrope_embedding(Q, K, cos, sin, positions3, mrope_section):
+    """(Q, K) rotated by multimodal RoPE; see Fast_MRoPE_Embedding_QK."""
+    return Fast_MRoPE_Embedding_QK.apply(Q, K, cos, sin, positions3, tuple(mrope_section))
 
 
 def inplace_rope_embedding(Q, K, cos, sin, position_ids):

@@ -33,6 +33,7 @@ from ..kernels import (
     apply_lora_qkv,
     fast_cross_entropy_loss,
     fast_rms_layernorm,
+    fast_mrope_embedding,
     fast_rope_embedding,
     unsloth_fused_ce_loss,
 )
@@ -64,6 +65,14 @@ def _rope_params(config):
     merged = dict(rs)
     merged.update(rp)
     return float(theta), kind, merged
+
+
+def _mrope_section(config):
+    """(s_t, s_h, s_w) rotary pairs per position stream of a Qwen2-VL style config, else None."""
+    rp = getattr(config, "rope_parameters", None) or {}
+    rs = getattr(config, "rope_scaling", None) or {}
+    sec = rp.get("mrope_section", None) or rs.get("mrope_section", None)
+    return tuple(int(x) for x in sec) if sec else None
 
 
 def compute_inv_freq(config):
@@ -196,7 +205,10 @@ def LlamaAttention_fast_forward(self, hidden_states, cos, sin, rope_position_ids
     Q = Q.view(bsz, q_len, n_heads, head_dim).transpose(1, 2)
     K = K.view(bsz, q_len, n_kv_heads, head_dim).transpose(1, 2)
     V = V.view(bsz, q_len, n_kv_heads, head_dim).transpose(1, 2)
-    Q, K = fast_rope_embedding(Q, K, cos, sin, rope_position_ids)        # in place on the strided views
+    if isinstance(rope_position_ids, tuple):                             # multimodal RoPE: (positions3, mrope_section)
+        Q, K = fast_mrope_embedding(Q, K, cos, sin, rope_position_ids[0], rope_position_ids[1])
+    else:
+        Q, K = fast_rope_embedding(Q, K, cos, sin, rope_position_ids)    # in place on the strided views
     attn_output = _attention(Q, K, V, seq_info, attention_mask, getattr(cfg, "sliding_window", None))
     return self.apply_o(self, attn_output)
 
@@ -248,6 +260,14 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
     if attention_mask is not None and (attention_mask.dim() != 2 or bool(torch.all(attention_mask != 0))):
         attention_mask = None
     rope_position_ids = None
+    mrope = None
+    if position_ids is not None and position_ids.dim() == 3 and position_ids.shape[0] == 3:
+        # Qwen2-VL style multimodal positions [3, B, T] (temporal, height, width): the text tower of BASELINE config 4
+        section = _mrope_section(self.config)
+        if section is None:
+            raise ValueError("position_ids of shape [3, B, T] need `mrope_section` in the config's rope parameters")
+        mrope = (position_ids.to(device=hidden_states.device, dtype=torch.int32).contiguous(), section)
+        position_ids = None
     if position_ids is not None:
         rope_position_ids = position_ids.to(device=hidden_states.device, dtype=torch.int32)    # :945-948
         if rope_position_ids.dim() == 1:
@@ -261,6 +281,8 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
         assert int(rope_position_ids.max()) < cos.shape[0]
     gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
     policy = getattr(self, "_unsloth_amd_layer_policy", None)
+    if mrope is not None:
+        rope_position_ids, policy = mrope, None          # (positions3, section): only the per-block composition below
     if policy is not None and self.training and torch.is_grad_enabled() \
             and all(_fast_layer.layer_supported(l, hidden_states, attention_mask) for l in self.layers):
         # use_gradient_checkpointing="unsloth": every layer is ONE manual-autograd Function that keeps what the
