@@ -418,13 +418,106 @@ def CausalLM_fast_forward(original_forward):
 
 
 # ------------------------------------------------------------------------------------------------
+# Class-level patch points (llama.py:2300-2319). The reference assigns its fast forwards to the HF classes so that
+# code which calls a LAYER directly (not the CausalLM) still runs the fused kernels. transformers 5.x passes
+# different arguments to these methods than the reference's pinned versions, so each patch below is an adapter with
+# HF's current signature around the same fast composition; instances that were not prepared by FastLlamaModel
+# (no `apply_qkv` hook, no rope tables) and cached / decoding calls fall through to the original method.
 _PATCHED = {}
 
 
+def _patch_method(cls, name, make):
+    key = (cls, name)
+    if key not in _PATCHED:
+        original = getattr(cls, name)
+        _PATCHED[key] = original
+        setattr(cls, name, make(original))
+
+
+def unpatch_all():
+    """Restore every class-level method replaced by pre_patch()."""
+    for (cls, name), original in list(_PATCHED.items()):
+        setattr(cls, name, original)
+    _PATCHED.clear()
+
+
+def _hf_attention_forward(original):
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None, **kwargs):
+        if (not hasattr(self, "apply_qkv") or past_key_values is not None or position_embeddings is None
+                or (attention_mask is not None and attention_mask.dim() != 2)
+                or hidden_states.dtype not in (torch.bfloat16, torch.float16) or not hidden_states.is_cuda):
+            return original(self, hidden_states, position_embeddings=position_embeddings,
+                            attention_mask=attention_mask, past_key_values=past_key_values, **kwargs)
+        cos, sin = position_embeddings                   # HF hands over the rows already gathered per token [B,T,D]
+        B, T, _ = hidden_states.shape
+        D = cos.shape[-1]
+        cos = cos.expand(B, T, D).reshape(B * T, D)
+        sin = sin.expand(B, T, D).reshape(B * T, D)
+        idx = torch.arange(B * T, dtype=torch.int32, device=hidden_states.device)   # table row == token
+        if attention_mask is not None and bool(torch.all(attention_mask != 0)):
+            attention_mask = None
+        out = LlamaAttention_fast_forward(self, hidden_states, cos, sin, idx, None, attention_mask)
+        return out, None
+    return forward
+
+
+def _hf_decoder_layer_forward(original):
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                position_embeddings=None, **kwargs):
+        if not hasattr(self.self_attn, "apply_qkv") or past_key_values is not None or position_embeddings is None:
+            return original(self, hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                            past_key_values=past_key_values, use_cache=use_cache,
+                            position_embeddings=position_embeddings, **kwargs)
+        residual = hidden_states
+        x = fast_rms_layernorm(self.input_layernorm, hidden_states)
+        x, _ = self.self_attn(hidden_states=x, attention_mask=attention_mask, position_ids=position_ids,
+                              past_key_values=None, use_cache=use_cache, position_embeddings=position_embeddings,
+                              **kwargs)
+        residual, x = fast_add_rms_layernorm(self.post_attention_layernorm, x, residual)
+        return residual + self.mlp(x)
+    return forward
+
+
+def _hf_model_forward(original):
+    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None,
+                inputs_embeds=None, use_cache=None, **kwargs):
+        fast = (getattr(self, "_unsloth_amd_rope", None) is not None and past_key_values is None
+                and (self.training or not use_cache))
+        if not fast:
+            return original(self, input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
+                            past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache,
+                            **kwargs)
+        from transformers.modeling_outputs import BaseModelOutputWithPast
+        h = LlamaModel_fast_forward(self, input_ids=input_ids, attention_mask=attention_mask,
+                                    position_ids=position_ids, inputs_embeds=inputs_embeds, **kwargs)
+        return BaseModelOutputWithPast(last_hidden_state=h, past_key_values=None)
+    return forward
+
+
+def PeftModel_fast_forward(self, input_ids=None, causal_mask=None, attention_mask=None, inputs_embeds=None,
+                           labels=None, output_attentions=None, output_hidden_states=None, return_dict=None,
+                           task_ids=None, num_logits_to_keep=0, logits_to_keep=0, **kwargs):
+    """llama.py:1594-1634: PEFT's wrapper forwards straight to the (patched) base model, dropping the adapter
+    bookkeeping arguments the fused path has no use for."""
+    return self.base_model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds,
+                           labels=labels, return_dict=return_dict, num_logits_to_keep=num_logits_to_keep,
+                           logits_to_keep=logits_to_keep, **kwargs)
+
+
 def _patch_causal_lm_class(cls):
-    if cls not in _PATCHED:
-        _PATCHED[cls] = cls.forward
-        cls.forward = CausalLM_fast_forward(cls.forward)
+    _patch_method(cls, "forward", CausalLM_fast_forward)
+
+
+def _patch_architecture(mod, prefix):
+    """Attention / DecoderLayer / Model / ForCausalLM of one modeling module (llama, mistral, qwen2 share the code)."""
+    for suffix, make in (("Attention", _hf_attention_forward), ("DecoderLayer", _hf_decoder_layer_forward),
+                         ("Model", _hf_model_forward)):
+        cls = getattr(mod, prefix + suffix, None)
+        if cls is not None:
+            _patch_method(cls, "forward", make)
+    cls = getattr(mod, prefix + "ForCausalLM", None)
+    if cls is not None:
+        _patch_causal_lm_class(cls)
 
 
 class FastLlamaModel:
@@ -433,19 +526,20 @@ class FastLlamaModel:
     @staticmethod
     def pre_patch():
         """llama.py:2288-2320: class-level forward replacement + HF RMSNorm class swap + loss mapping."""
-        from transformers.models.llama.modeling_llama import LlamaForCausalLM
+        import importlib
         from ..kernels import patch_loss_functions, patch_rms_layernorm
-        _patch_causal_lm_class(LlamaForCausalLM)
-        try:
-            from transformers.models.mistral.modeling_mistral import MistralForCausalLM
-            _patch_causal_lm_class(MistralForCausalLM)
+        for modname, prefix in (("llama", "Llama"), ("mistral", "Mistral"), ("qwen2", "Qwen2")):
+            try:
+                mod = importlib.import_module(f"transformers.models.{modname}.modeling_{modname}")
+            except Exception:
+                continue
+            _patch_architecture(mod, prefix)
+        try:                                             # real PEFT, when installed (not in this image)
+            import peft
+            _patch_method(peft.PeftModelForCausalLM, "forward", lambda original: PeftModel_fast_forward)
         except Exception:
             pass
-        try:
-            from transformers.models.qwen2.modeling_qwen2 import Qwen2ForCausalLM
-            _patch_causal_lm_class(Qwen2ForCausalLM)
-        except Exception:
-            pass
+        _patch_method(_lora.PeftModelForCausalLM, "forward", lambda original: PeftModel_fast_forward)
         patch_rms_layernorm()
         patch_loss_functions()
 

@@ -53,6 +53,70 @@ else:
     UnslothTrainer = UnslothTrainingArguments = _NeedsTRL
 
 
+def _config_only_names(config_class):
+    """Names a TRL `XConfig` accepts that plain `transformers.TrainingArguments` does not: since TRL 0.13 they can
+    no longer be passed to the Trainer itself."""
+    import inspect
+    from transformers import TrainingArguments
+    return set(inspect.signature(config_class).parameters) - set(inspect.signature(TrainingArguments).parameters)
+
+
+def _backwards_compatible_trainer(trainer_class, config_class):
+    """`__init__` wrapper of trainer.py:714-783: scripts written for TRL < 0.13 keep working --
+    `tokenizer=` becomes `processing_class=`, and keyword arguments that moved from `XTrainer(...)` to `XConfig(...)`
+    (max_seq_length, dataset_text_field, packing, ...) are set on the config object passed as `args`."""
+    import functools
+    import inspect
+    original_init = trainer_class.__init__
+    trainer_params = set(inspect.signature(original_init).parameters)
+
+    @functools.wraps(original_init)
+    def new_init(self, *args, **kwargs):
+        if "processing_class" in trainer_params and "tokenizer" in kwargs and "tokenizer" not in trainer_params:
+            kwargs["processing_class"] = kwargs.pop("tokenizer")
+        config = kwargs.get("args")
+        if config is not None:
+            moved = _config_only_names(config_class)
+            for key in [k for k in kwargs if k not in trainer_params]:
+                if key in moved or hasattr(config, key):
+                    setattr(config, key, kwargs.pop(key))
+        original_init(self, *args, **kwargs)
+    new_init._unsloth_backwards_compatible = True
+    return new_init
+
+
+def _patch_trl_trainer():
+    """trainer.py:988-1021: make every `trl.XTrainer` whose `trl.XConfig` exists accept the pre-0.13 calling
+    convention. Returns the list of patched trainer names ([] when TRL is absent, too old, or already patched)."""
+    try:
+        import trl
+        import trl.trainer
+    except Exception:
+        return []
+    if hasattr(trl, "__UNSLOTH_BACKWARDS_COMPATIBLE__"):
+        return []
+    try:
+        from packaging.version import Version
+        if Version(getattr(trl, "__version__", "0")) <= Version("0.11.0"):
+            return []
+    except Exception:
+        pass
+    names = dir(trl.trainer)
+    trainers = {n[: -len("Trainer")] for n in names if n.endswith("Trainer")}
+    configs = {n[: -len("Config")] for n in names if n.endswith("Config")}
+    done = []
+    for x in sorted(trainers & configs):
+        try:
+            tc, cc = getattr(trl, x + "Trainer", None) or getattr(trl.trainer, x + "Trainer"), \
+                getattr(trl, x + "Config", None) or getattr(trl.trainer, x + "Config")
+            tc.__init__ = _backwards_compatible_trainer(tc, cc)
+            done.append(x)
+        except Exception:
+            continue
+    trl.__UNSLOTH_BACKWARDS_COMPATIBLE__ = True
+    return done
+
+
 def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999)):
     params = [p for p in model.parameters() if p.requires_grad]
     fused = params[0].is_cuda
