@@ -41,7 +41,7 @@ def llama3_8b_config(n_layers=32, vocab=128256):
         attention_bias=False, mlp_bias=False)
 
 
-KERNEL_OF = {"uamd_gemm_nt_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nt": "gemm_nt_kernel<bf16,dense>",
+KERNEL_OF = {"uamd_gemm_nt_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nn_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nt": "gemm_nt_kernel<bf16,dense>",
              "uamd_gemm_nt_nf4": "gemm_nt_kernel<bf16,NF4>"}
 
 
@@ -59,9 +59,9 @@ class GemmTimer:
     def install(self):
         U, orig, recs = self.U, self.orig, self.records
 
-        def timed(X2d, groups, nf4, accumulate=False):
+        def timed(X2d, groups, nf4, accumulate=False, nn=False):
             if not self.enabled:
-                return orig(X2d, groups, nf4, accumulate)
+                return orig(X2d, groups, nf4, accumulate, nn)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             flops = 2.0 * X2d.shape[0] * X2d.shape[1] * sum(g.N for g in groups)
             flops += sum(2.0 * X2d.shape[0] * g.R * g.N for g in groups if g.lora_xa)
@@ -69,7 +69,7 @@ class GemmTimer:
             M_, K_ = X2d.shape
             nbytes = 2.0 * M_ * K_ + sum(2.0 * g.N * K_ + 2.0 * M_ * g.N * (2 if accumulate else 1) for g in groups)
             s.record()
-            name = orig(X2d, groups, nf4, accumulate)
+            name = orig(X2d, groups, nf4, accumulate, nn)
             e.record()
             recs.setdefault(KERNEL_OF[name], []).append((s, e, flops, nbytes))
             return name

@@ -210,6 +210,12 @@ int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group
  * K % 64 == 0 and every operand to span less than 4 GiB. */
 int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
+/* uamd_gemm_nn_256: the same kernels with B_g given as [K, N_g] (N contiguous, ldb = row stride) and the rank block's
+ * BK_g as [Rk, N_g]: C_g (+)= A @ B_g (+ XK @ BK_g). The dX products of the backward (dX = dY @ W with W stored
+ * [out, in], fast_lora.py:156, :193-204) contract over the weight's ROWS: they read the forward's row-major decode
+ * through transposing LDS reads instead of a transposed copy of W. N_g % 8 == 0, ldb % 8 == 0. */
+int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                     int n_groups, int accumulate, int dtype, void* stream);
 /* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
  *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernel (L2 reuse) */
 #define UAMD_TUNE_GLU_VAR 0     /* (UAMD_GLU_VAR) gated-MLP activation kernels: 0 = 2048-block grid-stride, 1 = uncapped grid,

@@ -108,8 +108,8 @@ def test_lora_qkv_backward_merged_gemm(monkeypatch):
     dd = d.to(DEV)
     launches = []
     orig = U._launch_gemm
-    monkeypatch.setattr(U, "_launch_gemm", lambda X2d, groups, nf4, accumulate=False: (
-        launches.append((tuple(X2d.shape), accumulate)), orig(X2d, groups, nf4, accumulate))[1])
+    monkeypatch.setattr(U, "_launch_gemm", lambda X2d, groups, nf4, accumulate=False, nn=False: (
+        launches.append((tuple(X2d.shape), accumulate)), orig(X2d, groups, nf4, accumulate, nn))[1])
     torch.autograd.backward([Q, Kk, V], [dd[..., :H], dd[..., H:H + Hkv], dd[..., H + Hkv:]])
     assert launches == [((Bz * T, H + 2 * Hkv), False)], launches
     dX = 0

@@ -140,6 +140,28 @@ def test_selective_recompute_saves_memory_in_the_expected_order():
     assert peaks["unsloth:all"] <= 1.1 * peaks[False], peaks
 
 
+def test_layer_called_with_hf_signature_runs_the_fused_path():
+    """class-level patch points (llama.py:2300-2319): code that calls a decoder layer / the base model with
+    transformers' own signatures gets the fused composition, with the same numbers as the CausalLM path."""
+    from unsloth_amd.models import llama as L
+    model = _tiny(gc=False, head_dim=128)
+    base = model.get_base_model()
+    ids, _, pos = _batch(seed=7)
+    ids, pos = ids.to(DEV), pos.to(DEV)
+    with torch.no_grad():
+        want = L.LlamaModel_fast_forward(base.model, input_ids=ids, position_ids=pos)
+        out = base.model(input_ids=ids, position_ids=pos.long())                 # HF LlamaModel signature
+        assert torch.equal(out.last_hidden_state, want)
+        h = base.model.embed_tokens(ids).to(torch.bfloat16)
+        pe = base.model.rotary_emb(h, pos.long())
+        layer = base.model.layers[0]
+        got = layer(h, position_embeddings=pe)                                    # HF LlamaDecoderLayer signature
+        cos, sin = base.model._unsloth_amd_rope.get(96, DEV, torch.bfloat16)
+        ref = L.LlamaDecoderLayer_fast_forward(layer, h, cos, sin, pos.reshape(-1))
+        got = got if torch.is_tensor(got) else got[0]
+        assert torch.equal(got, ref)
+
+
 def test_return_logits_branch_and_n_items():
     from oracle.ref_model import hf_reference_loss_and_lora_grads
     model = _tiny()

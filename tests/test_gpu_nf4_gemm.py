@@ -289,6 +289,58 @@ def test_gemm256_tile_heights(force256, half, M, N, K):
         L.uamd_set_tuning(6, 1)
 
 
+@pytest.mark.parametrize("half", [0, 2])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 192), (2048, 4096, 1024), (1000, 1024, 6144), (128, 8, 64),
+                                   (77, 4104, 128)])
+def test_gemm256_nn_form(half, dtype, M, N, K):
+    """uamd_gemm_nn_256: C = A @ B with B [K, N] row-major (the dX products: contraction over the weight's ROWS through
+    transposing LDS reads), both tile heights, rank block as [Rk, N] extra K tiles, accumulate, ragged M / N,
+    bitwise run-to-run determinism; and it equals the NT form fed the transposed operand bit for bit."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels.utils import _group, _launch_gemm, rank_block_bk
+    X = torch.randn(M, K, generator=g(161)).to(dtype)
+    B = (torch.randn(K, N, generator=g(162)) * 0.05).to(dtype)
+    P = torch.randn(M, 16, generator=g(163))
+    Al = torch.randn(16, N, generator=g(164)) * 0.05
+    L = _lib.lib()
+    Xd, Bd = X.to(DEV), B.to(DEV)
+    try:
+        L.uamd_set_tuning(6, half)
+        C = torch.empty(M, N, dtype=dtype, device=DEV)
+        _launch_gemm(Xd, [_group(Bd, C, N, Bd.stride(0))], nf4=False, nn=True)
+        ref = X.float() @ B.float()
+        _check_gemm(C, ref, dtype, K, f"gemm_nn {M}x{N}x{K} half={half}")
+        C2 = torch.empty_like(C)
+        _launch_gemm(Xd, [_group(Bd, C2, N, Bd.stride(0))], nf4=False, nn=True)
+        assert torch.equal(C, C2)
+        # same product through the NT form on B^T: identical accumulation order -> identical bits
+        Bt = Bd.t().contiguous()
+        C3 = torch.empty_like(C)
+        from unsloth_amd.kernels import utils as U
+        old = U.GEMM256_MODE
+        U.GEMM256_MODE = "on"
+        try:
+            _launch_gemm(Xd, [_group(Bt, C3, N, Bt.stride(0))], nf4=False)
+        finally:
+            U.GEMM256_MODE = old
+        assert torch.equal(C, C3)
+        # rank block: XK = T(P) zero-padded to 64 columns, BK = [2.0 * Al; 0] as [64, N]; then accumulate on top
+        xk = torch.zeros(M, 64, dtype=dtype, device=DEV)
+        xk[:, :16] = P.to(DEV)
+        bk = rank_block_bk([(Al.to(DEV), 0, 2.0)], 64, N, False, dtype, by_rows=True)
+        C4 = torch.empty_like(C)
+        _launch_gemm(Xd, [_group(Bd, C4, N, Bd.stride(0), xa=P.to(DEV), ld_xa=16, R=16, scale=2.0, xk=xk, bk=bk)],
+                     nf4=False, nn=True)
+        ref4 = ref + P.to(dtype).float() @ (2.0 * Al).to(dtype).float()
+        _check_gemm(C4, ref4, dtype, K, "gemm_nn + rank block")
+        C5 = C.clone()
+        _launch_gemm(Xd, [_group(Bd, C5, N, Bd.stride(0))], nf4=False, accumulate=True, nn=True)
+        _check_gemm(C5, C.float().cpu() + ref, dtype, K, "gemm_nn accumulate")
+    finally:
+        L.uamd_set_tuning(6, 1)
+
+
 def test_gemm256_transpose_detecting_and_k_order(force256):
     from unsloth_amd.kernels.utils import lora_linear_forward
     M, N, K = 512, 512, 256

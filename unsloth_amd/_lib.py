@@ -81,6 +81,8 @@ SIGNATURES = {
                              c_int, c_void_p]),
     "uamd_gemm_nt_256": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
                                  c_int, c_void_p]),
+    "uamd_gemm_nn_256": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
+                                 c_int, c_void_p]),
     "uamd_set_tuning": (c_int, [c_int, c_int]),
     "uamd_gemm_nt_nf4": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int,
                                  c_int, c_int, c_void_p]),

@@ -71,6 +71,8 @@ struct G256Args {
 };
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 
 // One wave-instruction of LDS-DMA: 64 lanes x 16 B from per-lane global addresses -> LDS [lds_addr,
 // lds_addr + 1024). Issued through inline asm ON PURPOSE: with the builtin, hipcc treats every later ds_read
@@ -133,7 +135,15 @@ __device__ unsigned* g_trace256 = nullptr;
 #define STAMP(KT, I) do { } while (0)
 #endif
 
-template <typename T>
+// BNN = false: B_g is [N, K] (K contiguous, the forward's weight layout): C = A @ B^T.
+// BNN = true : B_g is [K, N] (N contiguous): C = A @ B -- the dX products contract over the weight's ROWS, so they
+//              read the SAME row-major decode as the forward and no transposed copy of W is ever written. The B
+//              tile is then [64 k][256 n] in LDS (DMA pieces of 2 k-rows x 512 B), and the MFMA operand -- 8
+//              consecutive k for one n per lane -- comes out of it through two ds_read_b64_tr_b16 (each hands a
+//              lane 4 consecutive k of its column; semantics probed in profiles/r01_tr_probe.txt). Bank swizzle:
+//              32-byte granule ^= (k & 3) | ((k >> 3) & 1) << 2, applied on the DMA source column: the 8 rows a
+//              32-lane half of the transposing read touches land in 8 different granules of the 256-byte bank row.
+template <typename T, bool BNN>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -194,15 +204,30 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     };
     const uint64_t a_gbase = sgpr64(p.A), b_gbase = sgpr64(g.B);
     unsigned a_off[4], b_off[4];                    // byte offsets of this lane's row / slot (host: < 4 GiB)
+    // BNN: lane -> (k-row of the piece's pair = lane >> 5, physical 16-byte slot = lane & 31 of the 512-byte row)
+    const int nn_krow = lane >> 5;
+    auto nn_col = [&](int krow) {                   // source column (elements) of this lane's slot in k-row `krow`
+        const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+        int col = n0 + (((lane & 31) ^ (f << 1)) << 3);
+        return col + 8 <= N ? col : N - 8;          // columns past N are never stored
+    };
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         int ra = m0 + (c * 8 + wave) * 8 + sub_row;
-        int rb = n0 + (c * 8 + wave) * 8 + sub_row;
         ra = ra < M ? ra : M - 1;          // clamped rows are never stored
-        rb = rb < N ? rb : N - 1;
         a_off[c] = (unsigned)(((int64_t)ra * p.lda + sub_slot * 8) * (int64_t)sizeof(T));
-        b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
+        if (BNN) {
+            const int krow = (c * 8 + wave) * 2 + nn_krow;
+            b_off[c] = (unsigned)(((int64_t)krow * g.ldb + nn_col(krow)) * (int64_t)sizeof(T));
+        } else {
+            int rb = n0 + (c * 8 + wave) * 8 + sub_row;
+            rb = rb < N ? rb : N - 1;
+            b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
+        }
     }
+    // bytes from one K tile of B to the next: 64 columns (NT) or 64 rows (NN)
+    const uint64_t b_tile_step = BNN ? (uint64_t)__builtin_amdgcn_readfirstlane((int)g.ldb) * (TK * sizeof(T))
+                                     : (uint64_t)(TK * sizeof(T));
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
     // K tiles: nk_main of the operands proper, then the rank block's. Both counts are wave-uniform by construction;
     // readfirstlane tells the compiler so (loop bounds and branches on them stay on the scalar unit).
@@ -211,7 +236,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     // issue_main: the hot path, branch-free (tiles of A / B proper). c, stage are compile-time at every call site.
     auto issue_main = [&](int c, int kt, int stage) {
         const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-        dma16s(c < 4 ? a_off[c & 3] : b_off[c & 3], (c < 4 ? a_gbase : b_gbase) + (uint64_t)kt * (TK * sizeof(T)), dst);
+        if (c < 4) dma16s(a_off[c & 3], a_gbase + (uint64_t)kt * (TK * sizeof(T)), dst);
+        else dma16s(b_off[c & 3], b_gbase + (uint64_t)kt * b_tile_step, dst);
     };
     // issue_any: used only by the prologue and the last few tiles, where the tile being fetched may belong to the
     // rank block: same piece geometry, sources are XK / BK rows (addresses rebuilt here: no registers are held
@@ -226,12 +252,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
             issue_main(c, kt, stage);
         } else {
             const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-            int row = (c < 4 ? m0 : n0) + ((c & 3) * 8 + wave) * 8 + sub_row;
-            const int last = (c < 4 ? M : N) - 1;
-            row = row < last ? row : last;
-            const int ld = c < 4 ? ld_xk : ld_bk;
-            const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
-            dma16s(off, (c < 4 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
+            if (BNN && c >= 4) {                         // BK is [Rk, N] here: same geometry as B proper
+                const int krow = ((c & 3) * 8 + wave) * 2 + nn_krow;
+                const unsigned off = (unsigned)(((int64_t)krow * ld_bk + nn_col(krow)) * (int64_t)sizeof(T));
+                dma16s(off, bk_base + (uint64_t)(kt - nk_main) * ((uint64_t)ld_bk * (TK * sizeof(T))), dst);
+            } else {
+                int row = (c < 4 ? m0 : n0) + ((c & 3) * 8 + wave) * 8 + sub_row;
+                const int last = (c < 4 ? M : N) - 1;
+                row = row < last ? row : last;
+                const int ld = c < 4 ? ld_xk : ld_bk;
+                const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
+                dma16s(off, (c < 4 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
+            }
         }
     };
 
@@ -252,14 +284,25 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
                 af[i][ks] = u.f;
             }
     };
+    // BNN fragment addresses: k-row ks*32 + l4*8 + (l15 >> 2) (+4 for the second read), logical granule wn*4 + t
+    const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
+    const int nn_lane = 32 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
     auto read_b = [&](int stage, int nq) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { uint4 r; frag_t f; } u;
-                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + b_base + (nq * 2 + j) * 2048 + frag_off[ks]);
-                bf[nq * 2 + j][ks] = u.f;
+                if (BNN) {
+                    union { s16x4_t h[2]; frag_t f; } u;
+                    const int a0 = stage * STAGE_BYTES + nn_lane + ks * (32 * 512) + (((wn * 4 + nq * 2 + j) ^ nn_f) << 5);
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + a0));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + a0 + 4 * 512));
+                    bf[nq * 2 + j][ks] = u.f;
+                } else {
+                    union { uint4 r; frag_t f; } u;
+                    u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + b_base + (nq * 2 + j) * 2048 + frag_off[ks]);
+                    bf[nq * 2 + j][ks] = u.f;
+                }
             }
     };
     auto mma = [&](int mq, int nq) {
@@ -392,7 +435,7 @@ constexpr int TMH = 128;
 constexpr int STAGE_H = (TMH + TN) * TK * 2;       // 48 KiB
 constexpr int LDS_H = 3 * STAGE_H;                 // 144 KiB
 
-template <typename T>
+template <typename T, bool BNN>
 __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -440,6 +483,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
     };
     const uint64_t a_gbase = sgpr64(p.A), b_gbase = sgpr64(g.B);
     unsigned a_off[2], b_off[4];
+    const int nn_krow = lane >> 5;                  // BNN: see gemm_nt256_kernel
+    auto nn_col = [&](int krow) {
+        const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+        int col = n0 + (((lane & 31) ^ (f << 1)) << 3);
+        return col + 8 <= N ? col : N - 8;
+    };
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         int ra = m0 + (c * 8 + wave) * 8 + sub_row;
@@ -448,16 +497,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int rb = n0 + (c * 8 + wave) * 8 + sub_row;
-        rb = rb < N ? rb : N - 1;
-        b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
+        if (BNN) {
+            const int krow = (c * 8 + wave) * 2 + nn_krow;
+            b_off[c] = (unsigned)(((int64_t)krow * g.ldb + nn_col(krow)) * (int64_t)sizeof(T));
+        } else {
+            int rb = n0 + (c * 8 + wave) * 8 + sub_row;
+            rb = rb < N ? rb : N - 1;
+            b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
+        }
     }
+    const uint64_t b_tile_step = BNN ? (uint64_t)__builtin_amdgcn_readfirstlane((int)g.ldb) * (TK * sizeof(T))
+                                     : (uint64_t)(TK * sizeof(T));
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
     const int nk_main = __builtin_amdgcn_readfirstlane(K / TK);
     const int nk = __builtin_amdgcn_readfirstlane(nk_main + (g.lora_xk != nullptr ? g.Rk / TK : 0));
     auto issue_main = [&](int c, int kt, int stage) {       // c, stage compile-time
         const unsigned dst = lds_base + stage * STAGE_H + (c * 8 + wave) * 1024;
-        dma16s(c < 2 ? a_off[c] : b_off[c - 2], (c < 2 ? a_gbase : b_gbase) + (uint64_t)kt * (TK * sizeof(T)), dst);
+        if (c < 2) dma16s(a_off[c], a_gbase + (uint64_t)kt * (TK * sizeof(T)), dst);
+        else dma16s(b_off[c - 2], b_gbase + (uint64_t)kt * b_tile_step, dst);
     };
     const uint64_t xk_base = sgpr64(g.lora_xk), bk_base = sgpr64(g.lora_bk);
     const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
@@ -466,12 +523,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
             issue_main(c, kt, stage);
         } else {
             const unsigned dst = lds_base + stage * STAGE_H + (c * 8 + wave) * 1024;
-            int row = (c < 2 ? m0 + (c * 8 + wave) * 8 : n0 + ((c - 2) * 8 + wave) * 8) + sub_row;
-            const int last = (c < 2 ? M : N) - 1;
-            row = row < last ? row : last;
-            const int ld = c < 2 ? ld_xk : ld_bk;
-            const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
-            dma16s(off, (c < 2 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
+            if (BNN && c >= 2) {
+                const int krow = ((c - 2) * 8 + wave) * 2 + nn_krow;
+                const unsigned off = (unsigned)(((int64_t)krow * ld_bk + nn_col(krow)) * (int64_t)sizeof(T));
+                dma16s(off, bk_base + (uint64_t)(kt - nk_main) * ((uint64_t)ld_bk * (TK * sizeof(T))), dst);
+            } else {
+                int row = (c < 2 ? m0 + (c * 8 + wave) * 8 : n0 + ((c - 2) * 8 + wave) * 8) + sub_row;
+                const int last = (c < 2 ? M : N) - 1;
+                row = row < last ? row : last;
+                const int ld = c < 2 ? ld_xk : ld_bk;
+                const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
+                dma16s(off, (c < 2 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
+            }
         }
     };
     const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
@@ -489,14 +552,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
                 af[i][ks] = u.f;
             }
     };
+    const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
+    const int nn_lane = 16 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
     auto read_b = [&](int stage, int nq) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { uint4 r; frag_t f; } u;
-                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_H + b_lbase + (nq * 2 + j) * 2048 + frag_off[ks]);
-                bf[nq * 2 + j][ks] = u.f;
+                if (BNN) {
+                    union { s16x4_t h[2]; frag_t f; } u;
+                    const int a0 = stage * STAGE_H + nn_lane + ks * (32 * 512) + (((wn * 4 + nq * 2 + j) ^ nn_f) << 5);
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + a0));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + a0 + 4 * 512));
+                    bf[nq * 2 + j][ks] = u.f;
+                } else {
+                    union { uint4 r; frag_t f; } u;
+                    u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_H + b_lbase + (nq * 2 + j) * 2048 + frag_off[ks]);
+                    bf[nq * 2 + j][ks] = u.f;
+                }
             }
     };
     auto mma = [&](int nq) {
@@ -593,33 +666,33 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
     }
 }
 
-template <typename T>
+template <typename T, bool BNN>
 int launch256h(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256h_kernel<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256h_kernel<T, BNN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_H);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_nt256h_kernel<T>), dim3((unsigned)a.total_tiles), dim3(512), LDS_H, st, a);
+    hipLaunchKernelGGL((gemm_nt256h_kernel<T, BNN>), dim3((unsigned)a.total_tiles), dim3(512), LDS_H, st, a);
     return uamd_launch_status();
 }
 
-template <typename T>
+template <typename T, bool BNN>
 int launch256(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T, BNN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_nt256_kernel<T>), dim3((unsigned)a.total_tiles), dim3(512), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt256_kernel<T, BNN>), dim3((unsigned)a.total_tiles), dim3(512), LDS_BYTES, st, a);
     return uamd_launch_status();
 }
 
@@ -633,8 +706,8 @@ extern "C" int uamd_debug_g256_trace(unsigned* buf) {
 
 // Same contract as uamd_gemm_nt (dense B), 256x256x64 tiles. Requires K % 64 == 0. The LoRA term comes as the
 // rank block lora_xk / lora_bk (extra K tiles); a group that only carries lora_xa / lora_b is rejected.
-extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
-                                int n_groups, int accumulate, int dtype, void* stream) {
+static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups, int n_groups,
+                         int accumulate, int dtype, void* stream, bool bnn) {
     if (M < 0 || K <= 0 || n_groups < 1 || n_groups > UAMD_G256_MAX_GROUPS || !groups) return UAMD_ERR_ARG;
     if (M == 0) return UAMD_OK;
     if ((K & 63) || (lda & 7) || !aligned16(A)) return UAMD_ERR_ALIGN;
@@ -658,13 +731,19 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
             const uamd_gemm_group& g = groups[i];
             if (g.N <= 0 || !g.B || !g.C) return UAMD_ERR_ARG;
             if ((g.ldb & 7) || !aligned16(g.B)) return UAMD_ERR_ALIGN;
-            if ((int64_t)g.N * g.ldb * 2 >= kSpan) return UAMD_ERR_ARG;
+            if (bnn) {                          // B_g [K, N]: N % 8 == 0 (whole 16-byte slots), rows x ldb below 4 GiB
+                if ((g.N & 7) || g.N < 8) return UAMD_ERR_ALIGN;
+                if ((int64_t)K * g.ldb * 2 >= kSpan || g.ldb > 0x7fffffffLL / 128) return UAMD_ERR_ARG;
+            } else if ((int64_t)g.N * g.ldb * 2 >= kSpan) {
+                return UAMD_ERR_ARG;
+            }
             if (g.lora_xa && !g.lora_xk) return UAMD_ERR_ARG;     // this kernel takes the rank block as K tiles
             if (g.lora_xk) {
                 if (!g.lora_bk || g.Rk <= 0) return UAMD_ERR_ARG;
                 if ((g.Rk & 63) || (g.ld_xk & 7) || (g.ld_bk & 7) || !aligned16(g.lora_xk) || !aligned16(g.lora_bk))
                     return UAMD_ERR_ALIGN;
-                if ((int64_t)M * g.ld_xk * 2 >= kSpan || (int64_t)g.N * g.ld_bk * 2 >= kSpan) return UAMD_ERR_ARG;
+                if ((int64_t)M * g.ld_xk * 2 >= kSpan) return UAMD_ERR_ARG;
+                if ((int64_t)(bnn ? g.Rk : g.N) * g.ld_bk * 2 >= kSpan || g.ld_bk > 0x7fffffffLL / 128) return UAMD_ERR_ARG;
             }
             a.g[i] = g;
             tn += (g.N + TN - 1) / TN;
@@ -682,11 +761,24 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
     }
     hipStream_t st = (hipStream_t)stream;
     if (half) {
-        if (dtype == UAMD_BF16) return launch256h<bf16_t>(a, st);
-        if (dtype == UAMD_F16) return launch256h<f16_t>(a, st);
+        if (dtype == UAMD_BF16) return bnn ? launch256h<bf16_t, true>(a, st) : launch256h<bf16_t, false>(a, st);
+        if (dtype == UAMD_F16) return bnn ? launch256h<f16_t, true>(a, st) : launch256h<f16_t, false>(a, st);
         return UAMD_ERR_DTYPE;
     }
-    if (dtype == UAMD_BF16) return launch256<bf16_t>(a, st);
-    if (dtype == UAMD_F16) return launch256<f16_t>(a, st);
+    if (dtype == UAMD_BF16) return bnn ? launch256<bf16_t, true>(a, st) : launch256<bf16_t, false>(a, st);
+    if (dtype == UAMD_F16) return bnn ? launch256<f16_t, true>(a, st) : launch256<f16_t, false>(a, st);
     return UAMD_ERR_DTYPE;
+}
+
+extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                                int n_groups, int accumulate, int dtype, void* stream) {
+    return gemm256_entry(A, lda, M, K, groups, n_groups, accumulate, dtype, stream, false);
+}
+
+// C_g[M, N_g] (+)= A[M, K] @ B_g[K, N_g] (+ rank block XK[M, Rk] @ BK_g[Rk, N_g]): B and BK row-major with the OUTPUT
+// dimension contiguous. This is how the backward multiplies by a weight stored [out, in]: dX = dY @ W contracts
+// over W's rows, so it reads the same row-major NF4 decode as the forward (fast_lora.py:156, :193-204).
+extern "C" int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                                int n_groups, int accumulate, int dtype, void* stream) {
+    return gemm256_entry(A, lda, M, K, groups, n_groups, accumulate, dtype, stream, true);
 }

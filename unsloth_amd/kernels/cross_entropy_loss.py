@@ -100,13 +100,28 @@ def post_patch_loss_function(model):
     return model
 
 
+_LOSS_ORIGINALS = {}
+
+
 def patch_loss_functions(torch_compile=True):
     """:459-473: route transformers' ForCausalLM loss (and aliases of it) to the fast kernel."""
     try:
         import transformers.loss.loss_utils as _lu
         for key, fn in list(_lu.LOSS_MAPPING.items()):
             if key == "ForCausalLM" or getattr(fn, "__name__", "") == "ForCausalLMLoss":
+                _LOSS_ORIGINALS.setdefault(key, fn)
                 _lu.LOSS_MAPPING[key] = _unsloth_causal_lm_loss
+    except (ImportError, AttributeError):
+        pass
+
+
+def unpatch_loss_functions():
+    """Undo patch_loss_functions()."""
+    try:
+        import transformers.loss.loss_utils as _lu
+        for key, fn in _LOSS_ORIGINALS.items():
+            _lu.LOSS_MAPPING[key] = fn
+        _LOSS_ORIGINALS.clear()
     except (ImportError, AttributeError):
         pass
 
@@ -147,6 +162,22 @@ def fused_ce_chunk_rows(T, V, itemsize, device, target_gb=None):
     return max(256, min(4096, rows, (T + 255) // 256 * 256))
 
 
+def _nn_ok(rows, V, H):
+    """d(hidden) = dlogits [rows, V] @ W [V, H] can contract over W's ROWS in place (NN form of the 256-tile GEMM):
+    no transposed copy of the lm_head (1.05 GB at Llama-3's vocabulary) has to exist."""
+    return _u.NN_DX and V % 64 == 0 and H % 8 == 0 and _u._use_gemm256(rows, V, [H])
+
+
+def _dhidden(chunk, dlogits, weight, weight_t, out):
+    """out = dlogits @ W. `chunk` is the zero-padded [rows, Vp] buffer `dlogits` is a view of; `weight_t` (W^T,
+    [H, Vp]) is only built when the NN form does not apply."""
+    V, H = weight.shape
+    if weight_t is None:
+        _u._launch_gemm(dlogits, [_u._group(weight, out, H, weight.stride(0))], nf4=False, nn=True)
+    else:
+        _u._launch_gemm(chunk, [_u._group(weight_t, out, H, weight_t.stride(0))], nf4=False)
+
+
 class _FusedLinearCE(torch.autograd.Function):
     """loss = sum_rows CE(hidden @ W^T) / n_items without ever holding [T, V] logits.
 
@@ -177,8 +208,7 @@ class _FusedLinearCE(torch.autograd.Function):
             if need_grad:
                 dl = torch.ones(r1 - r0, dtype=torch.float32, device=dev) * inv_n
                 _ce_backward_(logits, dl, lse, lab, softcap, scale)        # logits <- dlogits
-                # dh = dlogits @ W : contraction over V -> NT GEMM against W^T [H, Vp]
-                _u._launch_gemm(chunk, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
+                _dhidden(chunk, logits, weight, weight_t, dh[r0:r1])
         ctx.save_for_backward(dh)
         return loss_sum * inv_n
 
@@ -239,9 +269,10 @@ def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, 
     W = lm_head_weight.detach()
     if W.dtype != h2d.dtype:
         W = W.to(h2d.dtype)
-    Wt = _transposed_weight(W)
     if chunk_rows is None:
         chunk_rows = fused_ce_chunk_rows(h2d.shape[0], W.shape[0], h2d.element_size(), h2d.device, target_gb)
+    nn = _nn_ok(min(int(chunk_rows), h2d.shape[0]), W.shape[0], W.shape[1]) and W.stride(1) == 1 and W.stride(0) % 8 == 0
+    Wt = None if nn else _transposed_weight(W)
     loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
                                 int(chunk_rows))
     if scaling is not None:

@@ -115,6 +115,7 @@ def fast_dequantize(W, quant_state=None, out=None, use_global_buffer=False):
 # ------------------------------------------------------------------------------------------------
 # GEMM plumbing
 def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0, xk=None, bk=None):
+    # (for uamd_gemm_nn_256 `B` is [K, N] and `bk` is [Rk, N]; the struct is the same)
     """One uamd_gemm_group. The LoRA term comes either as (xa fp32, lb, scale) -- the register prologue of the
     128x128 kernels -- or as the rank block (xk, bk) the 256x256 kernel contracts as extra K tiles; `xa` and `R` are
     kept in both cases (the benchmark's flop accounting reads them)."""
@@ -140,11 +141,15 @@ def _use_gemm256(M, K, Ns):
     return ((M + 255) // 256) * cols >= GEMM256_MIN_TILES or ((M + 127) // 128) * cols >= GEMM256_MIN_TILES
 
 
-def _launch_gemm(X2d, groups, nf4, accumulate=False):
+def _launch_gemm(X2d, groups, nf4, accumulate=False, nn=False):
+    """`nn`: the groups' B (and rank-block BK) are [K, N] row-major, C = A @ B (uamd_gemm_nn_256); callers check
+    `_use_gemm256` first -- only the 256-tile kernel family has that form."""
     arr = (GemmGroup * len(groups))(*groups)
     L = _lib.lib()
     M, K = X2d.shape
-    if nf4:
+    if nn:
+        fn, name = L.uamd_gemm_nn_256, "uamd_gemm_nn_256"
+    elif nf4:
         fn, name = L.uamd_gemm_nt_nf4, "uamd_gemm_nt_nf4"
     elif _use_gemm256(M, K, [g.N for g in groups]):
         fn, name = L.uamd_gemm_nt_256, "uamd_gemm_nt_256"
@@ -272,16 +277,17 @@ class _PreparedFactors:
         ent = self._entry(P)
         return ent[1] if tag == "rowmajor" else ent[2]
 
-    def get_pad(self, members, rows, width, transposed):
-        """members: [(P, col_off, scale)] written side by side into ONE zero-initialised [rows, width] buffer:
-        scale * P (transposed=False, P is [rows, r]) or scale * P^T (transposed=True, P is [r, rows]) at columns
-        col_off..col_off+r. Returns the buffer: the BK operand of the GEMM's rank-block K tiles."""
-        key = (tuple(id(P) for P, _, _ in members), rows, width, bool(transposed))
+    def get_pad(self, members, rows, width, transposed, by_rows=False):
+        """members: [(P, off, scale)] written into ONE zero-initialised [rows, width] buffer: scale * P
+        (transposed=False) or scale * P^T (transposed=True), side by side at COLUMN `off` (by_rows=False) or stacked
+        at ROW `off` (by_rows=True). Returns the buffer: the BK operand of the GEMM's rank-block K tiles
+        ([N, Rk] for the NT form, [Rk, N] for the NN form)."""
+        key = (tuple(id(P) for P, _, _ in members), rows, width, bool(transposed), bool(by_rows))
         buf = self.pad_bufs.get(key)
         if buf is None:
             buf = self.pad_bufs[key] = torch.zeros((rows, width), dtype=self.dtype, device=self.device)
-        for P, col, scale in members:
-            self._entry(P, (buf, int(col), float(scale), bool(transposed)))
+        for P, off, scale in members:
+            self._entry(P, (buf, int(off) * (width if by_rows else 1), float(scale), bool(transposed)))
         return buf
 
 
@@ -315,7 +321,7 @@ def _cached_cast(P, tag, dtype, build):
     return out
 
 
-def rank_block_bk(members, rows, width, transposed, dtype):
+def rank_block_bk(members, rows, width, transposed, dtype, by_rows=False):
     """BK operand of the GEMM's rank-block K tiles: a zero [rows, width] buffer with scale * P (or scale * P^T when
     `transposed`) at columns col_off.. for every member (P, col_off, scale). When the factors are fp32 CUDA
     Parameters (the training case) the buffer is persistent and kept current by the once-per-step
@@ -327,15 +333,19 @@ def rank_block_bk(members, rows, width, transposed, dtype):
         # plain tensors (tests, ad-hoc calls of matmul_lora): built per call with torch ops
         with torch.no_grad():
             buf = torch.zeros((rows, width), dtype=dtype, device=members[0][0].device)
-            for P, col, scale in members:
+            for P, off, scale in members:
                 src = P.detach().t() if transposed else P.detach()
-                buf[:, col:col + src.shape[1]] = (src.float() * float(scale)).to(dtype)
+                val = (src.float() * float(scale)).to(dtype)
+                if by_rows:
+                    buf[off:off + src.shape[0], :src.shape[1]] = val
+                else:
+                    buf[:, off:off + src.shape[1]] = val
         return buf
     key = (members[0][0].device, dtype)
     g = _PREPARED.get(key)
     if g is None:
         g = _PREPARED[key] = _PreparedFactors(members[0][0].device, dtype)
-    return g.get_pad(members, rows, width, transposed)
+    return g.get_pad(members, rows, width, transposed, by_rows)
 
 
 def lora_xa(X2d, A_list, out=None, out_k=None, k_cols=0):
@@ -563,6 +573,9 @@ def lora_dx_terms(dYs, projs):
 
 
 MERGE_DX = os.environ.get("UNSLOTH_AMD_MERGE_DX", "1") != "0"
+# dX = dY @ W through the NN form of the 256-tile GEMM (row-major decode, transposing LDS reads) instead of a
+# transposed decode + the NT form
+NN_DX = os.environ.get("UNSLOTH_AMD_NN_DX", "1") != "0"
 
 
 def _adjacent_columns(ts):
@@ -599,17 +612,33 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
     if any(q.shape[1] != Kin or q.dtype != dtype for (_, q, _, _, _) in projs):
         return None
     M, Ntot = dYcat.shape
+    A_list = [A for (_, _, A, _, _) in projs]
+    if out is None:
+        out = torch.empty((M, Kin), dtype=dtype, device=dYcat.device)
+    xks = [getattr(t, "_uamd_xk", None) for t in terms]
+    have_xk = all(x is not None and x[0] is xks[0][0] for x in xks)
+    if NN_DX and have_xk and _use_gemm256(M, Ntot, [Kin]) and Kin % 8 == 0:
+        # NN form: [W_q; W_k; W_v] stacked by ROWS is just the three row-major decodes one after the other -- the
+        # layout the forward uses -- and the GEMM contracts over those rows (no transposed copy of any weight)
+        Wcat = _nf4.scratch(dYcat.device, Ntot * Kin, dtype, slot=2).view(Ntot, Kin)
+        row = 0
+        for (W, q, _, _, _) in projs:
+            n = q.shape[0]
+            _nf4.dequantize_nf4(W, q, out=Wcat[row:row + n])
+            row += n
+        xk = xks[0][0]
+        bk = rank_block_bk([(A, x[1], s) for (_, _, A, _, s), x in zip(projs, xks)], xk.shape[1], Kin, False, dtype,
+                           by_rows=True)                      # [s_q A_q; s_k A_k; s_v A_v; 0] : [Rk, Kin]
+        g = _group(Wcat, out, Kin, Wcat.stride(0), xa=Pcat, ld_xa=Pcat.stride(0), R=Pcat.shape[1], scale=1.0, xk=xk, bk=bk)
+        _launch_gemm(dYcat, [g], nf4=False, accumulate=False, nn=True)
+        return out
     Wt = _nf4.scratch(dYcat.device, Kin * Ntot, dtype, slot=2).view(Kin, Ntot)
     col = 0
     for (W, q, _, _, _) in projs:
         n = q.shape[0]
         _nf4.dequantize_nf4(W, q, out=Wt[:, col:col + n], transpose=True)          # [Kin, n] at column `col`
         col += n
-    A_list = [A for (_, _, A, _, _) in projs]
-    if out is None:
-        out = torch.empty((M, Kin), dtype=dtype, device=dYcat.device)
-    xks = [getattr(t, "_uamd_xk", None) for t in terms]
-    if _use_gemm256(M, Ntot, [Kin]) and all(x is not None and x[0] is xks[0][0] for x in xks):
+    if _use_gemm256(M, Ntot, [Kin]) and have_xk:
         # rank block as extra K tiles: XK = [T(P_q) | T(P_k) | T(P_v) | 0], BK = [s_q A_q^T | s_k A_k^T | s_v A_v^T | 0]
         xk = xks[0][0]
         bk = rank_block_bk([(A, x[1], s) for (_, _, A, _, s), x in zip(projs, xks)], Kin, xk.shape[1], True, dtype)
@@ -643,11 +672,29 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
     for dY, (W, W_quant, A, B, s), xa in zip(dYs, projs, terms):
         dY2d = _rows2d(dY)
         M, N = dY2d.shape
+        Kin = W_quant.shape[1] if W_quant is not None else W.shape[1]
+        xk = getattr(xa, "_uamd_xk", None) if A is not None else None
+        if NN_DX and _use_gemm256(M, N, [Kin]) and Kin % 8 == 0 and (A is None or xk is not None):
+            # NN form: contract over the rows of the [N, Kin] weight as the forward decodes it
+            if W_quant is not None:
+                Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=True)
+            else:
+                Wd = W if (W.dtype == dtype and W.stride(1) == 1 and W.stride(0) % 8 == 0) else W.to(dtype).contiguous()
+            if Wd.dtype != dtype:
+                raise TypeError(f"quant_state.dtype {Wd.dtype} != activation dtype {dtype}: the dequantised weight "
+                                "would be misread by the GEMM (set quant_state.dtype to the compute dtype)")
+            if out is None:
+                out = torch.empty((M, Kin), dtype=dtype, device=dY.device)
+            kw = {}
+            if A is not None:
+                bk = rank_block_bk([(A, xk[1], s)], xk[0].shape[1], Kin, False, dtype, by_rows=True)   # s A at its rank rows
+                kw = dict(xa=xa, ld_xa=xa.stride(0), R=xa.shape[1], scale=s, xk=xk[0], bk=bk)
+            _launch_gemm(dY2d, [_group(Wd, out, Kin, Wd.stride(0), **kw)], nf4=False, accumulate=not first, nn=True)
+            first = False
+            continue
         if W_quant is not None:
-            Kin = W_quant.shape[1]
             Wt = _nf4.dequantize_nf4(W, W_quant, transpose=True, use_global_buffer=True)   # [Kin, N]
         else:
-            Kin = W.shape[1]
             Wt = W.to(dtype).t().contiguous()
         if out is None:
             out = torch.empty((M, Kin), dtype=dtype, device=dY.device)

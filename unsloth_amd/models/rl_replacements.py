@@ -16,8 +16,8 @@ import torch
 
 from .. import _lib
 from ..kernels import utils as _u
-from ..kernels.cross_entropy_loss import (Fast_CrossEntropyLoss, _ce_backward_, _ce_forward, _logits_chunk,
-                                          _transposed_weight)
+from ..kernels.cross_entropy_loss import (Fast_CrossEntropyLoss, _ce_backward_, _ce_forward, _dhidden, _logits_chunk,
+                                          _nn_ok, _transposed_weight)
 
 
 class _ChunkedLogProbs(torch.autograd.Function):
@@ -40,7 +40,7 @@ class _ChunkedLogProbs(torch.autograd.Function):
             if need_grad:
                 dl = torch.full((r1 - r0,), -1.0, dtype=torch.float32, device=dev)      # d(logprob) = -d(loss)
                 _ce_backward_(logits, dl, lse, idx, softcap, scale)                     # logits <- d logprob / d logits
-                _u._launch_gemm(chunk, [_u._group(weight_t, dh[r0:r1], H, weight_t.stride(0))], nf4=False)
+                _dhidden(chunk, logits, weight, weight_t, dh[r0:r1])
         ctx.save_for_backward(dh)
         return out
 
@@ -80,10 +80,11 @@ def chunked_hidden_states_selective_log_softmax(hidden_states, lm_head, index, c
     W = lm_head.detach()
     if W.dtype != h2d.dtype:
         W = W.to(h2d.dtype)
-    Wt = _transposed_weight(W)
     T = B * L
     chunks = max(1, int(chunks))
     chunk_rows = min(4096, max(256, -(-T // chunks)))         # <= 1 GB of transient logits at vocab 128k
+    nn = _nn_ok(min(chunk_rows, T), W.shape[0], H) and W.stride(1) == 1 and W.stride(0) % 8 == 0
+    Wt = None if nn else _transposed_weight(W)
     scale = _effective_scale(logit_scale_multiply, logit_scale_divide, logit_softcapping, temperature)
     out = _ChunkedLogProbs.apply(h2d, W, Wt, index.reshape(-1).to(torch.int64).contiguous(),
                                  float(logit_softcapping or 0), scale, int(chunk_rows))
