@@ -1,0 +1,85 @@
+"""Worker of tests/test_gpu_dp_rccl.py: one process per rank, RCCL ("nccl" backend) over the visible GPUs.
+Every rank builds the same tiny QLoRA model, trains one step on ITS batch through dp.LoRAGradArena (bucketed async
+all-reduce launched from the gradient hooks, overlapped with the backward), and checks the reduced gradients
+against a local replay of every rank's batch without any collective. Exit code 0 = pass."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def build(dev, gc):
+    from transformers import LlamaConfig
+    from unsloth_amd import FastLanguageModel
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=3, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128, vocab_size=1000, rms_norm_eps=1e-5,
+                      max_position_embeddings=256, rope_parameters={"rope_type": "default", "rope_theta": 5e5},
+                      tie_word_embeddings=False)
+    model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=128, load_in_4bit=True, device=dev,
+                                                 random_state=3407, use_gradient_checkpointing=gc)
+    model = FastLanguageModel.get_peft_model(model, r=8, lora_alpha=16, use_gradient_checkpointing=gc, random_state=3407)
+    g = torch.Generator().manual_seed(1)
+    for n, p in model.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_((torch.randn(p.shape, generator=g) * 0.05).to(dev))
+    return model
+
+
+def batch_of(rank, dev):
+    g = torch.Generator().manual_seed(100 + rank)
+    ids = torch.randint(0, 1000, (2, 64), generator=g)
+    labels = ids.clone()
+    labels[0, : 3 + rank] = -100
+    pos = torch.arange(64, dtype=torch.int32).unsqueeze(0).expand(2, 64).contiguous()
+    return dict(input_ids=ids.to(dev), labels=labels.to(dev), position_ids=pos.to(dev))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    from unsloth_amd.dp import LoRAGradArena, global_num_items
+    gc = os.environ.get("DP_TEST_GC", "off")
+    gc = {"off": False, "on": True}.get(gc, gc)
+    # ---- reference: every rank's batch replayed locally, loss normalised by the GLOBAL token count, grads summed
+    ref = build(dev, gc)
+    n_global = sum(int((batch_of(r, dev)["labels"][:, 1:] != -100).sum()) for r in range(world))
+    for r in range(world):
+        out = ref(**batch_of(r, dev), num_items_in_batch=n_global)
+        out.loss.backward()
+    want = {n: p.grad.detach().clone() for n, p in ref.named_parameters() if p.requires_grad}
+    del ref
+    # ---- data parallel: this rank's batch only, exchange through the arena
+    model = build(dev, gc)
+    arena = LoRAGradArena(model, bucket_bytes=int(os.environ.get("DP_TEST_BUCKET", 1 << 16)))
+    mine = batch_of(rank, dev)
+    n = global_num_items(mine["labels"])
+    assert int(n) == n_global, (int(n), n_global)
+    for step in range(2):                     # second step: the arena was zeroed, views kept
+        out = model(**mine, num_items_in_batch=n)
+        out.loss.backward()
+        arena.finish()
+        worst = 0.0
+        for name, p in model.named_parameters():
+            if p.requires_grad:
+                err = float((p.grad - want[name]).norm() / (want[name].norm() + 1e-30))
+                worst = max(worst, err)
+        assert worst < 1e-5, f"rank {rank} step {step}: reduced gradient differs from the local replay: {worst}"
+        arena.zero_grad()
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    assert int(one.item()) == world
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}/{world} ok: buckets {arena.describe()['buckets']}, worst rel err {worst:.2e}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

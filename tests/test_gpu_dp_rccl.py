@@ -1,0 +1,57 @@
+"""-m gpu: the data-parallel exchange on real RCCL. One GPU: a 1-rank "nccl" group (every collective is really
+issued, hooks + side stream + arena ordering exercised; UNSLOTH_AMD_DP_FORCE=1). Two or more visible GPUs: two ranks,
+different batches, reduced LoRA gradients == the local replay of both batches (skipped on a single-GPU box -- the
+driver's 8-GPU SCALE run is where N > 1 is measured; the N > 1 logic itself is covered on CPU by test_dp_gloo.py)."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, extra_env):
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {rank} failed:\n{out[-3000:]}"
+    return outs
+
+
+@pytest.mark.parametrize("gc", ["off", "unsloth"])
+def test_forced_one_rank_rccl_group(gc):
+    outs = _run(1, {"UNSLOTH_AMD_DP_FORCE": "1", "DP_TEST_GC": gc})
+    assert "rank 0/1 ok" in outs[0]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
+@pytest.mark.parametrize("gc,bucket", [("off", 1 << 16), ("unsloth", 1 << 30)])
+def test_two_rank_rccl_allreduce_matches_local_replay(gc, bucket):
+    outs = _run(2, {"DP_TEST_GC": gc, "DP_TEST_BUCKET": str(bucket)})
+    assert "rank 0/2 ok" in outs[0] and "rank 1/2 ok" in outs[1]
