@@ -226,6 +226,14 @@ def main():
         for bs in (1, 2):
             if bs != B:
                 alt_point(f"batch_{bs}_gc_off", False, bs)
+        if os.environ.get("BENCH_RESIDENT_ALT", "1") == "1":
+            # opt-in mode: decoded bf16 mirrors of the NF4 weights stay in HBM (+2 B/param), no decode launches
+            from unsloth_amd import nf4 as _nf4
+            _nf4.set_resident(True)
+            alt_point("weights_resident_bf16_gc_off (opt-in: UNSLOTH_AMD_RESIDENT_WEIGHTS=1)", False, B)
+            alt_point("weights_resident_bf16_batch_1", False, 1)
+            _nf4.set_resident(False)
+            torch.cuda.empty_cache()
     dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
     rccl_ranks = None
     if dist.is_initialized():

@@ -31,6 +31,15 @@ def _tiny(load_in_4bit=True, gc=True, r=8, layers=2, seed=3407, head_dim=32):
     return model
 
 
+def _tiny_base():
+    from transformers import LlamaConfig
+    from unsloth_amd import FastLanguageModel
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=1, num_attention_heads=8,
+                      num_key_value_heads=2, head_dim=32, vocab_size=1000, max_position_embeddings=512,
+                      tie_word_embeddings=False)
+    return FastLanguageModel.from_pretrained(config=cfg, max_seq_length=64, load_in_4bit=True, device=DEV)[0]
+
+
 def _batch(B=2, T=96, seed=0):
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(0, 1000, (B, T), generator=g)
@@ -164,6 +173,32 @@ def test_layer_called_with_hf_signature_runs_the_fused_path():
         assert rel_fro(got, ref) < 2e-3 and float((got != ref).float().mean()) < 0.2
 
 
+def test_resident_decoded_weights_are_bitwise_neutral():
+    """opt-in UNSLOTH_AMD_RESIDENT_WEIGHTS: the decoded bf16 mirrors kept in HBM change nothing but the launch count."""
+    from unsloth_amd import nf4
+    ids, labels, pos = _batch(seed=8)
+    batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    res = []
+    for on in (False, True):
+        nf4.set_resident(on)
+        try:
+            model = _tiny(gc=False, head_dim=128)
+            calls = []
+            real = nf4._lib.lib().uamd_nf4_dequantize
+            for step in range(2):
+                for p_ in model.parameters():
+                    p_.grad = None
+                out = model(**batch)
+                out.loss.backward()
+            res.append((out.loss.detach().clone(), _grads(model), len(nf4._RESIDENT_ONE)))
+        finally:
+            nf4.set_resident(False)
+    assert res[0][2] == 0 and res[1][2] == 2 * 7            # every projection of the 2 layers has a mirror
+    assert torch.equal(res[0][0], res[1][0])
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
 def test_return_logits_branch_and_n_items():
     from oracle.ref_model import hf_reference_loss_and_lora_grads
     model = _tiny()
@@ -262,6 +297,18 @@ def test_training_reduces_loss_and_adapters_round_trip(tmp_path):
     from safetensors.torch import load_file
     sd = load_file(os.path.join(str(tmp_path), "adapter_model.safetensors"))
     assert any(k.endswith("q_proj.lora_A.weight") for k in sd) and len(sd) == 2 * 7 * 2
+    # resume: a fresh model + load_adapter reproduces the trained model's loss exactly
+    with torch.no_grad():
+        want = float(model(**batch).loss)
+    fresh = _tiny(r=16)
+    loaded = fresh.load_adapter(str(tmp_path))
+    assert len(loaded) == 2 * 7 * 2
+    with torch.no_grad():
+        assert float(fresh(**batch).loss) == want
+    import pytest as _pt
+    from unsloth_amd import FastLanguageModel
+    with _pt.raises(NotImplementedError):
+        FastLanguageModel.get_peft_model(_tiny_base(), r=8, modules_to_save=["lm_head"])
 
 
 def test_bnb4bit_checkpoint_round_trip_and_merge(tmp_path):

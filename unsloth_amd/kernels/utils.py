@@ -467,6 +467,9 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
     if with_lora:
         xa, offs, xk = _xa_and_rank_block(X2d, [p[2] for p in with_lora], use256)
     results, dense_groups, nf4_groups, keep = [], [], [], []
+    resident = None
+    if _nf4.RESIDENT and len(projs) > 1 and all(q is not None for (_, q, _, _, _) in projs) and not any(fused_nf4):
+        _, resident = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
     li = 0
     for gi, (W, W_quant, A, B, s) in enumerate(projs):
         if W_quant is not None:
@@ -489,7 +492,9 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
             nf4_groups.append(_group(W, C, N, 0, absmax=_nf4.absmax_f32(W_quant), **kw))
         else:
             Wd = W
-            if W_quant is not None:
+            if resident is not None:
+                Wd = resident[gi]
+            elif W_quant is not None:
                 # one scratch slot per group member: the grouped launch reads all of them
                 Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=True, slot=8 + gi)
                 if Wd.dtype != dtype:
@@ -620,12 +625,15 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
     if NN_DX and have_xk and _use_gemm256(M, Ntot, [Kin]) and Kin % 8 == 0:
         # NN form: [W_q; W_k; W_v] stacked by ROWS is just the three row-major decodes one after the other -- the
         # layout the forward uses -- and the GEMM contracts over those rows (no transposed copy of any weight)
-        Wcat = _nf4.scratch(dYcat.device, Ntot * Kin, dtype, slot=2).view(Ntot, Kin)
-        row = 0
-        for (W, q, _, _, _) in projs:
-            n = q.shape[0]
-            _nf4.dequantize_nf4(W, q, out=Wcat[row:row + n])
-            row += n
+        if _nf4.RESIDENT:
+            Wcat, _ = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
+        else:
+            Wcat = _nf4.scratch(dYcat.device, Ntot * Kin, dtype, slot=2).view(Ntot, Kin)
+            row = 0
+            for (W, q, _, _, _) in projs:
+                n = q.shape[0]
+                _nf4.dequantize_nf4(W, q, out=Wcat[row:row + n])
+                row += n
         xk = xks[0][0]
         bk = rank_block_bk([(A, x[1], s) for (_, _, A, _, s), x in zip(projs, xks)], xk.shape[1], Kin, False, dtype,
                            by_rows=True)                      # [s_q A_q; s_k A_k; s_v A_v; 0] : [Rk, Kin]

@@ -121,6 +121,11 @@ class LoraModel(nn.Module):
         super().__init__()
         self.model = model
         self.peft_config = {adapter_name: config}
+        if config.modules_to_save:
+            # PEFT would clone embed_tokens / lm_head into trainable copies; this stand-in does not, and silently
+            # leaving them frozen would train something else than what was asked for
+            raise NotImplementedError(f"modules_to_save={config.modules_to_save!r}: trainable copies of whole modules "
+                                      "are not implemented by this PEFT stand-in (install `peft` to get them)")
         targets = config.target_modules
         if isinstance(targets, str):
             targets = [targets]
@@ -207,6 +212,36 @@ class PeftModelForCausalLM(nn.Module):
         cfg = {k: v for k, v in self.peft_config[self.active_adapter].to_dict().items()}
         with open(os.path.join(save_directory, "adapter_config.json"), "w") as f:
             json.dump(cfg, f, indent=2, default=str)
+
+
+def _load_adapter(self, directory, adapter_name=None, is_trainable=True):
+    """Reads `adapter_model.safetensors` written by `save_pretrained` (PEFT's key layout: no adapter name in the keys)
+    back into the LoRA factors, IN PLACE through `param.copy_` (bumps the version counters the cast caches watch).
+    Returns the list of keys that were loaded; raises on missing / unexpected / mis-shaped tensors."""
+    from safetensors.torch import load_file
+    from .kernels.utils import invalidate_cast_cache
+    name = adapter_name or self.active_adapter
+    sd = load_file(os.path.join(directory, "adapter_model.safetensors"))
+    own = {}
+    for k, prm in self.named_parameters():
+        if "lora_" in k:
+            key = ("base_model.model." + k.split("base_model.model.", 1)[-1]).replace("." + name, "")
+            own[key] = prm
+    missing, unexpected = sorted(set(own) - set(sd)), sorted(set(sd) - set(own))
+    if missing or unexpected:
+        raise KeyError(f"adapter checkpoint mismatch: missing {missing[:4]}..., unexpected {unexpected[:4]}...")
+    with torch.no_grad():
+        for key, prm in own.items():
+            t = sd[key]
+            if tuple(t.shape) != tuple(prm.shape):
+                raise ValueError(f"{key}: checkpoint {tuple(t.shape)} vs model {tuple(prm.shape)}")
+            prm.copy_(t.to(device=prm.device, dtype=prm.dtype))
+            prm.requires_grad_(bool(is_trainable))
+    invalidate_cast_cache()
+    return sorted(own)
+
+
+PeftModelForCausalLM.load_adapter = _load_adapter
 
 
 def _save_pretrained_merged(self, save_directory, tokenizer=None, save_method="merged_16bit", **kwargs):

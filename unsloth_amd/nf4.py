@@ -185,6 +185,48 @@ def quantize_nf4(W, blocksize=64, compress_statistics=True):
     return packed, qs
 
 
+# Opt-in (UNSLOTH_AMD_RESIDENT_WEIGHTS=1 or nf4.set_resident(True)): keep the DECODED bf16 copy of every NF4 weight in
+# HBM after its first decode instead of decoding it again at every use (2 decodes per weight per step: 7.4 ms of a
+# 250 ms step at 8192 tokens, 9 % of the step at 2048). Costs 2 B/param (14 GB for Llama-3-8B's projections) of the
+# 288 GB -- the NF4 bytes stay the source of truth (checkpoints, merging); frozen weights never change, so the mirror
+# cannot go stale. Off by default: the headline numbers decode from NF4 at every use like the reference does.
+import os as _os
+
+RESIDENT = _os.environ.get("UNSLOTH_AMD_RESIDENT_WEIGHTS", "0") == "1"
+_RESIDENT_ONE = {}       # id(quant_state) -> [rows, cols] decoded tensor (possibly a row slice of a group buffer)
+_RESIDENT_GROUP = {}     # tuple(id(quant_state)) -> stacked [sum rows, cols] buffer of projections that share an input
+
+
+def set_resident(on):
+    global RESIDENT
+    RESIDENT = bool(on)
+    if not on:
+        _RESIDENT_ONE.clear()
+        _RESIDENT_GROUP.clear()
+
+
+def resident_group(packed_list, qs_list):
+    """Stacked row-major decode [W_1; W_2; ...] of weights that share their input (q/k/v, gate/up), decoded once and
+    kept. Returns (buffer, [row slices]); the slices are also registered for single-weight lookups."""
+    key = tuple(id(q) for q in qs_list)
+    buf = _RESIDENT_GROUP.get(key)
+    if buf is None:
+        cols = qs_list[0].shape[1]
+        rows = sum(q.shape[0] for q in qs_list)
+        buf = torch.empty((rows, cols), dtype=qs_list[0].dtype, device=packed_list[0].device)
+        r = 0
+        for pk, q in zip(packed_list, qs_list):
+            dequantize_nf4(pk, q, out=buf[r:r + q.shape[0]])
+            _RESIDENT_ONE[id(q)] = buf[r:r + q.shape[0]]
+            r += q.shape[0]
+        _RESIDENT_GROUP[key] = buf
+    views, r = [], 0
+    for q in qs_list:
+        views.append(buf[r:r + q.shape[0]])
+        r += q.shape[0]
+    return buf, views
+
+
 _SCRATCH = {}
 
 
@@ -210,6 +252,12 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
     rows, cols = qs.shape
     dtype = qs.dtype
     shape = (cols, rows) if transpose else (rows, cols)
+    if RESIDENT and out is None and use_global_buffer and not transpose:
+        hit = _RESIDENT_ONE.get(id(qs))
+        if hit is not None and hit.dtype == dtype:
+            return hit
+        out = torch.empty(shape, dtype=dtype, device=packed.device)
+        _RESIDENT_ONE[id(qs)] = out
     if out is None:
         if use_global_buffer:
             if slot is None:
