@@ -253,8 +253,11 @@ def main():
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
                     pt = json.load(f)
-                if dom_name in pt:
-                    traffic = pt[dom_name]["traffic_bytes"]
+                stem = dom_name.split("<")[0]
+                ents = [v for k, v in pt.items() if k.startswith(stem) and isinstance(v, dict) and "traffic_bytes" in v]
+                if ents:       # the NT and NN template instances of the kernel: dispatch-weighted mean
+                    n = sum(max(1, e.get("dispatches", 1)) for e in ents)
+                    traffic = int(sum(e["traffic_bytes"] * max(1, e.get("dispatches", 1)) for e in ents) / n)
                     traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
             except (OSError, ValueError, KeyError):
                 pass

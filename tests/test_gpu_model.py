@@ -183,14 +183,12 @@ def test_resident_decoded_weights_are_bitwise_neutral():
         nf4.set_resident(on)
         try:
             model = _tiny(gc=False, head_dim=128)
-            calls = []
-            real = nf4._lib.lib().uamd_nf4_dequantize
             for step in range(2):
                 for p_ in model.parameters():
                     p_.grad = None
                 out = model(**batch)
                 out.loss.backward()
-            res.append((out.loss.detach().clone(), _grads(model), len(nf4._RESIDENT_ONE)))
+            res.append((out.loss.detach().clone(), _grads(model), nf4.resident_count()))
         finally:
             nf4.set_resident(False)
     assert res[0][2] == 0 and res[1][2] == 2 * 7            # every projection of the 2 layers has a mirror

@@ -82,6 +82,8 @@ class QuantState:
             self.state2.absmax = self.state2.absmax.to(device)
             self.state2.code = self.state2.code.to(device)
         self._absmax_f32 = None
+        self._resident = None
+        self._resident_group = None
         return self
 
     # ---- bitsandbytes checkpoint (safetensors) layout ---------------------------------------
@@ -193,33 +195,44 @@ def quantize_nf4(W, blocksize=64, compress_statistics=True):
 import os as _os
 
 RESIDENT = _os.environ.get("UNSLOTH_AMD_RESIDENT_WEIGHTS", "0") == "1"
-_RESIDENT_ONE = {}       # id(quant_state) -> [rows, cols] decoded tensor (possibly a row slice of a group buffer)
-_RESIDENT_GROUP = {}     # tuple(id(quant_state)) -> stacked [sum rows, cols] buffer of projections that share an input
+import weakref as _weakref
+
+_MIRRORED = _weakref.WeakSet()      # quant states that carry a decoded mirror (`_resident`, `_resident_group`)
 
 
 def set_resident(on):
     global RESIDENT
     RESIDENT = bool(on)
     if not on:
-        _RESIDENT_ONE.clear()
-        _RESIDENT_GROUP.clear()
+        for q in list(_MIRRORED):
+            q._resident = None
+            q._resident_group = None
+        _MIRRORED.clear()
+
+
+def resident_count():
+    return sum(1 for q in _MIRRORED if getattr(q, "_resident", None) is not None)
 
 
 def resident_group(packed_list, qs_list):
     """Stacked row-major decode [W_1; W_2; ...] of weights that share their input (q/k/v, gate/up), decoded once and
-    kept. Returns (buffer, [row slices]); the slices are also registered for single-weight lookups."""
-    key = tuple(id(q) for q in qs_list)
-    buf = _RESIDENT_GROUP.get(key)
-    if buf is None:
-        cols = qs_list[0].shape[1]
+    kept ON the quant states (the mirror lives exactly as long as the weight it mirrors). Returns
+    (buffer, [row slices]); the slices also serve single-weight lookups."""
+    first = qs_list[0]
+    ent = getattr(first, "_resident_group", None)
+    if ent is None or len(ent[0]) != len(qs_list) or any(a() is not b for a, b in zip(ent[0], qs_list)):
+        cols = first.shape[1]
         rows = sum(q.shape[0] for q in qs_list)
-        buf = torch.empty((rows, cols), dtype=qs_list[0].dtype, device=packed_list[0].device)
+        buf = torch.empty((rows, cols), dtype=first.dtype, device=packed_list[0].device)
         r = 0
         for pk, q in zip(packed_list, qs_list):
             dequantize_nf4(pk, q, out=buf[r:r + q.shape[0]])
-            _RESIDENT_ONE[id(q)] = buf[r:r + q.shape[0]]
+            q._resident = buf[r:r + q.shape[0]]
+            _MIRRORED.add(q)
             r += q.shape[0]
-        _RESIDENT_GROUP[key] = buf
+        first._resident_group = ([_weakref.ref(q) for q in qs_list], buf)
+        ent = first._resident_group
+    buf = ent[1]
     views, r = [], 0
     for q in qs_list:
         views.append(buf[r:r + q.shape[0]])
@@ -252,12 +265,13 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
     rows, cols = qs.shape
     dtype = qs.dtype
     shape = (cols, rows) if transpose else (rows, cols)
+    mirror_here = False
     if RESIDENT and out is None and use_global_buffer and not transpose:
-        hit = _RESIDENT_ONE.get(id(qs))
-        if hit is not None and hit.dtype == dtype:
+        hit = getattr(qs, "_resident", None)
+        if hit is not None and hit.dtype == dtype and hit.device == packed.device:
             return hit
         out = torch.empty(shape, dtype=dtype, device=packed.device)
-        _RESIDENT_ONE[id(qs)] = out
+        mirror_here = True
     if out is None:
         if use_global_buffer:
             if slot is None:
@@ -285,6 +299,9 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
                 _lib.ptr(out), rows, cols, qs.blocksize, _lib.dtype_code(dtype), int(transpose), ld_out,
                 _lib.stream_of(packed))
     _lib.check(rc, "uamd_nf4_dequantize")
+    if mirror_here:
+        qs._resident = out
+        _MIRRORED.add(qs)
     return out
 
 
