@@ -229,7 +229,10 @@ int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
 #define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has
                                  * fewer than 192 tiles (default), 0 = always 256 rows, 2 = always 128 rows */
-#define UAMD_TUNE_COUNT 7
+#define UAMD_TUNE_GEMM_PERSIST 7 /* (UAMD_GEMM_PERSIST) uamd_gemm_n{t,n}_256 with 256-row tiles: 1 = one persistent block per CU walks the
+                                 * tiles and prefetches the next tile's first K tiles during the current one's last (default), 0 = one
+                                 * block per tile */
+#define UAMD_TUNE_COUNT 8
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

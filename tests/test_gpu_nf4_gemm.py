@@ -341,6 +341,69 @@ def test_gemm256_nn_form(half, dtype, M, N, K):
         L.uamd_set_tuning(6, 1)
 
 
+@pytest.mark.parametrize("nn", [False, True])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,Ns,K,rank", [(4096, (4096, 1024, 1024), 512, True),      # 3 groups, odd K-tile count (8 + 1)
+                                         (4096 + 40, (4096 + 8,), 256, False),        # ragged M and N, even count (4)
+                                         (8192, (2560,), 1024, True),                  # 320 tiles: CUs get 1 or 2
+                                         (2048, (8192 + 256,), 448, True)])            # 7 + 1 K tiles
+def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
+    """gemm_nt256p_kernel (one block per CU walks the tiles, prefetching the next output tile's first K tiles during the
+    current one's last and swapping LDS stage addresses after an odd K-tile count) against gemm_nt256_kernel (one block
+    per tile): same per-tile accumulation order, so bit-identical -- multi-group launches with per-group rank blocks,
+    ragged edges, accumulate, both operand forms; run-to-run deterministic."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels.utils import _group, _launch_gemm
+    from unsloth_amd.kernels import utils as U
+    L = _lib.lib()
+    X = torch.randn(M, K, generator=g(171)).to(dtype).to(DEV)
+    xk = torch.zeros(M, 64, dtype=dtype, device=DEV)
+    xk[:, :16] = torch.randn(M, 16, generator=g(172)).to(dtype).to(DEV)
+    Bs, BKs = [], []
+    for i, N in enumerate(Ns):
+        Bs.append(((torch.randn(K, N, generator=g(173 + i)) if nn else torch.randn(N, K, generator=g(173 + i))) * 0.05).to(dtype).to(DEV))
+        bk = torch.zeros((64, N) if nn else (N, 64), dtype=dtype, device=DEV)
+        blk = (torch.randn(16, N, generator=g(183 + i)) * 0.05).to(dtype).to(DEV)
+        if nn:
+            bk[:16] = blk
+        else:
+            bk[:, :16] = blk.t()
+        BKs.append(bk)
+
+    def run(persist, accumulate):
+        outs = [torch.full((M, N), 0.25, dtype=dtype, device=DEV) for N in Ns]
+        groups = []
+        for i, N in enumerate(Ns):
+            use_rank = rank and i != 1          # the middle group of a 3-group launch goes without: per-group K-tile counts
+            groups.append(_group(Bs[i], outs[i], N, Bs[i].stride(0), xa=xk if use_rank else None, ld_xa=64, R=16, scale=1.0,
+                                 xk=xk if use_rank else None, bk=BKs[i] if use_rank else None))
+        L.uamd_set_tuning(7, persist)
+        _launch_gemm(X, groups, nf4=False, accumulate=accumulate, nn=nn)
+        return outs
+
+    old = U.GEMM256_MODE
+    U.GEMM256_MODE = "on"
+    try:
+        L.uamd_set_tuning(6, 0)                  # 256-row tiles (the persistent walk exists for those)
+        for accumulate in (False, True):
+            ref = run(0, accumulate)
+            for _ in range(2):
+                got = run(1, accumulate)
+                for r, o in zip(ref, got):
+                    assert torch.equal(r, o)
+        # and against the fp32 product
+        y = run(1, False)[0]
+        Xf = X.float().cpu()
+        want = Xf @ (Bs[0].float().cpu() if nn else Bs[0].float().cpu().t())
+        if rank:
+            want = want + xk.float().cpu() @ (BKs[0].float().cpu() if nn else BKs[0].float().cpu().t())
+        _check_gemm(y, want, dtype, K, "persistent gemm256")
+    finally:
+        U.GEMM256_MODE = old
+        L.uamd_set_tuning(6, 1)
+        L.uamd_set_tuning(7, 1)
+
+
 def test_gemm256_transpose_detecting_and_k_order(force256):
     from unsloth_amd.kernels.utils import lora_linear_forward
     M, N, K = 512, 512, 256

@@ -73,6 +73,8 @@ struct G256Args {
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((address_space(3))) u32x4_t lds_u32x4;
 
 // One wave-instruction of LDS-DMA: 64 lanes x 16 B from per-lane global addresses -> LDS [lds_addr,
 // lds_addr + 1024). Issued through inline asm ON PURPOSE: with the builtin, hipcc treats every later ds_read
@@ -424,6 +426,326 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Persistent form of gemm_nt256_kernel: one block per CU walks the virtual block ids v = blockIdx.x, + gridDim.x, ...
+// (same XCD-aware raster as above, so the set of tiles in flight at any time is the one the hardware dispatcher
+// would have picked) and treats the K tiles of consecutive OUTPUT tiles as one stream: while the last two K tiles
+// of an output tile are multiplied, the DMA slots that would sit idle fetch K tiles 0 and 1 of the next one, so a
+// new output tile starts with its operands already in LDS instead of a cold 64-KiB prologue (all 256 CUs bursting
+// at once: ~3 us of a ~100 us launch per tile), and the epilogue's stores overlap the next tile's loads. The two
+// wave groups keep their one-slot stagger across the boundary; the barrier sequence is the steady-state one.
+// Stage parity: an output tile with an odd number of K tiles leaves the stream in stage 1; the tile-local code
+// always numbers its stages 0, 1, so the two sets of LDS addresses (DMA destination base, fragment read offsets)
+// are held in registers and SWAPPED at such a boundary -- no address arithmetic enters the K loop.
+// Host contract (gemm256_entry): K >= 4 * 64, gridDim.x <= total_tiles.
+template <typename T, bool BNN>
+__global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Mfma2<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int M = p.M, total = p.total_tiles;
+    const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);
+
+    // virtual block id -> (first row, first column inside its group, group): see gemm_nt256_kernel
+    auto decode = [&](int v, int& m0, int& n0, int& gi) {
+        int tile;
+        {
+            const int q = total >> 3, r = total & 7, x = v & 7, j = v >> 3;
+            tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        }
+        const int gm = p.group_m, tiles_n = p.tile_start[UAMD_G256_MAX_GROUPS];
+        const int per_group = gm * tiles_n;
+        const int rg = tile / per_group;
+        const int first_m = rg * gm;
+        const int gsz = min(gm, p.tiles_m - first_m);
+        const int rem = tile - rg * per_group;
+        const int tn_lin = rem / gsz;
+        const int tm = first_m + (rem - tn_lin * gsz);
+        int g_ = 0, start = 0;
+#pragma unroll
+        for (int i = 1; i < UAMD_G256_MAX_GROUPS; ++i)
+            if (i < p.n_groups && tn_lin >= p.tile_start[i]) { g_ = i; start = p.tile_start[i]; }
+        gi = __builtin_amdgcn_readfirstlane(g_);
+        m0 = __builtin_amdgcn_readfirstlane(tm * TM);
+        n0 = __builtin_amdgcn_readfirstlane((tn_lin - start) * TN);
+    };
+    auto rank_tiles = [&](int gi) {
+        const uamd_gemm_group& g = p.g[gi];
+        return __builtin_amdgcn_readfirstlane(g.lora_xk != nullptr ? g.Rk / TK : 0);
+    };
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // ---- the ISSUE context: where DMA pieces come from. It belongs to the output tile being multiplied until its
+    //      last pieces are issued (L1 of its second-to-last K tile), then to the next one.
+    const int sub_row = lane >> 3;
+    const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
+    const int nn_krow = lane >> 5;
+    auto sgpr64 = [](const void* q) {
+        const uint64_t u = (uint64_t)(uintptr_t)q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t a_gbase = sgpr64(p.A);
+    int i_m0 = 0, i_n0 = 0, i_N = 0, ld_xk = 0, ld_bk = 0;
+    uint64_t b_gbase = 0, b_tile_step = 0, xk_base = 0, bk_base = 0;
+    unsigned a_off[4], b_off[4];
+    auto nn_col = [&](int krow, int ln) {
+        const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+        int col = i_n0 + (((ln & 31) ^ (f << 1)) << 3);
+        return col + 8 <= i_N ? col : i_N - 8;
+    };
+    auto set_issue = [&](int m0, int n0, int gi) {
+        const uamd_gemm_group& g = p.g[gi];
+        i_m0 = m0; i_n0 = n0; i_N = __builtin_amdgcn_readfirstlane(g.N);
+        b_gbase = sgpr64(g.B);
+        xk_base = sgpr64(g.lora_xk); bk_base = sgpr64(g.lora_bk);
+        ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk); ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
+        const int ldb = __builtin_amdgcn_readfirstlane((int)g.ldb);      // host: ldb < 2^31 / 128
+        b_tile_step = BNN ? (uint64_t)ldb * (TK * sizeof(T)) : (uint64_t)(TK * sizeof(T));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            int ra = m0 + (c * 8 + wave) * 8 + sub_row;
+            ra = ra < M ? ra : M - 1;
+            a_off[c] = (unsigned)(((int64_t)ra * p.lda + sub_slot * 8) * (int64_t)sizeof(T));
+            if (BNN) {
+                // k-row of piece c = c*16 + wave*2 + (lane >> 5): the swizzle term f(krow) does not depend on c, so
+                // the pieces differ by the wave-uniform 16 * ldb rows only -- that part rides in the scalar base
+                // (issue_main) and ONE per-lane offset serves all four pieces
+                const int krow = wave * 2 + nn_krow;
+                if (c == 0) b_off[0] = (unsigned)(((int64_t)krow * ldb + nn_col(krow, lane)) * (int64_t)sizeof(T));
+            } else {
+                int rb = n0 + (c * 8 + wave) * 8 + sub_row;
+                rb = rb < i_N ? rb : i_N - 1;
+                b_off[c] = (unsigned)(((int64_t)rb * g.ldb + sub_slot * 8) * (int64_t)sizeof(T));
+            }
+        }
+    };
+
+    // ---- LDS addresses of the two stages, swappable (see the header)
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    unsigned dstb[2];
+    dstb[0] = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024);
+    dstb[1] = dstb[0] + STAGE_BYTES;
+    const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
+    const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
+    const int nn_lane = 32 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
+    unsigned fa[2][2], fb[2][4];     // absolute LDS byte addresses (the dynamic region's base included)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) fa[s][ks] = lds_base + s * STAGE_BYTES + (grp * 8) * 2048 + (frag_off0 ^ (ks * 64));
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            fb[s][x] = lds_base + (BNN ? s * STAGE_BYTES + nn_lane + (((wn * 4 + x) ^ nn_f) << 5)
+                                       : s * STAGE_BYTES + 32 * 1024 + (wn * 4) * 2048 + (frag_off0 ^ ((x & 1) * 64)));
+    }
+    auto flip_stages = [&]() {
+        { const unsigned t = dstb[0]; dstb[0] = dstb[1]; dstb[1] = t; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { const unsigned t = fa[0][ks]; fa[0][ks] = fa[1][ks]; fa[1][ks] = t; }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const unsigned t = fb[0][x]; fb[0][x] = fb[1][x]; fb[1][x] = t; }
+    };
+
+    auto issue_main = [&](int c, int kt, int stage) {
+        const unsigned dst = dstb[stage] + c * 8192;
+        if (c < 4) dma16s(a_off[c & 3], a_gbase + (uint64_t)kt * (TK * sizeof(T)), dst);
+        else if (BNN) dma16s(b_off[0], b_gbase + (uint64_t)kt * b_tile_step + (uint64_t)(c & 3) * (b_tile_step >> 2), dst);
+        else dma16s(b_off[c & 3], b_gbase + (uint64_t)kt * b_tile_step, dst);
+    };
+    int nk = 0;                      // K tiles of the output tile being multiplied (operands proper + rank block)
+    auto issue_any = [&](int c, int kt, int stage) {
+        if (kt >= nk) {              // K tile kt - nk of the NEXT output tile: the issue context is already its
+            issue_main(c, kt - nk, stage);
+        } else if (kt < nk_main) {
+            issue_main(c, kt, stage);
+        } else {
+            const unsigned dst = dstb[stage] + c * 8192;
+            // an opaque copy of the lane id: the lane-only parts of these addresses are rebuilt here (a few VALU
+            // instructions per output tile) instead of being hoisted to the kernel entry and held -- or spilled --
+            // across the whole K loop
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const int sub_row = ln >> 3, nn_krow = ln >> 5;
+            const int sub_slot = (ln & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
+            if (BNN && c >= 4) {
+                const int krow = ((c & 3) * 8 + wave) * 2 + nn_krow;
+                const unsigned off = (unsigned)(((int64_t)krow * ld_bk + nn_col(krow, ln)) * (int64_t)sizeof(T));
+                dma16s(off, bk_base + (uint64_t)(kt - nk_main) * ((uint64_t)ld_bk * (TK * sizeof(T))), dst);
+            } else {
+                int row = (c < 4 ? i_m0 : i_n0) + ((c & 3) * 8 + wave) * 8 + sub_row;
+                const int last = (c < 4 ? M : i_N) - 1;
+                row = row < last ? row : last;
+                const int ld = c < 4 ? ld_xk : ld_bk;
+                const unsigned off = (unsigned)(((int64_t)row * ld + sub_slot * 8) * (int64_t)sizeof(T));
+                dma16s(off, (c < 4 ? xk_base : bk_base) + (uint64_t)(kt - nk_main) * (TK * sizeof(T)), dst);
+            }
+        }
+    };
+
+    frag_t af[4][2], bf[4][2];
+    auto read_a = [&](int stage, int mq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { u32x4_t r; frag_t f; } u;
+                u.r = *(const lds_u32x4*)(fa[stage][ks] + (mq * 4 + i) * 2048);
+                af[i][ks] = u.f;
+            }
+    };
+    auto read_b = [&](int stage, int nq) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (BNN) {
+                    union { s16x4_t h[2]; frag_t f; } u;
+                    const unsigned a0 = fb[stage][nq * 2 + j] + ks * (32 * 512);
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * 512));
+                    bf[nq * 2 + j][ks] = u.f;
+                } else {
+                    union { u32x4_t r; frag_t f; } u;
+                    u.r = *(const lds_u32x4*)(fb[stage][ks] + (nq * 2 + j) * 2048);
+                    bf[nq * 2 + j][ks] = u.f;
+                }
+            }
+    };
+    auto mma = [&](int mq, int nq) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mq * 4 + i][nq * 2 + j] = Mfma2<T>::run(bf[nq * 2 + j][ks], af[i][ks], acc[mq * 4 + i][nq * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto store_tile = [&](int m0, int n0, int gi) {
+        const uamd_gemm_group& g = p.g[gi];
+        T* Cg = (T*)g.C;
+        const int N = g.N;
+        const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + grp * 128 + i * 16 + l15;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+                if (n >= N) continue;
+                T* dst = Cg + (int64_t)m * g.ldc + n;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (n + 3 < N && vec_ok) {
+                    union { uint2 raw; T e[4]; } o;
+                    if (p.accumulate) {
+                        o.raw = *reinterpret_cast<const uint2*>(dst);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
+                    *reinterpret_cast<uint2*>(dst) = o.raw;
+                } else {
+                    for (int r = 0; r < 4 && n + r < N; ++r) {
+                        float x = v[r];
+                        if (p.accumulate) x += to_f32(dst[r]);
+                        dst[r] = from_f32<T>(x);
+                    }
+                }
+            }
+        }
+    };
+
+    int v = blockIdx.x;
+    int c_m0, c_n0, c_gi;
+    decode(v, c_m0, c_n0, c_gi);
+    set_issue(c_m0, c_n0, c_gi);
+    nk = nk_main + rank_tiles(c_gi);
+    // ---- prologue (first output tile of this block only): K tile 0 completely, first 3 pieces of K tile 1
+#pragma unroll
+    for (int c = 0; c < 8; ++c) issue_main(c, 0, 0);
+    issue_main(0, 1, 1); issue_main(1, 1, 1); issue_main(2, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    SLOT_BARRIER();
+    if (grp == 1) SLOT_BARRIER();          // anti-phase: group 1 runs one slot behind, for the whole walk
+
+// CHECK = 0: fast loop, every prefetched K tile is a tile of A / B proper of this output tile. CHECK = 1: the last
+// K tiles -- the prefetched one may be a rank-block tile, a tile of the next output tile (has_next) or nothing.
+#define MORE(CHECK, KT, D) (!(CHECK) || (KT) + (D) < nk || has_next)
+#define TILE_P(STAGE, KT, ISSUE, CHECK)                                                   \
+    do {                                                                                 \
+        /* L0 */                                                                         \
+        read_a(STAGE, 0); read_b(STAGE, 0);                                              \
+        if (MORE(CHECK, KT, 1)) { ISSUE(3, (KT) + 1, (STAGE) ^ 1); ISSUE(4, (KT) + 1, (STAGE) ^ 1); ISSUE(5, (KT) + 1, (STAGE) ^ 1); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(0, 0); SLOT_BARRIER();                                                       \
+        /* L1 */                                                                         \
+        read_b(STAGE, 1);                                                                \
+        if (MORE(CHECK, KT, 1)) { ISSUE(6, (KT) + 1, (STAGE) ^ 1); ISSUE(7, (KT) + 1, (STAGE) ^ 1); } \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(0, 1); SLOT_BARRIER();                                                       \
+        /* L2: the last piece of this output tile has been issued once KT + 2 == nk: hand the issue context over */ \
+        read_a(STAGE, 1);                                                                \
+        if ((CHECK) && has_next && (KT) + 2 == nk) set_issue(n_m0, n_n0, n_gi);          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                               \
+        SLOT_BARRIER();                                                                  \
+        mma(1, 1); SLOT_BARRIER();                                                       \
+        /* L3 */                                                                         \
+        if (MORE(CHECK, KT, 2)) {                                                                   \
+            ISSUE(0, (KT) + 2, STAGE); ISSUE(1, (KT) + 2, STAGE); ISSUE(2, (KT) + 2, STAGE); \
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                             \
+        } else {                                                                         \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             \
+        }                                                                                \
+        SLOT_BARRIER();                                                                  \
+        mma(1, 0); SLOT_BARRIER();                                                       \
+    } while (0)
+
+    for (;;) {
+        const int vn = v + (int)gridDim.x;
+        const bool has_next = vn < total;
+        int n_m0 = 0, n_n0 = 0, n_gi = 0;
+        if (has_next) decode(vn, n_m0, n_n0, n_gi);
+        int kt = 0;
+        for (; kt + 1 < nk_main - 2; kt += 2) {
+            TILE_P(0, kt, issue_main, 0);
+            TILE_P(1, kt + 1, issue_main, 0);
+        }
+        for (; kt + 1 < nk; kt += 2) {
+            TILE_P(0, kt, issue_any, 1);
+            TILE_P(1, kt + 1, issue_any, 1);
+        }
+        if (kt < nk) TILE_P(0, kt, issue_any, 1);
+        store_tile(c_m0, c_n0, c_gi);
+        if (!has_next) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (nk & 1) flip_stages();
+        c_m0 = n_m0; c_n0 = n_n0; c_gi = n_gi;
+        nk = nk_main + rank_tiles(c_gi);
+        v = vn;
+    }
+#undef TILE_P
+#undef MORE
+    if (grp == 0) SLOT_BARRIER();          // match group 1's extra barrier
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Half-height variant: 128 x 256 x 64 tiles, same LDS-DMA ping-pong, for launches whose 256 x 256 tiling would leave
 // CUs idle (M = 2048 tokens: o_proj / down_proj / every dX GEMM have 8 x 16 = 128 such tiles for 256 CUs; the
 // 128-row tiling gives 256). Each wave group owns 64 rows (wave tile 64 x 64, 32 MFMAs per K tile), a K tile is
@@ -696,6 +1018,35 @@ int launch256(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
+template <typename T, bool BNN>
+int launch256p(const G256Args& a, hipStream_t st, int n_cu) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256p_kernel<T, BNN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    const int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, BNN>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, a);
+    return uamd_launch_status();
+}
+
+// compute units of the current device (one persistent block each: 128 KiB of the CU's 160 KiB LDS)
+int cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
+    }
+    return n[dev];
+}
+
 }  // namespace
 
 #ifdef UAMD_G256_TRACE
@@ -763,6 +1114,13 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
     if (half) {
         if (dtype == UAMD_BF16) return bnn ? launch256h<bf16_t, true>(a, st) : launch256h<bf16_t, false>(a, st);
         if (dtype == UAMD_F16) return bnn ? launch256h<f16_t, true>(a, st) : launch256h<f16_t, false>(a, st);
+        return UAMD_ERR_DTYPE;
+    }
+    // persistent walk (UAMD_TUNE_GEMM_PERSIST, default on) when every CU gets more than one tile
+    const int n_cu = cu_count();
+    if (uamd_tuning_get(UAMD_TUNE_GEMM_PERSIST) && K >= 4 * TK && a.total_tiles > n_cu && (n_cu & 7) == 0) {
+        if (dtype == UAMD_BF16) return bnn ? launch256p<bf16_t, true>(a, st, n_cu) : launch256p<bf16_t, false>(a, st, n_cu);
+        if (dtype == UAMD_F16) return bnn ? launch256p<f16_t, true>(a, st, n_cu) : launch256p<f16_t, false>(a, st, n_cu);
         return UAMD_ERR_DTYPE;
     }
     if (dtype == UAMD_BF16) return bnn ? launch256<bf16_t, true>(a, st) : launch256<bf16_t, false>(a, st);
