@@ -31,7 +31,7 @@ def ref_attention(q, k, v, scale, allowed=None):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,T,Hq,Hk", [(1, 64, 4, 1), (2, 128, 8, 2), (1, 200, 4, 1), (1, 777, 8, 8), (2, 256, 8, 1),
-                                       (1, 2048, 8, 2), (1, 31, 2, 1)])
+                                       (1, 2048, 8, 2), (1, 31, 2, 1), (2, 1000, 4, 2)])
 def test_attn_forward_matches_fp32_oracle(dtype, B, T, Hq, Hk):
     from unsloth_amd.kernels.attention import attn_forward
     D = 128

@@ -185,9 +185,11 @@ def test_resident_decoded_weights_are_bitwise_neutral():
     from unsloth_amd import nf4
     ids, labels, pos = _batch(seed=8)
     batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    from unsloth_amd.kernels import utils as U
     res = []
     for on in (False, True):
         nf4.set_resident(on)
+        fused, U.FUSED_NF4 = U.FUSED_NF4, False     # 192 tokens would take the in-kernel NF4 decode: nothing to mirror
         try:
             model = _tiny(gc=False, head_dim=128)
             for step in range(2):
@@ -197,6 +199,7 @@ def test_resident_decoded_weights_are_bitwise_neutral():
                 out.loss.backward()
             res.append((out.loss.detach().clone(), _grads(model), nf4.resident_count()))
         finally:
+            U.FUSED_NF4 = fused
             nf4.set_resident(False)
     assert res[0][2] == 0 and res[1][2] == 2 * 7            # every projection of the 2 layers has a mirror
     assert torch.equal(res[0][0], res[1][0])

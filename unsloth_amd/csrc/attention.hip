@@ -86,6 +86,41 @@ __device__ __forceinline__ void dma16x2(const void* base, unsigned v0, unsigned 
         : "memory");
 }
 
+__device__ __forceinline__ void dma16x4g(const void* base, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                         unsigned d0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %2, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, %6\n\t"
+        "s_add_u32 m0, m0, 0x400\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %4, %6\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(d0), "s"(base)
+        : "memory", "scc");
+}
+__device__ __forceinline__ void dma16x1(const void* gptr, unsigned d0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(d0)
+        : "memory");
+}
+
 // max over the two lane halves (lanes l and l ^ 32) without touching the LDS pipe: v_permlane32_swap is a VALU
 // op, so the softmax does not wait (lgkmcnt) for operand reads that are in flight for the next MFMA phase.
 __device__ __forceinline__ float max_across_halves(float v) {
@@ -597,41 +632,6 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 constexpr int KD_STG = 4 * 16384 + 1024;             // 4 units x (Q 8 KiB + dO 8 KiB) + stats (LSE, Delta)
 constexpr int KD_V_OFF = 2 * KD_STG;                 // resident V tile
 constexpr int KD_LDS = KD_V_OFF + TILE_B;            // 149,504 B
-
-__device__ __forceinline__ void dma16x4g(const void* base, unsigned v0, unsigned v1, unsigned v2, unsigned v3,
-                                         unsigned d0) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %6\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %6\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %6\n\t"
-        "s_add_u32 m0, m0, 0x400\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %6\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(d0), "s"(base)
-        : "memory", "scc");
-}
-__device__ __forceinline__ void dma16x1(const void* gptr, unsigned d0) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gptr), "s"(d0)
-        : "memory");
-}
 
 template <typename T>
 __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
