@@ -229,9 +229,9 @@ int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
 #define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has
                                  * fewer than 192 tiles (default), 0 = always 256 rows, 2 = always 128 rows */
-#define UAMD_TUNE_GEMM_PERSIST 7 /* (UAMD_GEMM_PERSIST) uamd_gemm_n{t,n}_256 with 256-row tiles: 1 = one persistent block per CU walks the
-                                 * tiles and prefetches the next tile's first K tiles during the current one's last (default), 0 = one
-                                 * block per tile */
+#define UAMD_TUNE_GEMM_PERSIST 7 /* (UAMD_GEMM_PERSIST) uamd_gemm_n{t,n}_256 with 256-row tiles: one persistent block per CU walks the tiles
+                                 * and prefetches the next tile's first K tiles during the current one's last: 1 = when every CU gets
+                                 * >= 4 tiles (default), 2 = whenever it gets more than one, 0 = never (one block per tile) */
 #define UAMD_TUNE_COUNT 8
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
@@ -280,6 +280,50 @@ int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
                   void* dQ, void* dK, void* dV, float* Delta, const int64_t* strides, int B, int T, int Hq, int Hk,
                   int D, int lse_stride, float scale, int causal, const int* lo, const int* hi, int dtype,
                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Single-token decode: csrc/decode.hip.
+ *
+ * uamd_gemv: y_g[n] = W_g[n, :] . x (+ lora_scale_g * LB_g[n, :] . t_g + bias_g[n]) for up to 4 row groups sharing one
+ * token's x [K] (q|k|v, gate|up) in ONE launch. nf4 != 0: W_g is bitsandbytes-format NF4 (packed [N, K/2]; absmax per
+ * `blocksize` codes: fp32, or nested uint8 codes + code2 + absmax2 + offset decoded in the same kernel). Replaces
+ * fast_gemv and the bsz == 1 branch of fast_linear_forward (unsloth/kernels/utils.py:872-977, :1082-1125: bitsandbytes'
+ * cdequantize_blockwise_fp32 + cgemm_4bit_inference_naive_{fp16,bf16}, then torch mv / addmv for LoRA). t_g = A_g x comes
+ * from a previous uamd_gemv over the A rows with y_f32 = 1. K % 8 == 0 (nf4: K % 32 == 0, blocksize % 32 == 0),
+ * K <= 16384, R <= 64. */
+typedef struct {
+    const void* W;             /* nf4: uint8 [N, K/2]; else dtype [N, K], row stride ldw elements */
+    const uint8_t* absmax_u8;  /* nf4, nested: codes [N*K/blocksize] (with code2, absmax2, blocksize2, offset) */
+    const float* absmax_f32;   /* nf4, single level: [N*K/blocksize]; takes precedence */
+    const float* code2;        /* 256-entry map of the nested level (shared by all groups of a launch) */
+    const float* absmax2;
+    void* y;                   /* dtype [N] (float [N] when y_f32) */
+    const float* lora_t;       /* fp32 [R] = A x, or NULL */
+    const void* lora_b;        /* [N, ld_lb]: fp32 when lora_b_f32, else dtype */
+    const void* bias;          /* dtype [N] or NULL */
+    int64_t ldw, ld_lb;
+    float offset, lora_scale;
+    int N, R, blocksize2, lora_b_f32, y_f32, _pad;
+} uamd_gemv_group;
+int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize, int dtype,
+              void* stream);
+/* RoPE (rotate-half; fp32 products, one rounding -- the training kernel's arithmetic) on the new token's q and k in
+ * place in the fused row qkv [B, (Hq + 2 Hk) D], and append of k, v to the cache [B, Hk, s_max, D] at position
+ * kv_len[b] (a DEVICE array: the step is replayable as a hipGraph). rope_pos (device, NULL = kv_len) indexes the
+ * cos / sin tables [positions, >= D/2]. Replaces the six in-place torch ops + two permuted copies of
+ * LlamaAttention_fast_forward_inference (unsloth/models/llama.py:468-497). */
+int uamd_rope_kv_append(void* qkv, int64_t ld_qkv, const void* cos_t, const void* sin_t, int64_t ld_cs,
+                        const int* kv_len, const int* rope_pos, void* k_cache, void* v_cache, int64_t cache_sb,
+                        int64_t cache_sh, int B, int Hq, int Hk, int D, int s_max, int dtype, void* stream);
+/* Split-KV decode attention over the cache, D = 128, GQA by head index: out[b, h, :] = softmax(q[b, h] . K^T * scale) V
+ * over keys [max(0, len - window), len), len = kv_len[b] + len_add. Grid (nsplit, Hk, B), split s owns keys
+ * [s * split_keys, (s + 1) * split_keys) (split_keys % 16 == 0, nsplit * split_keys >= s_max); partials = fp32
+ * workspace [B, Hq, nsplit, D + 2]; a second launch combines them. Replaces llama.py:499-543 (expand + matmul +
+ * softmax + matmul over the whole cache, or SDPA). */
+int uamd_attn_decode(const void* q, int64_t q_sb, const void* k_cache, const void* v_cache, int64_t cache_sb,
+                     int64_t cache_sh, const int* kv_len, int len_add, float* partials, void* out, int64_t out_sb,
+                     int B, int Hq, int Hk, int D, int nsplit, int split_keys, int window, float scale, int dtype,
+                     void* stream);
 
 /* uamd_lora_xa2: same contract as uamd_lora_xa for R <= 64, streaming version (csrc/lora_side.hip): 32 rows per
  * block, K split over 4 waves, X and W through a per-wave LDS-DMA ring, fixed-order reduction. */

@@ -299,6 +299,33 @@ def nf4_dequantize_state(packed, qs, dtype=None):
     return torch.from_numpy(w).view(*qs.shape).to(dtype or qs.dtype)
 
 
+def nf4_fp32_weight(packed, qs):
+    """The fp32 value of every NF4 code (LUT * absmax in fp32, no rounding to the activation dtype): the exact weight
+    the decode GEMV is measured against."""
+    to_np = lambda t: t.detach().cpu().numpy()
+    if getattr(qs, "nested", False) or getattr(qs, "state2", None) is not None:
+        am = dequantize_absmax_np(to_np(qs.absmax), to_np(qs.state2.code), to_np(qs.state2.absmax),
+                                  float(qs.offset), qs.state2.blocksize)
+    else:
+        am = to_np(qs.absmax).astype(np.float32)
+    return torch.from_numpy(nf4_dequantize_np(to_np(packed), am, qs.blocksize)).view(*qs.shape)
+
+
+def gemv_4bit_naive(x, W32_codes_lut, absmax_rows, dtype, blocksize=64):
+    """Rounding points of bitsandbytes' kgemm_4bit_inference_naive, the kernel the reference's fast_gemv calls
+    (unsloth/kernels/utils.py:953-974; bitsandbytes >= 0.45.5 csrc/kernels.cu -- third party, source absent here,
+    restated from the published kernel: PARITY UNPINNED). Per output row: quant_map = T(NF4 code), local_absmax =
+    T(absmax), local_B = T(quant_map * local_absmax), local_C += float(T(local_A * local_B)) accumulated in fp32, the
+    row result rounded to T. `W32_codes_lut` = NF4 code value per weight (fp32 [N, K]), `absmax_rows` fp32 [N, K/blocksize],
+    x [K] in T. Returns fp32 [N] (the T-rounded outputs)."""
+    T = dtype
+    qm = W32_codes_lut.to(T)                                        # quant_map[i] = T(datatype[i])
+    am = absmax_rows.to(T).repeat_interleave(blocksize, dim=1)       # local_absmax = T(absmax)
+    B = (qm.float() * am.float()).to(T)                              # product in T
+    prod = (x.to(T).float()[None, :] * B.float()).to(T)              # local_A * local_B in T
+    return prod.float().sum(dim=1).to(T).float()
+
+
 # ------------------------------------------------------------------------------------------------
 # LoRA linear algebra                  unsloth/kernels/utils.py:1128-1170, unsloth/kernels/fast_lora.py
 def matmul_lora(X, W, A, B, s):

@@ -41,10 +41,11 @@ def test_struct_layouts_match_the_header(tmp_path):
     import ctypes
     import subprocess
     import numpy as np
-    from unsloth_amd._lib import GemmGroup, LoraTnProblem
+    from unsloth_amd._lib import GemmGroup, GemvGroup, LoraTnProblem
     from unsloth_amd.kernels.utils import _PreparedFactors
     fields = {"uamd_gemm_group": [f[0] for f in GemmGroup._fields_],
               "uamd_lora_tn_problem": [f[0] for f in LoraTnProblem._fields_],
+              "uamd_gemv_group": [f[0] for f in GemvGroup._fields_],
               "uamd_lora_prep_desc": ["src", "dst_rowmajor", "dst_transposed", "rows", "cols", "dst_pad", "pad_ld",
                                       "pad_scale", "pad_transposed"]}
     src = ["#include <stdio.h>", "#include <stddef.h>", '#include "unsloth_amd.h"', "int main(void) {"]
@@ -61,6 +62,9 @@ def test_struct_layouts_match_the_header(tmp_path):
     assert int(got["uamd_gemm_group"]) == ctypes.sizeof(GemmGroup)
     for f in fields["uamd_gemm_group"]:
         assert int(got[f"uamd_gemm_group.{f}"]) == getattr(GemmGroup, f).offset, f
+    assert int(got["uamd_gemv_group"]) == ctypes.sizeof(GemvGroup)
+    for f in fields["uamd_gemv_group"]:
+        assert int(got[f"uamd_gemv_group.{f}"]) == getattr(GemvGroup, f).offset, f
     assert int(got["uamd_lora_tn_problem"]) == ctypes.sizeof(LoraTnProblem)
     for f in fields["uamd_lora_tn_problem"]:
         assert int(got[f"uamd_lora_tn_problem.{f}"]) == getattr(LoraTnProblem, f).offset, f

@@ -1,0 +1,201 @@
+"""-m gpu: the single-token decode path (csrc/decode.hip, kernels/decode.py, models/decode.py) -- NF4 / 16-bit GEMV with
+LoRA and bias against the exact fp32 product (and never further from it than the rounding points of bitsandbytes'
+naive 4-bit GEMV the reference calls), RoPE + cache append against the training RoPE kernel, split-KV attention against
+an fp32 softmax over the cache, and the engine's logits against the training-path forward of the same model."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _nf4(N, K, seed, dtype, nested=True):
+    from unsloth_amd.nf4 import quantize_nf4
+    W = (torch.randn(N, K, generator=g(seed)) * 0.05).to(dtype)
+    packed, qs = quantize_nf4(W.to(DEV), compress_statistics=nested)
+    qs.dtype = dtype
+    return packed, qs, R.nf4_fp32_weight(packed, qs)          # exact fp32 value of every code
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nested", [True, False])
+@pytest.mark.parametrize("Ns,K,lora", [((256,), 256, False), ((4096, 1024, 1024), 4096, True), ((1024, 1024), 14336, True),
+                                       ((40,), 2080, True), ((5, 3, 2, 9), 8192, False)])
+def test_gemv_nf4_groups_lora_bias(dtype, nested, Ns, K, lora):
+    from unsloth_amd.kernels import decode as D
+    x = torch.randn(K, generator=g(1)).to(dtype)
+    projs, wants, naive = [], [], []
+    for i, N in enumerate(Ns):
+        packed, qs, W32 = _nf4(N, K, 10 + i, dtype, nested)
+        A = B = s = None
+        want = W32.double() @ x.double()
+        if lora:
+            A = (torch.randn(16, K, generator=g(20 + i)) * 0.05)
+            B = (torch.randn(N, 16, generator=g(30 + i)) * 0.05)
+            s = 2.0
+            want = want + s * (B.double() @ (A.to(dtype).double() @ x.double()))
+        bias = (torch.randn(N, generator=g(40 + i)) * 0.1).to(dtype) if i == 0 else None
+        if bias is not None:
+            want = want + bias.double()
+        projs.append((packed, qs, None if A is None else torch.nn.Parameter(A.to(DEV)),
+                      None if B is None else torch.nn.Parameter(B.to(DEV)), s, None if bias is None else bias.to(DEV)))
+        wants.append(want)
+        # the reference kernel's rounding points on the base product (first-level absmax in fp32 -> rows)
+        am = (R.nf4_fp32_weight(packed, qs).abs().view(N, K // 64, 64).max(dim=2).values)
+        code = W32 / am.repeat_interleave(64, dim=1).clamp_min(1e-30)
+        naive.append(R.gemv_4bit_naive(x, code, am, dtype).double())
+    ys = D.linear_group(x.to(DEV), projs)
+    ys2 = D.linear_group(x.to(DEV), projs)
+    for y, y2, want, nv, N, p in zip(ys, ys2, wants, naive, Ns, projs):
+        assert y.shape == (N,) and torch.equal(y, y2)                       # run-to-run deterministic
+        scale = want.abs().max().item() + 1e-6
+        err = (y.double().cpu() - want).abs().max().item() / scale
+        assert err < (6e-3 if dtype == torch.bfloat16 else 1.5e-3), err    # output rounding + 16-bit code table
+        if p[2] is None and p[5] is None:
+            base_want = want
+            err_naive = (nv - base_want).abs().max().item() / scale
+            assert err <= 1.25 * err_naive + 2e-3, (err, err_naive)        # never further from the truth than bnb's kernel
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,K", [(128, 512), (1000, 4096), (3, 14336), (128256 // 8, 4096)])
+def test_gemv_dense_and_fp32_out(dtype, N, K):
+    from unsloth_amd.kernels import decode as D
+    W = (torch.randn(N, K, generator=g(3)) * 0.05).to(dtype)
+    x = torch.randn(K, generator=g(4)).to(dtype)
+    (y,) = D.gemv(x.to(DEV), [dict(W=W.to(DEV), N=N, y_f32=True)], nf4=False)
+    want = W.double() @ x.double()
+    assert y.dtype == torch.float32
+    torch.testing.assert_close(y.double().cpu(), want, rtol=1e-4, atol=1e-4 * want.abs().max().item())
+    (y16,) = D.gemv(x.to(DEV), [dict(W=W.to(DEV), N=N)], nf4=False)
+    assert torch.equal(y16.cpu(), y.cpu().to(dtype))                      # same sum, one rounding
+
+
+def test_fast_linear_forward_and_fast_gemv_entry_points():
+    """utils.py:872-977 / :1082-1125 call shapes: X [1, 1, K] -> [1, 1, N]; bsz > 1 or q_len > 1 take matmul_lora."""
+    from unsloth_amd.kernels import fast_gemv, fast_linear_forward
+    from unsloth_amd.nf4 import Linear4bit
+    dtype = torch.bfloat16
+    lin = torch.nn.Linear(256, 384, bias=True).to(dtype)
+    q = Linear4bit.from_linear(lin.to(DEV), 64, True)
+    X = torch.randn(1, 1, 256, generator=g(5)).to(dtype).to(DEV)
+    W32 = R.nf4_fp32_weight(q.weight.data, q.weight.quant_state)
+    want = W32.double() @ X.view(-1).double().cpu()
+    y = fast_gemv(X, q.weight, q.weight.quant_state)
+    assert y.shape == (1, 1, 384)
+    torch.testing.assert_close(y.view(-1).double().cpu(), want, rtol=2e-2, atol=2e-2 * want.abs().max().item())
+    y2 = fast_linear_forward(q, X)                                         # plain 4-bit layer: + bias
+    torch.testing.assert_close(y2.view(-1).double().cpu(), want + lin.bias.double().cpu(), rtol=2e-2,
+                               atol=2e-2 * want.abs().max().item())
+    X3 = torch.randn(2, 3, 256, generator=g(6)).to(dtype).to(DEV)
+    y3 = fast_linear_forward(q, X3)
+    assert y3.shape == (2, 3, 384)
+    want3 = X3.double().cpu() @ W32.double().t() + lin.bias.double().cpu()
+    torch.testing.assert_close(y3.double().cpu(), want3, rtol=3e-2, atol=3e-2 * want3.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Hq,Hk", [(1, 8, 2), (3, 4, 4)])
+def test_rope_kv_append_matches_training_rope(dtype, B, Hq, Hk):
+    from unsloth_amd.kernels import decode as Dk
+    from unsloth_amd.kernels.rope_embedding import fast_rope_embedding
+    D, S = 128, 256
+    qkv = torch.randn(B, (Hq + 2 * Hk) * D, generator=g(7)).to(dtype).to(DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(S).float()[:, None] * inv[None, :]
+    cos = torch.cat([ang.cos(), ang.cos()], dim=1).to(dtype).to(DEV)
+    sin = torch.cat([ang.sin(), ang.sin()], dim=1).to(dtype).to(DEV)
+    kv_len = torch.tensor([5, 17, 200][:B], dtype=torch.int32, device=DEV)
+    kc = torch.zeros(B, Hk, S, D, dtype=dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    ref = qkv.clone()
+    Qr = ref[:, :Hq * D].view(B, 1, Hq, D).transpose(1, 2)
+    Kr = ref[:, Hq * D:(Hq + Hk) * D].view(B, 1, Hk, D).transpose(1, 2)
+    fast_rope_embedding(Qr, Kr, cos, sin, kv_len.clone())                  # in place on `ref`, positions = kv_len
+    Dk.rope_kv_append(qkv, cos, sin, kv_len, kc, vc, Hq, Hk, D)
+    assert torch.equal(qkv, ref)                                           # same arithmetic, bit for bit
+    for b in range(B):
+        L = int(kv_len[b])
+        assert torch.equal(kc[b, :, L], qkv[b, Hq * D:(Hq + Hk) * D].view(Hk, D))
+        assert torch.equal(vc[b, :, L], qkv[b, (Hq + Hk) * D:].view(Hk, D))
+        assert float(kc[b, :, :L].abs().sum()) == 0 and float(kc[b, :, L + 1:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Hq,Hk", [(4, 4), (4, 2), (8, 2), (8, 1)])
+@pytest.mark.parametrize("lens,window", [((1,), 0), ((16, 129), 0), ((1000, 37, 512), 0), ((700,), 256), ((100,), 256)])
+def test_attn_decode_matches_fp32_softmax(dtype, Hq, Hk, lens, window):
+    from unsloth_amd.kernels import decode as Dk
+    D, S, B = 128, 1024, len(lens)
+    G = Hq // Hk
+    q = torch.randn(B, Hq * D, generator=g(8)).to(dtype)
+    kc = torch.randn(B, Hk, S, D, generator=g(9)).to(dtype)
+    vc = torch.randn(B, Hk, S, D, generator=g(10)).to(dtype)
+    kv_len = torch.tensor([l - 1 for l in lens], dtype=torch.int32)        # len_add = 1: the new token is already appended
+    part = torch.empty(B, Hq, S // 128, D + 2, dtype=torch.float32, device=DEV)
+    out = torch.empty(B, Hq * D, dtype=dtype, device=DEV)
+    Dk.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), kv_len.to(DEV), out, part, 128, 1.0 / math.sqrt(D), len_add=1,
+                   window=window)
+    for b, L in enumerate(lens):
+        first = L - window if (window and L > window) else 0
+        for h in range(Hq):
+            k = kc[b, h // G, first:L].double()
+            v = vc[b, h // G, first:L].double()
+            s = (k @ q[b, h * D:(h + 1) * D].double()) / math.sqrt(D)
+            want = torch.softmax(s, dim=0) @ v
+            got = out[b, h * D:(h + 1) * D].double().cpu()
+            assert (got - want).abs().max().item() < (1.2e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
+def _tiny(load_in_4bit=True, r=8):
+    from transformers import LlamaConfig
+    from unsloth_amd import FastLanguageModel
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1408, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128, vocab_size=1000, rms_norm_eps=1e-5, max_position_embeddings=512,
+                      rope_parameters={"rope_type": "default", "rope_theta": 5e5}, tie_word_embeddings=False)
+    model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=256, load_in_4bit=load_in_4bit, device=DEV,
+                                                 random_state=3407, use_gradient_checkpointing=False)
+    model = FastLanguageModel.get_peft_model(model, r=r, lora_alpha=2 * r, use_gradient_checkpointing=False, random_state=3407)
+    gg = torch.Generator().manual_seed(11)
+    for n, p in model.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_((torch.randn(p.shape, generator=gg) * 0.05).to(DEV))
+    return model
+
+
+@pytest.mark.parametrize("load_in_4bit", [True, False])
+def test_engine_logits_match_training_path_forward(load_in_4bit, monkeypatch):
+    """Prefill + 6 graph-replayed steps: every step's logits equal (bf16 noise) the last-position logits of the
+    training-path forward over the same prefix; eager and hipGraph steps agree bit for bit; greedy generate is the
+    argmax chain."""
+    from unsloth_amd.models.decode import DecodeEngine
+    monkeypatch.setenv("UNSLOTH_RETURN_LOGITS", "1")
+    model = _tiny(load_in_4bit)
+    model.eval()
+    ids = torch.randint(0, 1000, (1, 21), generator=g(12)).to(DEV)
+    eng = DecodeEngine(model, max_seq_len=256, batch=1, use_graph=True)
+    eng_e = DecodeEngine(model, max_seq_len=256, batch=1, use_graph=False)
+    lg, lg_e = eng.prefill(ids), eng_e.prefill(ids)
+    assert torch.equal(lg, lg_e)
+    seq = ids
+    for step in range(6):
+        with torch.no_grad():
+            full = model(input_ids=seq).logits[:, -1].float()
+        scale = full.abs().max().item()
+        assert (lg - full).abs().max().item() < 4e-2 * scale, (step, (lg - full).abs().max().item(), scale)
+        nxt = torch.argmax(lg, dim=-1)
+        seq = torch.cat([seq, nxt.view(1, 1)], dim=1)
+        lg, lg_e = eng.step(nxt).clone(), eng_e.step(nxt).clone()
+        assert torch.equal(lg, lg_e), f"graph replay differs from the eager step at step {step}"
+    assert int(eng.kv_len[0]) == 27
+    out = DecodeEngine(model, max_seq_len=256).generate(ids, max_new_tokens=6)
+    assert torch.equal(out[:, :27], seq[:, :27])

@@ -377,7 +377,7 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
             use_rank = rank and i != 1          # the middle group of a 3-group launch goes without: per-group K-tile counts
             groups.append(_group(Bs[i], outs[i], N, Bs[i].stride(0), xa=xk if use_rank else None, ld_xa=64, R=16, scale=1.0,
                                  xk=xk if use_rank else None, bk=BKs[i] if use_rank else None))
-        L.uamd_set_tuning(7, persist)
+        L.uamd_set_tuning(7, 2 if persist else 0)
         _launch_gemm(X, groups, nf4=False, accumulate=accumulate, nn=nn)
         return outs
 

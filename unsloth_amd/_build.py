@@ -27,6 +27,7 @@ SOURCES = [
     "gemm256.hip",
     "lora_side.hip",
     "attention.hip",
+    "decode.hip",
 ]
 
 

@@ -35,6 +35,17 @@ class GemmGroup(ctypes.Structure):
     ]
 
 
+class GemvGroup(ctypes.Structure):
+    """uamd_gemv_group (include/unsloth_amd.h)."""
+
+    _fields_ = [
+        ("W", c_void_p), ("absmax_u8", c_void_p), ("absmax_f32", c_void_p), ("code2", c_void_p), ("absmax2", c_void_p),
+        ("y", c_void_p), ("lora_t", c_void_p), ("lora_b", c_void_p), ("bias", c_void_p),
+        ("ldw", c_int64), ("ld_lb", c_int64), ("offset", c_float), ("lora_scale", c_float),
+        ("N", c_int), ("R", c_int), ("blocksize2", c_int), ("lora_b_f32", c_int), ("y_f32", c_int), ("_pad", c_int),
+    ]
+
+
 class LoraTnProblem(ctypes.Structure):
     """uamd_lora_tn_problem (include/unsloth_amd.h)."""
 
@@ -102,6 +113,12 @@ SIGNATURES = {
                               c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
     "uamd_attn_bwd": (c_int, [c_void_p] * 10 + [ctypes.POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int,
                                                c_float, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "uamd_gemv": (c_int, [c_void_p, c_int, ctypes.POINTER(GemvGroup), c_int, c_int, c_int, c_int, c_void_p]),
+    "uamd_rope_kv_append": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "uamd_attn_decode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p,
+                                 c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                 c_void_p]),
     "uamd_debug_mfma_probe": (c_int, [c_void_p, c_void_p]),
 }
 

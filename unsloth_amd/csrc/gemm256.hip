@@ -1116,9 +1116,13 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
         if (dtype == UAMD_F16) return bnn ? launch256h<f16_t, true>(a, st) : launch256h<f16_t, false>(a, st);
         return UAMD_ERR_DTYPE;
     }
-    // persistent walk (UAMD_TUNE_GEMM_PERSIST, default on) when every CU gets more than one tile
+    // persistent walk (UAMD_TUNE_GEMM_PERSIST: 1 = when every CU gets >= 4 tiles (default), 2 = whenever it gets more than
+    // one, 0 = never). Measured (profiles/r02i_gemm_persist_ab.txt): +0.5 % at 7 tiles per CU, -2.5 % .. 0 at 2 tiles per CU
+    // (static assignment loses the dispatcher's balancing) -- the kernel is power-limited, idle slots it removes come back
+    // as clock.
     const int n_cu = cu_count();
-    if (uamd_tuning_get(UAMD_TUNE_GEMM_PERSIST) && K >= 4 * TK && a.total_tiles > n_cu && (n_cu & 7) == 0) {
+    const int persist = uamd_tuning_get(UAMD_TUNE_GEMM_PERSIST);
+    if (persist && K >= 4 * TK && (n_cu & 7) == 0 && a.total_tiles > n_cu && (persist >= 2 || a.total_tiles >= 4 * n_cu)) {
         if (dtype == UAMD_BF16) return bnn ? launch256p<bf16_t, true>(a, st, n_cu) : launch256p<bf16_t, false>(a, st, n_cu);
         if (dtype == UAMD_F16) return bnn ? launch256p<f16_t, true>(a, st, n_cu) : launch256p<f16_t, false>(a, st, n_cu);
         return UAMD_ERR_DTYPE;

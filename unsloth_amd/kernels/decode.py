@@ -1,0 +1,150 @@
+"""Single-token decode launchers (csrc/decode.hip); mirror of the decode half of unsloth/kernels/utils.py.
+
+`fast_gemv` / the bsz == 1 branch of `fast_linear_forward` (utils.py:872-977, :1082-1125) become ONE `uamd_gemv`
+launch per group of projections that share the token (q|k|v, gate|up), plus one small `uamd_gemv` over the LoRA A rows
+that share it. NF4 weights are read in bitsandbytes' format straight from the `Params4bit` storage: nothing is
+dequantised to memory.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from .._lib import GemvGroup
+
+MAX_GROUPS = 4
+
+
+def _nf4_fields(qs):
+    """(absmax_u8, absmax_f32, code2, absmax2, offset, blocksize2) of a quant state; python floats cached on it."""
+    if getattr(qs, "quant_type", "nf4") not in ("nf4", None):
+        raise NotImplementedError(f"uamd_gemv decodes NF4 only (quant_type {qs.quant_type!r})")
+    if qs.nested:
+        off = getattr(qs, "_offset_float", None)
+        if off is None:
+            off = qs._offset_float = float(qs.offset)          # one host sync per weight, outside any graph capture
+        return qs.absmax, None, qs.state2.code, qs.state2.absmax, off, int(qs.state2.blocksize)
+    return None, qs.absmax, None, None, 0.0, 0
+
+
+def lora_a_rows(A_list, dtype):
+    """[sum R_i, K] activation-dtype copy of the LoRA A factors that share an input, cached on the first Parameter
+    (the reference caches `lora_A._fast_lora = lora_A.to(dtype)`, utils.py:1104-1106; weights are frozen at inference)."""
+    key = A_list[0]
+    ent = getattr(key, "_uamd_fast_lora_rows", None)
+    vers = tuple(a._version for a in A_list)
+    if ent is None or ent[0] != vers or ent[1].dtype != dtype or len(ent[2]) != len(A_list):
+        rows = torch.cat([a.detach().to(dtype) for a in A_list], dim=0).contiguous()
+        ent = (vers, rows, [a.shape[0] for a in A_list])
+        key._uamd_fast_lora_rows = ent
+    return ent[1]
+
+
+def gemv(x, groups, nf4, blocksize=64):
+    """One launch. x: [K] (contiguous, 16-bit). groups: list of dicts with W, N and optionally qs (quant state),
+    y, y_f32, lora_t, lora_b, lora_scale, R, bias. Returns the list of outputs."""
+    _lib.require_gpu(x)
+    K = x.numel()
+    assert 1 <= len(groups) <= MAX_GROUPS
+    arr = (GemvGroup * len(groups))()
+    outs, keep = [], []
+    for i, g in enumerate(groups):
+        N = g["N"]
+        y_f32 = bool(g.get("y_f32", False))
+        y = g.get("y")
+        if y is None:
+            y = torch.empty(N, dtype=torch.float32 if y_f32 else x.dtype, device=x.device)
+        outs.append(y)
+        W = g["W"]
+        e = arr[i]
+        e.W = W.data_ptr()
+        if nf4:
+            a_u8, a_f32, code2, absmax2, off, bs2 = _nf4_fields(g["qs"])
+            e.absmax_u8 = a_u8.data_ptr() if a_u8 is not None else None
+            e.absmax_f32 = a_f32.data_ptr() if a_f32 is not None else None
+            e.code2 = code2.data_ptr() if code2 is not None else None
+            e.absmax2 = absmax2.data_ptr() if absmax2 is not None else None
+            e.offset, e.blocksize2, e.ldw = off, bs2, 0
+        else:
+            assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == x.dtype and W.shape[1] == K
+            e.ldw = W.stride(0)
+        e.y = y.data_ptr()
+        t = g.get("lora_t")
+        if t is not None:
+            B = g["lora_b"]
+            assert t.dtype == torch.float32 and B.stride(1) == 1
+            e.lora_t, e.lora_b, e.ld_lb = t.data_ptr(), B.data_ptr(), B.stride(0)
+            e.lora_scale, e.R = float(g["lora_scale"]), int(g["R"])
+            e.lora_b_f32 = int(B.dtype == torch.float32)
+            assert B.dtype in (torch.float32, x.dtype)
+            keep += [t, B]
+        bias = g.get("bias")
+        e.bias = bias.data_ptr() if bias is not None else None
+        e.N, e.y_f32 = N, int(y_f32)
+    with _lib.device_ctx(x):
+        rc = _lib.lib().uamd_gemv(_lib.ptr(x), K, arr, len(groups), int(bool(nf4)), int(blocksize),
+                                  _lib.dtype_code(x.dtype), _lib.stream_of(x))
+    _lib.check(rc, "uamd_gemv")
+    return outs
+
+
+def linear_group(x, projs, out=None):
+    """y_i = W_i x + s_i B_i (A_i x) (+ bias_i) for projections sharing the token x [K]: at most two launches (the A rows
+    of all members, then the weights). projs: (W, quant_state, A, B, s[, bias]) as get_lora_parameters(_bias) returns
+    them. `out`: optional preallocated [sum N_i] row the outputs are written into back to back. Returns the views."""
+    x = x.reshape(-1)
+    dtype = x.dtype
+    nf4 = projs[0][1] is not None
+    assert all((p[1] is not None) == nf4 for p in projs), "a launch is all-NF4 or all-16-bit"
+    Ns = [int(p[1].shape[0]) if p[1] is not None else int(p[0].shape[0]) for p in projs]
+    if out is None:
+        out = torch.empty(sum(Ns), dtype=dtype, device=x.device)
+    with_lora = [p for p in projs if p[2] is not None]
+    t_all = None
+    if with_lora:
+        A_rows = lora_a_rows([p[2] for p in with_lora], dtype)
+        (t_all,) = gemv(x, [dict(W=A_rows, N=A_rows.shape[0], y_f32=True)], nf4=False)
+    groups, col, r0 = [], 0, 0
+    for p, N in zip(projs, Ns):
+        W, qs, A, B, s = p[:5]
+        g = dict(W=W, N=N, qs=qs, y=out[col:col + N], bias=p[5] if len(p) > 5 else None)
+        if A is not None:
+            R = A.shape[0]
+            g.update(lora_t=t_all[r0:r0 + R], lora_b=B.detach(), lora_scale=s, R=R)
+            r0 += R
+        groups.append(g)
+        col += N
+    blocksize = int(projs[0][1].blocksize) if nf4 else 64
+    ys = []
+    for i in range(0, len(groups), MAX_GROUPS):
+        ys += gemv(x, groups[i:i + MAX_GROUPS], nf4=nf4, blocksize=blocksize)
+    return ys
+
+
+def rope_kv_append(qkv, cos, sin, kv_len, k_cache, v_cache, Hq, Hk, D, rope_pos=None):
+    """In place on qkv [B, (Hq + 2 Hk) D]; k_cache / v_cache [B, Hk, S_max, D]; kv_len int32 [B] on the device."""
+    B = qkv.shape[0]
+    assert qkv.stride(1) == 1 and k_cache.is_contiguous() and v_cache.is_contiguous() and kv_len.dtype == torch.int32
+    assert cos.stride(1) == 1 and sin.stride() == cos.stride() and cos.dtype == qkv.dtype
+    with _lib.device_ctx(qkv):
+        rc = _lib.lib().uamd_rope_kv_append(
+            _lib.ptr(qkv), qkv.stride(0), _lib.ptr(cos), _lib.ptr(sin), cos.stride(0), _lib.ptr(kv_len),
+            _lib.ptr(rope_pos) if rope_pos is not None else None, _lib.ptr(k_cache), _lib.ptr(v_cache),
+            k_cache.stride(0), k_cache.stride(1), B, Hq, Hk, D, k_cache.shape[2], _lib.dtype_code(qkv.dtype),
+            _lib.stream_of(qkv))
+    _lib.check(rc, "uamd_rope_kv_append")
+
+
+def attn_decode(q, k_cache, v_cache, kv_len, out, partials, split_keys, scale, len_add=1, window=0):
+    """q [B, Hq*D] (a view into the fused qkv row is fine), out [B, Hq*D]; partials fp32 [B, Hq, nsplit, D + 2]."""
+    B, Hk, S_max, D = k_cache.shape
+    Hq = partials.shape[1]
+    nsplit = partials.shape[2]
+    assert nsplit * split_keys >= S_max and q.stride(1) == 1 and out.stride(1) == 1
+    with _lib.device_ctx(q):
+        rc = _lib.lib().uamd_attn_decode(
+            _lib.ptr(q), q.stride(0), _lib.ptr(k_cache), _lib.ptr(v_cache), k_cache.stride(0), k_cache.stride(1),
+            _lib.ptr(kv_len), int(len_add), _lib.ptr(partials), _lib.ptr(out), out.stride(0), B, Hq, Hk, D, nsplit,
+            int(split_keys), int(window), float(scale), _lib.dtype_code(q.dtype), _lib.stream_of(q))
+    _lib.check(rc, "uamd_attn_decode")
+    return out

@@ -806,12 +806,33 @@ def matmul_lora(X, W, W_quant, A, B, s, out=None):
 
 
 def fast_linear_forward(proj, X, temp_lora=None, out=None):
-    """utils.py:1082-1125 (decode-time linear). Inference is out of scope; this keeps
-    the entry point working through the training GEMM."""
-    W, W_quant, A, B, s = get_lora_parameters(proj)
-    return matmul_lora(X, W, W_quant, A, B, s, out=out)
+    """utils.py:1082-1125, the decode-time linear. X [bsz, q_len, in]: a single token of a single sequence goes through
+    the GEMV kernels (csrc/decode.hip: NF4 decoded in the kernel, LoRA and bias folded into its reduction -- the
+    reference's cdequantize_blockwise_fp32 + cgemm_4bit_inference_naive + mv + addmv); everything else through
+    matmul_lora like the reference's q_len != 1 / bsz > 1 branches. `temp_lora` is accepted and unused (the A x
+    products of a launch land in one fp32 vector of their own)."""
+    from . import decode as _dk
+    W, W_quant, A, B, s, bias = get_lora_parameters_bias(proj)
+    bsz, q_len, in_dim = X.shape
+    n_out = int(W_quant.shape[0]) if W_quant is not None else int(W.shape[0])
+    if bsz == 1 and q_len == 1 and in_dim <= 16384 and X.dtype in (torch.bfloat16, torch.float16) \
+            and (W_quant is not None or W.dtype == X.dtype):
+        flat = out.view(-1) if out is not None else None
+        (y,) = _dk.linear_group(X.reshape(-1), [(W, W_quant, A, B, s, bias)], out=flat)
+        return y.view(1, 1, n_out)
+    y = matmul_lora(X, W, W_quant, A, B, s, out=out)
+    if bias is not None:
+        y += bias
+    return y
 
 
 def fast_gemv(X, W, quant_state, out=None):
-    """utils.py:872-977 (NF4 GEMV for single-token decode): out of scope, routed to the GEMM."""
-    return matmul_lora(X, W, quant_state, None, None, None, out=out)
+    """utils.py:872-977: out[1, 1, N] = X[1, 1, K] @ W^T for an NF4 weight (or a plain matmul when quant_state is None,
+    :880-881). One uamd_gemv launch; the nested absmax is decoded inside it."""
+    from . import decode as _dk
+    if quant_state is None:
+        return torch.matmul(X, W, out=out)
+    N = int(quant_state.shape[0])
+    flat = out.view(-1) if out is not None else None
+    (y,) = _dk.linear_group(X.reshape(-1), [(W, quant_state, None, None, None)], out=flat)
+    return y.view(1, 1, N)

@@ -1,0 +1,306 @@
+"""KV-cache decode path; counterpart of the inference half of unsloth/models/llama.py.
+
+Reference: LlamaAttention_fast_forward_inference (:352-569), fast_swiglu_inference (:572-606),
+fast_rms_layernorm_inference (:609-632), LlamaModel_fast_forward_inference (:1249-1364) and unsloth_fast_generate
+(:2167-2259): a Python loop of ~25 small torch / bitsandbytes calls per layer per token, with a KV cache that grows by
+KV_CACHE_INCREMENT re-allocations and host syncs for the rotary length.
+
+MI355X design: one `DecodeEngine` per (model, max_seq_len, batch):
+  * the KV cache is allocated ONCE at [layers][B, Hk, S_max, D] (288 GB of HBM: no growth, no copies);
+  * a token step is 14 launches per layer (fused add+RMSNorm, LoRA-A GEMV, grouped NF4 GEMV q|k|v, RoPE+append,
+    split-KV attention + combine, GEMV o, fused add+RMSNorm, LoRA-A GEMV, grouped GEMV gate|up, SwiGLU, LoRA-A GEMV, GEMV
+    down) that read the position from DEVICE memory, so the whole step -- all layers, final norm, lm_head GEMV, greedy
+    argmax, position increment -- is captured once as a hipGraph and replayed per token: the step is launch-bound
+    otherwise (~450 launches for ~0.6 ms of HBM traffic at Llama-3-8B NF4);
+  * prefill runs the training-path kernels (flash attention over the prompt) and writes K (post-RoPE) / V into the cache.
+Batch > 1 decodes through the fused NF4 GEMM instead of the GEMV (as the reference does, utils.py:1095-1097).
+"""
+import math
+
+import torch
+
+from ..kernels import decode as _dk
+from ..kernels.rms_layernorm import add_rms_fwd, rms_fwd
+from ..kernels.rope_embedding import fast_rope_embedding
+from ..kernels.swiglu import swiglu_fg_kernel
+from ..kernels.utils import get_lora_parameters_bias, matmul_lora
+
+SPLIT_KEYS = 128
+
+
+def _base(model):
+    m = model.get_base_model() if hasattr(model, "get_base_model") else model
+    return m
+
+
+class DecodeEngine:
+    """Greedy / sampled generation for a (PEFT-wrapped) Llama-family causal LM loaded by unsloth_amd."""
+
+    def __init__(self, model, max_seq_len=2048, batch=1, use_graph=True):
+        from . import llama as _ll
+        self.model = model
+        self.lm = _base(model)                    # LlamaForCausalLM
+        self.core = self.lm.model                 # LlamaModel
+        cfg = self.lm.config
+        self.cfg = cfg
+        self.dtype = _ll._model_dtype(self.core)
+        self.dev = self.core.embed_tokens.weight.device
+        self.B = batch
+        self.S = int(math.ceil(max_seq_len / SPLIT_KEYS) * SPLIT_KEYS)
+        self.Hq, self.Hk = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.D = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        if self.D != 128:
+            raise NotImplementedError("decode attention kernel: head_dim 128 only")
+        if getattr(cfg, "hidden_act", "silu") != "silu":
+            raise NotImplementedError("decode path: SwiGLU MLP only")
+        self.window = int(getattr(cfg, "sliding_window", None) or 0)
+        self.scale = 1.0 / math.sqrt(self.D)
+        self.use_graph = bool(use_graph) and batch == 1
+        L = len(self.core.layers)
+        kw = dict(dtype=self.dtype, device=self.dev)
+        self.k_cache = [torch.zeros(batch, self.Hk, self.S, self.D, **kw) for _ in range(L)]
+        self.v_cache = [torch.zeros(batch, self.Hk, self.S, self.D, **kw) for _ in range(L)]
+        self.kv_len = torch.zeros(batch, dtype=torch.int32, device=self.dev)
+        self.partials = torch.empty(batch, self.Hq, self.S // SPLIT_KEYS, self.D + 2, dtype=torch.float32, device=self.dev)
+        self.tok = torch.zeros(batch, 1, dtype=torch.long, device=self.dev)
+        self.next_tok = torch.zeros(batch, dtype=torch.long, device=self.dev)
+        self.logits = None
+        tables = _ll._rope_tables(self.core)
+        self.cos, self.sin = tables.get(self.S, self.dev, self.dtype)
+        self._graph = None
+        self._params = [self._layer_params(l) for l in self.core.layers]
+        self._head = self.lm.lm_head.weight
+        self._sample = None
+
+    # ---- per-layer parameter tuples, read once (adapters must not be switched under a live engine) -------------------
+    @staticmethod
+    def _layer_params(layer):
+        a, m = layer.self_attn, layer.mlp
+        g = get_lora_parameters_bias
+        return dict(qkv=[g(a.q_proj), g(a.k_proj), g(a.v_proj)], o=[g(a.o_proj)],
+                    gu=[g(m.gate_proj), g(m.up_proj)], down=[g(m.down_proj)],
+                    ln1=(layer.input_layernorm.weight, _eps(layer.input_layernorm)),
+                    ln2=(layer.post_attention_layernorm.weight, _eps(layer.post_attention_layernorm)))
+
+    # ---- prefill: prompt through the training-path kernels, K / V into the cache -----------------------------------------
+    @torch.no_grad()
+    def prefill(self, input_ids):
+        from . import llama as _ll
+        B, T = input_ids.shape
+        assert B == self.B and T <= self.S
+        core = self.core
+        h = core.embed_tokens(input_ids.to(self.dev)).to(self.dtype)
+        cos, sin = self.cos, self.sin
+        resid, delta = h, None
+        for li, layer in enumerate(core.layers):
+            w1, e1 = self._params[li]["ln1"]
+            if delta is None:
+                x = rms_fwd(resid, w1, e1)[0].view(B, T, -1)
+            else:
+                resid, x, _ = add_rms_fwd(delta, resid, w1, e1)
+                resid, x = resid.view(B, T, -1), x.view(B, T, -1)
+            attn = layer.self_attn
+            Q, K, V = attn.apply_qkv(attn, x)
+            Q = Q.view(B, T, self.Hq, self.D).transpose(1, 2)
+            K = K.view(B, T, self.Hk, self.D).transpose(1, 2)
+            V = V.view(B, T, self.Hk, self.D).transpose(1, 2)
+            Q, K = fast_rope_embedding(Q, K, cos, sin, None)
+            self.k_cache[li][:, :, :T].copy_(K)
+            self.v_cache[li][:, :, :T].copy_(V)
+            A = _ll._attention(Q, K, V, None, None, self.window or None)
+            o = attn.apply_o(attn, A)
+            w2, e2 = self._params[li]["ln2"]
+            resid, x, _ = add_rms_fwd(o, resid, w2, e2)
+            resid, x = resid.view(B, T, -1), x.view(B, T, -1)
+            delta = layer.mlp(x)
+        wn, en = core.norm.weight, _eps(core.norm)
+        _, xn, _ = add_rms_fwd(delta[:, -1:], resid[:, -1:], wn, en)
+        self.kv_len.fill_(T)
+        self.logits = self._lm_head(xn.view(B, -1))
+        return self.logits
+
+    def _lm_head(self, x):                       # x [B, H] -> fp32 logits [B, V]
+        W = self._head
+        if self.B == 1 and W.dtype == x.dtype and W.shape[1] <= 16384:
+            (y,) = _dk.gemv(x.reshape(-1), [dict(W=W, N=W.shape[0], y_f32=True)], nf4=False)
+            return y.view(1, -1)
+        return (x @ W.t().to(x.dtype)).float()
+
+    # ---- one token ----------------------------------------------------------------------------------------------------------
+    def _linear(self, x, projs):
+        """x [B, K] -> list of [B, N_i]."""
+        if self.B == 1:
+            return [y.view(1, -1) for y in _dk.linear_group(x, projs)]
+        outs = []
+        for p in projs:                           # batch > 1: the fused small-M NF4 GEMM (utils.py:1095-1097 does dequant + matmul)
+            y = matmul_lora(x, p[0], p[1], p[2], p[3], p[4])
+            if len(p) > 5 and p[5] is not None:
+                y = y + p[5]
+            outs.append(y)
+        return outs
+
+    @torch.no_grad()
+    def _step_body(self):
+        B, H = self.B, self.cfg.hidden_size
+        core = self.core
+        h = core.embed_tokens(self.tok).to(self.dtype).view(B, H)
+        resid, delta = h, None
+        for li in range(len(core.layers)):
+            P = self._params[li]
+            if delta is None:
+                x = rms_fwd(resid, *P["ln1"])[0]
+            else:
+                resid, x, _ = add_rms_fwd(delta, resid, *P["ln1"])
+            if B == 1:
+                qkv = torch.empty(1, (self.Hq + 2 * self.Hk) * self.D, dtype=self.dtype, device=self.dev)
+                _dk.linear_group(x, P["qkv"], out=qkv.view(-1))
+            else:
+                qkv = torch.cat(self._linear(x, P["qkv"]), dim=1)
+            _dk.rope_kv_append(qkv, self.cos, self.sin, self.kv_len, self.k_cache[li], self.v_cache[li],
+                               self.Hq, self.Hk, self.D)
+            a_out = torch.empty(B, self.Hq * self.D, dtype=self.dtype, device=self.dev)
+            _dk.attn_decode(qkv[:, :self.Hq * self.D], self.k_cache[li], self.v_cache[li], self.kv_len, a_out,
+                            self.partials, SPLIT_KEYS, self.scale, len_add=1, window=self.window)
+            (o,) = self._linear(a_out, P["o"])
+            resid, x, _ = add_rms_fwd(o, resid, *P["ln2"])
+            gate, up = self._linear(x, P["gu"])
+            hmid = swiglu_fg_kernel(gate.view(B, 1, -1), up.view(B, 1, -1)).view(B, -1)
+            (delta,) = self._linear(hmid, P["down"])
+        _, xn, _ = add_rms_fwd(delta, resid, core.norm.weight, _eps(core.norm))
+        self.logits = self._lm_head(xn)
+        self.kv_len.add_(1)
+        if self._sample is None:
+            self.next_tok.copy_(torch.argmax(self.logits, dim=-1))
+        return self.logits
+
+    def step(self, token_ids):
+        """Feed one token per sequence ([B] or [B, 1]); returns fp32 logits [B, V] for the next position."""
+        self.tok.copy_(token_ids.view(self.B, 1))
+        if not self.use_graph:
+            return self._step_body()
+        if self._graph is None:
+            # eager warm-up (first-use attribute calls, allocator growth), with the position restored afterwards
+            kv0 = self.kv_len.clone()
+            self._step_body()
+            self.kv_len.copy_(kv0)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._step_body()
+            self.kv_len.copy_(kv0)               # the capture itself does not execute
+        self._graph.replay()
+        return self.logits
+
+    @torch.no_grad()
+    def generate(self, input_ids, max_new_tokens=32, eos_token_id=None, do_sample=False, temperature=1.0, top_k=0,
+                 generator=None):
+        """Greedy (default) or temperature / top-k sampling. Returns [B, T + new] token ids."""
+        input_ids = input_ids.to(self.dev)
+        logits = self.prefill(input_ids)
+        out = [input_ids]
+        eos = None if eos_token_id is None else set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])
+        done = torch.zeros(self.B, dtype=torch.bool, device=self.dev)
+        room = self.S - input_ids.shape[1]
+        for i in range(min(max_new_tokens, room)):
+            if do_sample:
+                lg = logits / max(temperature, 1e-6)
+                if top_k:
+                    kth = torch.topk(lg, top_k, dim=-1).values[:, -1:]
+                    lg = lg.masked_fill(lg < kth, float("-inf"))
+                nxt = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).view(-1)
+            else:
+                nxt = torch.argmax(logits, dim=-1)
+            out.append(nxt.view(self.B, 1))
+            if eos is not None:
+                done |= torch.isin(nxt, torch.tensor(sorted(eos), device=self.dev))
+                if bool(done.all()):
+                    break
+            if i + 1 < min(max_new_tokens, room):
+                logits = self.step(nxt)
+        return torch.cat(out, dim=1)
+
+
+def _eps(norm):
+    return float(getattr(norm, "variance_epsilon", getattr(norm, "eps", 1e-6)))
+
+
+def unsloth_fast_generate(model, input_ids=None, max_new_tokens=32, max_seq_len=None, **kwargs):
+    """llama.py:2167-2259 counterpart: `model.generate(...)` after `FastLanguageModel.for_inference(model)`."""
+    input_ids = kwargs.pop("inputs", input_ids)
+    need = input_ids.shape[1] + max_new_tokens
+    eng = getattr(model, "_uamd_decode_engine", None)
+    if eng is None or eng.B != input_ids.shape[0] or eng.S < need:
+        eng = DecodeEngine(model, max_seq_len=max(need, max_seq_len or 0), batch=input_ids.shape[0])
+        model._uamd_decode_engine = eng
+    return eng.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=kwargs.get("eos_token_id"),
+                        do_sample=kwargs.get("do_sample", False), temperature=kwargs.get("temperature", 1.0),
+                        top_k=kwargs.get("top_k", 0))
+
+
+# ---- the reference's function names, for code written against unsloth/models/llama.py ----------------------------------------
+def fast_rms_layernorm_inference(self, X, XX=None, XX2=None, variance=None):
+    """llama.py:609-632 (the scratch arguments are accepted and unused: one kernel, statistics in registers)."""
+    return rms_fwd(X, self.weight, _eps(self))[0].view(X.shape)
+
+
+def fast_swiglu_inference(self, X, temp_gate=None, temp_up=None, gate_multiplier=None, down_multiplier=None):
+    """llama.py:572-606: down(silu(gate(X)) * up(X)) for one token per sequence; gate | up are one grouped launch."""
+    from ..kernels.utils import fast_linear_forward
+    bsz, q_len, _ = X.shape
+    if bsz == 1 and q_len == 1:
+        gate, up = _dk.linear_group(X.reshape(-1), [get_lora_parameters_bias(self.gate_proj),
+                                                    get_lora_parameters_bias(self.up_proj)])
+        gate, up = gate.view(1, 1, -1), up.view(1, 1, -1)
+    else:
+        gate, up = fast_linear_forward(self.gate_proj, X), fast_linear_forward(self.up_proj, X)
+    if gate_multiplier is not None:
+        gate = gate * gate_multiplier
+    h = swiglu_fg_kernel(gate, up)
+    down = fast_linear_forward(self.down_proj, h)
+    return down * down_multiplier if down_multiplier is not None else down
+
+
+def LlamaAttention_fast_forward_inference(self, hidden_states, past_key_value, position_ids, do_prefill=False,
+                                          attention_mask=None, rotary_seq_len=None):
+    """llama.py:352-569: one new token per sequence against the KV cache. `past_key_value` = (K, V) [B, Hk, S, D] seeds the
+    module's cache when `do_prefill` (allocated once at the model's max_seq_length instead of growing by
+    KV_CACHE_INCREMENT); returns (attention output [B, 1, hidden], (K, V) views of the cache incl. the new token).
+    Key-padding masks are not supported here (the training path handles them through SDPA)."""
+    from . import llama as _ll
+    from ..kernels.utils import fast_linear_forward
+    if attention_mask is not None:
+        raise NotImplementedError("decode attention takes no padding mask; left-pad-free batches only")
+    cfg = self.config
+    bsz = hidden_states.shape[0]
+    Hq, Hk, D = cfg.num_attention_heads, cfg.num_key_value_heads, self.head_dim
+    dev, dtype = hidden_states.device, hidden_states.dtype
+    K1, V1 = past_key_value
+    seq_len = K1.shape[-2]
+    st = getattr(self, "_uamd_kv", None)
+    if do_prefill or st is None or st["k"].shape[0] != bsz:
+        S = int(math.ceil(max(getattr(self, "max_seq_length", 0) or 0, seq_len + 1, 2048) / SPLIT_KEYS) * SPLIT_KEYS)
+        st = dict(k=torch.zeros(bsz, Hk, S, D, dtype=dtype, device=dev), v=torch.zeros(bsz, Hk, S, D, dtype=dtype, device=dev),
+                  len=torch.zeros(bsz, dtype=torch.int32, device=dev),
+                  part=torch.empty(bsz, Hq, S // SPLIT_KEYS, D + 2, dtype=torch.float32, device=dev))
+        st["k"][:, :, :seq_len].copy_(K1)
+        st["v"][:, :, :seq_len].copy_(V1)
+        self._uamd_kv = st
+    st["len"].fill_(seq_len)
+    qkv = torch.cat([fast_linear_forward(p, hidden_states).view(bsz, -1) for p in (self.q_proj, self.k_proj, self.v_proj)], dim=1) \
+        if bsz != 1 else torch.empty(1, (Hq + 2 * Hk) * D, dtype=dtype, device=dev)
+    if bsz == 1:
+        _dk.linear_group(hidden_states.reshape(-1), [get_lora_parameters_bias(p) for p in (self.q_proj, self.k_proj, self.v_proj)],
+                         out=qkv.view(-1))
+    if position_ids.dim() == 1:
+        position_ids = position_ids[:, None]
+    pos = position_ids[:, -1].to(device=dev, dtype=torch.int32).contiguous()
+    tables = getattr(self, "_uamd_rope", None)
+    if tables is None:
+        tables = self._uamd_rope = _ll.RopeTables(cfg)
+    cos, sin = tables.get(max(seq_len + 1, st["k"].shape[2]), dev, dtype)
+    _dk.rope_kv_append(qkv, cos, sin, st["len"], st["k"], st["v"], Hq, Hk, D, rope_pos=pos)
+    out = torch.empty(bsz, Hq * D, dtype=dtype, device=dev)
+    _dk.attn_decode(qkv[:, :Hq * D], st["k"], st["v"], st["len"], out, st["part"], SPLIT_KEYS, 1.0 / math.sqrt(D),
+                    len_add=1, window=int(getattr(cfg, "sliding_window", None) or 0))
+    A = fast_linear_forward(self.o_proj, out.view(bsz, 1, Hq * D))
+    return A, (st["k"][:, :, :seq_len + 1], st["v"][:, :, :seq_len + 1])
