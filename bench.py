@@ -234,6 +234,33 @@ def main():
             alt_point("weights_resident_bf16_batch_1", False, 1)
             _nf4.set_resident(False)
             torch.cuda.empty_cache()
+        if os.environ.get("BENCH_DECODE_ALT", "1") == "1":
+            # single-stream KV-cache decode of the same model through the GEMV kernels, one hipGraph per token
+            from unsloth_amd.models.decode import DecodeEngine
+            model.eval()
+            eng = DecodeEngine(model, max_seq_len=T, batch=1, use_graph=True)
+            new = 48
+            eng.prefill(torch.randint(0, V, (1, T - new - 8), generator=gi).to(dev))
+            tok = torch.zeros(1, dtype=torch.long, device=dev)
+            eng.step(tok)
+            eng.step(tok)                         # the second call replays the captured graph
+            sync()
+            t0 = time.time()
+            for _ in range(new):
+                eng.step(eng.next_tok)
+            sync()
+            dtok = (time.time() - t0) / new
+            cfgm = cfg
+            nparam = a.layers * (cfgm.hidden_size * (cfgm.num_attention_heads + 2 * cfgm.num_key_value_heads) * eng.D
+                                 + cfgm.hidden_size * cfgm.num_attention_heads * eng.D
+                                 + 3 * cfgm.hidden_size * cfgm.intermediate_size)
+            hbm_bytes = nparam * 0.516 + V * cfgm.hidden_size * 2 + a.layers * 2 * T * cfgm.num_key_value_heads * eng.D * 2
+            alt["decode_batch_1_context_%d (hipGraph per token)" % T] = {
+                "tokens_per_s": round(1.0 / dtok, 1), "ms_per_token": round(dtok * 1e3, 3),
+                "hbm_bytes_per_token": int(hbm_bytes), "frac_of_hbm_peak": round(hbm_bytes / dtok / 8.0e12, 3)}
+            del eng
+            torch.cuda.empty_cache()
+            model.train()
     dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
     rccl_ranks = None
     if dist.is_initialized():

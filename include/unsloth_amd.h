@@ -295,7 +295,7 @@ typedef struct {
     const void* W;             /* nf4: uint8 [N, K/2]; else dtype [N, K], row stride ldw elements */
     const uint8_t* absmax_u8;  /* nf4, nested: codes [N*K/blocksize] (with code2, absmax2, blocksize2, offset) */
     const float* absmax_f32;   /* nf4, single level: [N*K/blocksize]; takes precedence */
-    const float* code2;        /* 256-entry map of the nested level (shared by all groups of a launch) */
+    const float* code2;        /* 256-entry map of the nested level */
     const float* absmax2;
     void* y;                   /* dtype [N] (float [N] when y_f32) */
     const float* lora_t;       /* fp32 [R] = A x, or NULL */
@@ -307,7 +307,7 @@ typedef struct {
 } uamd_gemv_group;
 int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize, int dtype,
               void* stream);
-/* RoPE (rotate-half; fp32 products, one rounding -- the training kernel's arithmetic) on the new token's q and k in
+/* RoPE (rotate-half; the training kernel's arithmetic and rounding points) on the new token's q and k in
  * place in the fused row qkv [B, (Hq + 2 Hk) D], and append of k, v to the cache [B, Hk, s_max, D] at position
  * kv_len[b] (a DEVICE array: the step is replayable as a hipGraph). rope_pos (device, NULL = kv_len) indexes the
  * cos / sin tables [positions, >= D/2]. Replaces the six in-place torch ops + two permuted copies of

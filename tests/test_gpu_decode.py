@@ -49,10 +49,13 @@ def test_gemv_nf4_groups_lora_bias(dtype, nested, Ns, K, lora):
         projs.append((packed, qs, None if A is None else torch.nn.Parameter(A.to(DEV)),
                       None if B is None else torch.nn.Parameter(B.to(DEV)), s, None if bias is None else bias.to(DEV)))
         wants.append(want)
-        # the reference kernel's rounding points on the base product (first-level absmax in fp32 -> rows)
-        am = (R.nf4_fp32_weight(packed, qs).abs().view(N, K // 64, 64).max(dim=2).values)
-        code = W32 / am.repeat_interleave(64, dim=1).clamp_min(1e-30)
-        naive.append(R.gemv_4bit_naive(x, code, am, dtype).double())
+        # the reference kernel's rounding points on the base product (rows of whole 64-code blocks only)
+        if K % 64 == 0:
+            am = W32.abs().view(N, K // 64, 64).max(dim=2).values
+            code = W32 / am.repeat_interleave(64, dim=1).clamp_min(1e-30)
+            naive.append(R.gemv_4bit_naive(x, code, am, dtype).double())
+        else:
+            naive.append(None)
     ys = D.linear_group(x.to(DEV), projs)
     ys2 = D.linear_group(x.to(DEV), projs)
     for y, y2, want, nv, N, p in zip(ys, ys2, wants, naive, Ns, projs):
@@ -60,7 +63,7 @@ def test_gemv_nf4_groups_lora_bias(dtype, nested, Ns, K, lora):
         scale = want.abs().max().item() + 1e-6
         err = (y.double().cpu() - want).abs().max().item() / scale
         assert err < (6e-3 if dtype == torch.bfloat16 else 1.5e-3), err    # output rounding + 16-bit code table
-        if p[2] is None and p[5] is None:
+        if p[2] is None and p[5] is None and nv is not None:
             base_want = want
             err_naive = (nv - base_want).abs().max().item() / scale
             assert err <= 1.25 * err_naive + 2e-3, (err, err_naive)        # never further from the truth than bnb's kernel

@@ -61,162 +61,258 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     return v.u;
 }
 
+// Reductions on the VALU only (DPP), no LDS round trips: a ds_bpermute-based __shfl_xor costs ~100+ cycles of latency per
+// step, and a decode step is nothing but latency. row16_sum: every lane ends with the sum over its 16-lane row
+// (quad swaps, then the two mirror patterns pair each lane with the partial sum it is missing).
+#define UAMD_DPP_ADD(v, CTRL) ((v) + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, (v)), (CTRL), 0xf, 0xf, true)))
+__device__ __forceinline__ float row16_sum(float v) {
+    v = UAMD_DPP_ADD(v, 0xb1);      // quad_perm [1,0,3,2]
+    v = UAMD_DPP_ADD(v, 0x4e);      // quad_perm [2,3,0,1]
+    v = UAMD_DPP_ADD(v, 0x141);     // row_half_mirror
+    v = UAMD_DPP_ADD(v, 0x140);     // row_mirror
+    return v;
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {             // wave-uniform total of all 64 lanes
+    v = row16_sum(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+}
+
 #define UAMD_GEMV_MAX_GROUPS 4
 struct GemvArgs {
     const void* x;
-    int K, n_groups, blocksize, total_rows;
+    int K, n_groups, bs_shift, total_rows;         // blocksize = 1 << bs_shift
     int row_start[UAMD_GEMV_MAX_GROUPS + 1];
     uamd_gemv_group g[UAMD_GEMV_MAX_GROUPS];
 };
 
-// XREGS: registers holding this lane's slice of x = (iterations over K) x (pairs per 16-byte load)
-template <typename T, bool NF4, int XREGS>
-__global__ void __launch_bounds__(256) gemv_kernel(GemvArgs p) {
+// One block = 8 waves sharing the decode table and the token x in LDS; a wave takes RB ADJACENT rows per trip and
+// issues every global load of the trip (weights, absmax codes) before anything else -- on the first trip even before
+// the table is built -- so 4-8 KB per wave are in flight while the fixed costs are paid. NIT = iterations over K.
+constexpr int GEMV_THREADS = 512;
+template <typename T, bool NF4, int NIT, int RB>
+__global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
     constexpr int PAIRS = NF4 ? 16 : 4;              // 16-bit pairs of x per 16-byte weight load
     constexpr int ELEMS = 2 * PAIRS;                 // columns per lane per iteration
-    constexpr int NIT = XREGS / PAIRS;
-    __shared__ uint32_t lut2[NF4 ? 256 * 32 : 1];    // [byte][copy]: both decoded values of a byte, packed
-    __shared__ float code2[NF4 ? 256 : 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
+    // layout: x [NIT * 64 * ELEMS] T | code2 [4][256] float | lut2 [256][32] u32 (NF4 only)
+    T* xs = reinterpret_cast<T*>(gemv_smem);
+    float* code2 = reinterpret_cast<float*>(gemv_smem + NIT * 64 * ELEMS * sizeof(T));
+    uint32_t* lut2 = reinterpret_cast<uint32_t*>(code2 + UAMD_GEMV_MAX_GROUPS * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = p.K;
-    if (NF4) {
-        for (int i = tid; i < 256 * 32; i += 256) {
-            const int e = i >> 5;
-            lut2[i] = pack2<T>(kNF4d[e >> 4], kNF4d[e & 15]);      // high nibble = even element
-        }
-        code2[tid] = p.g[0].code2 ? p.g[0].code2[tid] : 0.f;       // one nested map per launch (host checks)
-    }
-    // this lane's columns: k0(i) = (i * 64 + lane) * ELEMS
-    uint32_t xr[NIT][PAIRS];
-    const T* xp = (const T*)p.x;
+    // columns past K: x is zero there, so the lane may read any valid address instead (no branches in the row loop)
+    int koff[NIT];
 #pragma unroll
     for (int i = 0; i < NIT; ++i) {
         const int k0 = (i * 64 + lane) * ELEMS;
-#pragma unroll
-        for (int q = 0; q < PAIRS / 4; ++q) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (k0 + q * 8 < K) v = *reinterpret_cast<const uint4*>(xp + k0 + q * 8);    // K % 8 == 0 (host)
-            xr[i][4 * q + 0] = v.x; xr[i][4 * q + 1] = v.y; xr[i][4 * q + 2] = v.z; xr[i][4 * q + 3] = v.w;
-        }
+        koff[i] = k0 < K ? k0 : 0;
     }
-    if (NF4) __syncthreads();
-    const uint32_t* lut_lane = lut2 + (lane & 31);
-
-    const int nwaves = gridDim.x * 4;
-    for (int row = blockIdx.x * 4 + wave; row < p.total_rows; row += nwaves) {
-        int gi = 0;
+    const int nwaves = gridDim.x * (GEMV_THREADS / 64);
+    int gis[RB], ns[RB];
+    float direct[RB];                                // 1: single-level fp32 absmax, 0: nested
+    uint4 w[RB][NIT];
+    uint32_t a8[RB][NIT];
+    float a2[RB][NIT];
+    auto load_rows = [&](int row0) {
 #pragma unroll
-        for (int i = 1; i < UAMD_GEMV_MAX_GROUPS; ++i)
-            if (i < p.n_groups && row >= p.row_start[i]) gi = i;
-        const uamd_gemv_group& g = p.g[gi];
-        const int n = row - p.row_start[gi];
-        // all loads of the row first (they are independent), then the arithmetic
-        uint4 w[NIT];
+        for (int r = 0; r < RB; ++r) {
+            const int row = min(row0 + r, p.total_rows - 1);         // a duplicate of the last row, not stored
+            int gi = 0;
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int k0 = (i * 64 + lane) * ELEMS;
-            w[i] = make_uint4(0, 0, 0, 0);
-            if (k0 < K) {
+            for (int i = 1; i < UAMD_GEMV_MAX_GROUPS; ++i)
+                if (i < p.n_groups && row >= p.row_start[i]) gi = i;
+            gis[r] = gi;
+            ns[r] = row - p.row_start[gi];
+            const uamd_gemv_group& g = p.g[gi];
+            direct[r] = g.absmax_f32 ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                a8[r][i] = 0;
+                a2[r][i] = 0.f;
                 if (NF4) {
-                    const int64_t e0 = (int64_t)n * K + k0;
-                    const uamd_u32x4 r = __builtin_nontemporal_load(reinterpret_cast<const uamd_u32x4*>((const uint8_t*)g.W + (e0 >> 1)));
-                    w[i] = make_uint4(r[0], r[1], r[2], r[3]);
+                    const int64_t e0 = (int64_t)ns[r] * K + koff[i];
+                    const uamd_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const uamd_u32x4*>((const uint8_t*)g.W + (e0 >> 1)));
+                    w[r][i] = make_uint4(v[0], v[1], v[2], v[3]);
+                    const int64_t blk = e0 >> p.bs_shift;
+                    if (g.absmax_f32) {
+                        a2[r][i] = g.absmax_f32[blk];
+                    } else {
+                        a8[r][i] = g.absmax_u8[blk];
+                        a2[r][i] = g.absmax2[blk >> g.blocksize2];       // (the host stores log2(blocksize2) here)
+                    }
                 } else {
-                    w[i] = *reinterpret_cast<const uint4*>((const T*)g.W + (int64_t)n * g.ldw + k0);
+                    w[r][i] = *reinterpret_cast<const uint4*>((const T*)g.W + (int64_t)ns[r] * g.ldw + koff[i]);
                 }
             }
         }
-        float acc = 0.f;
+    };
+    int row0 = (blockIdx.x * (GEMV_THREADS / 64) + wave_u) * RB;
+    if (row0 < p.total_rows) load_rows(row0);
+    // ---- block setup while those loads fly: x (zero-padded), the nested-absmax maps, the byte -> value-pair table
+    {
+        const T* xp = (const T*)p.x;
+        const int nvec = NIT * 64 * ELEMS / 8;
+        for (int v = tid; v < nvec; v += GEMV_THREADS) {
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (v * 8 < K) val = *reinterpret_cast<const uint4*>(xp + v * 8);        // K % 8 == 0 (host)
+            reinterpret_cast<uint4*>(xs)[v] = val;
+        }
+        if (NF4) {
+            for (int i = tid; i < UAMD_GEMV_MAX_GROUPS * 256; i += GEMV_THREADS) {
+                const int gi = i >> 8;
+                code2[i] = (gi < p.n_groups && p.g[gi].code2) ? p.g[gi].code2[i & 255] : 0.f;
+            }
+            if (tid < 256) {       // thread e builds entry e (high nibble = even element): 32 copies = 8 x 16 bytes
+                const uint32_t v = pack2<T>(kNF4d[tid >> 4], kNF4d[tid & 15]);
+                uint4* dst = reinterpret_cast<uint4*>(lut2 + tid * 32);
 #pragma unroll
-        for (int i = 0; i < NIT; ++i) {
-            const int k0 = (i * 64 + lane) * ELEMS;
-            if (k0 < K) {
-                const uint32_t ww[4] = {w[i].x, w[i].y, w[i].z, w[i].w};
-                float local = 0.f;
+                for (int c = 0; c < 8; ++c) dst[c] = make_uint4(v, v, v, v);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t* lut_lane = lut2 + (lane & 31);
+    const uint4* x_lane = reinterpret_cast<const uint4*>(xs) + lane * (PAIRS / 4);
+
+    for (; row0 < p.total_rows; row0 += nwaves * RB) {
+        float acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const uamd_gemv_group& g = p.g[gis[r]];
+            acc[r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                const uint32_t ww[4] = {w[r][i].x, w[r][i].y, w[r][i].z, w[r][i].w};
+                uint32_t xv[PAIRS];
+#pragma unroll
+                for (int q = 0; q < PAIRS / 4; ++q) {
+                    const uint4 t4 = x_lane[i * 64 * (PAIRS / 4) + q];
+                    xv[4 * q] = t4.x; xv[4 * q + 1] = t4.y; xv[4 * q + 2] = t4.z; xv[4 * q + 3] = t4.w;
+                }
                 if (NF4) {
-                    const int64_t blk = ((int64_t)n * K + k0) / p.blocksize;
-                    const float a = g.absmax_f32 ? g.absmax_f32[blk]
-                                                 : code2[g.absmax_u8[blk]] * g.absmax2[blk / g.blocksize2] + g.offset;
+                    // branch-free (a branch here splits the row into basic blocks and the dot products sink past all of them)
+                    const float a_nested = code2[gis[r] * 256 + a8[r][i]] * a2[r][i] + g.offset;
+                    const float a = direct[r] * a2[r][i] + (1.f - direct[r]) * a_nested;       // direct is exactly 0 or 1
+                    uint32_t dec[16];                        // all 16 table reads of the load first: one LDS latency, not 16
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const uint32_t byte = (ww[q] >> (8 * b)) & 0xffu;
-                            local = Dot2<T>::run(lut_lane[byte * 32], xr[i][4 * q + b], local);
-                        }
-                    acc += a * local;
-                } else {
+                        for (int b = 0; b < 4; ++b) dec[4 * q + b] = lut_lane[((ww[q] >> (8 * b)) & 0xffu) * 32];
+                    float l0 = 0.f, l1 = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) local = Dot2<T>::run(ww[q], xr[i][q], local);
-                    acc += local;
+                    for (int j = 0; j < 16; j += 2) {
+                        l0 = Dot2<T>::run(dec[j], xv[j], l0);
+                        l1 = Dot2<T>::run(dec[j + 1], xv[j + 1], l1);
+                    }
+                    acc[r] += a * (l0 + l1);
+                } else {
+                    float l0 = Dot2<T>::run(ww[0], xv[0], 0.f), l1 = Dot2<T>::run(ww[1], xv[1], 0.f);
+                    l0 = Dot2<T>::run(ww[2], xv[2], l0);
+                    l1 = Dot2<T>::run(ww[3], xv[3], l1);
+                    acc[r] += l0 + l1;
                 }
+                if (NIT > 2) __builtin_amdgcn_sched_barrier(0);    // keep the table / x reads of later iterations from piling up in registers
+            }
+            // LoRA: lane j adds s * B[n][j] * t[j]  (t = A x, fp32, from the preceding GEMV launch over the A rows)
+            if (g.lora_t && lane < g.R) {
+                const float bv = g.lora_b_f32 ? ((const float*)g.lora_b)[(int64_t)ns[r] * g.ld_lb + lane]
+                                              : to_f32(((const T*)g.lora_b)[(int64_t)ns[r] * g.ld_lb + lane]);
+                acc[r] += g.lora_scale * bv * g.lora_t[lane];
             }
         }
-        // LoRA: lane r adds s * B[n][r] * t[r]  (t = A x, fp32, from the preceding GEMV launch over the A rows)
-        if (g.lora_t && lane < g.R) {
-            const float bv = g.lora_b_f32 ? ((const float*)g.lora_b)[(int64_t)n * g.ld_lb + lane]
-                                          : to_f32(((const T*)g.lora_b)[(int64_t)n * g.ld_lb + lane]);
-            acc += g.lora_scale * bv * g.lora_t[lane];
-        }
-        acc = wave_sum(acc);
+        float tot[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) tot[r] = wave_sum_dpp(acc[r]);
+        const int cur = row0;
+        int gi_s[RB], n_s[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) { gi_s[r] = gis[r]; n_s[r] = ns[r]; }
+        if (row0 + nwaves * RB < p.total_rows) load_rows(row0 + nwaves * RB);        // next trip's loads before the stores
         if (lane == 0) {
-            if (g.bias) acc += to_f32(((const T*)g.bias)[n]);
-            if (g.y_f32) ((float*)g.y)[n] = acc;
-            else ((T*)g.y)[n] = from_f32<T>(acc);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                if (cur + r >= p.total_rows) break;
+                const uamd_gemv_group& g = p.g[gi_s[r]];
+                float v = tot[r];
+                if (g.bias) v += to_f32(((const T*)g.bias)[n_s[r]]);
+                if (g.y_f32) ((float*)g.y)[n_s[r]] = v;
+                else ((T*)g.y)[n_s[r]] = from_f32<T>(v);
+            }
         }
     }
+}
+
+template <typename T, bool NF4, int NIT, int RB>
+int launch_gemv_n(const GemvArgs& a, hipStream_t st) {
+    constexpr int ELEMS = NF4 ? 32 : 8;
+    const int lds = NIT * 64 * ELEMS * (int)sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 + (NF4 ? 256 * 32 * 4 : 0);
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (lds > 48 * 1024 && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemv_kernel<T, NF4, NIT, RB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    const int per_block = (GEMV_THREADS / 64) * RB;
+    int blocks = (a.total_rows + per_block - 1) / per_block;     // one trip per wave until the chip is full
+    if (blocks > 512) blocks = 512;                               // 2 blocks (16 waves) per CU
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((gemv_kernel<T, NF4, NIT, RB>), dim3(blocks), dim3(GEMV_THREADS), lds, st, a);
+    return uamd_launch_status();
 }
 
 template <typename T, bool NF4>
 int launch_gemv(const GemvArgs& a, hipStream_t st) {
     constexpr int ELEMS = NF4 ? 32 : 8;
     const int nit = (a.K + 64 * ELEMS - 1) / (64 * ELEMS);
-    const int pairs = NF4 ? 16 : 4;
-    int blocks = (a.total_rows + 7) / 8;                 // >= 2 rows per wave amortise the table / x setup
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
-    if (nit * pairs <= 32) hipLaunchKernelGGL((gemv_kernel<T, NF4, 32>), dim3(blocks), dim3(256), 0, st, a);
-    else if (nit * pairs <= 64) hipLaunchKernelGGL((gemv_kernel<T, NF4, 64>), dim3(blocks), dim3(256), 0, st, a);
-    else if (nit * pairs <= 128) hipLaunchKernelGGL((gemv_kernel<T, NF4, 128>), dim3(blocks), dim3(256), 0, st, a);
-    else return UAMD_ERR_ARG;                            // K > 16384 (NF4) / 4096 * 4 (dense): host splits K
-    return uamd_launch_status();
+    if constexpr (NF4) {                             // K <= 4096 | 8192 | 16384
+        if (nit <= 2) return launch_gemv_n<T, true, 2, 4>(a, st);
+        if (nit <= 4) return launch_gemv_n<T, true, 4, 2>(a, st);
+        if (nit <= 8) return launch_gemv_n<T, true, 8, 1>(a, st);
+    } else {                                         // K <= 4096 | 8192 | 16384
+        if (nit <= 8) return launch_gemv_n<T, false, 8, 2>(a, st);
+        if (nit <= 16) return launch_gemv_n<T, false, 16, 1>(a, st);
+        if (nit <= 32) return launch_gemv_n<T, false, 32, 1>(a, st);
+    }
+    return UAMD_ERR_ARG;                             // larger K: the caller splits it
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// RoPE (rotate-half, the training kernel's arithmetic: fp32 products, one rounding) on the new token's q and k, and the
+// RoPE (rotate-half, the training kernel's arithmetic and rounding points) on the new token's q and k, and the
 // append of k, v to the cache at position kv_len[b]. qkv: [B, (Hq + 2 Hk) D] as the fused q|k|v GEMV wrote it.
 template <typename T>
-__global__ void __launch_bounds__(256) rope_append_kernel(T* __restrict__ qkv, int64_t ld_qkv, const T* __restrict__ cos_t,
-                                                          const T* __restrict__ sin_t, int64_t ld_cs,
-                                                          const int* __restrict__ kv_len, const int* __restrict__ rope_pos,
-                                                          T* __restrict__ kc, T* __restrict__ vc, int64_t c_sb,
-                                                          int64_t c_sh, int Hq, int Hk, int D, int s_max) {
-    const int b = blockIdx.x;
+__global__ void __launch_bounds__(64) rope_append_kernel(T* __restrict__ qkv, int64_t ld_qkv, const T* __restrict__ cos_t,
+                                                         const T* __restrict__ sin_t, int64_t ld_cs,
+                                                         const int* __restrict__ kv_len, const int* __restrict__ rope_pos,
+                                                         T* __restrict__ kc, T* __restrict__ vc, int64_t c_sb,
+                                                         int64_t c_sh, int Hq, int Hk, int D, int s_max) {
+    const int h = blockIdx.x, b = blockIdx.y;            // h: q heads, then k heads, then v heads of the fused row
     const int half = D >> 1;
     const int len = kv_len[b];
     const int pos = rope_pos ? rope_pos[b] : len;
-    T* row = qkv + (int64_t)b * ld_qkv;
-    const int nrot = (Hq + Hk) * half;                  // (head, j) pairs to rotate
-    for (int i = threadIdx.x; i < nrot; i += 256) {
-        const int h = i / half, j = i - h * half;
-        T* v = row + (int64_t)h * D;                    // q heads then k heads are contiguous in the fused row
-        const float c = to_f32(cos_t[(int64_t)pos * ld_cs + j]), s = to_f32(sin_t[(int64_t)pos * ld_cs + j]);
-        const float x1 = to_f32(v[j]), x2 = to_f32(v[j + half]);
-        const T r1 = from_f32<T>(x1 * c - x2 * s), r2 = from_f32<T>(x2 * c + x1 * s);
-        v[j] = r1;
-        v[j + half] = r2;
-        if (h >= Hq && len < s_max) {
-            T* kd = kc + (int64_t)b * c_sb + (int64_t)(h - Hq) * c_sh + (int64_t)len * D;
-            kd[j] = r1;
-            kd[j + half] = r2;
+    T* v = qkv + (int64_t)b * ld_qkv + (int64_t)h * D;
+    if (h < Hq + Hk) {
+        T* kd = (h >= Hq && len < s_max) ? kc + (int64_t)b * c_sb + (int64_t)(h - Hq) * c_sh + (int64_t)len * D : nullptr;
+        for (int j = threadIdx.x; j < half; j += 64) {
+            const float c = to_f32(cos_t[(int64_t)pos * ld_cs + j]), s = to_f32(sin_t[(int64_t)pos * ld_cs + j]);
+            const float x1 = to_f32(v[j]), x2 = to_f32(v[j + half]);
+            // rounding points of the training kernel for 16-bit tables (csrc/rope_embedding.hip rotate<T, NATIVE>, i.e. the
+            // reference's Triton arithmetic in the cos / sin dtype): every product and the sum are rounded to T
+            const T r1 = from_f32<T>(round_to<T>(x1 * c) - round_to<T>(x2 * s));
+            const T r2 = from_f32<T>(round_to<T>(x2 * c) + round_to<T>(x1 * s));
+            v[j] = r1;
+            v[j + half] = r2;
+            if (kd) { kd[j] = r1; kd[j + half] = r2; }
         }
-    }
-    if (len < s_max) {
-        const T* vsrc = row + (int64_t)(Hq + Hk) * D;
-        for (int i = threadIdx.x; i < Hk * D; i += 256) {
-            const int h = i / D, j = i - h * D;
-            vc[(int64_t)b * c_sb + (int64_t)h * c_sh + (int64_t)len * D + j] = vsrc[i];
-        }
+    } else if (len < s_max) {
+        T* vd = vc + (int64_t)b * c_sb + (int64_t)(h - Hq - Hk) * c_sh + (int64_t)len * D;
+        for (int j = threadIdx.x; j < D; j += 64) vd[j] = v[j];
     }
 }
 
@@ -263,10 +359,7 @@ __global__ void __launch_bounds__(256) attn_decode_kernel(const T* __restrict__ 
             float a = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) a += qv[g][j] * to_f32(kk.e[j]);
-            a += __shfl_xor(a, 8, 64);
-            a += __shfl_xor(a, 4, 64);
-            a += __shfl_xor(a, 2, 64);
-            a += __shfl_xor(a, 1, 64);
+            a = row16_sum(a);                             // the key's 16 lanes all get q . k
             s[g] = valid ? a : -INFINITY;
         }
 #pragma unroll
@@ -326,14 +419,26 @@ __global__ void __launch_bounds__(128) attn_decode_combine_kernel(const float* _
                                                                   int64_t o_sb, int Hq, int nsplit) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* pp = part + ((int64_t)b * Hq + h) * nsplit * (DD + 2);
-    float mm = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) mm = fmaxf(mm, pp[s * (DD + 2) + DD]);
-    const float mr = mm == -INFINITY ? 0.f : mm;
-    float ll = 0.f, oo = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float a = __builtin_amdgcn_exp2f(pp[s * (DD + 2) + DD] - mr);
-        ll += pp[s * (DD + 2) + DD + 1] * a;
-        oo += pp[s * (DD + 2) + d] * a;
+    // running (max, sum, value) over the splits in a fixed order; 4 splits' loads in flight at a time
+    float mm = -INFINITY, ll = 0.f, oo = 0.f;
+    for (int s0 = 0; s0 < nsplit; s0 += 4) {
+        float ms[4], ls[4], os[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int s = min(s0 + j, nsplit - 1);
+            ms[j] = s0 + j < nsplit ? pp[s * (DD + 2) + DD] : -INFINITY;
+            ls[j] = pp[s * (DD + 2) + DD + 1];
+            os[j] = pp[s * (DD + 2) + d];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float mn = fmaxf(mm, ms[j]);
+            const float mr = mn == -INFINITY ? 0.f : mn;
+            const float a = __builtin_amdgcn_exp2f(mm - mr), c = __builtin_amdgcn_exp2f(ms[j] - mr);
+            ll = ll * a + ls[j] * c;
+            oo = oo * a + os[j] * c;
+            mm = mn;
+        }
     }
     out[(int64_t)b * o_sb + (int64_t)h * DD + d] = from_f32<T>(ll > 0.f ? oo / ll : 0.f);
 }
@@ -351,7 +456,9 @@ extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, in
     if ((K & 7) || !aligned16(x)) return UAMD_ERR_ALIGN;
     if (nf4 && (blocksize < 32 || (blocksize & 31) || (K & 31))) return UAMD_ERR_ARG;
     GemvArgs a;
-    a.x = x; a.K = K; a.n_groups = n_groups; a.blocksize = blocksize;
+    auto log2_exact = [](int v) { int sft = 0; while ((1 << sft) < v) ++sft; return (1 << sft) == v ? sft : -1; };
+    a.x = x; a.K = K; a.n_groups = n_groups; a.bs_shift = nf4 ? log2_exact(blocksize) : 0;
+    if (a.bs_shift < 0) return UAMD_ERR_ARG;
     int rows = 0;
     for (int i = 0; i < UAMD_GEMV_MAX_GROUPS; ++i) {
         a.row_start[i] = rows;
@@ -361,12 +468,15 @@ extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, in
             if (!aligned16(g.W)) return UAMD_ERR_ALIGN;
             if (nf4) {
                 if (!g.absmax_f32 && !(g.absmax_u8 && g.code2 && g.absmax2 && g.blocksize2 > 0)) return UAMD_ERR_ARG;
-                if (g.absmax_u8 && g.code2 != groups[0].code2) return UAMD_ERR_ARG;
             } else if (g.ldw & 7) {
                 return UAMD_ERR_ALIGN;
             }
             if (g.lora_t && (!g.lora_b || g.R <= 0 || g.R > 64)) return UAMD_ERR_ARG;
             a.g[i] = g;
+            if (nf4 && !g.absmax_f32) {
+                a.g[i].blocksize2 = log2_exact(g.blocksize2);
+                if (a.g[i].blocksize2 < 0) return UAMD_ERR_ARG;
+            }
             rows += g.N;
         } else {
             a.g[i] = groups[0];
@@ -390,11 +500,11 @@ extern "C" int uamd_rope_kv_append(void* qkv, int64_t ld_qkv, const void* cos_t,
         return UAMD_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UAMD_BF16)
-        hipLaunchKernelGGL((rope_append_kernel<bf16_t>), dim3(B), dim3(256), 0, st, (bf16_t*)qkv, ld_qkv, (const bf16_t*)cos_t,
+        hipLaunchKernelGGL((rope_append_kernel<bf16_t>), dim3(Hq + 2 * Hk, B), dim3(64), 0, st, (bf16_t*)qkv, ld_qkv, (const bf16_t*)cos_t,
                            (const bf16_t*)sin_t, ld_cs, kv_len, rope_pos, (bf16_t*)k_cache, (bf16_t*)v_cache, cache_sb,
                            cache_sh, Hq, Hk, D, s_max);
     else if (dtype == UAMD_F16)
-        hipLaunchKernelGGL((rope_append_kernel<f16_t>), dim3(B), dim3(256), 0, st, (f16_t*)qkv, ld_qkv, (const f16_t*)cos_t,
+        hipLaunchKernelGGL((rope_append_kernel<f16_t>), dim3(Hq + 2 * Hk, B), dim3(64), 0, st, (f16_t*)qkv, ld_qkv, (const f16_t*)cos_t,
                            (const f16_t*)sin_t, ld_cs, kv_len, rope_pos, (f16_t*)k_cache, (f16_t*)v_cache, cache_sb,
                            cache_sh, Hq, Hk, D, s_max);
     else
