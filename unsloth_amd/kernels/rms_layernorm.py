@@ -207,6 +207,8 @@ from transformers.models.llama.modeling_llama import LlamaRMSNorm
 
 class Unsloth_LlamaRMSNorm(LlamaRMSNorm):
     def forward(self, X):
+        if not X.is_cuda:                        # a stock model on the host (e.g. an fp32 reference): HF's own forward
+            return super().forward(X)
         return fast_rms_layernorm(self, X, gemma=False)
 
 
