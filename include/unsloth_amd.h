@@ -224,7 +224,8 @@ int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_STREAM_NT 2   /* (UAMD_STREAM_NT) streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
 #define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64, 2 = 64x256 with
                                  * the row tile as the fastest grid index (adjacent output segments written together) */
-#define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) reserved (attention kernel variants; no effect in this build) */
+#define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention: bit 0 = forward with 64 q rows per wave (attn_fwd64_kernel: 4 waves x 512 registers, hidden
+                                 * AGPR accumulators) for plain causal, G <= 4; default 0 (measured at parity with the 8-wave kernel) */
 #define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
 #define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has

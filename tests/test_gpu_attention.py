@@ -29,10 +29,20 @@ def ref_attention(q, k, v, scale, allowed=None):
     return o, lse
 
 
+@pytest.fixture(params=[0, 1], ids=["rows32x8waves", "rows64x4waves"])
+def fwd_variant(request):
+    """UAMD_TUNE_ATTN_VAR bit 0: the forward with 64 q rows per wave (attn_fwd64_kernel; G <= 4, plain causal)."""
+    from unsloth_amd import _lib
+    L = _lib.lib()
+    L.uamd_set_tuning(4, request.param)
+    yield request.param
+    L.uamd_set_tuning(4, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,T,Hq,Hk", [(1, 64, 4, 1), (2, 128, 8, 2), (1, 200, 4, 1), (1, 777, 8, 8), (2, 256, 8, 1),
-                                       (1, 2048, 8, 2), (1, 31, 2, 1), (2, 1000, 4, 2)])
-def test_attn_forward_matches_fp32_oracle(dtype, B, T, Hq, Hk):
+                                       (1, 2048, 8, 2), (1, 31, 2, 1), (2, 1000, 4, 2), (1, 1500, 2, 2), (1, 640, 4, 2)])
+def test_attn_forward_matches_fp32_oracle(fwd_variant, dtype, B, T, Hq, Hk):
     from unsloth_amd.kernels.attention import attn_forward
     D = 128
     # Q/K/V as column slices of one fused QKV projection output [B*T, (Hq+2Hk)*D]: the strided layout the model uses
@@ -151,3 +161,21 @@ def test_attn_band_batch_window():
     o_ref, _ = ref_attention(q.float(), k.float(), v.float(), 1.0 / math.sqrt(D), packed_mask(T, [T], W))
     o = flash_attention(q.to(DEV), k.to(DEV), v.to(DEV), None, attention_band(T, batch=B, sliding_window=W, device=DEV))
     assert (o.float().cpu() - o_ref).abs().max().item() <= 2e-2
+
+
+def test_attn_forward_rescale_heavy_inputs(fwd_variant):
+    """Scores that keep growing along the sequence (row max jumps by far more than the lazy-rescale threshold of 2^8 at
+    many half tiles) and a constant-score case (no rescale after the first half tile)."""
+    from unsloth_amd.kernels.attention import attn_forward
+    B, T, Hq, Hk, D = 1, 1024, 4, 1, 128
+    dtype = torch.bfloat16
+    q = torch.randn(B, T, Hq, D, generator=g(21)).to(dtype)
+    k = torch.randn(B, T, Hk, D, generator=g(22))
+    k = (k * torch.linspace(0.2, 6.0, T)[None, :, None, None]).to(dtype)       # later keys score much higher
+    v = torch.randn(B, T, Hk, D, generator=g(23)).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    for kk in (k, torch.zeros_like(k)):
+        o_ref, lse_ref = ref_attention(q.float(), kk.float(), v.float(), scale)
+        o, lse = attn_forward(q.to(DEV), kk.to(DEV), v.to(DEV), scale)
+        torch.testing.assert_close(lse.cpu(), lse_ref, rtol=1e-4, atol=5e-3)
+        assert (o.float().cpu() - o_ref).abs().max().item() <= 3e-2

@@ -44,6 +44,9 @@ def emit(out, name, secs, nbytes=None, flops=None, **kw):
 
 
 def main():
+    if os.environ.get('UAMD_DBG_LIB'):
+        from unsloth_amd import _lib as _l
+        _l.LIB_PATH = os.environ['UAMD_DBG_LIB']
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--tokens", type=int, nargs="+", default=[2048, 8192])

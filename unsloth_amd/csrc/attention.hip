@@ -135,6 +135,28 @@ __device__ __forceinline__ uint32_t pack_pair(float lo, float hi) {
     v.h[1] = from_f32<T>(hi);
     return v.u;
 }
+// the same through a vector conversion: selects the single v_cvt_pk_{bf16,f16}_f32 (the two scalar conversions above cost
+// 4 VALU instructions per pair in bf16). Used by attn_fwd64_kernel; the older kernels keep the form they were tuned with
+// (the packed form moves their register allocation over the 256-register edge).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2v_t;
+template <typename T>
+__device__ __forceinline__ uint32_t pack_pair2(float lo, float hi) {
+#if defined(UAMD_A64_DBG) && (UAMD_A64_DBG & 4)
+    return pack_pair<T>(lo, hi);
+#endif
+    const f32x2_t v = {lo, hi};
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        union { bf16x2v_t h; uint32_t u; } r;
+        r.h = __builtin_convertvector(v, bf16x2v_t);
+        return r.u;
+    } else {
+        union { f16x2v_t h; uint32_t u; } r;
+        r.h = __builtin_convertvector(v, f16x2v_t);
+        return r.u;
+    }
+}
 
 // -DUAMD_ATTN_TRACE: s_memtime stamps around the phases of forward tiles 8 and 9 (tools/attn_trace.py); never in the
 // shipped library.
@@ -415,6 +437,524 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             }
         if (lh == 0) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Forward with 64 q rows per wave: 4 waves per block, ONE wave per SIMD (512 registers).
+// Why: with 8 waves x 32 rows every wave reads the full K and V tiles from LDS for 32 rows of output -- 256 KB of LDS
+// reads per 64-key step per CU, half of them 8-byte transposing reads: ~3,000 cycles of LDS pipe against 2,048 cycles
+// of MFMA (profiles/r01_attn_fwd_trace.txt: tile period 5,800). Here every K / V^T fragment feeds TWO MFMAs (the
+// wave's two 32-row q blocks). With one wave per SIMD nobody else fills the matrix pipe during the softmax, so the wave
+// pipelines ITSELF over 32-key half tiles h = 0, 1, 2, ...; segment h is
+//     MFMA:  S^T(h+1) = K(h+1) Q^T  (16)   and   O^T += V^T(h-1) P^T(h-1)  (16)
+//     VALU:  row max of S^T(h), then  P^T(h) = exp2(S^T(h) c - m)
+// cut into chunks of {2-3 MFMAs, the VALU work of 4 scores} fenced with sched_barrier so the order in the source IS
+// the issue order. What the compiler must not decide (tools/experiments/README.md: the first version of this kernel
+// lost to its register allocation):
+//   * the O accumulators live in AGPRs a[0:127] for the whole kernel: their MFMAs are inline asm on PINNED tuples
+//     ("+{a[0:15]}" ...), and the only other thing that ever touches them, the online-softmax rescale, is inline asm on
+//     the same physical registers, in the slow path only;
+//   * the score accumulators are VGPRs (asm MFMAs in the VGPR-destination form): the softmax reads them directly.
+// The rescale is LAZY: a row's reference max is raised (and O, l rescaled) only when a half tile exceeds it by more
+// than 2^8 -- exp2(s - m_stale) <= 256 keeps fp32 / bf16 range, the 1/l normalisation is unchanged. The fast loop
+// contains no rescale code; a wave that needs one leaves the loop after the row max, runs the general segment (which
+// also handles the causal / ragged mask of the wave's last tile) and re-enters.
+// Same work per block as attn_fwd_kernel (q tile = 256 / G positions), same LDS-DMA tile format and swizzles, 4-stage
+// ring (128 KiB): a trip reads V of tiles t-1, t and K of tiles t, t+1; the refill happens mid-trip so that a tile has
+// two trips to land. Plain causal (no band), G in {1, 2, 4}.
+constexpr int NST4 = 4;
+constexpr int ATTN_LDS4 = NST4 * STAGE_B;            // 128 KiB
+constexpr float LAZY_RESCALE_LOG2 = 8.0f;
+
+// ---- O accumulators: AGPRs a0..a127, HIDDEN from the compiler (tuple i = a[16 i : 16 i + 15] = accumulator [dt * 2 + qb]).
+// They are not C++ values: every instruction that touches them is inline asm naming the physical registers, and every
+// such asm clobbers all 128, so the compiler keeps nothing of its own in them across these statements (a value pinned
+// only by a "+{a[..]}" constraint still gets copied to VGPRs at every control-flow merge: 128 moves per half tile).
+#ifndef UAMD_A64_DBG
+#define UAMD_A64_DBG 0
+#endif
+#if UAMD_A64_DBG & 2
+#define UAMD_A64_POST "\n\ts_nop 7\n\ts_nop 7"
+#else
+#define UAMD_A64_POST ""
+#endif
+#define UAMD_O_CLOBBER "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127"
+__device__ __forceinline__ void o_zero() {
+    asm volatile("v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\tv_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\tv_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\tv_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\tv_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\tv_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\tv_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\tv_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\tv_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\tv_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\tv_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\tv_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\tv_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\tv_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\tv_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\tv_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\tv_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\tv_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\tv_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\tv_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\tv_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\tv_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\tv_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\tv_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\tv_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\tv_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\tv_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\tv_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\tv_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\tv_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\tv_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\tv_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0" ::: UAMD_O_CLOBBER);
+}
+template <typename T, int I>
+__device__ __forceinline__ void pv_mfma_pinned(typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+    if constexpr (I == 0) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[0:15], %0, %1, a[0:15]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[0:15], %0, %1, a[0:15]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 1) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[16:31], %0, %1, a[16:31]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[16:31], %0, %1, a[16:31]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 2) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[32:47], %0, %1, a[32:47]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[32:47], %0, %1, a[32:47]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 3) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[48:63], %0, %1, a[48:63]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[48:63], %0, %1, a[48:63]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 4) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[64:79], %0, %1, a[64:79]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[64:79], %0, %1, a[64:79]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 5) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[80:95], %0, %1, a[80:95]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[80:95], %0, %1, a[80:95]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 6) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[96:111], %0, %1, a[96:111]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[96:111], %0, %1, a[96:111]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+    else if constexpr (I == 7) {
+        if constexpr (std::is_same<T, bf16_t>::value)
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 a[112:127], %0, %1, a[112:127]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+        else
+            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 a[112:127], %0, %1, a[112:127]" UAMD_A64_POST :: "v"(a), "v"(b) : UAMD_O_CLOBBER);
+    }
+}
+// tuple I *= alpha through a scratch VGPR; the s_nop runs cover MFMA-write -> accvgpr_read and accvgpr_write -> MFMA-read
+template <int I>
+__device__ __forceinline__ void scale_pinned(float alpha) {
+    float tmp;
+    if constexpr (I == 0)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a0\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a0, %0\n\tv_accvgpr_read_b32 %0, a1\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a1, %0\n\tv_accvgpr_read_b32 %0, a2\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a2, %0\n\tv_accvgpr_read_b32 %0, a3\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a3, %0\n\tv_accvgpr_read_b32 %0, a4\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a4, %0\n\tv_accvgpr_read_b32 %0, a5\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a5, %0\n\tv_accvgpr_read_b32 %0, a6\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a6, %0\n\tv_accvgpr_read_b32 %0, a7\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a7, %0\n\tv_accvgpr_read_b32 %0, a8\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a8, %0\n\tv_accvgpr_read_b32 %0, a9\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a9, %0\n\tv_accvgpr_read_b32 %0, a10\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a10, %0\n\tv_accvgpr_read_b32 %0, a11\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a11, %0\n\tv_accvgpr_read_b32 %0, a12\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a12, %0\n\tv_accvgpr_read_b32 %0, a13\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a13, %0\n\tv_accvgpr_read_b32 %0, a14\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a14, %0\n\tv_accvgpr_read_b32 %0, a15\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a15, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 1)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a16\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a16, %0\n\tv_accvgpr_read_b32 %0, a17\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a17, %0\n\tv_accvgpr_read_b32 %0, a18\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a18, %0\n\tv_accvgpr_read_b32 %0, a19\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a19, %0\n\tv_accvgpr_read_b32 %0, a20\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a20, %0\n\tv_accvgpr_read_b32 %0, a21\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a21, %0\n\tv_accvgpr_read_b32 %0, a22\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a22, %0\n\tv_accvgpr_read_b32 %0, a23\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a23, %0\n\tv_accvgpr_read_b32 %0, a24\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a24, %0\n\tv_accvgpr_read_b32 %0, a25\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a25, %0\n\tv_accvgpr_read_b32 %0, a26\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a26, %0\n\tv_accvgpr_read_b32 %0, a27\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a27, %0\n\tv_accvgpr_read_b32 %0, a28\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a28, %0\n\tv_accvgpr_read_b32 %0, a29\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a29, %0\n\tv_accvgpr_read_b32 %0, a30\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a30, %0\n\tv_accvgpr_read_b32 %0, a31\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a31, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 2)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a32\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a32, %0\n\tv_accvgpr_read_b32 %0, a33\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a33, %0\n\tv_accvgpr_read_b32 %0, a34\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a34, %0\n\tv_accvgpr_read_b32 %0, a35\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a35, %0\n\tv_accvgpr_read_b32 %0, a36\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a36, %0\n\tv_accvgpr_read_b32 %0, a37\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a37, %0\n\tv_accvgpr_read_b32 %0, a38\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a38, %0\n\tv_accvgpr_read_b32 %0, a39\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a39, %0\n\tv_accvgpr_read_b32 %0, a40\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a40, %0\n\tv_accvgpr_read_b32 %0, a41\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a41, %0\n\tv_accvgpr_read_b32 %0, a42\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a42, %0\n\tv_accvgpr_read_b32 %0, a43\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a43, %0\n\tv_accvgpr_read_b32 %0, a44\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a44, %0\n\tv_accvgpr_read_b32 %0, a45\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a45, %0\n\tv_accvgpr_read_b32 %0, a46\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a46, %0\n\tv_accvgpr_read_b32 %0, a47\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a47, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 3)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a48\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a48, %0\n\tv_accvgpr_read_b32 %0, a49\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a49, %0\n\tv_accvgpr_read_b32 %0, a50\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a50, %0\n\tv_accvgpr_read_b32 %0, a51\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a51, %0\n\tv_accvgpr_read_b32 %0, a52\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a52, %0\n\tv_accvgpr_read_b32 %0, a53\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a53, %0\n\tv_accvgpr_read_b32 %0, a54\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a54, %0\n\tv_accvgpr_read_b32 %0, a55\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a55, %0\n\tv_accvgpr_read_b32 %0, a56\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a56, %0\n\tv_accvgpr_read_b32 %0, a57\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a57, %0\n\tv_accvgpr_read_b32 %0, a58\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a58, %0\n\tv_accvgpr_read_b32 %0, a59\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a59, %0\n\tv_accvgpr_read_b32 %0, a60\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a60, %0\n\tv_accvgpr_read_b32 %0, a61\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a61, %0\n\tv_accvgpr_read_b32 %0, a62\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a62, %0\n\tv_accvgpr_read_b32 %0, a63\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a63, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 4)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a64\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a64, %0\n\tv_accvgpr_read_b32 %0, a65\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a65, %0\n\tv_accvgpr_read_b32 %0, a66\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a66, %0\n\tv_accvgpr_read_b32 %0, a67\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a67, %0\n\tv_accvgpr_read_b32 %0, a68\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a68, %0\n\tv_accvgpr_read_b32 %0, a69\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a69, %0\n\tv_accvgpr_read_b32 %0, a70\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a70, %0\n\tv_accvgpr_read_b32 %0, a71\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a71, %0\n\tv_accvgpr_read_b32 %0, a72\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a72, %0\n\tv_accvgpr_read_b32 %0, a73\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a73, %0\n\tv_accvgpr_read_b32 %0, a74\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a74, %0\n\tv_accvgpr_read_b32 %0, a75\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a75, %0\n\tv_accvgpr_read_b32 %0, a76\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a76, %0\n\tv_accvgpr_read_b32 %0, a77\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a77, %0\n\tv_accvgpr_read_b32 %0, a78\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a78, %0\n\tv_accvgpr_read_b32 %0, a79\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a79, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 5)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a80\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a80, %0\n\tv_accvgpr_read_b32 %0, a81\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a81, %0\n\tv_accvgpr_read_b32 %0, a82\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a82, %0\n\tv_accvgpr_read_b32 %0, a83\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a83, %0\n\tv_accvgpr_read_b32 %0, a84\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a84, %0\n\tv_accvgpr_read_b32 %0, a85\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a85, %0\n\tv_accvgpr_read_b32 %0, a86\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a86, %0\n\tv_accvgpr_read_b32 %0, a87\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a87, %0\n\tv_accvgpr_read_b32 %0, a88\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a88, %0\n\tv_accvgpr_read_b32 %0, a89\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a89, %0\n\tv_accvgpr_read_b32 %0, a90\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a90, %0\n\tv_accvgpr_read_b32 %0, a91\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a91, %0\n\tv_accvgpr_read_b32 %0, a92\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a92, %0\n\tv_accvgpr_read_b32 %0, a93\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a93, %0\n\tv_accvgpr_read_b32 %0, a94\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a94, %0\n\tv_accvgpr_read_b32 %0, a95\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a95, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 6)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a96\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a96, %0\n\tv_accvgpr_read_b32 %0, a97\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a97, %0\n\tv_accvgpr_read_b32 %0, a98\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a98, %0\n\tv_accvgpr_read_b32 %0, a99\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a99, %0\n\tv_accvgpr_read_b32 %0, a100\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a100, %0\n\tv_accvgpr_read_b32 %0, a101\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a101, %0\n\tv_accvgpr_read_b32 %0, a102\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a102, %0\n\tv_accvgpr_read_b32 %0, a103\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a103, %0\n\tv_accvgpr_read_b32 %0, a104\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a104, %0\n\tv_accvgpr_read_b32 %0, a105\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a105, %0\n\tv_accvgpr_read_b32 %0, a106\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a106, %0\n\tv_accvgpr_read_b32 %0, a107\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a107, %0\n\tv_accvgpr_read_b32 %0, a108\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a108, %0\n\tv_accvgpr_read_b32 %0, a109\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a109, %0\n\tv_accvgpr_read_b32 %0, a110\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a110, %0\n\tv_accvgpr_read_b32 %0, a111\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a111, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+    else if constexpr (I == 7)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a112\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a112, %0\n\tv_accvgpr_read_b32 %0, a113\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a113, %0\n\tv_accvgpr_read_b32 %0, a114\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a114, %0\n\tv_accvgpr_read_b32 %0, a115\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a115, %0\n\tv_accvgpr_read_b32 %0, a116\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a116, %0\n\tv_accvgpr_read_b32 %0, a117\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a117, %0\n\tv_accvgpr_read_b32 %0, a118\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a118, %0\n\tv_accvgpr_read_b32 %0, a119\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a119, %0\n\tv_accvgpr_read_b32 %0, a120\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a120, %0\n\tv_accvgpr_read_b32 %0, a121\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a121, %0\n\tv_accvgpr_read_b32 %0, a122\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a122, %0\n\tv_accvgpr_read_b32 %0, a123\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a123, %0\n\tv_accvgpr_read_b32 %0, a124\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a124, %0\n\tv_accvgpr_read_b32 %0, a125\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a125, %0\n\tv_accvgpr_read_b32 %0, a126\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a126, %0\n\tv_accvgpr_read_b32 %0, a127\n\ts_nop 0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a127, %0\n\ts_nop 4" : "=&v"(tmp) : "v"(alpha) : UAMD_O_CLOBBER);
+}
+// tuple I -> 16 floats (after the last MFMA: the leading s_nops cover its write)
+template <int I>
+__device__ __forceinline__ void read_pinned(float (&f)[16]) {
+    if constexpr (I == 0)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\tv_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3\n\tv_accvgpr_read_b32 %4, a4\n\tv_accvgpr_read_b32 %5, a5\n\tv_accvgpr_read_b32 %6, a6\n\tv_accvgpr_read_b32 %7, a7\n\tv_accvgpr_read_b32 %8, a8\n\tv_accvgpr_read_b32 %9, a9\n\tv_accvgpr_read_b32 %10, a10\n\tv_accvgpr_read_b32 %11, a11\n\tv_accvgpr_read_b32 %12, a12\n\tv_accvgpr_read_b32 %13, a13\n\tv_accvgpr_read_b32 %14, a14\n\tv_accvgpr_read_b32 %15, a15" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 1)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\tv_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19\n\tv_accvgpr_read_b32 %4, a20\n\tv_accvgpr_read_b32 %5, a21\n\tv_accvgpr_read_b32 %6, a22\n\tv_accvgpr_read_b32 %7, a23\n\tv_accvgpr_read_b32 %8, a24\n\tv_accvgpr_read_b32 %9, a25\n\tv_accvgpr_read_b32 %10, a26\n\tv_accvgpr_read_b32 %11, a27\n\tv_accvgpr_read_b32 %12, a28\n\tv_accvgpr_read_b32 %13, a29\n\tv_accvgpr_read_b32 %14, a30\n\tv_accvgpr_read_b32 %15, a31" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 2)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\tv_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35\n\tv_accvgpr_read_b32 %4, a36\n\tv_accvgpr_read_b32 %5, a37\n\tv_accvgpr_read_b32 %6, a38\n\tv_accvgpr_read_b32 %7, a39\n\tv_accvgpr_read_b32 %8, a40\n\tv_accvgpr_read_b32 %9, a41\n\tv_accvgpr_read_b32 %10, a42\n\tv_accvgpr_read_b32 %11, a43\n\tv_accvgpr_read_b32 %12, a44\n\tv_accvgpr_read_b32 %13, a45\n\tv_accvgpr_read_b32 %14, a46\n\tv_accvgpr_read_b32 %15, a47" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 3)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\tv_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51\n\tv_accvgpr_read_b32 %4, a52\n\tv_accvgpr_read_b32 %5, a53\n\tv_accvgpr_read_b32 %6, a54\n\tv_accvgpr_read_b32 %7, a55\n\tv_accvgpr_read_b32 %8, a56\n\tv_accvgpr_read_b32 %9, a57\n\tv_accvgpr_read_b32 %10, a58\n\tv_accvgpr_read_b32 %11, a59\n\tv_accvgpr_read_b32 %12, a60\n\tv_accvgpr_read_b32 %13, a61\n\tv_accvgpr_read_b32 %14, a62\n\tv_accvgpr_read_b32 %15, a63" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 4)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\tv_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67\n\tv_accvgpr_read_b32 %4, a68\n\tv_accvgpr_read_b32 %5, a69\n\tv_accvgpr_read_b32 %6, a70\n\tv_accvgpr_read_b32 %7, a71\n\tv_accvgpr_read_b32 %8, a72\n\tv_accvgpr_read_b32 %9, a73\n\tv_accvgpr_read_b32 %10, a74\n\tv_accvgpr_read_b32 %11, a75\n\tv_accvgpr_read_b32 %12, a76\n\tv_accvgpr_read_b32 %13, a77\n\tv_accvgpr_read_b32 %14, a78\n\tv_accvgpr_read_b32 %15, a79" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 5)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\tv_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83\n\tv_accvgpr_read_b32 %4, a84\n\tv_accvgpr_read_b32 %5, a85\n\tv_accvgpr_read_b32 %6, a86\n\tv_accvgpr_read_b32 %7, a87\n\tv_accvgpr_read_b32 %8, a88\n\tv_accvgpr_read_b32 %9, a89\n\tv_accvgpr_read_b32 %10, a90\n\tv_accvgpr_read_b32 %11, a91\n\tv_accvgpr_read_b32 %12, a92\n\tv_accvgpr_read_b32 %13, a93\n\tv_accvgpr_read_b32 %14, a94\n\tv_accvgpr_read_b32 %15, a95" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 6)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\tv_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99\n\tv_accvgpr_read_b32 %4, a100\n\tv_accvgpr_read_b32 %5, a101\n\tv_accvgpr_read_b32 %6, a102\n\tv_accvgpr_read_b32 %7, a103\n\tv_accvgpr_read_b32 %8, a104\n\tv_accvgpr_read_b32 %9, a105\n\tv_accvgpr_read_b32 %10, a106\n\tv_accvgpr_read_b32 %11, a107\n\tv_accvgpr_read_b32 %12, a108\n\tv_accvgpr_read_b32 %13, a109\n\tv_accvgpr_read_b32 %14, a110\n\tv_accvgpr_read_b32 %15, a111" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+    else if constexpr (I == 7)
+        asm volatile("s_nop 15\n\ts_nop 15\n\tv_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\tv_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115\n\tv_accvgpr_read_b32 %4, a116\n\tv_accvgpr_read_b32 %5, a117\n\tv_accvgpr_read_b32 %6, a118\n\tv_accvgpr_read_b32 %7, a119\n\tv_accvgpr_read_b32 %8, a120\n\tv_accvgpr_read_b32 %9, a121\n\tv_accvgpr_read_b32 %10, a122\n\tv_accvgpr_read_b32 %11, a123\n\tv_accvgpr_read_b32 %12, a124\n\tv_accvgpr_read_b32 %13, a125\n\tv_accvgpr_read_b32 %14, a126\n\tv_accvgpr_read_b32 %15, a127" : "=v"(f[0]), "=v"(f[1]), "=v"(f[2]), "=v"(f[3]), "=v"(f[4]), "=v"(f[5]), "=v"(f[6]), "=v"(f[7]), "=v"(f[8]), "=v"(f[9]), "=v"(f[10]), "=v"(f[11]), "=v"(f[12]), "=v"(f[13]), "=v"(f[14]), "=v"(f[15]));
+}
+// score MFMAs with the accumulator in VGPRs (the softmax reads it) and the Q^T operand in AGPRs ("a": the 64 registers
+// of Q fragments are MFMA-only, so they stay out of the VGPR file); first k-step with C = 0
+template <typename T>
+__device__ __forceinline__ void s_mfma_first(f32x16_t& s, typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+#if UAMD_A64_DBG & 1
+    f32x16_t z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    s = MfmaA<T>::run(a, b, z);
+    return;
+#endif
+    if constexpr (std::is_same<T, bf16_t>::value) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" UAMD_A64_POST : "=&v"(s) : "v"(a), "a"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" UAMD_A64_POST : "=&v"(s) : "v"(a), "a"(b));
+}
+template <typename T>
+__device__ __forceinline__ void s_mfma(f32x16_t& s, typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+#if UAMD_A64_DBG & 1
+    s = MfmaA<T>::run(a, b, s);
+    return;
+#endif
+#if UAMD_A64_DBG & 32
+    return;
+#endif
+    if constexpr (std::is_same<T, bf16_t>::value) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" UAMD_A64_POST : "+v"(s) : "v"(a), "a"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" UAMD_A64_POST : "+v"(s) : "v"(a), "a"(b));
+}
+// the LAST MFMA of a score chain carries the wait states its VALU readers need (XDL write -> VALU read: up to 19): the
+// compiler does not know these asm statements are MFMAs and may schedule a read of `s` right behind them
+template <typename T>
+__device__ __forceinline__ void s_mfma_last(f32x16_t& s, typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+#if UAMD_A64_DBG & 1
+    s = MfmaA<T>::run(a, b, s);
+    return;
+#endif
+    if constexpr (std::is_same<T, bf16_t>::value)
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7" : "+v"(s) : "v"(a), "a"(b));
+    else
+        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 7" : "+v"(s) : "v"(a), "a"(b));
+}
+template <typename T>
+__device__ __forceinline__ void pv_i(int i, typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+#if UAMD_A64_DBG & 8
+    return;
+#endif
+    switch (i) {                                  // i is a constant after unrolling: one case survives
+        case 0: pv_mfma_pinned<T, 0>(a, b); break;
+        case 1: pv_mfma_pinned<T, 1>(a, b); break;
+        case 2: pv_mfma_pinned<T, 2>(a, b); break;
+        case 3: pv_mfma_pinned<T, 3>(a, b); break;
+        case 4: pv_mfma_pinned<T, 4>(a, b); break;
+        case 5: pv_mfma_pinned<T, 5>(a, b); break;
+        case 6: pv_mfma_pinned<T, 6>(a, b); break;
+        default: pv_mfma_pinned<T, 7>(a, b); break;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) attn_fwd64_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename MfmaA<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = p.G, T_ = p.T;
+    const int QT = 64 * (4 / G);
+    const int npairs = p.Hk * p.B;
+    const int qtile = p.nqt - 1 - (int)(blockIdx.x / npairs);           // heaviest q tiles first
+    const int pair_ = (int)(blockIdx.x % npairs);
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
+    const int head = kvh * G + (wave % G);
+    const int qs = qtile * QT + (wave / G) * 64;                        // first q position of this wave
+
+    // ---- Q^T operand fragments of both 32-row q blocks (lane -> q = qs + 32 qb + l31, 8 d at 16 ks + 8 lh)
+    frag_t qf[2][8];
+    int q_pos[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        q_pos[qb] = qs + 32 * qb + l31;
+        const int q_ld = q_pos[qb] < T_ ? q_pos[qb] : T_ - 1;
+        const T* qp = (const T*)p.Q + b * p.q_sb + (int64_t)q_ld * p.q_st + (int64_t)head * p.q_sh + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            union { uint4 r; frag_t f; } u;
+            u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
+            qf[qb][ks] = u.f;
+        }
+    }
+
+    // ---- DMA plan: stage = K tile (64 rows x 256 B) then V tile; one DMA instruction = 4 rows; wave w issues
+    //      pieces 4w .. 4w+3 of K and of V (swizzles as in attn_fwd_kernel)
+    const int nt = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);     // tiles the block stages
+    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
+    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    const unsigned dst_w = lds_base + wave * 4096;
+    auto issue = [&](int t, int stage) {                                 // 8 DMA instructions per wave: K's 4, then V's 4
+        const int k0 = t * KT;
+        const unsigned d = dst_w + stage * STAGE_B;
+        // per-lane source offsets rebuilt per call from an opaque copy of the lane id (a dozen VALU instructions per
+        // tile): holding them would cost 8-20 registers for the whole kernel. Ragged last tile: masked rows re-read
+        // the last key.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        unsigned ko[4], vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 4 + (ln >> 4);
+            const int r = min(row, T_ - 1 - k0);
+            ko[i] = (unsigned)((int64_t)r * p.k_st * 2 + ((ln & 15) ^ (row & 15)) * 16);
+            vo[i] = (unsigned)((int64_t)r * p.v_st * 2 + ((ln & 15) ^ ((row & 3) << 2)) * 16);
+        }
+        dma16x4g(kbase + (int64_t)k0 * p.k_st, ko[0], ko[1], ko[2], ko[3], d);
+        dma16x4g(vbase + (int64_t)k0 * p.v_st, vo[0], vo[1], vo[2], vo[3], d + TILE_B);
+    };
+
+    const int kx = l31 & 15;
+    const int k_lane = l31 * 256 + (((kx & 14) | (lh ^ (kx & 1))) << 4);
+    const int sg = lane & 15, gh = (lane >> 4) & 1;
+    const int v_lane = (4 * lh + (sg >> 2)) * 256 + ((((sg >> 2) << 2) | (gh << 1) | ((sg >> 1) & 1)) << 4) + (sg & 1) * 8;
+    // K fragment (32 keys of half h x 16 d at k-step ks) / V^T fragment (32 d of tile dt x 16 keys of step c of half h)
+    auto kfrag = [&](int h, int ks) {
+        const unsigned char* sk = smem + ((h >> 1) & 3) * STAGE_B + (h & 1) * 32 * 256;
+        union { uint4 r; frag_t f; } u;
+        u.r = *reinterpret_cast<const uint4*>(sk + (k_lane ^ (ks * 32)));
+        return u.f;
+    };
+    auto vfrag = [&](int h, int c, int dt) {
+        const int hc = h < 0 ? 0 : h;                                    // h = -1: the all-zero P of the prologue times tile 0's V
+        const unsigned char* a0 = smem + ((hc >> 1) & 3) * STAGE_B + TILE_B + (((hc & 1) * 2 + c) * 16) * 256 + (v_lane ^ (dt << 6));
+        union { s16x4_t hh[2]; frag_t f; } va;
+        va.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        va.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * 256));
+        return va.f;
+    };
+
+    o_zero();                                                            // O^T accumulators [dt * 2 + qb] = a[0:127]
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const int nh = 2 * (min(qs + 63, T_ - 1) / KT + 1);                  // half tiles this wave multiplies (<= 2 nt)
+    const int nt_w = nh >> 1;
+    typedef union { uint32_t w[4]; frag_t f; } pfrag_t;                  // P^T operand: 8 keys x this lane's q
+
+    auto needs = [&](const float (&mt)[2]) {
+        const bool need = (mt[0] > m_run[0] + LAZY_RESCALE_LOG2) || (mt[1] > m_run[1] + LAZY_RESCALE_LOG2);
+        return __builtin_amdgcn_ballot_w64(need) != 0;
+    };
+    // exp2(s c - m) for 4 consecutive scores of q block qb (one fma + one exp each), their sum, two packed P words
+    auto probs4 = [&](const f32x16_t& st, int r0, float m_ref, float& ls, pfrag_t& pf) {
+        float e[4];
+#if UAMD_A64_DBG & 16
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = st[r0 + j];
+#else
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r0 + j], p.scale_log2, -m_ref));
+#endif
+        ls += (e[0] + e[1]) + (e[2] + e[3]);
+        pf.w[(r0 & 7) >> 1] = pack_pair2<T>(e[0], e[1]);
+        pf.w[((r0 & 7) >> 1) + 1] = pack_pair2<T>(e[2], e[3]);
+    };
+
+    // ---- FAST segment (every half tile but the wave's last two)
+    auto seg_fast = [&](int h, f32x16_t (&cur)[2], f32x16_t (&nxt)[2], pfrag_t (&pcur)[2][2], pfrag_t (&pprev)[2][2]) {
+        // every K / V^T fragment of the segment is requested NOW (64 registers): with one wave per SIMD nobody hides an LDS
+        // round trip, and a fragment requested one chunk ahead arrives after its MFMAs want to issue
+        frag_t kfa[8], vfa[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) kfa[ks] = kfrag(h + 1, ks);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) vfa[j] = vfrag(h - 1, j >> 2, j & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // part A: row max of S(h)  ||  S(h+1), k-steps 0..3
+        float mx[2] = {cur[0][0], cur[1][0]};
+        // one MFMA, then a few VALU instructions, fenced: a wave issues in order, so MFMAs placed back to back make the
+        // VALU work behind them wait for the matrix pipe (measured: MFMA time and VALU time simply added up)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                if (ks == 0) s_mfma_first<T>(nxt[qb], kfa[0], qf[qb][0]);
+                else s_mfma<T>(nxt[qb], kfa[ks], qf[qb][ks]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx[qb] = fmaxf(mx[qb], cur[qb][4 * ks + j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        float mt[2];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) mt[qb] = max_across_halves(mx[qb]) * p.scale_log2;
+        if (__builtin_expect(needs(mt), 0)) {
+            // rare: a row's max jumped. The pending product P(h-1) V(h-1) is relative to the old references: add it now,
+            // zero P(h-1) (part B then adds nothing), raise the references, rescale l and O (asm on the hidden registers)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pv_i<T>((j & 3) * 2 + 0, vfa[j], pprev[j >> 2][0].f);
+                pv_i<T>((j & 3) * 2 + 1, vfa[j], pprev[j >> 2][1].f);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pprev[c][qb].w[j] = 0u;
+            float alpha[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float m_new = fmaxf(m_run[qb], mt[qb]);
+                alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - (m_new == -INFINITY ? 0.f : m_new));
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha[qb];
+            }
+            scale_pinned<0>(alpha[0]); scale_pinned<1>(alpha[1]); scale_pinned<2>(alpha[0]); scale_pinned<3>(alpha[1]);
+            scale_pinned<4>(alpha[0]); scale_pinned<5>(alpha[1]); scale_pinned<6>(alpha[0]); scale_pinned<7>(alpha[1]);
+        }
+        // part B: P(h) = exp2(S(h) c - m)  ||  O += V(h-1) P(h-1) (16 MFMAs), S(h+1) k-steps 4..7 (8 MFMAs)
+        const float m_ref[2] = {m_run[0], m_run[1]};                    // finite: the first half tile always takes the branch above
+        float ls[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = j >> 2, dt = j & 3, qv = j >> 2, r0 = 4 * (j & 3);
+            float e[4];
+            pv_i<T>(dt * 2 + 0, vfa[j], pprev[c][0].f);
+            e[0] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[qv][r0 + 0], p.scale_log2, -m_ref[qv]));
+            e[1] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[qv][r0 + 1], p.scale_log2, -m_ref[qv]));
+            __builtin_amdgcn_sched_barrier(0);
+            pv_i<T>(dt * 2 + 1, vfa[j], pprev[c][1].f);
+            e[2] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[qv][r0 + 2], p.scale_log2, -m_ref[qv]));
+            e[3] = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[qv][r0 + 3], p.scale_log2, -m_ref[qv]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (j >= 6) s_mfma_last<T>(nxt[j & 1], kfa[7], qf[j & 1][7]);
+            else s_mfma<T>(nxt[j & 1], kfa[4 + (j >> 1)], qf[j & 1][4 + (j >> 1)]);
+            ls[qv] += (e[0] + e[1]) + (e[2] + e[3]);
+            pcur[r0 >> 3][qv].w[(r0 & 7) >> 1] = pack_pair2<T>(e[0], e[1]);
+            pcur[r0 >> 3][qv].w[((r0 & 7) >> 1) + 1] = pack_pair2<T>(e[2], e[3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        l_run[0] += ls[0];
+        l_run[1] += ls[1];
+    };
+    // ---- GENERAL segment: mask (the wave's diagonal / ragged tile), raise the references when needed, no interleaving
+    auto seg_slow = [&](int h, f32x16_t (&cur)[2], f32x16_t (&nxt)[2], pfrag_t (&pcur)[2][2], const pfrag_t (&pprev)[2][2],
+                        auto masked) {
+        float mt[2];
+        if (decltype(masked)::value) {
+            const int k0 = h * 32;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (key > q_pos[qb] || key >= T_) cur[qb][r] = -INFINITY;
+                }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float m = cur[qb][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, cur[qb][r]);
+            mt[qb] = max_across_halves(m) * p.scale_log2;
+        }
+        // the pending product first: it is relative to the old references
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const frag_t vf = vfrag(h - 1, c, dt);
+                pv_i<T>(dt * 2 + 0, vf, pprev[c][0].f);
+                pv_i<T>(dt * 2 + 1, vf, pprev[c][1].f);
+            }
+        if (needs(mt) || __builtin_amdgcn_ballot_w64(m_run[0] == -INFINITY || m_run[1] == -INFINITY) != 0) {
+            float alpha[2];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                const float m_new = fmaxf(m_run[qb], mt[qb]);
+                alpha[qb] = __builtin_amdgcn_exp2f(m_run[qb] - (m_new == -INFINITY ? 0.f : m_new));
+                m_run[qb] = m_new;
+                l_run[qb] *= alpha[qb];
+            }
+            scale_pinned<0>(alpha[0]); scale_pinned<1>(alpha[1]); scale_pinned<2>(alpha[0]); scale_pinned<3>(alpha[1]);
+            scale_pinned<4>(alpha[0]); scale_pinned<5>(alpha[1]); scale_pinned<6>(alpha[0]); scale_pinned<7>(alpha[1]);
+        }
+        // S(h+1): for the wave's very last half tile this multiplies whatever the next ring stage holds (never read)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const frag_t kf = kfrag(h + 1, ks);
+            if (ks == 0) { s_mfma_first<T>(nxt[0], kf, qf[0][0]); s_mfma_first<T>(nxt[1], kf, qf[1][0]); }
+            else if (ks == 7) { s_mfma_last<T>(nxt[0], kf, qf[0][7]); s_mfma_last<T>(nxt[1], kf, qf[1][7]); }
+            else { s_mfma<T>(nxt[0], kf, qf[0][ks]); s_mfma<T>(nxt[1], kf, qf[1][ks]); }
+        }
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float m_ref = m_run[qb] == -INFINITY ? 0.f : m_run[qb];
+            float ls = 0.f;
+#pragma unroll
+            for (int r0 = 0; r0 < 16; r0 += 4) probs4(cur[qb], r0, m_ref, ls, pcur[r0 >> 3][qb]);
+            l_run[qb] += ls;
+        }
+    };
+
+    // ---- prologue: tiles 0, 1, 2 in flight; scores of half tile 0; an all-zero "previous P"
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    if (nt > 2) issue(2, 2);
+    if (nt > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    f32x16_t sa[2], sb[2];
+    pfrag_t pa[2][2], pb[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pb[c][qb].w[j] = 0u;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const frag_t kf = kfrag(0, ks);
+        if (ks == 0) { s_mfma_first<T>(sa[0], kf, qf[0][0]); s_mfma_first<T>(sa[1], kf, qf[1][0]); }
+        else if (ks == 7) { s_mfma_last<T>(sa[0], kf, qf[0][7]); s_mfma_last<T>(sa[1], kf, qf[1][7]); }
+        else { s_mfma<T>(sa[0], kf, qf[0][ks]); s_mfma<T>(sa[1], kf, qf[1][ks]); }
+    }
+    // MID-trip step of trip t (between its two segments): segment 2t was the last reader of tile t-1, segment 2t+1 is
+    // the first reader of tile t+1. Wait for tile t+1 (issued two trips ago; tile t+2 may still fly), barrier (every
+    // wave is past segment 2t), refill the freed stage with tile t+3.
+    auto ring_step = [&](int t) {
+        if (t + 1 < nt) {
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 3 < nt) issue(t + 3, (t + 3) & 3);
+        }
+    };
+    int t = 0;
+    for (; t < nt_w - 1; ++t) {
+        seg_fast(2 * t, sa, sb, pa, pb);
+        ring_step(t);
+        seg_fast(2 * t + 1, sb, sa, pb, pa);
+    }
+    seg_slow(2 * t, sa, sb, pa, pb, std::true_type{});     // t == nt_w - 1: the wave's diagonal (and maybe ragged) tile
+    ring_step(t);
+    seg_slow(2 * t + 1, sb, sa, pb, pa, std::true_type{});
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const frag_t vf = vfrag(nh - 1, c, dt);
+            pv_i<T>(dt * 2 + 0, vf, pb[c][0].f);
+            pv_i<T>(dt * 2 + 1, vf, pb[c][1].f);
+        }
+    for (int tt = nt_w; tt < nt; ++tt) ring_step(tt);    // G < 4: a wave with an earlier q subtile keeps the ring going
+    // ---- epilogue: O = O^T / l, LSE = ln2 * (m + log2 l)
+    auto store_o = [&](auto dt_c, auto qb_c) {
+        constexpr int dt = decltype(dt_c)::value, qb = decltype(qb_c)::value;
+        float f[16];
+        read_pinned<dt * 2 + qb>(f);
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.0f / l_tot;
+        if (q_pos[qb] < T_) {
+            T* op = (T*)p.O + b * p.o_sb + (int64_t)q_pos[qb] * p.o_st + (int64_t)head * p.o_sh;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int d = dt * 32 + qd * 8 + lh * 4;
+                uint2 ov;
+                ov.x = pack_pair2<T>(f[qd * 4 + 0] * inv, f[qd * 4 + 1] * inv);
+                ov.y = pack_pair2<T>(f[qd * 4 + 2] * inv, f[qd * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + d) = ov;
+            }
+            if (dt == 0 && lh == 0)
+                p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos[qb]] = (m_run[qb] + log2f(l_tot)) * 0.6931471805599453f;
+        }
+    };
+    store_o(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    store_o(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    store_o(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    store_o(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    store_o(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+    store_o(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+    store_o(std::integral_constant<int, 3>{}, std::integral_constant<int, 0>{});
+    store_o(std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{});
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -989,6 +1529,20 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     int rc;
+    // 64 q rows per wave (4 waves, one per SIMD): plain causal, G <= 4 (UAMD_TUNE_ATTN_VAR bit 0)
+    if (!lo && G <= 4 && (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 1)) {
+        static bool attr64[2][64] = {{false}};
+        if (dtype == UAMD_BF16) {
+            if ((rc = set_lds_attr(&attn_fwd64_kernel<bf16_t>, ATTN_LDS4, &attr64[0][dev]))) return rc;
+            hipLaunchKernelGGL((attn_fwd64_kernel<bf16_t>), grid, dim3(256), ATTN_LDS4, st, a);
+        } else if (dtype == UAMD_F16) {
+            if ((rc = set_lds_attr(&attn_fwd64_kernel<f16_t>, ATTN_LDS4, &attr64[1][dev]))) return rc;
+            hipLaunchKernelGGL((attn_fwd64_kernel<f16_t>), grid, dim3(256), ATTN_LDS4, st, a);
+        } else {
+            return UAMD_ERR_DTYPE;
+        }
+        return uamd_launch_status();
+    }
     if (dtype == UAMD_BF16) {
         if (lo) {
             if ((rc = set_lds_attr(&attn_fwd_kernel<bf16_t, true>, ATTN_LDS, &attr_set[0][dev]))) return rc;
