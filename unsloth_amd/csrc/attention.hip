@@ -335,38 +335,42 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             __builtin_amdgcn_sched_barrier(0);
         }
         // ---- online softmax, log2 domain. lane: q = q_pos; register r of tile kt: key below
+        // MFMA time and (non-transcendental) VALU time ADD UP on a gfx950 SIMD (profiles/r02_mfma_valu_overlap.txt), so the
+        // softmax is written for instruction count: the scale rides in the exponent's fma (max(s) c = max(s c), c > 0),
+        // and O / l are rescaled only when some row's max rose (wave-uniform test; after the first tiles it rarely does)
         const int k0 = t * KT;
         float mt = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float s = st[kt][r] * p.scale_log2;
                 if (MODE == 1 || (MODE == 2 && rt_mask)) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key > q_pos || key >= T_ || key < lo_q) s = -INFINITY;
+                    if (key > q_pos || key >= T_ || key < lo_q) st[kt][r] = -INFINITY;
                 }
-                st[kt][r] = s;
-                mt = fmaxf(mt, s);
+                mt = fmaxf(mt, st[kt][r]);
             }
-        mt = max_across_halves(mt);
-        const float m_new = fmaxf(m_run, mt);
-        // a row whose band starts after this tile has seen only masked keys so far: keep the exponent finite
-        const float m_ref = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_ref);                    // first tile: exp2(-inf) = 0
-        m_run = m_new;
+        mt = max_across_halves(mt) * p.scale_log2;
+        if (__builtin_amdgcn_ballot_w64(mt > m_run) != 0) {
+            const float m_new = fmaxf(m_run, mt);
+            // a row whose band starts after this tile has seen only masked keys so far: keep the exponent finite
+            const float alpha = __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new));   // first tile: exp2(-inf) = 0
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o_acc[i] *= alpha;
+        }
+        const float m_ref = m_run == -INFINITY ? 0.f : m_run;
         float ls = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(st[kt][r] - m_ref);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][r], p.scale_log2, -m_ref));
                 st[kt][r] = e;
                 ls += e;
             }
-        l_run = l_run * alpha + ls;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o_acc[i] *= alpha;
+        l_run += ls;
 
         ASTAMP(ti, 5);
         // ---- O^T[d][q] += V^T P^T : per 16-key step u = 2 kt + c; lane half lh contracts keys
@@ -375,7 +379,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             const int kt = u >> 1, c = u & 1;
             union { uint32_t w[4]; frag_t f; } pb;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) pb.w[j] = pack_pair<T>(st[kt][8 * c + 2 * j], st[kt][8 * c + 2 * j + 1]);
+            for (int j = 0; j < 4; ++j) pb.w[j] = pack_pair2<T>(st[kt][8 * c + 2 * j], st[kt][8 * c + 2 * j + 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o_acc[dt] = MfmaA<T>::run(vsrc[dt], pb.f, o_acc[dt]);
         };
@@ -431,8 +435,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             for (int qd = 0; qd < 4; ++qd) {
                 const int d = dt * 32 + qd * 8 + lh * 4;
                 uint2 o;
-                o.x = pack_pair<T>(o_acc[dt][qd * 4 + 0] * inv, o_acc[dt][qd * 4 + 1] * inv);
-                o.y = pack_pair<T>(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv);
+                o.x = pack_pair2<T>(o_acc[dt][qd * 4 + 0] * inv, o_acc[dt][qd * 4 + 1] * inv);
+                o.y = pack_pair2<T>(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv);
                 *reinterpret_cast<uint2*>(op + d) = o;
             }
         if (lh == 0) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
@@ -1017,6 +1021,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
     if (lh == 0 && q_pos < T_) p.Delta[stat_idx] = delta;
     const float lse2 = p.LSE[stat_idx] * 1.4426950408889634f;
+    const float delta_s = delta * p.scale;
     const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
     const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
     const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
@@ -1104,18 +1109,19 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
             // dS^T = P^T (dP^T - Delta) * scale, masked entries 0
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pv = __builtin_amdgcn_exp2f(st[r] * p.scale_log2 - lse2);
+                float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], p.scale_log2, -lse2));
                 if (MODE == 1 || (MODE == 2 && rt_mask)) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (key > q_pos || key >= T_ || key < lo_q) pv = 0.f;
                 }
-                st[r] = pv * (dp[r] - delta) * p.scale;
+                st[r] = pv * __builtin_fmaf(dp[r], p.scale, -delta_s);        // (dP - Delta) * scale in one fma
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 union { uint32_t w[4]; frag_t f; } sb;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sb.w[j] = pack_pair<T>(st[8 * c + 2 * j], st[8 * c + 2 * j + 1]);
+                for (int j = 0; j < 4; ++j) sb.w[j] = BAND ? pack_pair<T>(st[8 * c + 2 * j], st[8 * c + 2 * j + 1])   // (the packed form spills in the band build)
+                                       : pack_pair2<T>(st[8 * c + 2 * j], st[8 * c + 2 * j + 1]);
 #pragma unroll
                 for (int dt = 0; dt < 4; ++dt) {
                     const int a0 = (kt * 32 + c * 16) * 256 + (t_lane ^ (dt << 6));
@@ -1152,8 +1158,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
             for (int qd = 0; qd < 4; ++qd) {
                 const int d = dt * 32 + qd * 8 + lh * 4;
                 uint2 o;
-                o.x = pack_pair<T>(dq_acc[dt][qd * 4 + 0], dq_acc[dt][qd * 4 + 1]);
-                o.y = pack_pair<T>(dq_acc[dt][qd * 4 + 2], dq_acc[dt][qd * 4 + 3]);
+                o.x = pack_pair2<T>(dq_acc[dt][qd * 4 + 0], dq_acc[dt][qd * 4 + 1]);
+                o.y = pack_pair2<T>(dq_acc[dt][qd * 4 + 2], dq_acc[dt][qd * 4 + 3]);
                 *reinterpret_cast<uint2*>(op + d) = o;
             }
     }
