@@ -79,3 +79,45 @@ def test_mrope_with_equal_streams_is_ordinary_rope():
     q2, k2 = fast_mrope_embedding(Q.clone(), K.clone(), cos.to(DEV), sin.to(DEV), idx.view(1, B, T).repeat(3, 1, 1).to(DEV),
                                   (16, 24, 24))
     assert torch.equal(q1, q2) and torch.equal(k1, k2)
+
+
+def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model():
+    """FastModel on a Qwen2-VL config = its language tower on the hand-kernel path: same weights in transformers'
+    Qwen2VLTextModel (fp32, host) + lm_head give the same loss for [3, B, T] multimodal positions, and text-only [B, T]
+    positions equal three identical streams."""
+    import torch.nn.functional as F
+    from transformers import Qwen2VLConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
+    from unsloth_amd import FastModel
+    from unsloth_amd.kernels.rms_layernorm import unpatch_rms_layernorm
+    vl = Qwen2VLConfig(text_config=dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                                        num_key_value_heads=2, vocab_size=1000, max_position_embeddings=512, rms_norm_eps=1e-6,
+                                        rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+                                        tie_word_embeddings=False),
+                       vision_config=dict(depth=1, embed_dim=32, hidden_size=512, num_heads=2))
+    model, _ = FastModel.from_pretrained(config=vl, max_seq_length=256, load_in_4bit=False, device="cuda",
+                                         use_gradient_checkpointing=False)
+    assert type(model).__name__ == "Qwen2ForCausalLM" and model._unsloth_amd_fast
+    B, T = 2, 48
+    gen = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 1000, (B, T), generator=gen)
+    pos3 = torch.stack([torch.arange(T).expand(B, T), torch.randint(0, 30, (B, T), generator=gen),
+                        torch.randint(0, 30, (B, T), generator=gen)])                      # temporal / height / width
+    labels = ids.clone()
+    model.train()
+    out = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=pos3.cuda())
+    out_t = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=torch.arange(T).expand(B, T).cuda())
+    out_3 = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=torch.arange(T).expand(3, B, T).contiguous().cuda())
+    assert abs(float(out_t.loss) - float(out_3.loss)) < 1e-6
+    # independent check: transformers' text model on the host in fp32 with the same (bf16-rounded) weights
+    unpatch_rms_layernorm()
+    ref = Qwen2VLTextModel(vl.text_config).float()
+    sd = {k[len("model."):]: v.float().cpu() for k, v in model.state_dict().items() if k.startswith("model.")}
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not [m for m in missing if "rotary" not in m], missing
+    with torch.no_grad():
+        h = ref(input_ids=ids, position_ids=pos3).last_hidden_state
+        logits = h @ model.lm_head.weight.float().cpu().t()
+        want = F.cross_entropy(logits[:, :-1].reshape(-1, 1000), labels[:, 1:].reshape(-1))
+    assert abs(float(out.loss) - float(want)) < 2e-2 * abs(float(want)), (float(out.loss), float(want))
+    assert abs(float(out.loss) - float(out_t.loss)) > 1e-4            # the height / width streams matter

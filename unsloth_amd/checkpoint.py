@@ -255,6 +255,28 @@ def load_prequantized_(model, directory, device, dtype=None):
     return missing, unexpected
 
 
+def load_language_tower_(model, directory):
+    """Fill a causal LM built from a VLM's text config (models/loader.py: FastModel) with the language-tower tensors of
+    the VLM checkpoint in `directory`: `model.language_model.X` / `language_model.model.X` -> `model.X`, `lm_head.*` as is;
+    vision-tower tensors are skipped. Returns the parameter names the checkpoint did not provide."""
+    own = dict(model.named_parameters())
+    own.update(dict(model.named_buffers()))
+    seen = set()
+    for name, t in iter_checkpoint_tensors(directory):
+        key = name
+        for prefix, repl in (("model.language_model.", "model."), ("language_model.model.", "model."),
+                             ("language_model.lm_head.", "lm_head.")):
+            if key.startswith(prefix):
+                key = repl + key[len(prefix):]
+                break
+        if key in own:
+            with torch.no_grad():
+                own[key].copy_(t.to(device=own[key].device, dtype=own[key].dtype))
+            seen.add(key)
+    tied = getattr(model.config, "tie_word_embeddings", False)
+    return [n for n, _ in model.named_parameters() if n not in seen and not (tied and n == "lm_head.weight")]
+
+
 def reinit_rotary_buffers_(model, device):
     """Non-persistent rotary buffers (`inv_freq`, `original_inv_freq`) never travel in a checkpoint; after
     `to_empty` they are uninitialised memory, and HF's own forward (which the decode / generation path uses) reads

@@ -135,6 +135,83 @@ class FastLanguageModel:
         return FastLlamaModel.for_inference(model)
 
 
+# VLM configs whose language tower is a Llama-family decoder the hand-kernel path covers (text_config.model_type -> the
+# causal-LM architecture it is rebuilt as). Qwen2-VL / Qwen2.5-VL: a Qwen2 decoder (q/k/v bias, SwiGLU, RMSNorm) with
+# multimodal RoPE -- three position streams over sections of the rotary dimension (BASELINE config 4).
+VLM_TEXT_TOWERS = {"qwen2_vl_text": "qwen2", "qwen2_5_vl_text": "qwen2"}
+
+
+def text_tower_config(config):
+    """The causal-LM config of a supported VLM's language tower (mrope parameters kept), or None. `config` may be the
+    VLM config (with `.text_config`) or the text config itself."""
+    tc = getattr(config, "text_config", None) or config
+    arch = VLM_TEXT_TOWERS.get(getattr(tc, "model_type", None))
+    if arch is None:
+        return None
+    from transformers import Qwen2Config
+    d = tc.to_dict()
+    keep = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+            "num_key_value_heads", "hidden_act", "max_position_embeddings", "initializer_range", "rms_norm_eps",
+            "use_cache", "tie_word_embeddings", "use_sliding_window", "sliding_window", "max_window_layers",
+            "layer_types", "attention_dropout", "pad_token_id", "bos_token_id", "eos_token_id")
+    kw = {k: d[k] for k in keep if k in d and d[k] is not None}
+    rope = dict(d.get("rope_parameters") or {})
+    legacy = d.get("rope_scaling") or {}
+    if "mrope_section" not in rope and legacy.get("mrope_section"):
+        rope["mrope_section"] = legacy["mrope_section"]
+    if "mrope_section" not in rope:                      # Qwen2-VL's published split of the 64 rotary pairs
+        half = (d["hidden_size"] // d["num_attention_heads"]) // 2
+        rope["mrope_section"] = [half // 4, (half - half // 4) // 2, half - half // 4 - (half - half // 4) // 2]
+    rope.setdefault("rope_type", "default")
+    out = Qwen2Config(**kw, rope_parameters=rope)
+    if not getattr(out, "use_sliding_window", False):
+        out.sliding_window = None
+    return out
+
+
 class FastModel(FastLanguageModel):
-    """loader.py:1140-2184 is the generic / VLM loader backed by unsloth_zoo's torch.compile path; here
-    it is an alias of the language-model loader for the supported architectures."""
+    """loader.py:1140-2184: the reference's generic loader (text models of any architecture, VLMs, full fine-tuning),
+    backed there by unsloth_zoo's torch.compile path. Here:
+      * a language model of a supported architecture (llama / mistral / qwen2) -> the hand-kernel path (FastLanguageModel);
+      * a VLM whose language tower is one (Qwen2-VL, Qwen2.5-VL) -> that TOWER as a causal LM on the hand-kernel path,
+        multimodal RoPE included: position_ids [3, B, T] (temporal, height, width) with the config's `mrope_section`;
+        text-only [B, T] positions work unchanged. The vision encoder is not built (its patch embeddings enter the
+        tower as `inputs_embeds`, which the fast forward accepts); a local checkpoint directory is read with the
+        `model.language_model.` prefix mapped onto the tower;
+      * anything else raises, naming what the reference would do."""
+
+    @staticmethod
+    def from_pretrained(model_name=None, max_seq_length=2048, dtype=None, load_in_4bit=True, config=None,
+                        full_finetuning=False, auto_model=None, *args, **kwargs):
+        from transformers import AutoConfig
+        if config is None and model_name is not None and os.path.isdir(str(model_name)):
+            config = AutoConfig.from_pretrained(model_name, trust_remote_code=kwargs.get("trust_remote_code", False))
+        if config is None:
+            return FastLanguageModel.from_pretrained(model_name, max_seq_length, dtype, load_in_4bit, *args, **kwargs)
+        if getattr(config, "model_type", None) in SUPPORTED:
+            return FastLanguageModel.from_pretrained(model_name, max_seq_length, dtype, load_in_4bit, config=config,
+                                                     full_finetuning=full_finetuning, *args, **kwargs)
+        tower = text_tower_config(config)
+        if tower is None:
+            raise NotImplementedError(
+                f"FastModel: model_type={getattr(config, 'model_type', None)!r} has no hand-kernel path here "
+                f"(supported: {SUPPORTED} and the language towers of {sorted(VLM_TEXT_TOWERS)}). The reference sends "
+                "other architectures through unsloth_zoo's compiled generic path (loader.py:1140-2184), which is out "
+                "of scope (SURVEY 8(f4)).")
+        if model_name is not None and os.path.isdir(str(model_name)):
+            # weights of the tower only: build from the mapped config, then fill from the VLM checkpoint's language_model keys
+            model, tok = FastLanguageModel.from_pretrained(None, max_seq_length, dtype, False, config=tower,
+                                                           full_finetuning=full_finetuning, *args, **kwargs)
+            from .. import checkpoint as _ckpt
+            missing = _ckpt.load_language_tower_(model, str(model_name))
+            if missing:
+                raise RuntimeError(f"{model_name}: no tensors for {missing[:8]} ... in the checkpoint's language tower")
+            if load_in_4bit:
+                quantize_model_nf4_(model)
+                FastLlamaModel.post_load(model, max_seq_length, model.config.dtype)
+            return model, tok
+        return FastLanguageModel.from_pretrained(None, max_seq_length, dtype, load_in_4bit, config=tower,
+                                                 full_finetuning=full_finetuning, *args, **kwargs)
+
+
+FastVisionModel = FastModel        # loader.py:2187: the reference's alias
