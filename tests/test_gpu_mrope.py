@@ -119,5 +119,5 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model():
         h = ref(input_ids=ids, position_ids=pos3).last_hidden_state
         logits = h @ model.lm_head.weight.float().cpu().t()
         want = F.cross_entropy(logits[:, :-1].reshape(-1, 1000), labels[:, 1:].reshape(-1))
-    assert abs(float(out.loss) - float(want)) < 2e-2 * abs(float(want)), (float(out.loss), float(want))
-    assert abs(float(out.loss) - float(out_t.loss)) > 1e-4            # the height / width streams matter
+    assert abs(float(out.loss) - float(want)) < 2e-3 * abs(float(want)), (float(out.loss), float(want))
+    assert float(out.loss) != float(out_t.loss)                       # the height / width streams reach the result
