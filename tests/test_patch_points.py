@@ -100,3 +100,14 @@ def test_patch_trl_trainer_without_trl_is_a_no_op():
         return          # a real TRL is present: covered by the stand-in test's logic
     except Exception:
         assert T._patch_trl_trainer() == []
+
+
+def test_recompute_policy_schedules():
+    """"all*3,attn": a per-layer schedule between two selective-recompute policies (models/fast_layer.py)."""
+    from unsloth_amd.models.fast_layer import POLICIES, policy_for_layer, resolve_policy_spec
+    assert resolve_policy_spec("attn") == POLICIES["attn"]
+    assert resolve_policy_spec("qkv+eg") == frozenset({"qkv", "eg"})
+    sched = resolve_policy_spec("all*3,min*2,attn")
+    got = [policy_for_layer(sched, i) for i in range(8)]
+    assert got[:3] == [POLICIES["all"]] * 3 and got[3:5] == [POLICIES["min"]] * 2 and got[5:] == [POLICIES["attn"]] * 3
+    assert policy_for_layer(POLICIES["min"], 7) == POLICIES["min"]

@@ -47,6 +47,35 @@ def resolve_policy(policy):
     return frozenset(policy)
 
 
+def resolve_policy_spec(spec):
+    """"attn" | "qkv+h1" | "all*3,attn": one policy, or a comma-separated schedule over the layers in order -- `name*count`
+    covers `count` layers, a segment without a count covers all remaining ones (speed/memory dial between two policies:
+    every layer moved from "attn" to "all" trades ~0.45 GB at 8192 tokens of Llama-3-8B for one gate/up GEMM less in the
+    backward). Returns a frozenset (uniform) or a list of (count or None, frozenset)."""
+    def one(name):
+        name = name.strip()
+        return resolve_policy(name.split("+") if "+" in name else name)
+    if "," not in spec and "*" not in spec:
+        return one(spec)
+    out = []
+    for seg in spec.split(","):
+        name, _, cnt = seg.partition("*")
+        out.append((int(cnt) if cnt else None, one(name)))
+    return out
+
+
+def policy_for_layer(policy, index):
+    """The policy of decoder layer `index` under a uniform policy or a schedule (resolve_policy_spec)."""
+    if not isinstance(policy, list):
+        return policy
+    i = 0
+    for cnt, pol in policy:
+        if cnt is None or index < i + cnt:
+            return pol
+        i += cnt
+    return policy[-1][1]
+
+
 def layer_supported(layer, hidden, attention_mask):
     """The whole-layer Function covers what the fused hooks cover: LoRA (or plain frozen) projections without bias /
     dropout / DoRA, SwiGLU MLP, head_dim 128 flash attention, no key-padding mask, 16-bit activations."""

@@ -292,9 +292,9 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
         band = None if (seq_info is None and window is None) else \
             _attention_band(seq_info, bsz, q_len, window, hidden_states.device)
         residual, delta = hidden_states, None
-        for layer in self.layers:
+        for li, layer in enumerate(self.layers):
             residual, delta = _fast_layer.decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids,
-                                                                band, policy)
+                                                                band, _fast_layer.policy_for_layer(policy, li))
         return fast_add_rms_layernorm(self.norm, delta, residual)[1]
     if gc and not hidden_states.requires_grad:
         hidden_states.requires_grad_(True)      # reentrant checkpoint needs an input that requires grad
@@ -645,13 +645,15 @@ class FastLlamaModel:
                        and the post-attention residual, re-run only norm2 + the gate/up GEMM in the backward
                        (the SwiGLU output and the down projection are never recomputed).
                        "unsloth:min" keeps only the layer input (the memory of `True`), "unsloth:all" keeps
-                       everything (the speed of `False`); UNSLOTH_AMD_GC_POLICY overrides the default "attn"."""
+                       everything (the speed of `False`); a schedule such as "unsloth:all*4,attn" keeps everything in
+                       the first 4 layers and applies "attn" to the rest (a dial between the two);
+                       UNSLOTH_AMD_GC_POLICY overrides the default "attn"."""
         base = model.get_base_model() if hasattr(model, "get_base_model") else model
         policy = None
         mode = use_gradient_checkpointing
         if isinstance(mode, str) and mode.split(":")[0] == "unsloth":
             name = mode.split(":", 1)[1] if ":" in mode else os.environ.get("UNSLOTH_AMD_GC_POLICY", "attn")
-            policy = _fast_layer.resolve_policy(name.split("+") if "+" in name else name)
+            policy = _fast_layer.resolve_policy_spec(name)
         gc = bool(mode)
         base.model.gradient_checkpointing = gc
         base.model._unsloth_amd_layer_policy = policy
