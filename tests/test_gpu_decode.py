@@ -202,3 +202,31 @@ def test_engine_logits_match_training_path_forward(load_in_4bit, monkeypatch):
     assert int(eng.kv_len[0]) == 27
     out = DecodeEngine(model, max_seq_len=256).generate(ids, max_new_tokens=6)
     assert torch.equal(out[:, :27], seq[:, :27])
+
+
+def test_for_inference_generate_and_back_to_training():
+    """FastLanguageModel.for_inference(model): model.generate is the decode engine (greedy = the engine's argmax chain,
+    sampling reproducible under a seeded generator); for_training restores HF's generate and training still works."""
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.models.decode import DecodeEngine
+    model = _tiny(True)
+    FastLanguageModel.for_inference(model)
+    assert not model.training and hasattr(model, "_old_generate")
+    ids = torch.randint(0, 1000, (1, 9), generator=g(13)).to(DEV)
+    out = model.generate(input_ids=ids, max_new_tokens=5)
+    want = DecodeEngine(model, max_seq_len=128).generate(ids, max_new_tokens=5)
+    assert out.shape == (1, 14) and torch.equal(out, want)
+    eng = DecodeEngine(model, max_seq_len=128)
+    s1 = eng.generate(ids, max_new_tokens=6, do_sample=True, temperature=0.8, top_k=20, generator=torch.Generator(DEV).manual_seed(3))
+    s2 = eng.generate(ids, max_new_tokens=6, do_sample=True, temperature=0.8, top_k=20, generator=torch.Generator(DEV).manual_seed(3))
+    assert torch.equal(s1, s2) and s1.shape == (1, 15)
+    # early stop on an eos id: the first generated token of the greedy chain
+    eos = int(out[0, 9])
+    short = eng.generate(ids, max_new_tokens=5, eos_token_id=eos)
+    assert short.shape == (1, 10)
+    FastLanguageModel.for_training(model, use_gradient_checkpointing=False)
+    assert model.training and not hasattr(model, "_old_generate")
+    lab = ids.clone()
+    loss = model(input_ids=ids, labels=lab).loss
+    loss.backward()
+    assert torch.isfinite(loss)

@@ -661,17 +661,32 @@ class FastLlamaModel:
             if hasattr(m, "gradient_checkpointing"):
                 m.gradient_checkpointing = gc
         base._unsloth_amd_fast = True
+        if hasattr(model, "_old_generate"):                    # undo for_inference (llama.py:3873-3885)
+            model.generate = model._old_generate
+            del model._old_generate
+        if hasattr(model, "_uamd_decode_engine"):
+            del model._uamd_decode_engine
         model.train()
         return model
 
     @staticmethod
     def for_inference(model):
-        """llama.py:3888-3929."""
+        """llama.py:3888-3929: eval mode, no checkpointing, and `model.generate` = the KV-cache decode engine
+        (models/decode.py: unsloth_fast_generate, the counterpart of llama.py:2167-2259) for the architectures it covers
+        (head_dim 128, SwiGLU); the HF `generate` stays reachable as `model._old_generate`, as in the reference."""
+        from types import MethodType
+        from . import decode as _decode
         base = model.get_base_model() if hasattr(model, "get_base_model") else model
         for m in base.modules():
             if hasattr(m, "gradient_checkpointing"):
                 m.gradient_checkpointing = False
         model.eval()
+        cfg = base.config
+        head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+        if head_dim == 128 and getattr(cfg, "hidden_act", "silu") == "silu" and not hasattr(model, "_old_generate"):
+            if hasattr(model, "generate"):
+                model._old_generate = model.generate
+            model.generate = MethodType(_decode.unsloth_fast_generate, model)
         return model
 
 
