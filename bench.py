@@ -281,7 +281,7 @@ def main():
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:
                     pt = json.load(f)
-                stem = dom_name.split("<")[0]
+                stem = dom_name.split("<")[0].replace("_kernel", "")      # gemm_nt256: the plain, persistent (p) and NN instances
                 ents = [v for k, v in pt.items() if k.startswith(stem) and isinstance(v, dict) and "traffic_bytes" in v]
                 if ents:       # the NT and NN template instances of the kernel: dispatch-weighted mean
                     n = sum(max(1, e.get("dispatches", 1)) for e in ents)
