@@ -200,6 +200,15 @@ def test_engine_logits_match_training_path_forward(load_in_4bit, monkeypatch):
         lg, lg_e = eng.step(nxt).clone(), eng_e.step(nxt).clone()
         assert torch.equal(lg, lg_e), f"graph replay differs from the eager step at step {step}"
     assert int(eng.kv_len[0]) == 27
+    # a second prompt on the SAME engine (graph already captured): the replayed steps must return the graph's logits,
+    # not the tensor prefill() produced
+    lg2 = eng.prefill(ids)
+    assert torch.equal(lg2, lg_e.new_tensor(lg2))           # (finite, same device)
+    first = torch.argmax(lg2, dim=-1)
+    again = eng.step(first).clone()
+    eng_f = DecodeEngine(model, max_seq_len=256, batch=1, use_graph=False)
+    eng_f.prefill(ids)
+    assert torch.equal(again, eng_f.step(first))
     out = DecodeEngine(model, max_seq_len=256).generate(ids, max_new_tokens=6)
     assert torch.equal(out[:, :27], seq[:, :27])
 

@@ -187,8 +187,10 @@ class DecodeEngine:
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
                 self._step_body()
+            self._graph_logits = self.logits     # the graph's static output buffer (prefill() rebinds self.logits)
             self.kv_len.copy_(kv0)               # the capture itself does not execute
         self._graph.replay()
+        self.logits = self._graph_logits
         return self.logits
 
     @torch.no_grad()
