@@ -229,13 +229,13 @@ def test_return_logits_branch_and_n_items():
 def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypatch):
     """position ids restart per document (indexed RoPE), attention is block-diagonal, boundary targets are
     masked: the packed row must equal the documents run separately. head_dim 128 = the band (lo, hi) path of the
-    flash kernels, 32 = SDPA with the dense packed mask."""
+    flash kernels, 32 = the same kernels on zero-padded heads (kernels/attention.flash_attention_padded)."""
     from oracle.ref_model import hf_reference_loss_and_lora_grads
     from unsloth_amd.kernels import attention as flash
     from unsloth_amd.utils.packing import enable_padding_free_metadata
     bands = []
-    real = flash.flash_attention
-    monkeypatch.setattr(flash, "flash_attention", lambda q, k, v, s=None, band=None: (bands.append(band), real(q, k, v, s, band))[1])
+    real = flash.attn_forward
+    monkeypatch.setattr(flash, "attn_forward", lambda q, k, v, s=None, band=None: (bands.append((q.shape[-1], band)), real(q, k, v, s, band))[1])
     model = _tiny(head_dim=head_dim)
     g = torch.Generator().manual_seed(5)
     docs = [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (40, 17, 64)]
@@ -243,7 +243,8 @@ def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypa
     out = model(**batch)
     out.loss.backward()
     got = _grads(model)
-    assert (len(bands) > 0 and all(b is not None for b in bands)) == (head_dim == 128)
+    # both head dims run the band kernels (32: zero-padded heads), nothing builds a dense [T, T] mask
+    assert len(bands) > 0 and all(d == 128 and b is not None for d, b in bands)
     # oracle: each document alone; sum of token losses / total targets
     tot, n_tot, ref = 0.0, 0, None
     for d in docs:
@@ -282,6 +283,51 @@ def test_packed_batch_of_two_rows_equals_per_document_oracle(head_dim, gc):
     for d in docs:
         di = torch.tensor([d])
         n = len(d) - 1
+        loss, grads = hf_reference_loss_and_lora_grads(model, di, di.clone(), None)
+        tot += float(loss) * n
+        n_tot += n
+        ref = {k: v * n for k, v in grads.items()} if ref is None else {k: ref[k] + grads[k] * n for k in ref}
+    want = tot / n_tot
+    assert abs(float(out.loss) - want) <= 2e-3 * abs(want), (float(out.loss), want)
+    total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]),
+                    torch.cat([(ref[k] / n_tot).flatten() for k in sorted(got)]))
+    assert total < 4e-2, total
+
+
+@pytest.mark.parametrize("head_dim", [128, 64])
+def test_key_padding_mask_rows_equal_the_unpadded_rows(head_dim, monkeypatch):
+    """attention_mask with right- and left-padded rows (labels -100 on the padding): the rows become packed documents
+    [padding | tokens | padding] on the band kernels (models/llama.py, kernels/attention.padding_mask_documents) and
+    must equal every row run alone without padding -- no dense mask, no SDPA."""
+    from oracle.ref_model import hf_reference_loss_and_lora_grads
+    from unsloth_amd.kernels import attention as flash
+    calls = []
+    real = flash.attn_forward
+    monkeypatch.setattr(flash, "attn_forward", lambda q, k, v, s=None, band=None: (calls.append(band is not None), real(q, k, v, s, band))[1])
+    sdpa = []
+    real_sdpa = torch.nn.functional.scaled_dot_product_attention
+    monkeypatch.setattr(torch.nn.functional, "scaled_dot_product_attention",
+                        lambda *a, **k: (sdpa.append(1), real_sdpa(*a, **k))[1])
+    model = _tiny(head_dim=head_dim, gc=False)
+    g = torch.Generator().manual_seed(21)
+    T, lens, left = 80, [80, 51, 33], [False, False, True]
+    docs = [torch.randint(0, 1000, (n,), generator=g) for n in lens]
+    ids = torch.zeros((3, T), dtype=torch.long)
+    mask = torch.zeros((3, T), dtype=torch.long)
+    labels = torch.full((3, T), -100, dtype=torch.long)
+    pos = torch.zeros((3, T), dtype=torch.int32)
+    for b, (d, n, lf) in enumerate(zip(docs, lens, left)):
+        s0 = T - n if lf else 0
+        ids[b, s0:s0 + n], mask[b, s0:s0 + n], labels[b, s0:s0 + n] = d, 1, d
+        pos[b, s0:s0 + n] = torch.arange(n, dtype=torch.int32)
+    out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    out.loss.backward()
+    got = _grads(model)
+    assert calls and all(calls) and not sdpa
+    tot, n_tot, ref = 0.0, 0, None
+    for d in docs:
+        di = d.unsqueeze(0)
+        n = di.shape[1] - 1
         loss, grads = hf_reference_loss_and_lora_grads(model, di, di.clone(), None)
         tot += float(loss) * n
         n_tot += n

@@ -168,3 +168,30 @@ def test_adjacent_columns_detection():
     assert part is not None and part.shape == (6, 12) and torch.equal(part, buf[:, 8:])
     three_d = buf.view(2, 3, 20)[..., :8].reshape(-1, 8)            # the [B, T, H] -> [B*T, H] view autograd hands over
     assert _adjacent_columns([three_d, buf.view(2, 3, 20)[..., 8:12].reshape(-1, 4)]) is not None
+
+
+def test_padding_mask_as_documents_matches_the_dense_key_mask_on_real_rows():
+    """kernels/attention.padding_mask_documents: right / left / two-sided padding become packed documents whose band
+    equals causal AND key-mask on every REAL query row; padding rows keep a non-empty key set; holes -> None."""
+    import torch
+    from unsloth_amd.kernels.attention import attention_band, padding_mask_documents
+    T = 12
+    mask = torch.tensor([[1] * 12,
+                         [1] * 7 + [0] * 5,              # right padding
+                         [0] * 4 + [1] * 8,              # left padding
+                         [0] * 2 + [1] * 6 + [0] * 4,    # both
+                         [0] * 12], dtype=torch.int64)   # an all-padding row
+    docs = padding_mask_documents(mask)
+    assert docs.dtype == torch.int32 and docs.tolist() == [0, 12, 0, 0, 7, 5, 4, 8, 0, 2, 6, 4, 0, 0, 12]
+    lo, hi = attention_band(T, batch=mask.shape[0], seq_lengths=docs)
+    pos = torch.arange(T)
+    for b in range(mask.shape[0]):
+        band_allowed = (pos[None, :] >= lo[b][:, None]) & (pos[None, :] <= pos[:, None])          # [q, key]
+        dense = (pos[None, :] <= pos[:, None]) & (mask[b] != 0)[None, :]
+        real = mask[b] != 0
+        assert torch.equal(band_allowed[real], dense[real]), b
+        assert bool(band_allowed.any(1).all())                     # no empty softmax row, padding rows included
+        # hi: the last query that sees each key = end of its run
+        assert bool((hi[b] >= pos).all())
+    holes = torch.tensor([[1, 1, 0, 1, 1, 0]])
+    assert padding_mask_documents(holes) is None

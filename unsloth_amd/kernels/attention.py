@@ -64,6 +64,24 @@ def attention_band(T, batch=1, seq_lengths=None, sliding_window=None, device="cp
     return lo.to(torch.int32).view(batch, T).contiguous(), hi.to(torch.int32).view(batch, T).contiguous()
 
 
+def padding_mask_documents(attention_mask):
+    """A key-padding mask [B, T] (non-zero = real token) whose real tokens are CONTIGUOUS in every row (right padding,
+    left padding, or both) as packed-document lengths over the flattened batch: per row [pad_left, real, pad_right].
+    Under a causal mask a real query then attends exactly the real keys before it -- the semantics of the SDPA /
+    flash-attn padding paths (attention_dispatch.py:560-617) -- and a padding query (whose output and gradient are
+    never used: its label is -100) attends the padding run it sits in, so no row of the softmax is empty (a left-padded
+    row is all -inf, i.e. NaN, under a dense key mask). Returns int32 [3 B] lengths (zeros included; attention_band drops
+    them) or None when some row has holes. Integer work on the mask's device; one host sync for the contiguity test."""
+    m = attention_mask != 0
+    B, T = m.shape
+    n = m.sum(1)
+    first = torch.where(n > 0, m.int().argmax(1), torch.zeros_like(n))
+    last = T - 1 - m.flip(1).int().argmax(1)
+    if not bool(((last - first + 1 == n) | (n == 0)).all()):
+        return None
+    return torch.stack([first, n, T - first - n], 1).reshape(-1).to(torch.int32)
+
+
 def _band_ptrs(band, B, T, dev):
     if band is None:
         return None, None
@@ -142,3 +160,24 @@ class FlashAttention(torch.autograd.Function):
 
 def flash_attention(q, k, v, scale=None, band=None):
     return FlashAttention.apply(q, k, v, scale, band)
+
+
+def supported_padded(q, k, v):
+    """Head dims below 128 (TinyLlama's 64, ...) can run on the head_dim-128 kernels with zero-padded heads."""
+    D = q.shape[-1]
+    return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and 0 < D < 128
+            and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) in (1, 2, 4, 8))
+
+
+def flash_attention_padded(q, k, v, scale=None, band=None):
+    """head_dim < 128 on the head_dim-128 kernels: Q, K, V zero-padded to 128 columns (Q K^T is unchanged, the padded
+    columns of P V are zero and dropped; the softmax scale stays 1/sqrt(D)). Costs the copies and 128/D of the flops --
+    used where the alternative is a dense [T, T] additive mask (packed / windowed / padded batches); plain causal
+    batches of such models go to the library's flash kernel through SDPA. The padding and the slice are torch ops, so
+    autograd carries dQ/dK/dV back to the unpadded views."""
+    D = q.shape[-1]
+    if scale is None:
+        scale = 1.0 / math.sqrt(D)
+    pad = (0, 128 - D)
+    qp, kp, vp = (torch.nn.functional.pad(t, pad) for t in (q, k, v))
+    return FlashAttention.apply(qp, kp, vp, scale, band)[..., :D]

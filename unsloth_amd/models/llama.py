@@ -177,6 +177,11 @@ def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
         if _flash.supported(q, k, v):
             band = None if (seq_info is None and window is None) else _attention_band(seq_info, B, T, window, Q.device)
             return _flash.flash_attention(q, k, v, None, band).reshape(B, T, Hq * D)
+        if (seq_info is not None or window is not None) and _flash.supported_padded(q, k, v):
+            # smaller heads (TinyLlama: 64) with a packed / windowed / padded batch: zero-padded heads on the same
+            # kernels instead of a dense [T, T] mask
+            band = _attention_band(seq_info, B, T, window, Q.device)
+            return _flash.flash_attention_padded(q, k, v, None, band).reshape(B, T, Hq * D)
     if seq_info is None and attention_mask is None and window is None:
         A = F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
         return A.transpose(1, 2).reshape(B, T, Hq * D)
@@ -250,6 +255,7 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
                             **kwargs):
     """llama.py:866-1245, training path. `self` is the HF LlamaModel."""
     invalidate_cast_cache()          # cached bf16 copies of the LoRA factors live for ONE forward/backward
+    _nf4.decode_ahead_step_begin()   # the NF4 decode requests since the last forward become this step's plan
     if inputs_embeds is None:
         inputs_embeds = self.embed_tokens(input_ids)
     dtype = _model_dtype(self)
@@ -259,6 +265,12 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
     # padding masks that are all ones are dropped in training (:1017-1019)
     if attention_mask is not None and (attention_mask.dim() != 2 or bool(torch.all(attention_mask != 0))):
         attention_mask = None
+    if attention_mask is not None and seq_info is None and attention_mask.shape == (bsz, q_len):
+        # right- / left-padded rows are packed documents [padding | tokens | padding]: the band kernels take them,
+        # nothing builds a dense mask (rows with holes keep the SDPA branch)
+        docs = _flash.padding_mask_documents(attention_mask.to(hidden_states.device))
+        if docs is not None:
+            seq_info, attention_mask = (docs, None, None), None
     rope_position_ids = None
     mrope = None
     if position_ids is not None and position_ids.dim() == 3 and position_ids.shape[0] == 3:
