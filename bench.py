@@ -227,14 +227,6 @@ def main():
         for bs in (1, 2):
             if bs != B:
                 alt_point(f"batch_{bs}_gc_off", False, bs)
-        from unsloth_amd import nf4 as _nf4a
-        if _nf4a.DECODE_AHEAD and os.environ.get("BENCH_DECODE_AHEAD_ALT", "1") == "1":
-            # A/B of nf4.DecodeAhead (default on): the same steps with every NF4 decode in stream order
-            _nf4a.set_decode_ahead(False)
-            alt_point("nf4_decode_in_stream_order_gc_off (UNSLOTH_AMD_DECODE_AHEAD=0)", False, B)
-            alt_point("nf4_decode_in_stream_order_batch_1", False, 1)
-            _nf4a.set_decode_ahead(True)
-            torch.cuda.empty_cache()
         if os.environ.get("BENCH_RESIDENT_ALT", "1") == "1":
             # opt-in mode: decoded bf16 mirrors of the NF4 weights stay in HBM (+2 B/param), no decode launches
             from unsloth_amd import nf4 as _nf4

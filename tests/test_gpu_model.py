@@ -320,6 +320,7 @@ def test_key_padding_mask_rows_equal_the_unpadded_rows(head_dim, monkeypatch):
         s0 = T - n if lf else 0
         ids[b, s0:s0 + n], mask[b, s0:s0 + n], labels[b, s0:s0 + n] = d, 1, d
         pos[b, s0:s0 + n] = torch.arange(n, dtype=torch.int32)
+        labels[b, s0] = -100      # a left-padded row: the padding token in front must not be asked to predict token 0
     out = model(input_ids=ids.to(DEV), attention_mask=mask.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
     out.loss.backward()
     got = _grads(model)

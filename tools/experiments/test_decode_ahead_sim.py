@@ -9,7 +9,9 @@ import random
 import pytest
 import torch
 
-from unsloth_amd import nf4
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import decode_ahead as nf4
 
 
 class _Stream:

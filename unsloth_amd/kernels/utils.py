@@ -468,14 +468,8 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
         xa, offs, xk = _xa_and_rank_block(X2d, [p[2] for p in with_lora], use256)
     results, dense_groups, nf4_groups, keep = [], [], [], []
     resident = None
-    if all(q is not None for (_, q, _, _, _) in projs) and not any(fused_nf4) \
-            and (len(projs) > 1 or not _nf4.RESIDENT) and (_nf4.RESIDENT or _nf4.DECODE_AHEAD):
-        # the group's row-major decodes stacked in ONE buffer: resident mirrors (opt-in) or the decode-ahead slots
-        # (nf4.DecodeAhead: this group was decoded on the side stream while the previous GEMM ran)
-        _, resident = _nf4.decode_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
-        if resident[0].dtype != dtype:
-            raise TypeError(f"quant_state.dtype {resident[0].dtype} != activation dtype {dtype}: the dequantised "
-                            "weight would be misread by the GEMM (set quant_state.dtype to the compute dtype)")
+    if _nf4.RESIDENT and len(projs) > 1 and all(q is not None for (_, q, _, _, _) in projs) and not any(fused_nf4):
+        _, resident = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
     li = 0
     for gi, (W, W_quant, A, B, s) in enumerate(projs):
         if W_quant is not None:
@@ -631,8 +625,8 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
     if NN_DX and have_xk and _use_gemm256(M, Ntot, [Kin]) and Kin % 8 == 0:
         # NN form: [W_q; W_k; W_v] stacked by ROWS is just the three row-major decodes one after the other -- the
         # layout the forward uses -- and the GEMM contracts over those rows (no transposed copy of any weight)
-        if _nf4.RESIDENT or _nf4.DECODE_AHEAD:
-            Wcat, _ = _nf4.decode_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
+        if _nf4.RESIDENT:
+            Wcat, _ = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
         else:
             Wcat = _nf4.scratch(dYcat.device, Ntot * Kin, dtype, slot=2).view(Ntot, Kin)
             row = 0
@@ -690,9 +684,7 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
         xk = getattr(xa, "_uamd_xk", None) if A is not None else None
         if NN_DX and _use_gemm256(M, N, [Kin]) and Kin % 8 == 0 and (A is None or xk is not None):
             # NN form: contract over the rows of the [N, Kin] weight as the forward decodes it
-            if W_quant is not None and _nf4.DECODE_AHEAD and not _nf4.RESIDENT:
-                Wd = _nf4.decode_group([W], [W_quant])[0]
-            elif W_quant is not None:
+            if W_quant is not None:
                 Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=True)
             else:
                 Wd = W if (W.dtype == dtype and W.stride(1) == 1 and W.stride(0) % 8 == 0) else W.to(dtype).contiguous()

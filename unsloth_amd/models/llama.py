@@ -255,7 +255,6 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
                             **kwargs):
     """llama.py:866-1245, training path. `self` is the HF LlamaModel."""
     invalidate_cast_cache()          # cached bf16 copies of the LoRA factors live for ONE forward/backward
-    _nf4.decode_ahead_step_begin()   # the NF4 decode requests since the last forward become this step's plan
     if inputs_embeds is None:
         inputs_embeds = self.embed_tokens(input_ids)
     dtype = _model_dtype(self)
