@@ -179,3 +179,54 @@ def test_attn_forward_rescale_heavy_inputs(fwd_variant):
         o, lse = attn_forward(q.to(DEV), kk.to(DEV), v.to(DEV), scale)
         torch.testing.assert_close(lse.cpu(), lse_ref, rtol=1e-4, atol=5e-3)
         assert (o.float().cpu() - o_ref).abs().max().item() <= 3e-2
+
+
+PADDED_CASES = [  # B, T, Hq, Hk, D, packed lengths, window
+    (1, 200, 7, 1, 128, None, None),                  # G = 7 -> padded to 8
+    (2, 333, 28, 4, 128, None, None),                 # Qwen2.5-7B / Qwen2-VL-7B head layout
+    (1, 256, 6, 2, 128, [100, 156], None),            # G = 3 -> 4, packed
+    (1, 192, 5, 1, 128, None, 48),                    # G = 5 -> 8, sliding window
+    (2, 160, 8, 2, 64, None, None),                   # TinyLlama / Llama-3.2-1B head_dim
+    (1, 300, 4, 4, 64, [64, 36, 200], None),
+    (1, 128, 14, 2, 64, None, None),                  # Qwen2.5-0.5B: G = 7 AND head_dim 64
+    (1, 96, 4, 2, 96, None, None),
+]
+
+
+@pytest.mark.parametrize("B,T,Hq,Hk,D,lengths,window", PADDED_CASES)
+def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
+    """Head dims below 128 and group sizes 3 / 5 / 6 / 7 run on the native kernels zero-padded (kernels/attention.py
+    _pad_qkv): outputs, LSE and all three gradients against the fp32 oracle on the UNPADDED problem, and the gradient
+    buffers keep the dQ | dK | dV column-block layout."""
+    from unsloth_amd.kernels.attention import attention_band, attn_backward, attn_forward, native, supported
+    dtype = torch.bfloat16
+    qkv = torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(31)).to(dtype)
+    do = torch.randn(B, T, Hq, D, generator=g(32)).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    allowed = packed_mask(T, lengths or [T], window) if (lengths or window) else None
+    qr = qkv[..., :Hq * D].view(B, T, Hq, D).float().requires_grad_(True)
+    kr = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D).float().requires_grad_(True)
+    vr = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D).float().requires_grad_(True)
+    o_ref, lse_ref = ref_attention(qr, kr, vr, scale, allowed)
+    o_ref.backward(do.float())
+    band = None
+    if lengths or window:
+        # the same documents in every batch row
+        band = attention_band(T, batch=B, seq_lengths=(lengths + [T - sum(lengths)]) * B if lengths else None,
+                              sliding_window=window, device=DEV)
+    qd = qkv.to(DEV)
+    q = qd[..., :Hq * D].view(B, T, Hq, D)
+    k = qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qd[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    assert supported(q, k, v) and not native(q, k, v)
+    o, lse = attn_forward(q, k, v, None, band)                      # default scale = 1 / sqrt(D) of the REAL head dim
+    assert o.shape == (B, T, Hq, D) and lse.shape == (B, Hq, T)
+    torch.testing.assert_close(lse.cpu(), lse_ref.detach(), rtol=1e-4, atol=2e-3)
+    assert (o.float().cpu() - o_ref.detach()).abs().max().item() <= 2e-2
+    dq, dk, dv = attn_backward(do.to(DEV), q, k, v, o, lse, None, band)
+    assert dq.shape == q.shape and dk.shape == k.shape and dv.shape == v.shape
+    assert dk.data_ptr() == dq.data_ptr() + Hq * D * 2 and dv.data_ptr() == dk.data_ptr() + Hk * D * 2
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        e = (got.float().cpu() - want).abs().max().item()
+        ref = want.abs().max().item()
+        assert e <= 3e-2 * max(ref, 1.0), (name, e, ref)

@@ -134,7 +134,7 @@ def test_rope_kv_append_matches_training_rope(dtype, B, Hq, Hk):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("Hq,Hk", [(4, 4), (4, 2), (8, 2), (8, 1)])
+@pytest.mark.parametrize("Hq,Hk", [(4, 4), (4, 2), (8, 2), (8, 1), (7, 1), (28, 4), (6, 2), (5, 1)])
 @pytest.mark.parametrize("lens,window", [((1,), 0), ((16, 129), 0), ((1000, 37, 512), 0), ((700,), 256), ((100,), 256)])
 def test_attn_decode_matches_fp32_softmax(dtype, Hq, Hk, lens, window):
     from unsloth_amd.kernels import decode as Dk

@@ -529,15 +529,23 @@ extern "C" int uamd_attn_decode(const void* q, int64_t q_sb, const void* k_cache
 #define UAMD_DECODE_LAUNCH(TT, GG)                                                                                       \
     hipLaunchKernelGGL((attn_decode_kernel<TT, GG>), grid, dim3(256), 0, st, (const TT*)q, q_sb, (const TT*)k_cache,      \
                        (const TT*)v_cache, cache_sb, cache_sh, kv_len, partials, Hq, nsplit, split_keys, window, sl2, len_add)
+    // every group size up to 8 (the kernel loops over its G query heads; Qwen2.5-7B / Qwen2-VL-7B: G = 7)
+#define UAMD_DECODE_G(TT)                                                                             \
+    switch (G) {                                                                                      \
+        case 1: UAMD_DECODE_LAUNCH(TT, 1); break; case 2: UAMD_DECODE_LAUNCH(TT, 2); break;           \
+        case 3: UAMD_DECODE_LAUNCH(TT, 3); break; case 4: UAMD_DECODE_LAUNCH(TT, 4); break;           \
+        case 5: UAMD_DECODE_LAUNCH(TT, 5); break; case 6: UAMD_DECODE_LAUNCH(TT, 6); break;           \
+        case 7: UAMD_DECODE_LAUNCH(TT, 7); break; case 8: UAMD_DECODE_LAUNCH(TT, 8); break;           \
+        default: return UAMD_ERR_ARG;                                                                 \
+    }
     if (dtype == UAMD_BF16) {
-        if (G == 1) UAMD_DECODE_LAUNCH(bf16_t, 1); else if (G == 2) UAMD_DECODE_LAUNCH(bf16_t, 2);
-        else if (G == 4) UAMD_DECODE_LAUNCH(bf16_t, 4); else if (G == 8) UAMD_DECODE_LAUNCH(bf16_t, 8); else return UAMD_ERR_ARG;
+        UAMD_DECODE_G(bf16_t)
     } else if (dtype == UAMD_F16) {
-        if (G == 1) UAMD_DECODE_LAUNCH(f16_t, 1); else if (G == 2) UAMD_DECODE_LAUNCH(f16_t, 2);
-        else if (G == 4) UAMD_DECODE_LAUNCH(f16_t, 4); else if (G == 8) UAMD_DECODE_LAUNCH(f16_t, 8); else return UAMD_ERR_ARG;
+        UAMD_DECODE_G(f16_t)
     } else {
         return UAMD_ERR_DTYPE;
     }
+#undef UAMD_DECODE_G
 #undef UAMD_DECODE_LAUNCH
     int rc = uamd_launch_status();
     if (rc) return rc;

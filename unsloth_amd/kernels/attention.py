@@ -17,9 +17,43 @@ _I64x12 = ctypes.c_int64 * 12
 _I64x24 = ctypes.c_int64 * 24
 
 
-def supported(q, k, v):
+_GROUPS = (1, 2, 4, 8)          # query heads per KV head the kernels are built for (8 waves per block)
+
+
+def native(q, k, v):
+    """Shapes the kernels take as they are: head_dim 128, G = Hq / Hk in {1, 2, 4, 8}."""
     return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 128
-            and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) in (1, 2, 4, 8))
+            and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) in _GROUPS)
+
+
+def supported(q, k, v):
+    """Native shapes, plus the ones that run on the same kernels after zero-padding (`_pad_qkv`): head dims below 128
+    (TinyLlama / Llama-3.2-1B: 64) and group sizes 3, 5, 6, 7 (Qwen2.5-7B / Qwen2-VL-7B: 28 query heads on 4 KV heads)."""
+    return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and 0 < q.shape[-1] <= 128
+            and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) <= 8)
+
+
+def _pad_qkv(q, k, v):
+    """Zero-padding onto a native shape. Head dim D < 128: extra zero columns change neither Q K^T nor the real columns
+    of P V. Group size G not in {1,2,4,8}: every KV group gets Gp - G extra query heads that are all zero -- their
+    scores are 0, their dO is 0 (the caller never sees their output), so they add exactly nothing to dK / dV
+    (dV += P^T dO = 0; dP = dO V^T = 0 and Delta = 0 give dS = 0). Returns (qp [B,T,Hk*Gp,128], kp, vp, G, Gp)."""
+    B, T, Hq, D = q.shape
+    Hk = k.shape[2]
+    G = Hq // Hk
+    Gp = next(g for g in _GROUPS if g >= G)
+    F = torch.nn.functional
+    qp = F.pad(q.reshape(B, T, Hk, G, D), (0, 128 - D, 0, Gp - G)).view(B, T, Hk * Gp, 128)
+    kp = F.pad(k, (0, 128 - D)) if D != 128 else k
+    vp = F.pad(v, (0, 128 - D)) if D != 128 else v
+    return qp, kp, vp, G, Gp
+
+
+def _pad_like_q(x, G, Gp):
+    """[B,T,Hq,D] -> [B,T,Hk*Gp,128] with the same zero padding as the queries (for O and dO)."""
+    B, T, Hq, D = x.shape
+    Hk = Hq // G
+    return torch.nn.functional.pad(x.reshape(B, T, Hk, G, D), (0, 128 - D, 0, Gp - G)).view(B, T, Hk * Gp, 128)
 
 
 def _strides(*ts):
@@ -100,6 +134,21 @@ def attn_forward(q, k, v, scale=None, band=None):
     Hk = k.shape[2]
     if scale is None:
         scale = 1.0 / math.sqrt(D)
+    if not native(q, k, v):
+        assert supported(q, k, v), "head_dim <= 128 and at most 8 query heads per KV head"
+        qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
+        op, lsep = _forward_native(qp, kp, vp, scale, band)
+        o = op.view(B, T, Hk, Gp, 128)[:, :, :, :G, :D].reshape(B, T, Hq, D)
+        Tp = _pad32(T)
+        lse = torch.as_strided(lsep, (B, Hk, Gp, Tp), (Hk * Gp * Tp, Gp * Tp, Tp, 1))[:, :, :G].reshape(B, Hq, Tp)
+        return o, lse[:, :, :T]
+    return _forward_native(q, k, v, scale, band)
+
+
+def _forward_native(q, k, v, scale, band):
+    """The launch itself: head_dim 128, G in {1, 2, 4, 8}."""
+    B, T, Hq, D = q.shape
+    Hk = k.shape[2]
     o = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
     Tp = _pad32(T)
     lse = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
@@ -122,6 +171,27 @@ def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
         scale = 1.0 / math.sqrt(D)
     Tp = _pad32(T)
     assert lse.stride(1) == Tp and lse.stride(2) == 1, "pass the LSE returned by attn_forward"
+    if not native(q, k, v):
+        qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
+        lse_full = torch.as_strided(lse, (B, Hq, Tp), (Hq * Tp, Tp, 1))
+        lsep = torch.nn.functional.pad(lse_full.view(B, Hk, G, Tp), (0, 0, 0, Gp - G)).view(B, Hk * Gp, Tp)
+        dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, _pad_like_q(o, G, Gp), lsep[:, :, :T], scale, band)
+        # same contract as below: dQ | dK | dV as column blocks of ONE buffer
+        dqkv = torch.empty((B, T, (Hq + 2 * Hk) * D), dtype=q.dtype, device=q.device)
+        dq = dqkv[..., :Hq * D].view(B, T, Hq, D)
+        dk = dqkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+        dv = dqkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+        dq.view(B, T, Hk, G, D).copy_(dqp.view(B, T, Hk, Gp, 128)[:, :, :, :G, :D])
+        dk.copy_(dkp[..., :D])
+        dv.copy_(dvp[..., :D])
+        return dq, dk, dv
+    return _backward_native(do, q, k, v, o, lse, scale, band)
+
+
+def _backward_native(do, q, k, v, o, lse, scale, band):
+    B, T, Hq, D = q.shape
+    Hk = k.shape[2]
+    Tp = _pad32(T)
     if do.stride(3) != 1:
         do = do.contiguous()
     # dQ | dK | dV side by side in ONE [B, T, (Hq + 2 Hk) D] buffer, the layout of a fused QKV projection output:
@@ -142,7 +212,7 @@ def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
 
 
 class FlashAttention(torch.autograd.Function):
-    """o = causal_attention(q, k, v) on [B,T,H,128] views; saves (q, k, v, o, lse) like flash-attention."""
+    """o = causal_attention(q, k, v) on [B,T,H,D] views; saves (q, k, v, o, lse) like flash-attention."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale, band):
@@ -160,24 +230,3 @@ class FlashAttention(torch.autograd.Function):
 
 def flash_attention(q, k, v, scale=None, band=None):
     return FlashAttention.apply(q, k, v, scale, band)
-
-
-def supported_padded(q, k, v):
-    """Head dims below 128 (TinyLlama's 64, ...) can run on the head_dim-128 kernels with zero-padded heads."""
-    D = q.shape[-1]
-    return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and 0 < D < 128
-            and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) in (1, 2, 4, 8))
-
-
-def flash_attention_padded(q, k, v, scale=None, band=None):
-    """head_dim < 128 on the head_dim-128 kernels: Q, K, V zero-padded to 128 columns (Q K^T is unchanged, the padded
-    columns of P V are zero and dropped; the softmax scale stays 1/sqrt(D)). Costs the copies and 128/D of the flops --
-    used where the alternative is a dense [T, T] additive mask (packed / windowed / padded batches); plain causal
-    batches of such models go to the library's flash kernel through SDPA. The padding and the slice are torch ops, so
-    autograd carries dQ/dK/dV back to the unpadded views."""
-    D = q.shape[-1]
-    if scale is None:
-        scale = 1.0 / math.sqrt(D)
-    pad = (0, 128 - D)
-    qp, kp, vp = (torch.nn.functional.pad(t, pad) for t in (q, k, v))
-    return FlashAttention.apply(qp, kp, vp, scale, band)[..., :D]

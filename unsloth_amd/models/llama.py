@@ -165,23 +165,24 @@ def _attention_band(seq_info, B, T, window, device):
 def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
     """causal (GQA, packed, windowed) attention. Q [B,Hq,T,D], K/V [B,Hk,T,D] (strided views of the [B,T,H,D]
     projection outputs) -> [B, T, Hq*D].
-    Causal batches with head_dim 128 -- plain, packed (block-diagonal over `seq_info` documents) or
-    sliding-window -- take the hand-written CDNA4 kernels (kernels/attention.py), which read the [B,T,H,D]
-    memory directly and write the o_proj input layout: no transposes, no copies, no dense mask. Batches with a
-    key-padding `attention_mask` (and other head dims) use torch SDPA with an explicit mask (run_attention's
-    SDPA branch, attention_dispatch.py:560-617)."""
+    Causal batches -- plain, packed (block-diagonal over `seq_info` documents; right- / left-padded rows arrive
+    here as documents too, see LlamaModel_fast_forward) or sliding-window -- take the hand-written CDNA4 kernels
+    (kernels/attention.py), which read the [B,T,H,D] memory directly and write the o_proj input layout: no
+    transposes, no copies, no dense mask. What is left for torch SDPA (run_attention's SDPA branch,
+    attention_dispatch.py:560-617): plain causal batches of models with heads below 128 (the library's flash
+    kernel), key-padding masks with holes, more than 8 query heads per KV head."""
     B, Hq, T, D = Q.shape
     window = sliding_window if (sliding_window is not None and 0 < sliding_window < T) else None   # mistral.py:116-120
     if attention_mask is None and _USE_FLASH:
         q, k, v = Q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2)          # [B,T,H,D] views
-        if _flash.supported(q, k, v):
-            band = None if (seq_info is None and window is None) else _attention_band(seq_info, B, T, window, Q.device)
+        need_band = seq_info is not None or window is not None
+        # shapes the kernels take as they are; group sizes 3/5/6/7 at head_dim 128 (Qwen2.5-7B, Qwen2-VL-7B: 28 query
+        # heads on 4 KV heads) and smaller heads with a packed / windowed / padded batch run on the same kernels
+        # zero-padded (kernels/attention._pad_qkv) -- nothing builds a dense [T, T] mask. Plain causal batches of
+        # small-head models (TinyLlama: 64) go to the library's flash kernel through SDPA below.
+        if _flash.native(q, k, v) or (_flash.supported(q, k, v) and (need_band or D == 128)):
+            band = _attention_band(seq_info, B, T, window, Q.device) if need_band else None
             return _flash.flash_attention(q, k, v, None, band).reshape(B, T, Hq * D)
-        if (seq_info is not None or window is not None) and _flash.supported_padded(q, k, v):
-            # smaller heads (TinyLlama: 64) with a packed / windowed / padded batch: zero-padded heads on the same
-            # kernels instead of a dense [T, T] mask
-            band = _attention_band(seq_info, B, T, window, Q.device)
-            return _flash.flash_attention_padded(q, k, v, None, band).reshape(B, T, Hq * D)
     if seq_info is None and attention_mask is None and window is None:
         A = F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
         return A.transpose(1, 2).reshape(B, T, Hq * D)
