@@ -81,7 +81,8 @@ def test_mrope_with_equal_streams_is_ordinary_rope():
     assert torch.equal(q1, q2) and torch.equal(k1, k2)
 
 
-def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model():
+@pytest.mark.parametrize("hidden,heads,kv", [(512, 4, 2), (896, 7, 1)])      # 7:1 = Qwen2-VL-7B's 28:4 grouping (G = 7)
+def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, kv):
     """FastModel on a Qwen2-VL config = its language tower on the hand-kernel path: same weights in transformers'
     Qwen2VLTextModel (fp32, host) + lm_head give the same loss for [3, B, T] multimodal positions, and text-only [B, T]
     positions equal three identical streams."""
@@ -90,8 +91,8 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model():
     from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
     from unsloth_amd import FastModel
     from unsloth_amd.kernels.rms_layernorm import unpatch_rms_layernorm
-    vl = Qwen2VLConfig(text_config=dict(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
-                                        num_key_value_heads=2, vocab_size=1000, max_position_embeddings=512, rms_norm_eps=1e-6,
+    vl = Qwen2VLConfig(text_config=dict(hidden_size=hidden, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=heads,
+                                        num_key_value_heads=kv, vocab_size=1000, max_position_embeddings=512, rms_norm_eps=1e-6,
                                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
                                         tie_word_embeddings=False),
                        vision_config=dict(depth=1, embed_dim=32, hidden_size=512, num_heads=2))
@@ -105,7 +106,14 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model():
                         torch.randint(0, 30, (B, T), generator=gen)])                      # temporal / height / width
     labels = ids.clone()
     model.train()
-    out = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=pos3.cuda())
+    from unsloth_amd.kernels import attention as flash
+    calls, real = [], flash._forward_native
+    flash._forward_native = lambda q, k, v, s, band: (calls.append(q.shape[2] // k.shape[2]), real(q, k, v, s, band))[1]
+    try:
+        out = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=pos3.cuda())
+    finally:
+        flash._forward_native = real
+    assert calls and all(g_ in (1, 2, 4, 8) for g_ in calls)            # the hand kernels ran (7 query heads: padded to 8)
     out_t = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=torch.arange(T).expand(B, T).cuda())
     out_3 = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=torch.arange(T).expand(3, B, T).contiguous().cuda())
     assert abs(float(out_t.loss) - float(out_3.loss)) < 1e-6
