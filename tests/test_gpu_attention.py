@@ -59,6 +59,13 @@ def test_attn_forward_matches_fp32_oracle(fwd_variant, dtype, B, T, Hq, Hk):
     tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
     err = (o.float().cpu() - o_ref).abs().max().item()
     assert err <= tol, err
+    # norm-wise bounds at 2x the measured worst case over these shapes (tools/attn_err_probe.py on MI355X: relative
+    # Frobenius error 2.0e-3 / 2.5e-4, worst single query row 3.2e-3 / 3.8e-4 for bf16 / fp16 -- i.e. the rounding of
+    # the output and of P to the 16-bit type, nothing else)
+    d = o.float().cpu() - o_ref
+    assert (d.norm() / o_ref.norm()).item() <= (4e-3 if dtype == torch.bfloat16 else 5e-4)
+    rows = d.flatten(0, -2).norm(dim=-1) / o_ref.flatten(0, -2).norm(dim=-1).clamp_min(1e-20)
+    assert rows.max().item() <= (6.5e-3 if dtype == torch.bfloat16 else 8e-4)
     o2, _ = attn_forward(qd[..., :Hq * D].view(B, T, Hq, D), qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D),
                          qd[..., (Hq + Hk) * D:].view(B, T, Hk, D), scale)
     assert torch.equal(o, o2)
@@ -89,6 +96,9 @@ def test_attn_backward_matches_fp32_autograd(dtype, B, T, Hq, Hk):
         ref = want.abs().max().item()
         tol = (3e-2 if dtype == torch.bfloat16 else 6e-3) * max(ref, 1.0)
         assert err <= tol, (name, err, ref)
+        # measured (tools/attn_err_probe.py): relative Frobenius error <= 2.7e-3 (bf16) / 3.4e-4 (fp16) on every gradient
+        rel = ((got.float().cpu() - want).norm() / want.norm()).item()
+        assert rel <= (5.5e-3 if dtype == torch.bfloat16 else 7e-4), (name, rel)
     dq2, dk2, dv2 = attn_backward(do.to(DEV), q, k, v, o, lse, scale)
     assert torch.equal(dq, dq2) and torch.equal(dk, dk2) and torch.equal(dv, dv2)
 
