@@ -114,6 +114,8 @@ def main():
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and os.environ.get("BENCH_ALT_MULTI", "0") != "1":
+        a.alt_steps = 0            # the other operating points are a 1-GPU report; a scaling run times the primary only
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
