@@ -154,8 +154,10 @@ def main():
             n_train += p.numel()
             if "lora_B" in n:           # non-zero B so every LoRA gradient is exercised with real numbers
                 p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
-    opt = make_optimizer(model, lr=2e-4)
     arena = LoRAGradArena(model) if (world > 1 or force_dp) else None
+    # optim.FlatAdamW: parameters / gradients / moments in flat arenas, one launch per step (the gradients live in the
+    # data-parallel arena when there is one; UNSLOTH_AMD_FLAT_ADAMW=0 = torch's fused AdamW)
+    opt = make_optimizer(model, lr=2e-4, arena=arena)
     B, T, V = a.batch, a.seq, cfg.vocab_size
     gi = torch.Generator(device="cpu").manual_seed(rank)       # different data per rank
 
@@ -315,7 +317,7 @@ def main():
                        "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
                        "gradient_checkpointing": GC_MODE[a.gc], "trainable_params": n_train,
-                       "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": "AdamW(fused) fp32 on LoRA params"},
+                       "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": type(opt).__name__ + " fp32 on LoRA params"},
             "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T, "rccl_ranks": rccl_ranks,
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,

@@ -92,3 +92,17 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f"{f} imports oracle/"
+
+
+def test_flat_adamw_has_no_cpu_fallback():
+    """optim.FlatAdamW on host parameters: construction works (it is bookkeeping), the step refuses to run."""
+    import pytest
+    import torch
+    from unsloth_amd.optim import FlatAdamW
+    from unsloth_amd.trainer import make_optimizer
+    m = torch.nn.Linear(8, 4, bias=False)
+    assert isinstance(make_optimizer(m), torch.optim.AdamW) and not isinstance(make_optimizer(m), FlatAdamW)
+    opt = FlatAdamW(m)
+    m.weight.grad.add_(1.0)
+    with pytest.raises(Exception):
+        opt.step()

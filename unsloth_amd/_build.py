@@ -28,6 +28,7 @@ SOURCES = [
     "lora_side.hip",
     "attention.hip",
     "decode.hip",
+    "adamw.hip",
 ]
 
 

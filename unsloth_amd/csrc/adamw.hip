@@ -1,0 +1,83 @@
+// AdamW over ONE flat fp32 arena: parameters, gradients and both moments of all LoRA factors laid out back to back
+// (unsloth_amd/optim.py FlatAdamW; gradients = dp.LoRAGradArena). One launch per optimizer step.
+//
+// Where it sits on the reference's path: the optimizer step that closes every training step of the benchmark
+// (unsloth/trainer.py:445-623 builds torch / bitsandbytes optimizers through HF's Trainer; the tokens/s metric times
+// forward + backward + this). torch's fused AdamW walks the 448 LoRA tensors in multi_tensor_apply chunks: 52 launches,
+// 2.5 ms per step for 168 MB of parameters (profiles/r02z_bench_kernel_stats.csv) -- 8 streams of 168 MB are 0.22 ms of
+// HBM time. The arithmetic is torch.optim.AdamW's (decoupled weight decay, bias-corrected moments; fp32 throughout):
+//     p  -= lr * wd * p
+//     m   = b1 * m + (1 - b1) * g
+//     v   = b2 * v + (1 - b2) * g * g
+//     p  -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)            bc1 = 1 - b1^t, bc2 = 1 - b2^t
+// `grad_scale` multiplies g first (gradient clipping: the caller passes clip / norm, 1 = none); `zero_grad` != 0 writes
+// zeros back into g in the same pass (the arena is ADDED into by uamd_lora_tn, so it must start every step at zero:
+// this replaces a separate 168 MB fill).
+// HBM-bound: 16 B read + 12 (16 with zero_grad) B written per parameter.
+#include "common.h"
+
+namespace {
+
+struct AdamArgs {
+    float* p; float* g; float* m; float* v;
+    int64_t n;
+    float lr_wd, b1, b2, eps, step_size, bc2_sqrt, grad_scale;
+    int zero_grad;
+};
+
+__device__ __forceinline__ void adamw_one(float& p, float& g, float& m, float& v, const AdamArgs& a) {
+    const float gr = g * a.grad_scale;
+    // same association as torch's fused kernel (fused_adam_utils.cuh adam_math): ... - step_size * m / denom
+    p = p - a.lr_wd * p;
+    m = a.b1 * m + (1.0f - a.b1) * gr;
+    v = a.b2 * v + (1.0f - a.b2) * gr * gr;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * m / denom;
+}
+
+__global__ void __launch_bounds__(256) adamw_flat_kernel(AdamArgs a) {
+    const int64_t n4 = a.n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 p = reinterpret_cast<const float4*>(a.p)[i];
+        float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<const float4*>(a.m)[i];
+        float4 v = reinterpret_cast<const float4*>(a.v)[i];
+        adamw_one(p.x, g.x, m.x, v.x, a);
+        adamw_one(p.y, g.y, m.y, v.y, a);
+        adamw_one(p.z, g.z, m.z, v.z, a);
+        adamw_one(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        if (a.zero_grad) reinterpret_cast<float4*>(a.g)[i] = float4{0.f, 0.f, 0.f, 0.f};
+    }
+    // tail (n % 4 elements): first threads of block 0
+    const int64_t t = (n4 << 2) + threadIdx.x;
+    if (blockIdx.x == 0 && t < a.n) {
+        adamw_one(a.p[t], a.g[t], a.m[t], a.v[t], a);
+        if (a.zero_grad) a.g[t] = 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int uamd_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, float bias_correction1, float bias_correction2_sqrt,
+                               float grad_scale, int zero_grad, void* stream) {
+    if (!p || !g || !m || !v || n < 0) return UAMD_ERR_ARG;
+    if (!(bias_correction1 > 0.f) || !(bias_correction2_sqrt > 0.f)) return UAMD_ERR_ARG;
+    if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return UAMD_ERR_ALIGN;
+    if (n == 0) return UAMD_OK;
+    AdamArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
+    a.lr_wd = (float)((double)lr * (double)weight_decay); a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    a.step_size = (float)((double)lr / (double)bias_correction1); a.bc2_sqrt = bias_correction2_sqrt;
+    a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+    const int64_t n4 = (n + 3) >> 2;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;            // 16 blocks per CU, grid-stride beyond
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return uamd_launch_status();
+}

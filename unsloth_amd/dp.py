@@ -68,6 +68,7 @@ class LoRAGradArena:
         self.buckets.append([b_start, off, b_count])
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)      # per step: which buckets already have a collective in flight
+        self.writes = 0                                    # gradients accumulated so far (optim.FlatAdamW: "is the arena dirty?")
         self._handles = []
         self._sync = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
@@ -113,6 +114,7 @@ class LoRAGradArena:
             v.copy_(p.grad)
             p.grad = v
         b = self._bucket_of[id(p)]
+        self.writes += 1
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
             self._pending[b] = 0

@@ -1,0 +1,141 @@
+"""FlatAdamW: torch.optim.AdamW's arithmetic over ONE flat fp32 arena -- one HIP launch per optimizer step.
+
+The reference trains through HF's Trainer with a torch / bitsandbytes optimizer (unsloth/trainer.py:445-623); the
+benchmark's step is forward + backward + AdamW on the LoRA factors. torch's fused AdamW needs 52 multi_tensor_apply
+launches (2.5 ms) for the 448 factors of Llama-3-8B r=16 -- 168 MB of parameters, 0.2 ms of HBM time. MI355X-first
+layout instead: parameters, gradients (dp.LoRAGradArena, which the fused LoRA-gradient kernel ADDS into), exp_avg and
+exp_avg_sq are four flat fp32 buffers with the same offsets, `p.data` / `p.grad` / the optimizer state are views into
+them, and `uamd_adamw_flat` (csrc/adamw.hip) walks them once -- zeroing the gradient arena in the same pass, which is
+the `zero_grad` of the next step.
+
+Interface: a torch.optim.Optimizer (param_groups / state / state_dict / LR schedulers / step hooks work as usual) with
+one parameter group. `step(grad_scale=...)` takes the clipping factor; parameters that received no gradient are
+skipped exactly like torch does. No CPU fallback: the step raises without the HIP library.
+"""
+import math
+
+import torch
+
+from . import _lib
+from .dp import LoRAGradArena
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, arena=None):
+        """`arena`: the dp.LoRAGradArena that already owns the gradients (data-parallel runs); else one is created
+        (single rank: no collective is ever issued)."""
+        if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid AdamW hyper-parameters")
+        self.arena = arena if arena is not None else LoRAGradArena(model)
+        self._owns_arena = arena is None
+        params = list(self.arena.params)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        g = self.arena.arena
+        n = g.numel()
+        self.flat_p = torch.empty(n, dtype=torch.float32, device=g.device)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=g.device)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=g.device)
+        self._views = []                     # (param, offset, numel, grad view)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                gv = self.arena._views[id(p)]
+                assert gv.data_ptr() == g.data_ptr() + 4 * off, "arena order changed under the optimizer"
+                self.flat_p[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[off:off + k].view(p.shape)          # the parameter now LIVES in the flat buffer
+                self.state[p] = dict(step=torch.zeros((), dtype=torch.float32),
+                                     exp_avg=self.flat_m[off:off + k].view(p.shape),
+                                     exp_avg_sq=self.flat_v[off:off + k].view(p.shape))
+                self._views.append((p, off, k, gv))
+                off += k
+        self._t = 0
+        self._writes_seen = self.arena.writes    # arena.writes at the moment the arena was last known to be all zeros
+
+    # ------------------------------------------------------------------------------------------
+    def _runs(self):
+        """Contiguous [start, end) element ranges whose parameters have a gradient; every gradient is (moved) in the
+        arena first. One range = the whole arena in a normal LoRA step."""
+        runs, cur = [], None
+        base = self.flat_p.data_ptr()
+        for p, off, k, gv in self._views:
+            if p.data_ptr() != base + 4 * off:
+                # someone re-pointed p.data (module.to(...), a checkpoint loader that assigns .data): adopt the new
+                # values and bring the parameter home again -- stepping a detached copy would silently train nothing
+                self.flat_p[off:off + k].copy_(p.data.reshape(-1).to(self.flat_p.dtype))
+                p.data = self.flat_p[off:off + k].view(p.shape)
+            gr = p.grad
+            if gr is None:
+                cur = None
+                continue
+            if gr.data_ptr() != gv.data_ptr():
+                gv.copy_(gr)                 # autograd built a fresh tensor (the view had been dropped)
+                p.grad = gv
+            if cur is not None and cur[1] == off:
+                cur[1] = off + k
+            else:
+                cur = [off, off + k]
+                runs.append(cur)
+        return runs
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        grp = self.param_groups[0]
+        if len(self.param_groups) != 1:
+            raise NotImplementedError("FlatAdamW: one parameter group (use torch.optim.AdamW for per-group settings)")
+        b1, b2 = grp["betas"]
+        self._t += 1
+        t = self._t
+        bc1 = 1.0 - b1 ** t
+        bc2_sqrt = math.sqrt(1.0 - b2 ** t)
+        runs = self._runs()
+        _lib.require_gpu(self.flat_p)
+        g = self.arena.arena
+        L = _lib.lib()
+        with _lib.device_ctx(self.flat_p):
+            for s, e in runs:
+                # (a run that does not start on a 16-byte boundary cannot happen for LoRA factors: every numel is a
+                # multiple of 4; the C side checks)
+                rc = L.uamd_adamw_flat(self.flat_p.data_ptr() + 4 * s, g.data_ptr() + 4 * s, self.flat_m.data_ptr() + 4 * s,
+                                       self.flat_v.data_ptr() + 4 * s, e - s, float(grp["lr"]), float(b1), float(b2),
+                                       float(grp["eps"]), float(grp["weight_decay"]), bc1, bc2_sqrt, float(grad_scale), 1,
+                                       _lib.stream_of(self.flat_p))
+                _lib.check(rc, "uamd_adamw_flat")
+        for p, _, _, _ in self._views:
+            if p.grad is not None:
+                self.state[p]["step"] += 1
+        # every range that had a gradient is zero again; ranges without one were never written
+        self._writes_seen = self.arena.writes
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        """The step already zeroed the arena in its own pass; the gradient views stay attached (the fused LoRA-gradient
+        kernel adds into them). Called without a step in between (gradients thrown away): one fill."""
+        if self.arena.writes != self._writes_seen:
+            self.arena.arena.zero_()
+            self._writes_seen = self.arena.writes
+        for p, _, _, gv in self._views:
+            p.grad = gv
+
+    def grad_norm(self):
+        return self.arena.arena.norm()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # torch replaced the state tensors by copies: move them back into the flat buffers and re-attach the views
+        with torch.no_grad():
+            for p, off, k, _ in self._views:
+                st = self.state[p]
+                self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                st["exp_avg"] = self.flat_m[off:off + k].view(p.shape)
+                st["exp_avg_sq"] = self.flat_v[off:off + k].view(p.shape)
+                self._t = max(self._t, int(st["step"]))
+
+    def close(self):
+        if self._owns_arena:
+            self.arena.close()

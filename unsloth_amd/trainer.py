@@ -7,6 +7,7 @@ through the fused path, backward, LoRA-grad exchange (unsloth_amd/dp.py), optimi
 also what bench.py times. Loss normalisation follows the reference's contract: sum of
 token losses / global non-ignored token count, passed as `num_items_in_batch`.
 """
+import os
 import time
 
 import torch
@@ -117,8 +118,16 @@ def _patch_trl_trainer():
     return done
 
 
-def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999)):
+def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999), arena=None, flat=None):
+    """AdamW on the trainable (LoRA) parameters. On the GPU with fp32 parameters: optim.FlatAdamW -- parameters,
+    gradients and moments in flat arenas, ONE launch per step (`arena`: the dp.LoRAGradArena of a data-parallel run, else
+    the optimizer creates its own). `flat=False` (or UNSLOTH_AMD_FLAT_ADAMW=0) keeps torch's fused AdamW."""
     params = [p for p in model.parameters() if p.requires_grad]
+    if flat is None:
+        flat = os.environ.get("UNSLOTH_AMD_FLAT_ADAMW", "1") != "0"
+    if flat and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
+        from .optim import FlatAdamW
+        return FlatAdamW(model, lr=lr, betas=betas, weight_decay=weight_decay, arena=arena)
     fused = params[0].is_cuda
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)
 
@@ -133,7 +142,9 @@ def training_step(model, batch, optimizer, arena=None, num_items=None):
     if arena is not None:
         arena.finish()
     optimizer.step()
-    if arena is not None:
+    if getattr(optimizer, "flat_p", None) is not None:
+        optimizer.zero_grad()              # FlatAdamW: the step zeroed the gradient arena in its own pass
+    elif arena is not None:
         arena.zero_grad()
     else:
         optimizer.zero_grad(set_to_none=True)
