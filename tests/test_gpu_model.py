@@ -431,7 +431,7 @@ def test_grad_arena_direct_accumulation_matches_autograd():
         p.grad = None
     arena = LoRAGradArena(model)
     try:
-        assert len(GRAD_SINKS) == len(ref)
+        assert sum(1 for r in GRAD_SINKS.values() if r() is arena) == len(ref)
         arena.zero_grad()
         model(**kw).loss.backward()
         arena.finish()
@@ -446,4 +446,4 @@ def test_grad_arena_direct_accumulation_matches_autograd():
         assert worst <= 1e-6, worst
     finally:
         arena.close()
-    assert not GRAD_SINKS
+    assert not any(r() is arena for r in GRAD_SINKS.values())

@@ -51,10 +51,13 @@ def test_flat_adamw_matches_torch_adamw(wd, lr):
         ref.zero_grad(set_to_none=True)
         assert float(opt.arena.arena.abs().max()) == 0.0          # zeroed by the step's own pass
     for n, p in model.named_parameters():
-        torch.testing.assert_close(p.data, rp[n].data, rtol=2e-6, atol=1e-7)
+        # torch's single-tensor path updates exp_avg by lerp_ (m + (1 - b1)(g - m)), the kernel by b1 m + (1 - b1) g like
+        # torch's fused path: the two differ by a few ulp of the LARGER term, hence absolute bounds at the operands' scale
+        # (|g| up to ~6 here; measured worst differences 1.5e-8 on exp_avg, 2.4e-7 on the parameters)
+        torch.testing.assert_close(p.data, rp[n].data, rtol=1e-5, atol=1e-6)
         st, rst = opt.state[p], ref.state[rp[n]]
-        torch.testing.assert_close(st["exp_avg"], rst["exp_avg"], rtol=2e-6, atol=1e-9)
-        torch.testing.assert_close(st["exp_avg_sq"], rst["exp_avg_sq"], rtol=2e-6, atol=1e-12)
+        torch.testing.assert_close(st["exp_avg"], rst["exp_avg"], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(st["exp_avg_sq"], rst["exp_avg_sq"], rtol=1e-5, atol=1e-10)
         assert int(st["step"]) == 6
         assert p.data_ptr() >= opt.flat_p.data_ptr() and p.data_ptr() < opt.flat_p.data_ptr() + opt.flat_p.numel() * 4
 

@@ -76,9 +76,13 @@ class LoRAGradArena:
         # the fused LoRA-gradient kernel adds straight into the arena (kernels/utils.py GRAD_SINKS): no
         # AccumulateGrad kernel per parameter; .ready() does the bucket bookkeeping the autograd hook would do
         if direct and self.arena.is_cuda:
+            import weakref
             from .kernels.utils import GRAD_SINKS
+            for k in [k for k, ref in GRAD_SINKS.items() if ref() is None]:      # arenas that died without close()
+                del GRAD_SINKS[k]
+            me = weakref.ref(self)        # weak: the registry must not keep an arena (and through it a model) alive
             for p in self.params:
-                GRAD_SINKS[id(p)] = self
+                GRAD_SINKS[id(p)] = me
 
     def grad_view(self, p):
         """Arena slice the fused gradient kernel ADDS into. If the optimizer dropped the gradient
@@ -99,7 +103,8 @@ class LoRAGradArena:
     def close(self):
         from .kernels.utils import GRAD_SINKS
         for p in self.params:
-            if GRAD_SINKS.get(id(p)) is self:
+            ref = GRAD_SINKS.get(id(p))
+            if ref is not None and ref() is self:
                 del GRAD_SINKS[id(p)]
         for h in self._hooks:
             h.remove()

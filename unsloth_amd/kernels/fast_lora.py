@@ -21,6 +21,7 @@ import torch
 
 from .utils import (
     GRAD_SINKS,
+    grad_sink,
     cast_lora,
     get_lora_parameters,
     lora_dx_terms,
@@ -74,7 +75,7 @@ def _lora_grads_fused(items):
         probs.append((P, X2d, r, False, s))
         probs.append((XA, dY2d, r, True, s))
         for prm in (A, B):
-            sink = GRAD_SINKS.get(id(prm)) if GRAD_SINKS else None
+            sink = grad_sink(prm)
             sinks.append((sink, prm))
             targets.append(sink.grad_view(prm) if sink is not None else None)
     outs = lora_tn(probs, targets if any(t is not None for t in targets) else None)

@@ -741,6 +741,20 @@ def lora_tn_supported(Zs):
 GRAD_SINKS = {}
 
 
+def grad_sink(param):
+    """The live sink that owns `param`'s gradient, or None. Entries hold WEAK references to their arena: an arena that
+    is alive keeps its parameters alive, so a hit can never belong to a dead parameter whose id() was recycled."""
+    if not GRAD_SINKS:
+        return None
+    ref = GRAD_SINKS.get(id(param))
+    if ref is None:
+        return None
+    sink = ref()
+    if sink is None:
+        GRAD_SINKS.pop(id(param), None)
+    return sink
+
+
 def lora_tn(problems, targets=None):
     """problems: [(P fp32 [M, >=R] with unit column stride, Z [M, N], R, out_nr, scale)].
     Returns the fp32 products, [R, N] (out_nr False: lora_A.grad layout) or [N, R] (True: lora_B.grad layout).
