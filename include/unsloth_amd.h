@@ -362,9 +362,10 @@ int uamd_lora_prepare(const uamd_lora_prep_desc* descs_dev, const int* tile_pref
  * multi_tensor_apply launches torch's fused AdamW needs for the 448 LoRA factors (the step that closes the reference's
  * training step, unsloth/trainer.py:445-623 via HF Trainer). bias_correction1 = 1 - beta1^t, bias_correction2_sqrt =
  * sqrt(1 - beta2^t) for step t >= 1; grad_scale multiplies g first (clipping; 1 = none); zero_grad != 0 writes zeros
- * back into g in the same pass. All four pointers 16-byte aligned. */
-int uamd_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                    float weight_decay, float bias_correction1, float bias_correction2_sqrt, float grad_scale,
+ * back into g in the same pass. Scalars are doubles (derived constants such as 1 - beta2 are formed in double and
+ * rounded once). All four pointers 16-byte aligned. */
+int uamd_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, double bias_correction1, double bias_correction2_sqrt, double grad_scale,
                     int zero_grad, void* stream);
 
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */

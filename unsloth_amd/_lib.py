@@ -108,8 +108,7 @@ SIGNATURES = {
     "uamd_add_rms_layernorm_bwd": (c_int, [c_void_p] * 6 + [c_int64, c_int, c_int64, c_int64, c_int64, c_int64, c_int,
                                                              c_int, c_void_p]),
     "uamd_lora_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "uamd_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float,
-                                c_float, c_float, c_float, c_float, c_int, c_void_p]),
+    "uamd_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [ctypes.c_double] * 8 + [c_int, c_void_p]),
     "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int,
                               c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),

@@ -21,7 +21,7 @@ namespace {
 struct AdamArgs {
     float* p; float* g; float* m; float* v;
     int64_t n;
-    float lr_wd, b1, b2, eps, step_size, bc2_sqrt, grad_scale;
+    float lr_wd, b1, b2, omb1, omb2, eps, step_size, bc2_sqrt, grad_scale;
     int zero_grad;
 };
 
@@ -29,8 +29,8 @@ __device__ __forceinline__ void adamw_one(float& p, float& g, float& m, float& v
     const float gr = g * a.grad_scale;
     // same association as torch's fused kernel (fused_adam_utils.cuh adam_math): ... - step_size * m / denom
     p = p - a.lr_wd * p;
-    m = a.b1 * m + (1.0f - a.b1) * gr;
-    v = a.b2 * v + (1.0f - a.b2) * gr * gr;
+    m = a.b1 * m + a.omb1 * gr;
+    v = a.b2 * v + a.omb2 * gr * gr;
     const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
     p = p - a.step_size * m / denom;
 }
@@ -62,18 +62,21 @@ __global__ void __launch_bounds__(256) adamw_flat_kernel(AdamArgs a) {
 
 }  // namespace
 
-extern "C" int uamd_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
-                               float eps, float weight_decay, float bias_correction1, float bias_correction2_sqrt,
-                               float grad_scale, int zero_grad, void* stream) {
+extern "C" int uamd_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2,
+                               double eps, double weight_decay, double bias_correction1, double bias_correction2_sqrt,
+                               double grad_scale, int zero_grad, void* stream) {
     if (!p || !g || !m || !v || n < 0) return UAMD_ERR_ARG;
-    if (!(bias_correction1 > 0.f) || !(bias_correction2_sqrt > 0.f)) return UAMD_ERR_ARG;
+    if (!(bias_correction1 > 0.0) || !(bias_correction2_sqrt > 0.0)) return UAMD_ERR_ARG;
     if (!aligned16(p) || !aligned16(g) || !aligned16(m) || !aligned16(v)) return UAMD_ERR_ALIGN;
     if (n == 0) return UAMD_OK;
     AdamArgs a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n;
-    a.lr_wd = (float)((double)lr * (double)weight_decay); a.b1 = beta1; a.b2 = beta2; a.eps = eps;
-    a.step_size = (float)((double)lr / (double)bias_correction1); a.bc2_sqrt = bias_correction2_sqrt;
-    a.grad_scale = grad_scale; a.zero_grad = zero_grad;
+    // hyper-parameters arrive as doubles (Python floats) and every derived constant is formed in double, then rounded
+    // once -- like torch, whose kernels receive 1 - beta as a double-computed scalar (1.0f - 0.999f is off by 1.3e-5)
+    a.lr_wd = (float)(lr * weight_decay); a.b1 = (float)beta1; a.b2 = (float)beta2;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps;
+    a.step_size = (float)(lr / bias_correction1); a.bc2_sqrt = (float)bias_correction2_sqrt;
+    a.grad_scale = (float)grad_scale; a.zero_grad = zero_grad;
     const int64_t n4 = (n + 3) >> 2;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;            // 16 blocks per CU, grid-stride beyond
