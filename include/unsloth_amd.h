@@ -233,9 +233,7 @@ int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_GEMM_PERSIST 7 /* (UAMD_GEMM_PERSIST) uamd_gemm_n{t,n}_256 with 256-row tiles: one persistent block per CU walks the tiles
                                  * and prefetches the next tile's first K tiles during the current one's last: 1 = when every CU gets
                                  * >= 4 tiles (default), 2 = whenever it gets more than one, 0 = never (one block per tile) */
-#define UAMD_TUNE_GEMM_W4 8     /* (UAMD_GEMM_W4) uamd_gemm_n{t,n}_256 with 256-row tiles: 1 = the 4-wave x 128x128 form (one wave per SIMD,
-                                 * accumulators in AGPRs, one barrier per K tile); bit-identical results. Default 0 */
-#define UAMD_TUNE_COUNT 9
+#define UAMD_TUNE_COUNT 8
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

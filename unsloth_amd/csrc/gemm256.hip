@@ -30,8 +30,6 @@
 // K = 14336); the round-1 register prologue (fp32 XA loads + conversions + 32 MFMAs before the loop) cost 4-8 %.
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -1036,8 +1034,6 @@ int launch256p(const G256Args& a, hipStream_t st, int n_cu) {
     return uamd_launch_status();
 }
 
-#include "gemm256_w4.inc"
-
 // compute units of the current device (one persistent block each: 128 KiB of the CU's 160 KiB LDS)
 int cu_count() {
     static int n[64] = {0};
@@ -1124,11 +1120,6 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
     // one, 0 = never). Measured (profiles/r02i_gemm_persist_ab.txt): +0.5 % at 7 tiles per CU, -2.5 % .. 0 at 2 tiles per CU
     // (static assignment loses the dispatcher's balancing) -- the kernel is power-limited, idle slots it removes come back
     // as clock.
-    if (uamd_tuning_get(UAMD_TUNE_GEMM_W4)) {       // 4 waves x 128 x 128 (gemm256_w4.inc), one block per tile
-        if (dtype == UAMD_BF16) return bnn ? launch256w4<bf16_t, true>(a, st) : launch256w4<bf16_t, false>(a, st);
-        if (dtype == UAMD_F16) return bnn ? launch256w4<f16_t, true>(a, st) : launch256w4<f16_t, false>(a, st);
-        return UAMD_ERR_DTYPE;
-    }
     const int n_cu = cu_count();
     const int persist = uamd_tuning_get(UAMD_TUNE_GEMM_PERSIST);
     if (persist && K >= 4 * TK && (n_cu & 7) == 0 && a.total_tiles > n_cu && (persist >= 2 || a.total_tiles >= 4 * n_cu)) {
