@@ -213,7 +213,7 @@ def main():
 
         def alt_point(tag, gc_mode, bs):
             data = None if bs == B else make_batches(bs)
-            adt, apeak, _, ags = measure(gc_mode, a.alt_steps, 2, data)     # 2 warm-up steps: allocator growth, decoded mirrors
+            adt, apeak, _, ags = measure(gc_mode, a.alt_steps, 3, data)     # 3 warm-up steps: allocator growth after empty_cache(), decoded mirrors
             dom_ = max(ags.values(), key=lambda r: r["total_ms"]) if ags else None
             alt[tag] = {"gradient_checkpointing": gc_mode, "batch": bs, "steps": a.alt_steps,
                         "value": round(bs * T * a.alt_steps * world / adt, 1),
