@@ -73,6 +73,21 @@ def main():
                 worst = max(worst, err)
         assert worst < 1e-5, f"rank {rank} step {step}: reduced gradient differs from the local replay: {worst}"
         arena.zero_grad()
+    # ---- the whole training step on top of the same arena: optim.FlatAdamW steps on the REDUCED gradients in one
+    #      launch and zeroes the arena in the same pass; every rank must end with identical parameters
+    from unsloth_amd.optim import FlatAdamW
+    from unsloth_amd.trainer import make_optimizer, training_step
+    opt = make_optimizer(model, lr=1e-3, arena=arena)
+    assert isinstance(opt, FlatAdamW) and opt.arena is arena
+    before = opt.flat_p.clone()
+    for step in range(2):
+        training_step(model, mine, opt, arena, n)
+        assert float(arena.arena.abs().max()) == 0.0, "the optimizer step leaves the gradient arena zeroed"
+    assert float((opt.flat_p - before).abs().max()) > 0.0
+    mx, mn = opt.flat_p.clone(), opt.flat_p.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    assert torch.equal(mx, mn), "replicas diverged after the optimizer step"
     one = torch.ones(1, device=dev)
     dist.all_reduce(one)
     assert int(one.item()) == world
