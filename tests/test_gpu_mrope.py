@@ -81,8 +81,10 @@ def test_mrope_with_equal_streams_is_ordinary_rope():
     assert torch.equal(q1, q2) and torch.equal(k1, k2)
 
 
-@pytest.mark.parametrize("hidden,heads,kv", [(512, 4, 2), (896, 7, 1)])      # 7:1 = Qwen2-VL-7B's 28:4 grouping (G = 7)
-def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, kv):
+@pytest.mark.parametrize("hidden,heads,kv,inter,vocab", [
+    (512, 4, 2, 1024, 1000), (896, 7, 1, 1024, 1000),       # 7:1 = Qwen2-VL-7B's 28:4 grouping (G = 7)
+    (3584, 28, 4, 18944, 152064)])                         # BASELINE config 4: the text tower at its real widths
+def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, kv, inter, vocab):
     """FastModel on a Qwen2-VL config = its language tower on the hand-kernel path: same weights in transformers'
     Qwen2VLTextModel (fp32, host) + lm_head give the same loss for [3, B, T] multimodal positions, and text-only [B, T]
     positions equal three identical streams."""
@@ -91,8 +93,8 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, 
     from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
     from unsloth_amd import FastModel
     from unsloth_amd.kernels.rms_layernorm import unpatch_rms_layernorm
-    vl = Qwen2VLConfig(text_config=dict(hidden_size=hidden, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=heads,
-                                        num_key_value_heads=kv, vocab_size=1000, max_position_embeddings=512, rms_norm_eps=1e-6,
+    vl = Qwen2VLConfig(text_config=dict(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=2 if hidden < 2048 else 1,
+                                        num_attention_heads=heads, num_key_value_heads=kv, vocab_size=vocab, max_position_embeddings=512, rms_norm_eps=1e-6,
                                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
                                         tie_word_embeddings=False),
                        vision_config=dict(depth=1, embed_dim=32, hidden_size=512, num_heads=2))
@@ -101,7 +103,7 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, 
     assert type(model).__name__ == "Qwen2ForCausalLM" and model._unsloth_amd_fast
     B, T = 2, 48
     gen = torch.Generator().manual_seed(5)
-    ids = torch.randint(0, 1000, (B, T), generator=gen)
+    ids = torch.randint(0, vocab, (B, T), generator=gen)
     pos3 = torch.stack([torch.arange(T).expand(B, T), torch.randint(0, 30, (B, T), generator=gen),
                         torch.randint(0, 30, (B, T), generator=gen)])                      # temporal / height / width
     labels = ids.clone()
@@ -126,6 +128,6 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, 
     with torch.no_grad():
         h = ref(input_ids=ids, position_ids=pos3).last_hidden_state
         logits = h @ model.lm_head.weight.float().cpu().t()
-        want = F.cross_entropy(logits[:, :-1].reshape(-1, 1000), labels[:, 1:].reshape(-1))
+        want = F.cross_entropy(logits[:, :-1].reshape(-1, vocab), labels[:, 1:].reshape(-1))
     assert abs(float(out.loss) - float(want)) < 2e-3 * abs(float(want)), (float(out.loss), float(want))
     assert float(out.loss) != float(out_t.loss)                       # the height / width streams reach the result
