@@ -93,6 +93,12 @@ class GemmTimer:
 
 
 def main():
+    # stdout must carry exactly ONE line, the JSON record. Libraries print to the C-level stdout behind Python's back
+    # (RCCL's version banner at the first collective, flushed at exit, i.e. AFTER the record): keep the real stdout
+    # aside for the record and send everything else written to fd 1 to stderr.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -322,7 +328,7 @@ def main():
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }
-        print(json.dumps(rec), flush=True)
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
