@@ -9,8 +9,8 @@ them, and `uamd_adamw_flat` (csrc/adamw.hip) walks them once -- zeroing the grad
 the `zero_grad` of the next step.
 
 Interface: a torch.optim.Optimizer (param_groups / state / state_dict / LR schedulers / step hooks work as usual) with
-one parameter group. `step(grad_scale=...)` takes the clipping factor; parameters that received no gradient are
-skipped exactly like torch does. No CPU fallback: the step raises without the HIP library.
+one parameter group. `step(grad_scale=...)` takes the clipping factor; parameters whose gradient is None are skipped
+like torch does (all parameters share one step counter: in LoRA training every factor gets a gradient every step). No CPU fallback: the step raises without the HIP library.
 """
 import math
 
@@ -36,6 +36,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=g.device)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=g.device)
         self._views = []                     # (param, offset, numel, grad view)
+        self._step_t = torch.zeros((), dtype=torch.float32)
         off = 0
         with torch.no_grad():
             for p in params:
@@ -44,7 +45,7 @@ class FlatAdamW(torch.optim.Optimizer):
                 assert gv.data_ptr() == g.data_ptr() + 4 * off, "arena order changed under the optimizer"
                 self.flat_p[off:off + k].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[off:off + k].view(p.shape)          # the parameter now LIVES in the flat buffer
-                self.state[p] = dict(step=torch.zeros((), dtype=torch.float32),
+                self.state[p] = dict(step=self._step_t,          # ONE shared host scalar: one increment per step, not 448
                                      exp_avg=self.flat_m[off:off + k].view(p.shape),
                                      exp_avg_sq=self.flat_v[off:off + k].view(p.shape))
                 self._views.append((p, off, k, gv))
@@ -105,9 +106,7 @@ class FlatAdamW(torch.optim.Optimizer):
                                        float(grp["eps"]), float(grp["weight_decay"]), bc1, bc2_sqrt, float(grad_scale), 1,
                                        _lib.stream_of(self.flat_p))
                 _lib.check(rc, "uamd_adamw_flat")
-        for p, _, _, _ in self._views:
-            if p.grad is not None:
-                self.state[p]["step"] += 1
+        self._step_t += 1                    # (shared by every parameter's state entry)
         # every range that had a gradient is zero again; ranges without one were never written
         self._writes_seen = self.arena.writes
         return loss
@@ -135,6 +134,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 st["exp_avg"] = self.flat_m[off:off + k].view(p.shape)
                 st["exp_avg_sq"] = self.flat_v[off:off + k].view(p.shape)
                 self._t = max(self._t, int(st["step"]))
+                st["step"] = self._step_t
+            self._step_t.fill_(float(self._t))
 
     def close(self):
         if self._owns_arena:
