@@ -132,6 +132,9 @@ def main():
     force_dp = os.environ.get("UNSLOTH_AMD_DP_FORCE", "0") == "1"     # 1-rank RCCL group: exercises the DP path on one GPU
     if world > 1 or force_dp:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one node over xGMI: RCCL's bootstrap needs no NIC; keep it off interface / InfiniBand probing
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         if force_dp and world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")

@@ -28,6 +28,9 @@ def _run(world, extra_env):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+        # one node, no fabric: keep RCCL's bootstrap off interface / InfiniBand probing (seen to take 100 s on one box)
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        env.setdefault("NCCL_IB_DISABLE", "1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py")], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
