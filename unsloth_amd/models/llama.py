@@ -16,7 +16,7 @@ The composition reads HF module ATTRIBUTES (q_proj, input_layernorm.weight, ...)
 own layer forwards on the training path, so it is insensitive to transformers' internal attention /
 cache / mask API (the installed 5.15 is above the reference's ceiling).
 Attention is the hand-written causal GQA flash kernel pair of csrc/attention.hip (kernels/attention.py; SURVEY 8(f1));
-torch SDPA only serves key-padding masks and head dims the kernels do not cover.
+torch SDPA only serves key-padding masks with holes, small plain-causal batches of small-head models and G > 8.
 """
 import math
 import os
