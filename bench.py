@@ -187,8 +187,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(gc_mode, steps, warmup, data=None):
-        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+    def measure(gc_mode, steps, warmup, data=None, per_step=False):
+        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks.
+        per_step (the short `alt` points only, never the primary): every step is bracketed on its own and the MEDIAN step
+        time x K is returned -- a 3-step point is otherwise at the mercy of one allocator stall after empty_cache()."""
         bt, ni = data if data is not None else (batches, n_items)
         model.for_training(use_gradient_checkpointing=gc_mode)
         losses = []
@@ -199,10 +201,19 @@ def main():
         timer.reset()
         timer.enabled = True
         t0 = time.perf_counter()
-        for i in range(steps):
-            losses.append(training_step(model, bt[i % 2], opt, arena, ni))
-        sync()
-        dt = time.perf_counter() - t0
+        if per_step:
+            times = []
+            for i in range(steps):
+                ts = time.perf_counter()
+                losses.append(training_step(model, bt[i % 2], opt, arena, ni))
+                sync()
+                times.append(time.perf_counter() - ts)
+            dt = sorted(times)[len(times) // 2] * steps
+        else:
+            for i in range(steps):
+                losses.append(training_step(model, bt[i % 2], opt, arena, ni))
+            sync()
+            dt = time.perf_counter() - t0
         timer.enabled = False
         peak = torch.cuda.max_memory_allocated()
         if world > 1:
@@ -222,9 +233,9 @@ def main():
 
         def alt_point(tag, gc_mode, bs):
             data = None if bs == B else make_batches(bs)
-            adt, apeak, _, ags = measure(gc_mode, a.alt_steps, 3, data)     # 3 warm-up steps: allocator growth after empty_cache(), decoded mirrors
+            adt, apeak, _, ags = measure(gc_mode, a.alt_steps, 3, data, per_step=True)     # 3 warm-up steps: allocator growth after empty_cache(), decoded mirrors
             dom_ = max(ags.values(), key=lambda r: r["total_ms"]) if ags else None
-            alt[tag] = {"gradient_checkpointing": gc_mode, "batch": bs, "steps": a.alt_steps,
+            alt[tag] = {"gradient_checkpointing": gc_mode, "batch": bs, "steps": a.alt_steps, "timing": "median step x steps",
                         "value": round(bs * T * a.alt_steps * world / adt, 1),
                         "ms_per_step": round(adt / a.alt_steps * 1e3, 2), "peak_vram_gb": round(apeak / 2**30, 2),
                         "gemm_tflops": round(dom_["tflops"], 1) if dom_ else None,
