@@ -201,6 +201,10 @@ typedef struct {
     int64_t ld_xk, ld_bk;
     int Rk;
     int _pad2;
+    /* bias of the base layer (activation dtype, [N_g]) added in the epilogue before the single rounding, or NULL.
+     * Qwen2-style q/k/v projections carry one; the reference falls back to the un-fused PEFT path for them
+     * (unsloth/models/llama.py:3695-3772). Pass it on the forward launch only (never with accumulate != 0 chains). */
+    const void* bias;
 } uamd_gemm_group;
 
 int uamd_gemm_nt(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,

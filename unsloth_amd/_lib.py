@@ -31,7 +31,7 @@ class GemmGroup(ctypes.Structure):
         ("lora_b", c_void_p), ("ldb", c_int64), ("ldc", c_int64), ("ld_xa", c_int64),
         ("ld_lb", c_int64), ("N", c_int), ("R", c_int), ("lora_scale", c_float), ("_pad", c_int),
         ("lora_xk", c_void_p), ("lora_bk", c_void_p), ("ld_xk", c_int64), ("ld_bk", c_int64), ("Rk", c_int),
-        ("_pad2", c_int),
+        ("_pad2", c_int), ("bias", c_void_p),
     ]
 
 

@@ -122,6 +122,45 @@ __device__ __forceinline__ void load_w(const WT* __restrict__ w, float* out) {
     }
 }
 
+
+// GEMM epilogue shared by the MFMA kernels (gemm.hip, gemm256.hip): a lane holds C[m][n .. n+3] in fp32; `bias` (the
+// base layer's bias, activation dtype, NULL = none) is added BEFORE the single rounding to the activation dtype and
+// `accumulate` adds the existing C (dX += ...).
+template <typename T>
+__device__ __forceinline__ void store_c4(T* dst, float v0, float v1, float v2, float v3, int n, int N, bool vec_ok,
+                                         int accumulate, const T* bias) {
+    float v[4] = {v0, v1, v2, v3};
+    if (n + 3 < N && vec_ok) {
+        union { uint2 raw; T e[4]; } o;
+        if (bias) {
+            union { uint2 raw; T e[4]; } bv;
+            if ((reinterpret_cast<uintptr_t>(bias + n) & 7) == 0) {
+                bv.raw = *reinterpret_cast<const uint2*>(bias + n);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bv.e[r] = bias[n + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32(bv.e[r]);
+        }
+        if (accumulate) {
+            o.raw = *reinterpret_cast<const uint2*>(dst);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
+        *reinterpret_cast<uint2*>(dst) = o.raw;
+    } else {
+        for (int r = 0; r < 4 && n + r < N; ++r) {
+            float x = v[r];
+            if (bias) x += to_f32(bias[n + r]);
+            if (accumulate) x += to_f32(dst[r]);
+            dst[r] = from_f32<T>(x);
+        }
+    }
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static inline int uamd_launch_status() {

@@ -402,25 +402,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l4 * 4;
             if (n >= N) continue;
-            T* dst = Cg + (int64_t)m * g.ldc + n;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (n + 3 < N && vec_ok) {
-                union { uint2 raw; T e[4]; } o;
-                if (p.accumulate) {
-                    o.raw = *reinterpret_cast<const uint2*>(dst);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
-                *reinterpret_cast<uint2*>(dst) = o.raw;
-            } else {
-                for (int r = 0; r < 4 && n + r < N; ++r) {
-                    float x = v[r];
-                    if (p.accumulate) x += to_f32(dst[r]);
-                    dst[r] = from_f32<T>(x);
-                }
-            }
+            store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
+                        p.accumulate, (const T*)g.bias);
         }
     }
 }
@@ -643,25 +626,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + j * 16 + l4 * 4;
                 if (n >= N) continue;
-                T* dst = Cg + (int64_t)m * g.ldc + n;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (n + 3 < N && vec_ok) {
-                    union { uint2 raw; T e[4]; } o;
-                    if (p.accumulate) {
-                        o.raw = *reinterpret_cast<const uint2*>(dst);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
-                    *reinterpret_cast<uint2*>(dst) = o.raw;
-                } else {
-                    for (int r = 0; r < 4 && n + r < N; ++r) {
-                        float x = v[r];
-                        if (p.accumulate) x += to_f32(dst[r]);
-                        dst[r] = from_f32<T>(x);
-                    }
-                }
+                store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
+                            p.accumulate, (const T*)g.bias);
             }
         }
     };
@@ -965,25 +931,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l4 * 4;
             if (n >= N) continue;
-            T* dst = Cg + (int64_t)m * g.ldc + n;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (n + 3 < N && vec_ok) {
-                union { uint2 raw; T e[4]; } o;
-                if (p.accumulate) {
-                    o.raw = *reinterpret_cast<const uint2*>(dst);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
-                *reinterpret_cast<uint2*>(dst) = o.raw;
-            } else {
-                for (int r = 0; r < 4 && n + r < N; ++r) {
-                    float x = v[r];
-                    if (p.accumulate) x += to_f32(dst[r]);
-                    dst[r] = from_f32<T>(x);
-                }
-            }
+            store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
+                        p.accumulate, (const T*)g.bias);
         }
     }
 }

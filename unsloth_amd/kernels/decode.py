@@ -30,9 +30,14 @@ def _nf4_fields(qs):
 def lora_a_rows(A_list, dtype):
     """[sum R_i, K] activation-dtype copy of the LoRA A factors that share an input, cached on the first Parameter
     (the reference caches `lora_A._fast_lora = lora_A.to(dtype)`, utils.py:1104-1106; weights are frozen at inference)."""
+    from .utils import _CAST_EPOCH
     key = A_list[0]
     ent = getattr(key, "_uamd_fast_lora_rows", None)
-    vers = tuple(a._version for a in A_list)
+    # validity = the rule kernels/utils._cached_cast uses: _version alone is not enough -- the fused optimizers
+    # (optim.FlatAdamW's raw HIP kernel, torch's fused AdamW) update parameters WITHOUT bumping it, so the global
+    # optimizer-step / model-forward epoch and the storage address are part of the key (generate -> train -> generate
+    # must not multiply the trained B by the pre-training A)
+    vers = (_CAST_EPOCH[0],) + tuple((a._version, a.data_ptr()) for a in A_list)
     if ent is None or ent[0] != vers or ent[1].dtype != dtype or len(ent[2]) != len(A_list):
         rows = torch.cat([a.detach().to(dtype) for a in A_list], dim=0).contiguous()
         ent = (vers, rows, [a.shape[0] for a in A_list])

@@ -132,7 +132,8 @@ def mlp_backward(dY, X, e, g, xas, gate, up, down, act_bwd, inplace=True):
 
 
 def qkv_forward(X, q, k, v):
-    """Returns (Q, K, V, (xa_q, xa_k, xa_v)); fast_lora.py:393-405."""
+    """Returns (Q, K, V, (xa_q, xa_k, xa_v)); fast_lora.py:393-405. Each projection is (W, W_quant, A, B, s) or, with the
+    base layer's bias, (W, W_quant, A, B, s, bias): the bias is added in the GEMM epilogue (Qwen2's q/k/v)."""
     (Q, K, V), xa = lora_linear_forward(X, [q, k, v], return_xa=True)
     return Q, K, V, tuple(xa)
 
@@ -229,13 +230,25 @@ def apply_lora_mlp_geglu_approx(self, X):
     return _apply_mlp(self, X, geglu_approx_forward_kernel, geglu_approx_backward_kernel)
 
 
+def _bias_grad(dY, bias, needed):
+    """d bias = column sums of dY (only when the bias itself trains: full fine-tuning / bias="all")."""
+    if bias is None or not needed:
+        return None
+    return dY.reshape(-1, dY.shape[-1]).sum(dim=0, dtype=torch.float32).to(bias.dtype)
+
+
 class LoRA_QKV(torch.autograd.Function):
+    """The reference's signature (fast_lora.py:335-540) plus three optional trailing arguments: the base layers' biases.
+    The reference refuses biased projections on this path (llama.py:3695-3772: Qwen2 falls back to PEFT's forward);
+    here the bias rides in the GEMM epilogue and, being an additive constant, drops out of dX and of every LoRA gradient."""
+
     @staticmethod
     @_custom_fwd
     def forward(ctx, X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB, VS,
-                inplace=True):
-        Q, K, V, xa = qkv_forward(X, (QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS))
-        ctx.custom_saved_tensors = (QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS)
+                inplace=True, Qb=None, Kb=None, Vb=None):
+        Q, K, V, xa = qkv_forward(X, (QW, QW_quant, QA, QB, QS, Qb), (KW, KW_quant, KA, KB, KS, Kb),
+                                  (VW, VW_quant, VA, VB, VS, Vb))
+        ctx.custom_saved_tensors = (QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS, Qb, Kb, Vb)
         ctx.save_for_backward(X, QA, QB, KA, KB, VA, VB)
         ctx.xa = xa
         ctx.inplace = inplace
@@ -244,29 +257,35 @@ class LoRA_QKV(torch.autograd.Function):
     @staticmethod
     @_custom_bwd
     def backward(ctx, dQ, dK, dV):
-        QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS = ctx.custom_saved_tensors
+        QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS, Qb, Kb, Vb = ctx.custom_saved_tensors
         X, QA, QB, KA, KB, VA, VB = ctx.saved_tensors
+        nig = ctx.needs_input_grad
+        d_bias = (_bias_grad(dQ, Qb, nig[17]), _bias_grad(dK, Kb, nig[18]), _bias_grad(dV, Vb, nig[19]))
         dX, (d_QA, d_QB, d_KA, d_KB, d_VA, d_VB) = qkv_backward(
             dQ, dK, dV, X, ctx.xa, (QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS),
             ctx.inplace)
         return (dX, None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None,
-                d_VA, d_VB, None, None)
+                d_VA, d_VB, None, None, *d_bias)
 
 
 def apply_lora_qkv(self, X, inplace=True):
     QW, QW_quant, QA, QB, QS = get_lora_parameters(self.q_proj)
     KW, KW_quant, KA, KB, KS = get_lora_parameters(self.k_proj)
     VW, VW_quant, VA, VB, VS = get_lora_parameters(self.v_proj)
+    biases = tuple(getattr(getattr(p, "base_layer", p), "bias", None) for p in (self.q_proj, self.k_proj, self.v_proj))
+    if all(b is None for b in biases):
+        return LoRA_QKV.apply(X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB,
+                              VS, inplace)
     return LoRA_QKV.apply(X, QW, QW_quant, QA, QB, QS, KW, KW_quant, KA, KB, KS, VW, VW_quant, VA, VB,
-                          VS, inplace)
+                          VS, inplace, *biases)
 
 
 class LoRA_W(torch.autograd.Function):
     @staticmethod
     @_custom_fwd
-    def forward(ctx, X, W, W_quant, A, B, S):
-        XW, xa = w_forward(X, (W, W_quant, A, B, S))
-        ctx.custom_saved_tensors = (W, W_quant, S)
+    def forward(ctx, X, W, W_quant, A, B, S, bias=None):
+        XW, xa = w_forward(X, (W, W_quant, A, B, S, bias))
+        ctx.custom_saved_tensors = (W, W_quant, S, bias)
         ctx.save_for_backward(A, B, X)
         ctx.xa = xa
         return XW
@@ -274,15 +293,19 @@ class LoRA_W(torch.autograd.Function):
     @staticmethod
     @_custom_bwd
     def backward(ctx, dY):
-        W, W_quant, S = ctx.custom_saved_tensors
+        W, W_quant, S, bias = ctx.custom_saved_tensors
         A, B, X = ctx.saved_tensors
+        d_bias = _bias_grad(dY, bias, ctx.needs_input_grad[6])
         dX, (d_A, d_B) = w_backward(dY, X, ctx.xa, (W, W_quant, A, B, S))
-        return dX, None, None, d_A, d_B, None
+        return dX, None, None, d_A, d_B, None, d_bias
 
 
 def apply_lora_o(self, X):
     OW, OW_quant, OA, OB, OS = get_lora_parameters(self.o_proj)
-    return LoRA_W.apply(X, OW, OW_quant, OA, OB, OS)
+    bias = getattr(getattr(self.o_proj, "base_layer", self.o_proj), "bias", None)
+    if bias is None:
+        return LoRA_W.apply(X, OW, OW_quant, OA, OB, OS)
+    return LoRA_W.apply(X, OW, OW_quant, OA, OB, OS, bias)
 
 
 @torch._disable_dynamo

@@ -114,7 +114,7 @@ def fast_dequantize(W, quant_state=None, out=None, use_global_buffer=False):
 
 # ------------------------------------------------------------------------------------------------
 # GEMM plumbing
-def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0, xk=None, bk=None):
+def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0, xk=None, bk=None, bias=None):
     # (for uamd_gemm_nn_256 `B` is [K, N] and `bk` is [Rk, N]; the struct is the same)
     """One uamd_gemm_group. The LoRA term comes either as (xa fp32, lb, scale) -- the register prologue of the
     128x128 kernels -- or as the rank block (xk, bk) the 256x256 kernel contracts as extra K tiles; `xa` and `R` are
@@ -126,7 +126,7 @@ def _group(B, C, N, ldb, absmax=None, xa=None, ld_xa=0, lb=None, R=0, scale=0.0,
         N=N, R=R, lora_scale=float(scale), _pad=0,
         lora_xk=xk.data_ptr() if xk is not None else None, lora_bk=bk.data_ptr() if bk is not None else None,
         ld_xk=xk.stride(0) if xk is not None else 0, ld_bk=bk.stride(0) if bk is not None else 0,
-        Rk=xk.shape[1] if xk is not None else 0, _pad2=0)
+        Rk=xk.shape[1] if xk is not None else 0, _pad2=0, bias=bias.data_ptr() if bias is not None else None)
 
 
 def _use_gemm256(M, K, Ns):
@@ -469,6 +469,10 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
     X2d = _rows2d(X)
     M, K = X2d.shape
     lead = X.shape[:-1]
+    # a projection may carry the base layer's bias as a 6th element (get_lora_parameters_bias order): it is added in the
+    # GEMM epilogue, in fp32, before the single rounding (Qwen2's q/k/v; the reference leaves such layers un-fused)
+    biases = [(p[5] if len(p) > 5 else None) for p in projs]
+    projs = [tuple(p[:5]) for p in projs]
     with_lora = [p for p in projs if p[2] is not None]
     Ns = [(q.shape[0] if q is not None else W.shape[0]) for (W, q, _, _, _) in projs]
     fused_nf4 = [q is not None and FUSED_NF4 and M < FUSED_NF4_MAX_M and q.blocksize == 64 and K % 64 == 0
@@ -491,17 +495,24 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
         N = Ns[gi]
         C = outs[gi] if outs is not None else torch.empty((M, N), dtype=dtype, device=X.device)
         kw = {}
+        if biases[gi] is not None:
+            bias = biases[gi].detach()
+            if bias.dtype != dtype or not bias.is_contiguous():
+                bias = bias.to(dtype).contiguous()
+            assert bias.numel() == N
+            keep.append(bias)
+            kw["bias"] = bias
         if A is not None:
             o, rp = offs[li]
             li += 1
             if xk is not None and not fused_nf4[gi]:
                 bk = rank_block_bk([(B, o, s)], N, xk.shape[1], False, dtype)
                 keep.append(bk)
-                kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), R=rp, scale=s, xk=xk, bk=bk)
+                kw.update(xa=xa[:, o:], ld_xa=xa.stride(0), R=rp, scale=s, xk=xk, bk=bk)
             else:
                 lb = _pad_rank(B, rp, dtype)
                 keep.append(lb)
-                kw = dict(xa=xa[:, o:], ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
+                kw.update(xa=xa[:, o:], ld_xa=xa.stride(0), lb=lb, R=rp, scale=s)
         if fused_nf4[gi]:
             nf4_groups.append(_group(W, C, N, 0, absmax=_nf4.absmax_f32(W_quant), **kw))
         else:
@@ -545,6 +556,7 @@ def lora_dx_terms(dYs, projs):
     [M, 64k] rank block (attached to the returned tensor as `_uamd_xk = (xk, col_off)`): the XK operand of that
     GEMM's extra K tiles."""
     terms = []
+    projs = [tuple(p[:5]) for p in projs]              # (a 6th element, the bias, plays no part in any gradient but its own)
     ranks = [None if A is None else A.shape[0] for (_, _, A, _, _) in projs]
     dY2 = [_rows2d(dY) for dY in dYs]
     M = dY2[0].shape[0]
@@ -685,6 +697,7 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
     scratch (one launch) and fed to the same NT GEMM. `out` (e.g. the saved X, reference's
     inplace=True) receives the result. `terms` = lora_dx_terms(dYs, projs) when the caller already has them."""
     dtype = dYs[0].dtype
+    projs = [tuple(p[:5]) for p in projs]
     if terms is None:
         terms = lora_dx_terms(dYs, projs)
     merged = _lora_linear_dx_merged(dYs, projs, out, terms) if MERGE_DX else None

@@ -88,6 +88,12 @@ class DecodeEngine:
         from . import llama as _ll
         B, T = input_ids.shape
         assert B == self.B and T <= self.S
+        # parameters were updated since the token step was captured (an optimizer stepped, a training forward ran): the
+        # graph holds pointers to activation-dtype copies of the LoRA factors that are stale now -- capture again
+        from ..kernels.utils import _CAST_EPOCH
+        if getattr(self, "_epoch", None) != _CAST_EPOCH[0]:
+            self._graph = None
+            self._epoch = _CAST_EPOCH[0]
         core = self.core
         h = core.embed_tokens(input_ids.to(self.dev)).to(self.dtype)
         cos, sin = self.cos, self.sin
@@ -195,12 +201,15 @@ class DecodeEngine:
 
     @torch.no_grad()
     def generate(self, input_ids, max_new_tokens=32, eos_token_id=None, do_sample=False, temperature=1.0, top_k=0,
-                 generator=None):
-        """Greedy (default) or temperature / top-k sampling. Returns [B, T + new] token ids."""
+                 generator=None, pad_token_id=None):
+        """Greedy (default) or temperature / top-k sampling. Returns [B, T + new] token ids. Rows that have produced an
+        end-of-sequence token keep emitting `pad_token_id` (default: the first eos id), like HF's generate."""
         input_ids = input_ids.to(self.dev)
         logits = self.prefill(input_ids)
         out = [input_ids]
-        eos = None if eos_token_id is None else set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id])
+        eos = None if eos_token_id is None else sorted(set(eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]))
+        eos_t = None if eos is None else torch.tensor(eos, device=self.dev)
+        pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
         done = torch.zeros(self.B, dtype=torch.bool, device=self.dev)
         room = self.S - input_ids.shape[1]
         for i in range(min(max_new_tokens, room)):
@@ -212,9 +221,11 @@ class DecodeEngine:
                 nxt = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).view(-1)
             else:
                 nxt = torch.argmax(logits, dim=-1)
+            if eos_t is not None:
+                nxt = torch.where(done, torch.full_like(nxt, pad), nxt)      # finished rows: padding from here on
             out.append(nxt.view(self.B, 1))
-            if eos is not None:
-                done |= torch.isin(nxt, torch.tensor(sorted(eos), device=self.dev))
+            if eos_t is not None:
+                done |= torch.isin(nxt, eos_t)
                 if bool(done.all()):
                     break
             if i + 1 < min(max_new_tokens, room):
@@ -226,17 +237,56 @@ def _eps(norm):
     return float(getattr(norm, "variance_epsilon", getattr(norm, "eps", 1e-6)))
 
 
-def unsloth_fast_generate(model, input_ids=None, max_new_tokens=32, max_seq_len=None, **kwargs):
-    """llama.py:2167-2259 counterpart: `model.generate(...)` after `FastLanguageModel.for_inference(model)`."""
+# generate() arguments the decode engine implements itself; anything else a caller passes changes what HF's generate would
+# return, so such calls go to the original `generate` (kept as `model._old_generate` by for_inference) instead of being
+# silently ignored
+_ENGINE_KWARGS = {"max_new_tokens", "max_length", "eos_token_id", "pad_token_id", "do_sample", "temperature", "top_k",
+                  "attention_mask", "use_cache", "generator", "max_seq_len", "return_dict_in_generate", "output_scores",
+                  "generation_config", "tokenizer"}
+
+
+def unsloth_fast_generate(model, input_ids=None, max_new_tokens=None, max_seq_len=None, **kwargs):
+    """llama.py:2167-2259 counterpart: `model.generate(...)` after `FastLanguageModel.for_inference(model)`.
+    The reference forwards every keyword to HF's generate; the engine covers greedy / temperature / top-k decoding of
+    unpadded batches. Calls outside that (top_p, repetition_penalty, beams, streamers, logits processors, a padded
+    attention_mask, ...) are handed to HF's own generate (`model._old_generate`) -- or raise when it is unavailable."""
     input_ids = kwargs.pop("inputs", input_ids)
+    attention_mask = kwargs.get("attention_mask", None)
+    padded = attention_mask is not None and not bool(torch.all(attention_mask != 0))
+    neutral = {"top_p": (None, 1.0), "repetition_penalty": (None, 1.0), "num_beams": (None, 1), "streamer": (None,),
+               "num_return_sequences": (None, 1), "min_new_tokens": (None, 0), "return_dict_in_generate": (None, False),
+               "output_scores": (None, False), "generation_config": (None,)}
+    unsupported = [k for k, v in kwargs.items()
+                   if (k not in _ENGINE_KWARGS and not (k in neutral and v in neutral[k]))
+                   or (k in ("return_dict_in_generate", "output_scores", "generation_config") and v)]
+    if padded or unsupported:
+        old = getattr(model, "_old_generate", None)
+        if old is None:
+            raise NotImplementedError(f"unsloth_fast_generate: unsupported arguments {unsupported or ['padded attention_mask']}")
+        return old(input_ids, max_new_tokens=max_new_tokens, **kwargs) if max_new_tokens is not None else old(input_ids, **kwargs)
+    gen_cfg = getattr(model, "generation_config", None)
+    if gen_cfg is None:
+        gen_cfg = getattr(_base(model), "generation_config", None)
+    if max_new_tokens is None:
+        max_length = kwargs.get("max_length", None)
+        if max_length is not None:
+            max_new_tokens = max(int(max_length) - input_ids.shape[1], 0)
+        else:
+            max_new_tokens = getattr(gen_cfg, "max_new_tokens", None) or 32
+    eos = kwargs.get("eos_token_id", None)
+    if eos is None and gen_cfg is not None:
+        eos = getattr(gen_cfg, "eos_token_id", None)
+    pad = kwargs.get("pad_token_id", None)
+    if pad is None and gen_cfg is not None:
+        pad = getattr(gen_cfg, "pad_token_id", None)
     need = input_ids.shape[1] + max_new_tokens
     eng = getattr(model, "_uamd_decode_engine", None)
     if eng is None or eng.B != input_ids.shape[0] or eng.S < need:
         eng = DecodeEngine(model, max_seq_len=max(need, max_seq_len or 0), batch=input_ids.shape[0])
         model._uamd_decode_engine = eng
-    return eng.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=kwargs.get("eos_token_id"),
+    return eng.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=eos,
                         do_sample=kwargs.get("do_sample", False), temperature=kwargs.get("temperature", 1.0),
-                        top_k=kwargs.get("top_k", 0))
+                        top_k=kwargs.get("top_k", 0) or 0, generator=kwargs.get("generator", None), pad_token_id=pad)
 
 
 # ---- the reference's function names, for code written against unsloth/models/llama.py ----------------------------------------

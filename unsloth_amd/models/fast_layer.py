@@ -34,7 +34,7 @@ from ..kernels.fast_lora import (
 )
 from ..kernels.rms_layernorm import add_rms_fwd, rms_bwd_, rms_fwd
 from ..kernels.utils import lora_linear_forward
-from ..kernels.rope_embedding import _launch_qk, _tables
+from ..kernels.rope_embedding import Fast_MRoPE_Embedding_QK, _launch_qk, _tables
 from ..kernels.swiglu import swiglu_DWf_DW_dfg_kernel, swiglu_fg_kernel
 
 POLICIES = {"min": frozenset(), "attn": frozenset({"qkv", "h1"}), "all": frozenset({"x1", "qkv", "h1", "x2", "eg"})}
@@ -87,6 +87,10 @@ def layer_supported(layer, hidden, attention_mask):
         return False
     if getattr(getattr(mlp, "forward", None), "__func__", None) is not apply_lora_mlp_swiglu:
         return False
+    for m in [getattr(attn, n) for n in _PROJ[:4]] + [getattr(mlp, n) for n in _PROJ[4:]]:
+        b = getattr(getattr(m, "base_layer", m), "bias", None)
+        if b is not None and (b.requires_grad or m in (mlp.gate_proj, mlp.up_proj, mlp.down_proj)):
+            return False
     cfg = getattr(attn, "config", None)
     groups = (cfg.num_attention_heads // cfg.num_key_value_heads) if cfg is not None else 1
     # (group sizes 3 / 5 / 6 / 7 run zero-padded inside kernels/attention.attn_forward / attn_backward)
@@ -99,8 +103,23 @@ def _eps(norm):
 
 class _Static:
     """Non-tensor context of one layer call (weights, norm parameters, rope tables, band, shapes)."""
-    __slots__ = ("projs", "w1", "w2", "eps1", "eps2", "cos", "sin", "idx", "band", "n_heads", "n_kv", "head_dim",
+    __slots__ = ("projs", "biases", "w1", "w2", "eps1", "eps2", "cos", "sin", "idx", "band", "n_heads", "n_kv", "head_dim",
                  "scale", "keep", "shape")
+
+
+def _rope(st, q4, k4, backward):
+    """RoPE in place on the [B, T, H, D] projection outputs: per-token indices (or none), or -- `st.idx` a
+    (positions3 int32 [3, B*T], (s_t, s_h, s_w)) pair -- the multimodal variant of the Qwen2-VL text tower."""
+    q, k = q4.transpose(1, 2), k4.transpose(1, 2)
+    if isinstance(st.idx, tuple):
+        pos3, sec = st.idx
+        Fast_MRoPE_Embedding_QK._run(q, k, st.cos, st.sin, pos3, int(sec[0]), int(sec[1]), backward)
+    else:
+        _launch_qk(q, k, st.cos, st.sin, st.idx, backward)
+
+
+def _with_bias(projs, biases, idx):
+    return [projs[i] + (biases[i],) for i in idx]
 
 
 class DecoderLayerFunction(torch.autograd.Function):
@@ -122,15 +141,15 @@ class DecoderLayerFunction(torch.autograd.Function):
             x1, r1 = rms_fwd(h0, st.w1, st.eps1)
         else:
             h0, x1, r1 = add_rms_fwd(delta, residual, st.w1, st.eps1)
-        Q, K, V, xa_qkv = qkv_forward(x1, projs[0], projs[1], projs[2])
+        Q, K, V, xa_qkv = qkv_forward(x1, *_with_bias(projs, st.biases, (0, 1, 2)))
         B_, T_ = shape[0], shape[1]
         q4 = Q.view(B_, T_, st.n_heads, st.head_dim)
         k4 = K.view(B_, T_, st.n_kv, st.head_dim)
         v4 = V.view(B_, T_, st.n_kv, st.head_dim)
-        _launch_qk(q4.transpose(1, 2), k4.transpose(1, 2), st.cos, st.sin, st.idx, False)       # RoPE in place
+        _rope(st, q4, k4, False)                                                                 # RoPE in place
         O, lse = _flash.attn_forward(q4, k4, v4, st.scale, st.band)
         attn = O.view(-1, st.n_heads * st.head_dim)
-        o, xa_o = w_forward(attn, projs[3])
+        o, xa_o = w_forward(attn, projs[3] + (st.biases[3],))
         h1, x2, r2 = add_rms_fwd(o, h0, st.w2, st.eps2)
         del o
         # ---- MLP block
@@ -182,14 +201,14 @@ class DecoderLayerFunction(torch.autograd.Function):
             if x1 is None:
                 x1, _ = rms_fwd(h0, st.w1, st.eps1)
             if "qkv" not in keep:
-                Q, K, V = lora_linear_forward(x1, [projs[0], projs[1], projs[2]])
+                Q, K, V = lora_linear_forward(x1, _with_bias(projs, st.biases, (0, 1, 2)))
                 q4 = Q.view(B_, T_, nh, hd)
                 k4 = K.view(B_, T_, nkv, hd)
-                _launch_qk(q4.transpose(1, 2), k4.transpose(1, 2), st.cos, st.sin, st.idx, False)
+                _rope(st, q4, k4, False)
                 O, lse = _flash.attn_forward(q4, k4, V.view(B_, T_, nkv, hd), st.scale, st.band)
             attn = O.view(-1, nh * hd)
             if h1 is None:
-                o, _ = w_forward(attn, projs[3])
+                o, _ = w_forward(attn, projs[3] + (st.biases[3],))
                 h1, x2, _ = add_rms_fwd(o, h0, st.w2, st.eps2)
                 del o
             elif x2 is None:
@@ -212,7 +231,7 @@ class DecoderLayerFunction(torch.autograd.Function):
             dq, dk, dv = _flash.attn_backward(d_attn.view(B_, T_, nh, hd), Q.view(B_, T_, nh, hd),
                                               K.view(B_, T_, nkv, hd), V.view(B_, T_, nkv, hd),
                                               O.view(B_, T_, nh, hd), lse, st.scale, st.band)
-            _launch_qk(dq.transpose(1, 2), dk.transpose(1, 2), st.cos, st.sin, st.idx, True)
+            _rope(st, dq, dk, True)
             dx1, g_qkv = qkv_backward(dq.reshape(-1, nh * hd), dk.reshape(-1, nkv * hd), dv.reshape(-1, nkv * hd), x1,
                                       (xa_q, xa_k, xa_v), projs[0], projs[1], projs[2], True)
             # ---- norm1 backward + the residual path: d h0 = rms'(dx1) + d h1
@@ -231,10 +250,17 @@ def decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids, b
     st = _Static()
     mods = [getattr(attn, n) for n in _PROJ[:4]] + [getattr(layer.mlp, n) for n in _PROJ[4:]]
     st.projs = [get_lora_parameters(m) for m in mods]
+    # frozen biases of the attention projections (Qwen2: q/k/v) ride in the GEMM epilogue; a TRAINABLE bias needs its
+    # own gradient and keeps the per-block Functions (layer_supported)
+    st.biases = [getattr(getattr(m, "base_layer", m), "bias", None) for m in mods]
     st.w1, st.w2 = layer.input_layernorm.weight, layer.post_attention_layernorm.weight
     st.eps1, st.eps2 = _eps(layer.input_layernorm), _eps(layer.post_attention_layernorm)
     st.cos, st.sin = _tables(cos, sin)
-    st.idx = rope_position_ids
+    if isinstance(rope_position_ids, tuple):          # (positions3 [3, B, T], mrope_section)
+        st.idx = (rope_position_ids[0].reshape(3, -1).contiguous(), tuple(rope_position_ids[1]))
+        assert sum(st.idx[1]) == attn.head_dim // 2, "mrope_section must cover head_dim / 2 rotary pairs"
+    else:
+        st.idx = rope_position_ids
     st.band = band
     st.n_heads, st.n_kv, st.head_dim = cfg.num_attention_heads, cfg.num_key_value_heads, attn.head_dim
     st.scale = None

@@ -297,7 +297,7 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
     gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
     policy = getattr(self, "_unsloth_amd_layer_policy", None)
     if mrope is not None:
-        rope_position_ids, policy = mrope, None          # (positions3, section): only the per-block composition below
+        rope_position_ids = mrope                        # (positions3, section): every composition below takes the pair
     if policy is not None and self.training and torch.is_grad_enabled() \
             and all(_fast_layer.layer_supported(l, hidden_states, attention_mask) for l in self.layers):
         # use_gradient_checkpointing="unsloth": every layer is ONE manual-autograd Function that keeps what the
@@ -624,11 +624,15 @@ class FastLlamaModel:
         FastLlamaModel.for_training(model, use_gradient_checkpointing)
         n_mlp = n_qkv = n_o = 0
 
-        def ok(proj):
+        def ok(proj, bias_ok=False):
+            # the reference's preconditions (:3695-3772) -- except that a FROZEN bias on an attention projection
+            # (Qwen2's q/k/v) stays on the fused path here: it rides in the GEMM epilogue (uamd_gemm_group.bias)
             if not isinstance(proj, _lora.LoraLayer):
                 return False
             ad = proj.active_adapters[0]
-            return (isinstance(proj.lora_dropout[ad], torch.nn.Identity) and proj.base_layer.bias is None
+            bias = proj.base_layer.bias
+            return (isinstance(proj.lora_dropout[ad], torch.nn.Identity)
+                    and (bias is None or (bias_ok and not bias.requires_grad))
                     and not proj.use_dora[ad] and len(proj.lora_magnitude_vector) == 0)
 
         for layer in inner.layers:
@@ -636,10 +640,10 @@ class FastLlamaModel:
             if all(hasattr(mlp, n) and ok(getattr(mlp, n)) for n in ("gate_proj", "up_proj", "down_proj")):
                 mlp.forward = MethodType(apply_lora_mlp_swiglu, mlp)                # :3725
                 n_mlp += 1
-            if all(ok(getattr(attn, n)) for n in ("q_proj", "k_proj", "v_proj")):
+            if all(ok(getattr(attn, n), True) for n in ("q_proj", "k_proj", "v_proj")):
                 attn.apply_qkv = apply_lora_qkv                                     # :3748
                 n_qkv += 1
-            if ok(attn.o_proj):
+            if ok(attn.o_proj, True):
                 attn.apply_o = apply_lora_o                                         # :3766
                 n_o += 1
         base._unsloth_amd_patched = (n_qkv, n_o, n_mlp)

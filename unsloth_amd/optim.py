@@ -26,6 +26,14 @@ class FlatAdamW(torch.optim.Optimizer):
         (single rank: no collective is ever issued)."""
         if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("invalid AdamW hyper-parameters")
+        if arena is None:
+            # two live arenas over the same parameters would both hook gradient accumulation and fight over p.grad and
+            # the fused-gradient sinks (the second one's copies racing the first one's collectives): refuse
+            from .kernels.utils import grad_sink
+            for p in model.parameters():
+                if p.requires_grad and grad_sink(p) is not None:
+                    raise RuntimeError("FlatAdamW: these parameters already belong to a live dp.LoRAGradArena; pass it "
+                                       "as `arena=` (trainer.make_optimizer(model, arena=arena))")
         self.arena = arena if arena is not None else LoRAGradArena(model)
         self._owns_arena = arena is None
         params = list(self.arena.params)
@@ -125,16 +133,30 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        # torch replaced the state tensors by copies: move them back into the flat buffers and re-attach the views
+        # torch replaced the state tensors by copies: move them back into the flat buffers and re-attach the views.
+        # The step counter becomes the LOADED one (loading an earlier checkpoint into an optimizer that has already
+        # stepped must restart the bias correction there); a parameter the checkpoint has no state for (saved before the
+        # first step) starts from zero moments. All parameters share one step counter -- a parameter that received no
+        # gradient on some steps is bias-corrected with the run's step count, not its own (torch counts per parameter;
+        # in LoRA training every factor gets a gradient every step, so the two agree).
+        loaded_t = None
         with torch.no_grad():
             for p, off, k, _ in self._views:
-                st = self.state[p]
-                self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
-                self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                st = self.state.get(p, None)
+                if not st or "exp_avg" not in st:
+                    self.flat_m[off:off + k].zero_()
+                    self.flat_v[off:off + k].zero_()
+                    st = self.state[p] = {}
+                else:
+                    self.flat_m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    self.flat_v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    if "step" in st:
+                        t = int(st["step"])
+                        loaded_t = t if loaded_t is None else max(loaded_t, t)
                 st["exp_avg"] = self.flat_m[off:off + k].view(p.shape)
                 st["exp_avg_sq"] = self.flat_v[off:off + k].view(p.shape)
-                self._t = max(self._t, int(st["step"]))
                 st["step"] = self._step_t
+            self._t = 0 if loaded_t is None else loaded_t
             self._step_t.fill_(float(self._t))
 
     def close(self):

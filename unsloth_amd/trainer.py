@@ -155,10 +155,12 @@ def unsloth_train(model, batches, optimizer=None, arena=None, max_steps=None, lo
     """trainer.py:49-57 counterpart for pre-tokenised batches (dicts with input_ids/labels[/position_ids/
     packed_seq_lengths] already on the model's device). Returns the list of per-step losses."""
     model.train()
-    if optimizer is None:
-        optimizer = make_optimizer(model)
+    if arena is None and optimizer is not None and getattr(optimizer, "arena", None) is not None:
+        arena = optimizer.arena                    # FlatAdamW built over (or with) an arena: that one exchanges the gradients
     if arena is None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        arena = LoRAGradArena(model)
+        arena = LoRAGradArena(model)               # BEFORE the optimizer: FlatAdamW adopts it instead of creating a second one
+    if optimizer is None:
+        optimizer = make_optimizer(model, arena=arena)
     losses, t0 = [], time.time()
     for step, batch in enumerate(batches):
         if max_steps is not None and step >= max_steps:
@@ -167,3 +169,9 @@ def unsloth_train(model, batches, optimizer=None, arena=None, max_steps=None, lo
         if log_every and (step + 1) % log_every == 0:
             print(f"step {step + 1}: loss {float(losses[-1]):.4f}  ({time.time() - t0:.1f}s)", flush=True)
     return [float(l) for l in losses]
+
+
+# trainer.py:988-1021 runs this at import time: scripts written for TRL < 0.13 (tokenizer=, config-only keyword arguments)
+# work as soon as `unsloth_amd.trainer` is imported. No-op without TRL.
+if HAS_TRL:
+    _patch_trl_trainer()
