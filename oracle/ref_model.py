@@ -57,24 +57,52 @@ NAMES = (("self_attn", "q_proj"), ("self_attn", "k_proj"), ("self_attn", "v_proj
          ("mlp", "gate_proj"), ("mlp", "up_proj"), ("mlp", "down_proj"))
 
 
-def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids=None, n_items=None):
-    """Returns (loss fp32, {param_name: grad}) computed by a stock HF model on the CPU."""
+def _vl_text_config(cfg):
+    """transformers' Qwen2VLTextConfig with the dimensions / rope parameters of the product's Qwen2 tower config."""
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLTextConfig
+    d = cfg.to_dict()
+    keep = ("vocab_size", "hidden_size", "intermediate_size", "num_hidden_layers", "num_attention_heads",
+            "num_key_value_heads", "hidden_act", "max_position_embeddings", "rms_norm_eps", "tie_word_embeddings")
+    kw = {k: d[k] for k in keep if k in d}
+    return Qwen2VLTextConfig(**kw, rope_parameters=dict(d.get("rope_parameters") or {}))
+
+
+def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids=None, n_items=None, device="cpu",
+                                     return_model=False, loss_fn=None):
+    """Returns (loss fp32, {param_name: grad}) computed by a stock HF model in fp32 -- on the CPU by default; `device`
+    = "cuda" runs the same stock-HF fp32 composition on the GPU (torch's own fp32 GEMMs and eager attention: still no
+    kernel of the product) so that the BASELINE configurations can be checked at their stated sizes in seconds.
+    position_ids [3, B, T] (multimodal RoPE): the backbone is transformers' Qwen2VLTextModel + an lm_head matmul.
+    Biases of the base projections (Qwen2's q/k/v) are copied. `loss_fn(logits fp32 [B, T, V]) -> scalar` replaces the
+    causal-LM cross entropy (per-token log-prob objectives of the GRPO / DPO path)."""
     from transformers import AutoModelForCausalLM
     base = fast_model.get_base_model() if hasattr(fast_model, "get_base_model") else fast_model
     cfg = copy.deepcopy(base.config)
     cfg.dtype = torch.float32
     cfg._attn_implementation = "eager"
+    mrope = position_ids is not None and position_ids.dim() == 3
+    dev = torch.device(device)
     with _stock_hf_classes():
-        ref = AutoModelForCausalLM.from_config(cfg).to(torch.float32)
-    # the product patches LlamaForCausalLM.forward at class level: make sure THIS instance runs stock HF
-    ref._unsloth_amd_fast = False
+        if mrope:
+            from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextModel
+            tcfg = _vl_text_config(cfg)
+            tcfg._attn_implementation = "eager"
+            backbone = Qwen2VLTextModel(tcfg).to(torch.float32)
+            ref = None
+        else:
+            ref = AutoModelForCausalLM.from_config(cfg).to(torch.float32)
+            backbone = ref.model
+            # the product patches LlamaForCausalLM.forward at class level: make sure THIS instance runs stock HF
+            ref._unsloth_amd_fast = False
+    lm_head_w = base.lm_head.weight.detach().float().cpu()
     with torch.no_grad():
-        ref.model.embed_tokens.weight.copy_(base.model.embed_tokens.weight.detach().float().cpu())
-        ref.lm_head.weight.copy_(base.lm_head.weight.detach().float().cpu())
-        ref.model.norm.weight.copy_(base.model.norm.weight.detach().float().cpu())
+        backbone.embed_tokens.weight.copy_(base.model.embed_tokens.weight.detach().float().cpu())
+        backbone.norm.weight.copy_(base.model.norm.weight.detach().float().cpu())
+        if ref is not None:
+            ref.lm_head.weight.copy_(lm_head_w)
     lora = {}
     eff = {}
-    for li, (layer, rlayer) in enumerate(zip(base.model.layers, ref.model.layers)):
+    for li, (layer, rlayer) in enumerate(zip(base.model.layers, backbone.layers)):
         with torch.no_grad():
             rlayer.input_layernorm.weight.copy_(layer.input_layernorm.weight.detach().float().cpu())
             rlayer.post_attention_layernorm.weight.copy_(layer.post_attention_layernorm.weight.detach().float().cpu())
@@ -83,20 +111,39 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
             W, A, B, s = _base_and_lora(proj)
             target = getattr(getattr(rlayer, parent), name)
             Weff = (W + s * B @ A) if A is not None else W
+            bias = getattr(getattr(proj, "base_layer", proj), "bias", None)
             with torch.no_grad():
                 target.weight.copy_(Weff)
-            target.weight.requires_grad_(A is not None)
+                if bias is not None:
+                    target.bias.copy_(bias.detach().float().cpu())
+                else:
+                    assert target.bias is None
             if A is not None:
                 lora[(li, parent, name)] = (A, B, s)
                 eff[(li, parent, name)] = target.weight
-    ids = input_ids.cpu()
-    lab = labels.cpu()
-    out = ref(input_ids=ids, position_ids=None if position_ids is None else position_ids.cpu().long(), use_cache=False)
-    logits = out.logits.float()
-    shift = R.shift_labels(lab)
-    V = logits.shape[-1]
-    n = torch.count_nonzero(shift != -100) if n_items is None else n_items
-    loss = torch.nn.functional.cross_entropy(logits.view(-1, V), shift.view(-1), ignore_index=-100, reduction="sum") / n
+    for p in backbone.parameters():
+        p.requires_grad_(False)
+    (ref if ref is not None else backbone).to(dev)
+    for k in eff:
+        eff[k].requires_grad_(True)
+    ids = input_ids.to(dev)
+    lab = labels.to(dev)
+    pos = None if position_ids is None else position_ids.to(dev).long()
+    if mrope:
+        h = backbone(input_ids=ids, position_ids=pos, use_cache=False).last_hidden_state
+        logits = h.float() @ lm_head_w.to(dev).t()
+    else:
+        for p in ref.lm_head.parameters():
+            p.requires_grad_(False)
+        logits = ref(input_ids=ids, position_ids=pos, use_cache=False).logits.float()
+    if loss_fn is not None:
+        loss = loss_fn(logits)
+    else:
+        shift = R.shift_labels(lab)
+        V = logits.shape[-1]
+        n = torch.count_nonzero(shift != -100) if n_items is None else n_items
+        loss = torch.nn.functional.cross_entropy(logits.view(-1, V), shift.view(-1), ignore_index=-100,
+                                                 reduction="sum") / n
     grads = {}
     if eff:
         keys = list(eff)
@@ -104,6 +151,9 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
         for k, dW in zip(keys, dWs):
             A, B, s = lora[k]
             li, parent, name = k
+            dW = dW.float().cpu()
             grads[f"layers.{li}.{parent}.{name}.lora_A"] = s * B.t() @ dW
             grads[f"layers.{li}.{parent}.{name}.lora_B"] = s * dW @ A.t()
-    return loss.detach(), grads
+    if return_model:
+        return loss.detach().cpu(), grads, (ref if ref is not None else backbone)
+    return loss.detach().cpu(), grads

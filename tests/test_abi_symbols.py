@@ -106,3 +106,19 @@ def test_flat_adamw_has_no_cpu_fallback():
     m.weight.grad.add_(1.0)
     with pytest.raises(Exception):
         opt.step()
+
+
+def test_no_cxx_mangled_or_undeclared_exports():
+    """The dynamic symbol table of the C-ABI library holds C names only: every defined `uamd_*` / `cdequantize_*` export
+    is declared in include/unsloth_amd.h, and nothing C++-mangled leaks out (`_Z15uamd_tuning_geti`)."""
+    import re
+    import subprocess
+    from unsloth_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "unsloth_amd.h")).read()
+    declared = set(re.findall(r"\b((?:uamd|cdequantize)_\w+)\s*\(", header))
+    mangled = [n for n in names if n.startswith("_Z")]
+    assert not mangled, mangled
+    stray = [n for n in names if (n.startswith("uamd_") or n.startswith("cdequantize_")) and n not in declared]
+    assert not stray, f"exported but not declared in the header: {stray}"

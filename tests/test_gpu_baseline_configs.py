@@ -42,7 +42,7 @@ def _check(model, T, vocab, n_layers, loss_tol=1e-3):
     assert set(got) == set(ref)
     worst = max(rel_fro(got[k], ref[k]) for k in got)
     total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]), torch.cat([ref[k].flatten() for k in sorted(got)]))
-    assert worst < 8e-2 and total < 3e-2, (worst, total)
+    assert worst < 2.5e-2 and total < 1.5e-2, (worst, total)
 
 
 def test_config1_tinyllama_widths_lora_r8_seq512():

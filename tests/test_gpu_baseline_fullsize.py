@@ -1,0 +1,238 @@
+"""-m gpu: the BASELINE.json configurations as parity cases AT THEIR STATED SIZES: real widths, the
+stated sequence length, the stated quantisation / rank, >= 2 decoder layers, every gradient-checkpointing mode -- the whole
+drop-in surface (from_pretrained -> get_peft_model -> forward / backward) on the HIP path against the
+implementation-independent oracle: stock HuggingFace modules in fp32 over oracle-dequantised NF4 weights + merged LoRA
+(oracle/ref_model.py; run on the GPU in fp32 here so that 8B-wide layers at 2048-4096 tokens take seconds -- torch's own
+fp32 GEMMs and eager attention, no kernel of the product).
+
+  config 2  Llama-3-8B widths, QLoRA NF4 r=16, seq 2048, batch 1 and 4, use_gradient_checkpointing False / "unsloth" / True
+  config 4  Qwen2-VL-7B language tower (3584 / 18944 / 28:4 heads / vocab 152064, q/k/v BIAS), NF4 + LoRA r=32, seq 4096,
+            [3, B, T] multimodal positions, against transformers' Qwen2VLTextModel; modes False and "unsloth"
+  config 5  Mistral-7B widths, NF4 + LoRA r=16, seq 4096 (sliding window 4096: inactive, mistral.py:116-120), the causal-LM
+            loss AND the chunked per-token log-prob leg of the GRPO / DPO runs on lm_head [32000, 4096]
+  (config 1 -- TinyLlama, seq 512 -- is already at its stated size in tests/test_gpu_baseline_configs.py; config 3 -- full
+   fine-tuning -- in tests/test_gpu_full_finetune.py)
+
+Bounds: loss within 1e-3 (north star); every LoRA gradient within 2.5e-2 relative Frobenius, all of them together within
+1.5e-2 (2x what this suite measures: profiles/r03_fullsize_parity.json).
+"""
+import json
+import os
+
+import pytest
+import torch
+
+from tests._util import rel_fro
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+REPORT = {}
+LOSS_TOL, WORST_TOL, TOTAL_TOL = 1e-3, 2.5e-2, 1.5e-2
+
+
+def _report(name, **kw):
+    REPORT[name] = kw
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "fullsize_parity.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _build(cfg, r, max_seq, fast_model=False):
+    from unsloth_amd import FastLanguageModel, FastModel
+    cls = FastModel if fast_model else FastLanguageModel
+    model, _ = cls.from_pretrained(config=cfg, max_seq_length=max_seq, load_in_4bit=True, device=DEV, random_state=3407,
+                                   use_gradient_checkpointing=False)
+    model = FastLanguageModel.get_peft_model(model, r=r, lora_alpha=r, use_gradient_checkpointing=False, random_state=3407)
+    g = torch.Generator().manual_seed(3407)
+    for n, p in model.named_parameters():
+        if "lora_B" in n:                      # PEFT's default B = 0 would zero half of the gradients
+            p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(DEV))
+    return model
+
+
+def _grads(model):
+    return {"layers." + n.split(".layers.", 1)[1].replace(".default.weight", ""): p.grad.detach().float().cpu()
+            for n, p in model.named_parameters() if p.requires_grad}
+
+
+def _zero(model):
+    for p in model.parameters():
+        p.grad = None
+
+
+def _compare(name, loss, got, ref_loss, ref):
+    dl = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
+    assert set(got) == set(ref)
+    worst = max(rel_fro(got[k], ref[k]) for k in got)
+    total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]), torch.cat([ref[k].flatten() for k in sorted(got)]))
+    _report(name, loss=float(loss), oracle_loss=float(ref_loss), loss_rel_err=dl, worst_grad_rel_fro=worst,
+            total_grad_rel_fro=total)
+    assert dl <= LOSS_TOL, (name, float(loss), float(ref_loss))
+    assert worst < WORST_TOL and total < TOTAL_TOL, (name, worst, total)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def llama3_8b_two_layers():
+    from transformers import LlamaConfig
+    cfg = LlamaConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=8, head_dim=128, vocab_size=128256, rms_norm_eps=1e-5, max_position_embeddings=8192,
+                      rope_parameters={"rope_type": "llama3", "rope_theta": 5e5, "factor": 8.0, "low_freq_factor": 1.0,
+                                       "high_freq_factor": 4.0, "original_max_position_embeddings": 8192},
+                      tie_word_embeddings=False)
+    model = _build(cfg, r=16, max_seq=2048)
+    yield model
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_config2_llama3_8b_qlora_r16_seq2048_every_checkpointing_mode(llama3_8b_two_layers, batch):
+    from oracle.ref_model import hf_reference_loss_and_lora_grads
+    from unsloth_amd import FastLanguageModel
+    model = llama3_8b_two_layers
+    assert model.get_base_model()._unsloth_amd_patched == (2, 2, 2), "fused hooks not installed on every layer"
+    T = 2048
+    g = torch.Generator().manual_seed(batch)
+    ids = torch.randint(0, 128256, (batch, T), generator=g)
+    labels = ids.clone()
+    labels[0, :11] = -100
+    pos = torch.arange(T, dtype=torch.int32).unsqueeze(0).expand(batch, T).contiguous()
+    ref_loss, ref = hf_reference_loss_and_lora_grads(model, ids, labels, pos, device="cuda")
+    torch.cuda.empty_cache()
+    seen = {}
+    for mode in (False, "unsloth", True):
+        FastLanguageModel.for_training(model, use_gradient_checkpointing=mode)
+        _zero(model)
+        out = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+        out.loss.backward()
+        got = _grads(model)
+        _compare(f"config2_b{batch}_gc_{mode}", out.loss, got, ref_loss, ref)
+        seen[mode] = (float(out.loss), got)
+    # the three modes run the same kernels on the same inputs: selective recompute is BITWISE the no-checkpoint result
+    assert seen[False][0] == seen["unsloth"][0]
+    assert all(torch.equal(seen[False][1][k], seen["unsloth"][1][k]) for k in seen[False][1])
+    _zero(model)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_config5_mistral_7b_lora_r16_seq4096_loss_and_logprob_leg():
+    from transformers import MistralConfig
+    from oracle.ref_model import hf_reference_loss_and_lora_grads
+    from unsloth_amd.models.rl_replacements import chunked_hidden_states_selective_log_softmax
+    cfg = MistralConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=2, num_attention_heads=32,
+                        num_key_value_heads=8, head_dim=128, vocab_size=32000, rms_norm_eps=1e-5, max_position_embeddings=32768,
+                        sliding_window=4096, rope_parameters={"rope_type": "default", "rope_theta": 1e4},
+                        tie_word_embeddings=False)
+    model = _build(cfg, r=16, max_seq=4096)
+    assert model.get_base_model()._unsloth_amd_patched == (2, 2, 2)
+    T, V = 4096, 32000
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, V, (1, T), generator=g)
+    pos = torch.arange(T, dtype=torch.int32).unsqueeze(0)
+    # --- leg 1: causal-LM loss (the fused linear-CE path), window inactive at seq 4096
+    out = model(input_ids=ids.to(DEV), labels=ids.to(DEV), position_ids=pos.to(DEV))
+    out.loss.backward()
+    ref_loss, ref = hf_reference_loss_and_lora_grads(model, ids, ids.clone(), pos, device="cuda")
+    _compare("config5_ce", out.loss, _grads(model), ref_loss, ref)
+    _zero(model)
+    torch.cuda.empty_cache()
+    # --- leg 2: per-token log-probs of the next token, chunked over lm_head [32000, 4096] (GRPO / DPO), with a
+    #     completion mask and per-token weights standing in for advantages; forward values AND LoRA gradients
+    mask = torch.zeros(1, T - 1)
+    mask[0, T // 2:] = 1.0                                   # "completion" = second half
+    wts = torch.randn(1, T - 1, generator=g) * mask
+    nxt = ids[:, 1:]
+    box = {}
+
+    def objective(logits):                                    # fp32 oracle: log_softmax(logits)[next token]
+        lp = torch.log_softmax(logits[:, :-1].float(), dim=-1).gather(-1, nxt.to(logits.device).unsqueeze(-1)).squeeze(-1)
+        box["lp"] = lp.detach().cpu()
+        return -(lp * wts.to(lp.device)).sum() / mask.sum()
+
+    ref_obj, ref2 = hf_reference_loss_and_lora_grads(model, ids, ids.clone(), pos, device="cuda", loss_fn=objective)
+    os.environ["UNSLOTH_RETURN_HIDDEN_STATES"] = "1"
+    try:
+        hidden = model(input_ids=ids.to(DEV), position_ids=pos.to(DEV)).logits        # hidden states in the logits slot
+    finally:
+        os.environ["UNSLOTH_RETURN_HIDDEN_STATES"] = "0"
+    assert hidden.shape == (1, T, 4096)
+    lm_head = model.get_base_model().lm_head.weight
+    lp = chunked_hidden_states_selective_log_softmax(hidden[:, :-1], lm_head, nxt.to(DEV), chunks=4)
+    err = (lp.detach().cpu() - box["lp"]).abs().max().item()
+    scale = box["lp"].abs().max().item() + 1.0
+    obj = -(lp * wts.to(DEV)).sum() / mask.sum().to(DEV)
+    obj.backward()
+    got = _grads(model)
+    worst = max(rel_fro(got[k], ref2[k]) for k in got)
+    total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]), torch.cat([ref2[k].flatten() for k in sorted(got)]))
+    _report("config5_logprobs", max_abs_err=err, scale=scale, objective=float(obj), oracle_objective=float(ref_obj),
+            worst_grad_rel_fro=worst, total_grad_rel_fro=total)
+    assert err <= 2e-3 * scale, (err, scale)
+    assert abs(float(obj) - float(ref_obj)) <= 2e-3 * max(1.0, abs(float(ref_obj)))
+    assert worst < 2 * WORST_TOL and total < 2 * TOTAL_TOL, (worst, total)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_config4_qwen2_vl_7b_tower_nf4_lora_r32_seq4096_mrope():
+    from transformers import Qwen2VLConfig
+    from oracle.ref_model import hf_reference_loss_and_lora_grads
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.kernels import attention as flash
+    from unsloth_amd.models import fast_layer
+    vocab = 152064
+    vl = Qwen2VLConfig(text_config=dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=2, num_attention_heads=28,
+                                        num_key_value_heads=4, vocab_size=vocab, max_position_embeddings=32768, rms_norm_eps=1e-6,
+                                        rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+                                        tie_word_embeddings=False),
+                       vision_config=dict(depth=1, embed_dim=32, hidden_size=3584, num_heads=2))
+    model = _build(vl, r=32, max_seq=4096, fast_model=True)
+    base = model.get_base_model()
+    assert type(base).__name__ == "Qwen2ForCausalLM"
+    assert base.model.layers[0].self_attn.q_proj.base_layer.bias is not None            # Qwen2: q/k/v carry a bias ...
+    g = torch.Generator().manual_seed(4)
+    for layer in base.model.layers:                                                     # ... (random-init gives zeros)
+        for n in ("q_proj", "k_proj", "v_proj"):
+            b = getattr(layer.self_attn, n).base_layer.bias
+            b.data.copy_((torch.randn(b.shape, generator=g) * 0.1).to(b.device, b.dtype))
+    assert base._unsloth_amd_patched == (2, 2, 2), "biased q/k/v must stay on the grouped fused path"
+    B, T = 1, 4096
+    ids = torch.randint(0, vocab, (B, T), generator=g)
+    # an image-like block in the middle: the temporal stream stalls while height / width run over a 32 x 32 grid
+    t = torch.arange(T)
+    img0, side = 1024, 32
+    in_img = (t >= img0) & (t < img0 + side * side)
+    k = (t - img0).clamp(min=0)
+    pos_t = torch.where(in_img, torch.full_like(t, img0), torch.where(t < img0, t, t - side * side + side))
+    pos_h = torch.where(in_img, img0 + k // side, pos_t)
+    pos_w = torch.where(in_img, img0 + k % side, pos_t)
+    pos3 = torch.stack([pos_t, pos_h, pos_w]).unsqueeze(1).contiguous()                 # [3, B, T]
+    labels = ids.clone()
+    labels[0, img0:img0 + side * side] = -100                                           # no loss on image tokens
+    ref_loss, ref = hf_reference_loss_and_lora_grads(model, ids, labels, pos3, device="cuda")
+    torch.cuda.empty_cache()
+    calls = {"attn": [], "layer_fn": 0}
+    real_native, real_layer = flash._forward_native, fast_layer.decoder_layer_forward
+    flash._forward_native = lambda q, k_, v, s, band: (calls["attn"].append(q.shape[2] // k_.shape[2]), real_native(q, k_, v, s, band))[1]
+
+    def counted(*a, **kw):
+        calls["layer_fn"] += 1
+        return real_layer(*a, **kw)
+    import unsloth_amd.models.llama as L
+    L._fast_layer.decoder_layer_forward = counted
+    try:
+        for mode in (False, "unsloth"):
+            FastLanguageModel.for_training(model, use_gradient_checkpointing=mode)
+            _zero(model)
+            out = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos3.to(DEV))
+            out.loss.backward()
+            _compare(f"config4_gc_{mode}", out.loss, _grads(model), ref_loss, ref)
+    finally:
+        flash._forward_native = real_native
+        L._fast_layer.decoder_layer_forward = real_layer
+    assert calls["attn"] and all(g_ == 8 for g_ in calls["attn"])        # 7 query heads per KV head: padded onto the G = 8 kernels
+    assert calls["layer_fn"] == 2, "multimodal positions must go through the whole-layer Function under 'unsloth'"

@@ -3,6 +3,7 @@ LoRA and bias against the exact fp32 product (and never further from it than the
 naive 4-bit GEMV the reference calls), RoPE + cache append against the training RoPE kernel, split-KV attention against
 an fp32 softmax over the cache, and the engine's logits against the training-path forward of the same model."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -239,3 +240,79 @@ def test_for_inference_generate_and_back_to_training():
     loss = model(input_ids=ids, labels=lab).loss
     loss.backward()
     assert torch.isfinite(loss)
+
+
+def test_generate_train_generate_uses_the_trained_factors():
+    """the decode path caches activation-dtype copies of the LoRA A factors; FlatAdamW updates the
+    parameters with a raw HIP kernel that never bumps Parameter._version. generate -> a few optimizer steps -> generate
+    must decode with the TRAINED factors: the engine's logits equal the training-path forward of the updated model, both
+    with a fresh engine and with the engine (and its captured hipGraph) that was alive during training."""
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.models.decode import DecodeEngine
+    from unsloth_amd.trainer import make_optimizer, training_step
+    model = _tiny(True)
+    ids = torch.randint(0, 1000, (1, 17), generator=g(21)).to(DEV)
+    FastLanguageModel.for_inference(model)
+    before = model.generate(input_ids=ids, max_new_tokens=4)
+    eng_live = DecodeEngine(model, max_seq_len=128)                      # stays alive across the training steps
+    lg0 = eng_live.prefill(ids).clone()
+    eng_live.step(torch.argmax(lg0, dim=-1))                             # captures the graph
+    FastLanguageModel.for_training(model, use_gradient_checkpointing=False)
+    opt = make_optimizer(model, lr=5e-2)                                 # FlatAdamW: large steps so the logits move
+    assert type(opt).__name__ == "FlatAdamW"
+    tr = torch.randint(0, 1000, (2, 48), generator=g(22)).to(DEV)
+    for _ in range(3):
+        training_step(model, dict(input_ids=tr, labels=tr.clone()), opt)
+    os.environ["UNSLOTH_RETURN_LOGITS"] = "1"
+    try:
+        model.eval()
+        with torch.no_grad():
+            full = model(input_ids=ids).logits[:, -1].float()
+    finally:
+        os.environ.pop("UNSLOTH_RETURN_LOGITS")
+    scale = full.abs().max().item()
+    assert (full - lg0.float()).abs().max().item() > 0.1 * scale, "training did not move the logits: test is vacuous"
+    for eng in (DecodeEngine(model, max_seq_len=128), eng_live):
+        lg = eng.prefill(ids).float()
+        assert (lg - full).abs().max().item() < 4e-2 * scale
+        nxt = torch.argmax(lg, dim=-1)
+        step_lg = eng.step(nxt).float().clone()
+        with torch.no_grad():
+            os.environ["UNSLOTH_RETURN_LOGITS"] = "1"
+            try:
+                full2 = model(input_ids=torch.cat([ids, nxt.view(1, 1)], dim=1)).logits[:, -1].float()
+            finally:
+                os.environ.pop("UNSLOTH_RETURN_LOGITS")
+        assert (step_lg - full2).abs().max().item() < 4e-2 * full2.abs().max().item(), "decode step used stale LoRA factors"
+    FastLanguageModel.for_inference(model)
+    after = model.generate(input_ids=ids, max_new_tokens=4)
+    assert after.shape == before.shape
+
+
+def test_fast_generate_kwargs_follow_hf_semantics():
+    """eos / pad default from generation_config, finished rows emit the pad id, max_length is
+    honoured, and arguments the engine does not implement (top_p, a padded attention_mask, ...) go to HF's generate
+    instead of being dropped."""
+    from unsloth_amd import FastLanguageModel
+    model = _tiny(True)
+    FastLanguageModel.for_inference(model)
+    ids = torch.randint(0, 1000, (2, 9), generator=g(23)).to(DEV)
+    free = model.generate(input_ids=ids, max_new_tokens=6)
+    eos = int(free[0, 9])                                   # row 0 stops after its first token
+    base = model.get_base_model()
+    base.generation_config.eos_token_id = eos
+    base.generation_config.pad_token_id = 7
+    model.generation_config = base.generation_config
+    out = model.generate(input_ids=ids, max_new_tokens=6)
+    assert out[0, 9] == eos and bool((out[0, 10:] == 7).all()), out[0]
+    assert model.generate(input_ids=ids, max_length=12).shape[1] <= 12
+    calls = []
+    model._old_generate = lambda *a, **k: (calls.append(k), free)[1]
+    model.generate(input_ids=ids, max_new_tokens=3, top_p=0.9)
+    assert calls and calls[-1].get("top_p") == 0.9
+    mask = torch.ones_like(ids)
+    mask[1, :3] = 0
+    model.generate(input_ids=ids, max_new_tokens=3, attention_mask=mask)
+    assert len(calls) == 2 and calls[-1].get("attention_mask") is mask
+    model.generate(input_ids=ids, max_new_tokens=3, attention_mask=torch.ones_like(ids), top_p=1.0)
+    assert len(calls) == 2                                   # neutral values stay on the engine

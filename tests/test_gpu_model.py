@@ -69,10 +69,10 @@ def test_loss_and_lora_grads_match_hf_oracle(load_in_4bit, head_dim):
     got = _grads(model)
     assert set(got) == set(ref_grads)
     worst = max(rel_fro(got[k], ref_grads[k]) for k in got)
-    assert worst < 8e-2, worst
+    assert worst < 2.5e-2, worst                 # measured 1.2e-2 (bf16 end to end); 2x
     total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]),
                     torch.cat([ref_grads[k].flatten() for k in sorted(got)]))
-    assert total < 3e-2, total
+    assert total < 1.5e-2, total
 
 
 def test_gradient_checkpointing_is_bitwise_neutral_and_run_to_run_deterministic():
@@ -222,11 +222,11 @@ def test_return_logits_branch_and_n_items():
         os.environ.pop("UNSLOTH_RETURN_LOGITS")
     assert out.logits.shape == (2, 96, 1000)
     ref_loss, _ = hf_reference_loss_and_lora_grads(model, ids, labels, pos)
-    assert abs(float(out.loss) - float(ref_loss)) <= 1e-2 * abs(float(ref_loss))
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
     # num_items_in_batch only rescales (global token count under DP)
     out2 = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV), num_items_in_batch=1000)
     n = int((labels[:, 1:] != -100).sum())
-    assert abs(float(out2.loss) * 1000 / n - float(ref_loss)) <= 1e-2 * abs(float(ref_loss))
+    assert abs(float(out2.loss) * 1000 / n - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
 
 
 @pytest.mark.parametrize("head_dim", [32, 128])
@@ -259,7 +259,7 @@ def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypa
         n_tot += n
         ref = {k: v * n for k, v in grads.items()} if ref is None else {k: ref[k] + grads[k] * n for k in ref}
     want = tot / n_tot
-    assert abs(float(out.loss) - want) <= 1e-2 * abs(want), (float(out.loss), want)
+    assert abs(float(out.loss) - want) <= 1e-3 * abs(want), (float(out.loss), want)
     total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]),
                     torch.cat([(ref[k] / n_tot).flatten() for k in sorted(got)]))
     assert total < 4e-2, total
@@ -418,7 +418,7 @@ def test_bnb4bit_checkpoint_round_trip_and_merge(tmp_path):
     finally:
         patch_rms_layernorm()
     ref_loss = torch.nn.functional.cross_entropy(logits[0, :-1], labels[0, 1:], ignore_index=-100)
-    assert abs(float(ref_loss) - loss0) <= 1e-2 * abs(loss0), (float(ref_loss), loss0)
+    assert abs(float(ref_loss) - loss0) <= 2e-3 * abs(loss0), (float(ref_loss), loss0)   # (the merged weights are rounded to bf16 once more)
 
 
 def test_grad_arena_direct_accumulation_matches_autograd():

@@ -482,3 +482,36 @@ def test_lora_tn_matches_fp64(dtype, M, N, R):
     outs2 = lora_tn(probs)
     for a, b in zip(outs, outs2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,K,Ns,nf4", [(300, 512, (512, 128, 128), False), (4096, 3584, (3584, 512, 512), True),
+                                        (64, 256, (264,), True), (2048, 1024, (1024,), False)])
+def test_grouped_gemm_epilogue_bias(M, K, Ns, nf4):
+    """uamd_gemm_group.bias: Y_g = X W_g^T + b_g (+ LoRA), the bias added in fp32 before the single rounding -- every
+    kernel family (128 x 128 register-staged, fused NF4, 256 x 256 / 128 x 256 LDS-DMA, persistent walk) shares the
+    epilogue. Qwen2's q/k/v shape (3584 -> 3584 | 512 | 512) included."""
+    from unsloth_amd.kernels.utils import lora_linear_forward
+    from unsloth_amd.nf4 import quantize_nf4
+    X = (torch.randn(M, K, generator=g(31)) * 0.5).to(torch.bfloat16).to(DEV)
+    projs, want = [], []
+    for i, N in enumerate(Ns):
+        W = (torch.randn(N, K, generator=g(32 + i)) * 0.05).to(torch.bfloat16)
+        b = (torch.randn(N, generator=g(40 + i)) * 2.0).to(torch.bfloat16)
+        A = (torch.randn(16, K, generator=g(50 + i)) * 0.05)
+        B = (torch.randn(N, 16, generator=g(60 + i)) * 0.05)
+        if nf4:
+            packed, qs = quantize_nf4(W.to(DEV), compress_statistics=True)
+            Wd = R.nf4_dequantize_state(packed, qs).float()
+            projs.append((packed, qs, A.to(DEV), B.to(DEV), 2.0, b.to(DEV)))
+        else:
+            Wd = W.float()
+            projs.append((W.to(DEV), None, A.to(DEV), B.to(DEV), 2.0, b.to(DEV)))
+        xa = (X.float().cpu() @ A.to(torch.bfloat16).float().t()).to(torch.bfloat16).float()       # utils.py:1166 rounding point
+        want.append(X.float().cpu() @ Wd.t() + b.float() + 2.0 * xa @ B.to(torch.bfloat16).float().t())
+    outs = lora_linear_forward(X, projs)
+    plain = lora_linear_forward(X, [p[:5] for p in projs])
+    for o, p_, w, pr in zip(outs, plain, want, projs):
+        assert rel_fro(o, w) < 4e-3, rel_fro(o, w)
+        # against the bias-free launch: exactly the bias, up to the one rounding
+        d = (o.float() - p_.float()).cpu() - pr[5].float().cpu()
+        assert d.abs().max().item() <= 2.0 ** -7 * (w.abs().max().item())

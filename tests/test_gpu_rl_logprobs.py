@@ -1,6 +1,7 @@
 """-m gpu: chunked per-token log-probs (GRPO/DPO path) against the plain fp32 formula
 log_softmax(f(h @ W^T))[index] on the CPU. unsloth_zoo's implementation is not in the repository (parity unpinned);
-tolerance: the logits chunk is rounded to bf16 by the GEMM, so |err| <= ~2^-8 * |logit| on the log-prob."""
+tolerance: 2e-3 of the log-prob scale (the logits chunk is rounded to bf16 by the GEMM -- the reference's own rounding
+point: zoo computes the chunk under bf16 autocast -- so |err| ~ 2^-9 |logit|)."""
 import pytest
 import torch
 
@@ -44,11 +45,11 @@ def test_hidden_states_logprobs_forward_backward(B, L, H, V, kw):
     got = f(hd, W.to(DEV), idx.to(DEV), **kw)
     assert got.shape == (B, L) and got.dtype == torch.float32
     scale = want.detach().abs().max().item() + 1.0
-    assert (got.detach().cpu() - want.detach()).abs().max().item() <= 2e-2 * scale
+    assert (got.detach().cpu() - want.detach()).abs().max().item() <= 2e-3 * scale
     (got * up.to(DEV)).sum().backward()
     gref = hr.grad
     err = (hd.grad.float().cpu() - gref).norm() / gref.norm()
-    assert err <= 3e-2, float(err)
+    assert err <= 1.5e-2, float(err)
 
 
 def test_logits_logprobs_match_formula():

@@ -6,7 +6,7 @@
 
 #include "unsloth_amd.h"   // C ABI: error codes, dtype codes, entry-point prototypes
 
-int uamd_tuning_get(int knob);   // abi.hip
+__attribute__((visibility("hidden"))) int uamd_tuning_get(int knob);   // abi.hip; library-internal (not part of the C ABI)
 
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;

@@ -33,7 +33,10 @@ def _layer_index(name):
 class LoRAGradArena:
     def __init__(self, model, process_group=None, bucket_bytes=None, overlap=True, direct=True):
         if bucket_bytes is None:
-            bucket_bytes = int(float(os.environ.get("UNSLOTH_AMD_DP_BUCKET_MB", "64")) * (1 << 20))
+            # 16 MB = 3 decoder layers of Llama-3-8B r=16 factors (5.24 MB per layer): 11 buckets, so that the LAST one --
+            # layers 2..0, the only exchange nothing can overlap -- is 16 MB, not the 64+ MB of a 3-bucket split; still
+            # far above the size where an xGMI ring is latency-bound (per-layer buckets)
+            bucket_bytes = int(float(os.environ.get("UNSLOTH_AMD_DP_BUCKET_MB", "16")) * (1 << 20))
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("no trainable parameters")
@@ -73,6 +76,10 @@ class LoRAGradArena:
         self._sync = True
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         self._views = {id(p): p.grad for p in self.params}
+        import weakref as _weakref
+        me_ = _weakref.ref(self)
+        for p in self.params:
+            p._uamd_arena = me_              # "this parameter's gradient lives in a live arena" (optim.FlatAdamW checks it)
         # the fused LoRA-gradient kernel adds straight into the arena (kernels/utils.py GRAD_SINKS): no
         # AccumulateGrad kernel per parameter; .ready() does the bucket bookkeeping the autograd hook would do
         if direct and self.arena.is_cuda:
@@ -109,6 +116,10 @@ class LoRAGradArena:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            ref = getattr(p, "_uamd_arena", None)
+            if ref is not None and ref() is self:
+                del p._uamd_arena
 
     # ------------------------------------------------------------------------------------------
     def _hook(self, p):
@@ -185,7 +196,22 @@ def global_num_items(labels, group=None):
     return n
 
 
+_ROTARY_INV_FREQ_BUFFER_NAMES = ("inv_freq", "short_inv_freq", "long_inv_freq")
+
+
 def exclude_rope_inv_freq_from_ddp(model):
-    """loader_utils.py:849-865 equivalent: rotary tables are not module buffers here (RopeTables keeps
-    them out of state_dict and of any broadcast), so there is nothing to exclude; kept for API parity."""
+    """loader_utils.py:849-865: a user who wraps the model in torch's DistributedDataParallel anyway (instead of the
+    LoRAGradArena exchange above) must not have the HF rotary modules' `inv_freq` buffers broadcast -- they may sit on
+    the CPU (transformers v5 leaves non-persistent buffers where meta-init put them) and the product never
+    reads them (RopeTables rebuilds cos / sin from the config). Adds their fully qualified names to the list DDP reads
+    (`_ddp_params_and_buffers_to_ignore`); re-run after PEFT wrapping, the names change. Returns the model."""
+    ignored = list(getattr(model, "_ddp_params_and_buffers_to_ignore", None) or [])
+    for module_name, module in model.named_modules():
+        for buffer_name, _ in module.named_buffers(recurse=False):
+            if buffer_name in _ROTARY_INV_FREQ_BUFFER_NAMES:
+                fqn = f"{module_name}.{buffer_name}" if module_name else buffer_name
+                if fqn not in ignored:
+                    ignored.append(fqn)
+    if ignored:
+        model._ddp_params_and_buffers_to_ignore = ignored
     return model

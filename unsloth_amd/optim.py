@@ -29,9 +29,9 @@ class FlatAdamW(torch.optim.Optimizer):
         if arena is None:
             # two live arenas over the same parameters would both hook gradient accumulation and fight over p.grad and
             # the fused-gradient sinks (the second one's copies racing the first one's collectives): refuse
-            from .kernels.utils import grad_sink
             for p in model.parameters():
-                if p.requires_grad and grad_sink(p) is not None:
+                owner = getattr(p, "_uamd_arena", None)
+                if p.requires_grad and owner is not None and owner() is not None:
                     raise RuntimeError("FlatAdamW: these parameters already belong to a live dp.LoRAGradArena; pass it "
                                        "as `arena=` (trainer.make_optimizer(model, arena=arena))")
         self.arena = arena if arena is not None else LoRAGradArena(model)
