@@ -229,7 +229,9 @@ int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64, 2 = 64x256 with
                                  * the row tile as the fastest grid index (adjacent output segments written together) */
 #define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention: bit 0 = forward with 64 q rows per wave (attn_fwd64_kernel: 4 waves x 512 registers, hidden
-                                 * AGPR accumulators) for plain causal, G <= 4; default 0 (measured at parity with the 8-wave kernel) */
+                                 * AGPR accumulators) for plain causal, G <= 4; default 0 (measured at parity with the 8-wave kernel);
+                                 * bit 1 = dK/dV backward with the round-1 kernel (8 waves x 32 keys) instead of attn_bwd_dkdv4_kernel
+                                 * (4 waves x 64 keys, one per SIMD, hidden AGPR accumulators) */
 #define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
 #define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has
@@ -273,7 +275,8 @@ int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* w
  * LSE [B,Hq,lse_stride] fp32 (natural log-sum-exp of the scaled scores, saved for the backward; lse_stride =
  * T rounded up to a multiple of 32, pad zero-filled by the caller). Hq/Hk in {1,2,4,8}.
  * uamd_attn_bwd: two launches (dQ + Delta = rowsum(dO*O), then dK/dV), deterministic, no atomics. `strides` has
- * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [B,Hq,lse_stride] fp32 scratch.
+ * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [2,B,Hq,lse_stride] fp32 scratch (plane 0:
+ * rowsum(dO*O), plane 1: LSE*log2(e); both written by the first launch, read by the second).
  * Band (packed documents / sliding window; block-diagonal causal mask of utils/packing.py:650-693, window rule
  * `q - key < W`): query q attends keys lo[q] <= key <= q, equivalently key is seen by queries key <= q <= hi[key].
  * lo, hi: int32 [B, T], non-decreasing along T, lo[q] <= q <= hi[q]; NULL (both) = plain causal. Tiles outside

@@ -71,10 +71,20 @@ def test_attn_forward_matches_fp32_oracle(fwd_variant, dtype, B, T, Hq, Hk):
     assert torch.equal(o, o2)
 
 
+@pytest.fixture(params=[0, 2], ids=["dkdv_4waves_x64keys", "dkdv_8waves_x32keys"])
+def bwd_variant(request):
+    """UAMD_TUNE_ATTN_VAR bit 1: the dK/dV backward of round 1 (8 waves x 32 keys) instead of attn_bwd_dkdv4_kernel."""
+    from unsloth_amd import _lib
+    L = _lib.lib()
+    L.uamd_set_tuning(4, request.param)
+    yield request.param
+    L.uamd_set_tuning(4, 0)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,T,Hq,Hk", [(1, 64, 4, 1), (2, 128, 8, 2), (1, 200, 4, 1), (1, 333, 8, 8), (2, 256, 8, 1),
-                                       (1, 1024, 8, 2), (1, 31, 2, 1), (1, 96, 4, 2)])
-def test_attn_backward_matches_fp32_autograd(dtype, B, T, Hq, Hk):
+                                       (1, 1024, 8, 2), (1, 31, 2, 1), (1, 96, 4, 2), (1, 2048, 8, 2), (2, 777, 4, 4)])
+def test_attn_backward_matches_fp32_autograd(bwd_variant, dtype, B, T, Hq, Hk):
     from unsloth_amd.kernels.attention import attn_backward, attn_forward
     D = 128
     qkv = (torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(2)) * 1.0).to(dtype)
@@ -131,7 +141,7 @@ BAND_CASES = [  # T, Hq, Hk, packed lengths (None = one sequence), window
 
 
 @pytest.mark.parametrize("T,Hq,Hk,lengths,window", BAND_CASES)
-def test_attn_band_forward_backward(T, Hq, Hk, lengths, window):
+def test_attn_band_forward_backward(bwd_variant, T, Hq, Hk, lengths, window):
     """packed documents / sliding window: the kernels skip and mask by the (lo, hi) band; oracle = dense mask."""
     from unsloth_amd.kernels.attention import attention_band, attn_backward, attn_forward
     dtype, B, D = torch.bfloat16, 1, 128

@@ -24,6 +24,7 @@
 //     read by the transposing 8-byte reads, 4 rows x 64 B per 32 lanes -> slot ^= (row & 3) << 2. Both swizzles
 //     are applied on the per-lane DMA SOURCE address (the DMA destination is lane-linear).
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 
@@ -57,6 +58,10 @@ constexpr int ATTN_LDS = NST * STAGE_B;  // 96 KiB
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4a_t;
+typedef __attribute__((address_space(3))) u32x4a_t lds_u32x4a;
+typedef __attribute__((ext_vector_type(2))) float f32x2a_t;
+typedef __attribute__((address_space(3))) f32x2a_t lds_f32x2a;
 
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O; float* LSE;
@@ -708,7 +713,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int hc = h < 0 ? 0 : h;                                    // h = -1: the all-zero P of the prologue times tile 0's V
         const unsigned char* a0 = smem + ((hc >> 1) & 3) * STAGE_B + TILE_B + (((hc & 1) * 2 + c) * 16) * 256 + (v_lane ^ (dt << 6));
         union { s16x4_t hh[2]; frag_t f; } va;
-        va.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        va.hh[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a0);
         va.hh[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 8 * 256));
         return va.f;
     };
@@ -1019,8 +1024,11 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     }
     delta += __shfl_xor(delta, 32, 64);
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
-    if (lh == 0 && q_pos < T_) p.Delta[stat_idx] = delta;
     const float lse2 = p.LSE[stat_idx] * 1.4426950408889634f;
+    if (lh == 0 && q_pos < T_) {
+        p.Delta[stat_idx] = delta;
+        p.Delta[(int64_t)p.B * p.Hq * p.lse_st + stat_idx] = lse2;        // plane 1: LSE log2(e), for attn_bwd_dkdv4_kernel
+    }
     const float delta_s = delta * p.scale;
     const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
     const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
@@ -1418,6 +1426,450 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Backward, part 2, round-3 structure: dK, dV with ONE wave per SIMD.
+// What was wrong with attn_bwd_dkdv_kernel (8 waves x 256 registers, profiles/r02zz_pmc_mfma_busy.md: MFMA-busy 21 %,
+// 9,500 cycles per 2,048-cycle step): 128 accumulator registers + 32 of K^T + 32 of scores leave no room to read
+// operands ahead, so hipcc emits `ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma` 32 times per step (every MFMA pays a full
+// LDS round trip), K^T is re-loaded from L2 at the top of every step behind a vmcnt the whole block waits on, every
+// step ends in a full-block `vmcnt(0) + s_barrier`, and each wave reads Q, dO, Q^T, dO^T from LDS for only 32 keys.
+// Here a block is 4 waves = the 4 units of the old kernel (query heads of the group / q slices), each wave owns BOTH
+// 32-key halves of the block's 64 keys and the whole 512-entry register file of its SIMD:
+//   * accumulators dK^T, dV^T for 64 keys = 256 AGPRs a0..a255, touched only by inline asm naming the physical
+//     registers (attn_acc256.inc; with compiler-managed accumulators hipcc copies tuples between the files at every
+//     control-flow merge and spills), K^T fragments resident in 64 VGPRs for the whole kernel (no reload), V in LDS
+//     (row reads, shared by the 4 waves);
+//   * every Q / dO / Q^T / dO^T fragment read from LDS feeds TWO MFMAs (one per key half): 0.75 KB of LDS reads per
+//     MFMA instead of 1.25;
+//   * the Q / dO staging ring is PRIVATE to the wave (2 stages x 16 KiB + a 256-byte line of LSE2 / Delta, filled by
+//     the wave's own LDS-DMA): a step starts on the wave's own `vmcnt(0)` -- no block barrier anywhere in the loop,
+//     the four SIMDs drift freely;
+//   * a step is a hand-pipelined stream of 32 chunks of two MFMAs (see `body`), each MFMA group with independent VALU
+//     work beside it:
+//       S = Q K^T (16 MFMA)            | operand prefetch
+//       dP = dO V^T (16 MFMA)          | P = exp2(S c - LSE2), packed to 16 bit; the next step's LDS-DMA
+//       dV^T += dO^T P (16 MFMA)       | dS' = P (dP - Delta), packed  (the softmax scale is applied to dK^T once, at the end)
+//       dK^T += Q^T dS' (16 MFMA)      |
+// LSE2 = LSE log2(e) is written next to Delta by attn_bwd_dq_kernel (plane 1 of the Delta scratch). Same Q / dO / V
+// LDS tile formats and swizzles as the old kernel; same fixed-order reduction of the 4 units at the end.
+// LDS map: [V tile 16 KiB][stats 2 KiB: (stage, unit) x (32 LSE2 | 32 Delta)][ring: unit x stage x (Q 8 KiB | dO 8 KiB)]
+// -- the ring is unit-major so that stage / operand / k-step select an IMMEDIATE offset (< 64 KiB) on a per-lane constant.
+constexpr int KD4_STATS_OFF = TILE_B;                 // 16 KiB
+constexpr int KD4_RING_OFF = KD4_STATS_OFF + 2048;    // 18 KiB
+constexpr int KD4_LDS = KD4_RING_OFF + 4 * 32768;     // 149,504 B
+
+// one LDS-DMA wave-instruction of 4 bytes per lane: lane l copies [gptr_l, +4) to LDS [dst + 4 l)
+__device__ __forceinline__ void dma4x1(const void* gptr, unsigned d0) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gptr), "s"(d0)
+        : "memory");
+}
+
+// compile-time loop: f(std::integral_constant<int, K>{}) for K = 0 .. N - 1 (every index a constant expression: register
+// arrays indexed with it never go to scratch, `if constexpr` chains fold)
+template <typename F, int... Ks>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Ks...>) {
+    (f(std::integral_constant<int, Ks>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+// score MFMAs with the accumulator in VGPRs (the softmax reads it), as inline asm: with the builtin hipcc parks these
+// accumulators in AGPRs a0..a63 between the asm statements -- on top of the pinned dV^T tuples. The wait states a VALU
+// reader needs behind the chain's last MFMA are provided by the schedule (>= 2 MFMA issue slots, see the kernel).
+template <typename T>
+__device__ __forceinline__ void vmfma_first(f32x16_t& s, typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+    if constexpr (std::is_same<T, bf16_t>::value) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(s) : "v"(a), "v"(b));
+}
+template <typename T>
+__device__ __forceinline__ void vmfma(f32x16_t& s, typename MfmaA<T>::frag a, typename MfmaA<T>::frag b) {
+    if constexpr (std::is_same<T, bf16_t>::value) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
+}
+
+#include "attn_acc256.inc"
+// tuple I of the accumulator file -> this wave's slab of the reduction buffer: red[unit][(I & 7) * 16 + r][lane]
+template <int I>
+__device__ __forceinline__ void acc256_to_lds(float* red, int unit, int lane) {
+    float f[16];
+    acc256_read<I>(f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(unit * 128 + (I & 7) * 16 + r) * 64 + lane] = f[r];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) attn_bwd_dkdv4_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename MfmaA<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int unit = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = p.G, T_ = p.T;
+    const int hpp = G < 4 ? G : 4;                    // heads per pass
+    const int npass = G / hpp, nslice = 4 / hpp;
+    const int hin = unit % hpp, slice = unit / hpp;
+    const int npairs = p.Hk * p.B;
+    const int jt = (int)(blockIdx.x / npairs);        // key tile 0 sees every q tile (causal): heaviest first
+    const int pair_ = (int)(blockIdx.x % npairs);
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
+    const int k0 = jt * KT;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    // band upper edge: last query that attends a key (non-decreasing in key); per key half
+    int hi_k[2], key[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        key[kh] = k0 + kh * 32 + l31;
+        const int key_ld = key[kh] < T_ ? key[kh] : T_ - 1;
+        hi_k[kh] = p.hi ? p.hi[(int64_t)b * T_ + key_ld] : T_ - 1;
+    }
+    const int hi_w0 = __builtin_amdgcn_readfirstlane(hi_k[0]);                   // smallest edge of the tile
+    const int hi_blk = p.hi ? p.hi[(int64_t)b * T_ + min(k0 + KT - 1, T_ - 1)] : T_ - 1;
+
+    // ---- V tile -> LDS (swizzle C), 16 pieces of 1 KiB, 4 per wave
+    {
+        const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh + (int64_t)k0 * p.v_st;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (unit * 4 + i) * 4 + (lane >> 4);
+            const int r = min(row, T_ - 1 - k0);
+            dma16x1(vbase + (int64_t)r * p.v_st + ((lane & 15) ^ swz_c(row)) * 8, lds_base + (unit * 4 + i) * 1024);
+        }
+    }
+    // ---- K^T operand (B of S = Q K^T: lane -> key, 8 d at 16 ks + 8 lh), both key halves, resident
+    frag_t kf[2][8];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int key_ld = key[kh] < T_ ? key[kh] : T_ - 1;
+        const T* kp = (const T*)p.K + b * p.k_sb + (int64_t)key_ld * p.k_st + (int64_t)kvh * p.k_sh + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            union { uint4 r; frag_t f; } u;
+            u.r = *reinterpret_cast<const uint4*>(kp + ks * 16);
+            kf[kh][ks] = u.f;
+        }
+    }
+
+    // DMA source offsets of the wave's Q and dO tiles: piece i (rows 4 i + (lane >> 4)) = base(+16 rows for i >= 4)
+    // + row * stride * 2 + (dsw0 ^ ((i & 3) << 4))   (swz_c(row) = ((lane >> 4) << 2) | (i & 3) for these rows)
+    const int dsw0 = ((lane & 15) ^ ((lane >> 4) << 2)) << 4;
+    unsigned qo[4], doo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        qo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.q_st * 2) + (unsigned)(dsw0 ^ (i << 4));
+        doo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.do_st * 2) + (unsigned)(dsw0 ^ (i << 4));
+    }
+    const int nq32 = (T_ + 31) / 32;
+    const int q32_first = k0 / 32;
+    const int nsteps = (min(nq32, hi_blk / 32 + 1) - q32_first + nslice - 1) / nslice;
+
+    // ---- per-lane ABSOLUTE LDS byte addresses (swizzle C; the dynamic region's base included), made opaque once:
+    //      stage / operand / k-step / c are immediates on them
+    const unsigned ring_u = lds_base + KD4_RING_OFF + unit * 32768;
+    const int r_lane = l31 * 256 + ((swz_c(l31 & 15) ^ lh) << 4);
+    const int sg = lane & 15, gh = (lane >> 4) & 1;
+    const int t_lane = (4 * lh + (sg >> 2)) * 256 +
+                       ((((sg >> 2) << 2) | (((gh << 1) | ((sg >> 1) & 1)) ^ lh)) << 4) + (sg & 1) * 8;
+    unsigned cq[8], cv[8], ct[4], ct2[4];              // row reads of the ring / of V; transposing reads (two 4-row blocks)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        cv[ks] = lds_base + (unsigned)(r_lane ^ (ks * 32));
+        cq[ks] = ring_u + (unsigned)(r_lane ^ (ks * 32));
+        asm volatile("" : "+v"(cq[ks]), "+v"(cv[ks]));
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        ct[dt] = ring_u + (unsigned)(t_lane ^ (dt << 6));
+        ct2[dt] = ring_u + (unsigned)((t_lane ^ (dt << 6)) ^ 32) + 8 * 256;
+        asm volatile("" : "+v"(ct[dt]), "+v"(ct2[dt]));
+    }
+    unsigned cs = lds_base + KD4_STATS_OFF + unit * 256 + lh * 16;   // stats line: + stage * 1024 + quad * 32 + (pair in quad) * 8 (+ 128: Delta)
+    asm volatile("" : "+v"(cs));
+
+    // accumulators: a[0:127] = dV^T tuples (kh * 4 + dt), a[128:255] = dK^T tuples (8 + kh * 4 + dt); asm-owned
+    acc256_zero();
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // the V tile is in LDS for every wave
+    asm volatile("" ::: "memory");
+
+    const float* lse2_all = p.Delta + (int64_t)p.B * p.Hq * p.lse_st;            // plane 1 of the scratch: LSE * log2(e)
+    for (int pass = 0; pass < npass; ++pass) {
+        const int head = kvh * G + pass * hpp + hin;
+        const T* qbase = (const T*)p.Q + b * p.q_sb + (int64_t)head * p.q_sh;
+        const T* dobase = (const T*)p.dO + b * p.do_sb + (int64_t)head * p.do_sh;
+        const float* lse_row = lse2_all + ((int64_t)b * p.Hq + head) * p.lse_st;
+        const float* del_row = p.Delta + ((int64_t)b * p.Hq + head) * p.lse_st;
+        auto q0_of = [&](int step) { return (q32_first + step * nslice + slice) * 32; };
+        // tile a step's DMA fetches: its own q tile, or (idle slice at the end of the sequence) the last valid one
+        auto fetch_q0 = [&](int step) {
+            const int q0 = q0_of(step);
+            return q0 >= T_ ? (nq32 - 1) * 32 : q0;
+        };
+        // part: -1 = everything, 0 / 1 = Q rows 0-15 / 16-31, 2 / 3 = dO rows 0-15 / 16-31, 4 = the LSE2 | Delta line.
+        // FULL: the tile has all 32 rows (precomputed offsets, no branch); else rows past the end re-read the last row.
+        auto issue = [&](int q0, int stage, int part, auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            const unsigned d = lds_base + KD4_RING_OFF + unit * 32768 + stage * 16384;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                if (!(part < 0 || part == h)) continue;
+                const T* base = h < 2 ? qbase : dobase;
+                const int64_t st_ = h < 2 ? p.q_st : p.do_st;
+                if (FULL) {
+                    const unsigned* o = h < 2 ? qo : doo;
+                    dma16x4g(base + (int64_t)(q0 + (h & 1) * 16) * st_, o[0], o[1], o[2], o[3], d + h * 4096);
+                } else {
+                    unsigned o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = min(((h & 1) * 4 + i) * 4 + (lane >> 4), T_ - 1 - q0);
+                        o[i] = (unsigned)((int64_t)r * st_ * 2) + (unsigned)(dsw0 ^ (i << 4));
+                    }
+                    dma16x4g(base + (int64_t)q0 * st_, o[0], o[1], o[2], o[3], d + h * 4096);
+                }
+            }
+            // LSE2 (lanes 0-31) | Delta (lanes 32-63) of rows q0 .. q0 + 31 (the stat rows are padded to a multiple of 32)
+            if (part < 0 || part == 4)
+                dma4x1((lh ? del_row : lse_row) + q0 + l31, lds_base + KD4_STATS_OFF + (stage * 4 + unit) * 256);
+        };
+
+        // The step is a stream of 32 CHUNKS of two MFMAs (one LDS operand fragment x the two key halves):
+        //   0-7   S[kh]   += Q[:, ks] K^T[kh]          operand: Q rows (1 b128 read)
+        //   8-15  dP[kh]  += dO[:, ks] V^T[kh]         operands: dO rows, V rows of both halves (3 reads)
+        //   16-23 dV^T[kh][dt] += dO^T[dt, c] P[kh][c] operand: dO^T (2 transposing reads)
+        //   24-31 dK^T[kh][dt] += Q^T[dt, c] dS[kh][c] operand: Q^T
+        // software-pipelined by hand: chunk k + 2's operands are requested before chunk k's MFMAs (every MFMA here is
+        // inline asm -- the accumulators are registers hipcc must not touch -- so the compiler cannot see what a fragment
+        // feeds), and the VALU work rides beside MFMAs that do not depend on it:
+        //   chunks 9-15  P = exp2(S c - LSE2) and its packing, pair by pair (S is complete after chunk 7)
+        //   chunks 17-23 dS' = P (dP - Delta) and its packing (dP is complete after chunk 15)
+        //   chunks 8-12  the next step's LDS-DMA (4 x 4 KiB of Q / dO + the stats line)
+        // A VALU read of an MFMA result is always >= 2 MFMA issue slots behind the chain's last MFMA (the XDL write -> VALU
+        // read wait states are covered by the MFMAs in between). Placement is pinned with EMPTY volatile asm statements
+        // (volatile asms keep their order, and every MFMA is one): inputs are made opaque AFTER the chunk's MFMAs -- a pure
+        // fp expression would otherwise float up to right behind the MFMA chain that produces its operand -- and results
+        // are consumed by an empty asm BEFORE the next chunk's MFMAs, so a packed operand is never written right in front
+        // of the (asm) MFMA that reads it.
+        auto body = [&](auto masked, auto stage_c, int q0, int qn) {
+            constexpr bool MASK = decltype(masked)::value;
+            constexpr int STAGE = decltype(stage_c)::value;
+            constexpr int SO = STAGE * 16384;
+            f32x16_t sc[2], dp[2];
+            union { uint32_t w[8]; frag_t f[2]; } pb[2], sb[2];   // P / dS' as B operands: f[c] = rows 16 c .. 16 c + 15
+            frag_t ob[3][3];
+            float2 st2[2][3];                                     // stats of the pairs of the next chunk (ping-pong)
+            auto rd128 = [&](unsigned addr) {
+                union { u32x4a_t r; frag_t f; } u;
+                u.r = *(const lds_u32x4a*)(uintptr_t)addr;
+                return u.f;
+            };
+            auto rdtr = [&](unsigned a0, unsigned a1) {
+                union { s16x4_t h[2]; frag_t f; } t;
+                t.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a0);
+                t.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a1);
+                return t.f;
+            };
+            auto reads = [&](auto kc, frag_t* o) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < 8) {
+                    o[0] = rd128(cq[k] + SO);
+                } else if constexpr (k < 16) {
+                    constexpr int ks = k - 8;
+                    o[0] = rd128(cq[ks] + (SO + 8192));
+                    o[1] = rd128(cv[ks]);
+                    o[2] = rd128(cv[ks] + 32 * 256);
+                } else if constexpr (k < 24) {
+                    constexpr int c = (k - 16) >> 2, dt = (k - 16) & 3;
+                    o[0] = rdtr(ct[dt] + (SO + 8192 + c * 4096), ct2[dt] + (SO + 8192 + c * 4096));
+                } else {
+                    constexpr int c = (k - 24) >> 2, dt = (k - 24) & 3;
+                    o[0] = rdtr(ct[dt] + (SO + c * 4096), ct2[dt] + (SO + c * 4096));
+                }
+            };
+            auto mfmas = [&](auto kc, const frag_t* o, auto half_c) {     // half = key half: the chunk's first / second MFMA
+                constexpr int k = decltype(kc)::value, kh = decltype(half_c)::value;
+                if constexpr (k < 8) {
+                    if constexpr (k == 0) vmfma_first<T>(sc[kh], o[0], kf[kh][0]);
+                    else vmfma<T>(sc[kh], o[0], kf[kh][k]);
+                } else if constexpr (k < 16) {
+                    if constexpr (k == 8) vmfma_first<T>(dp[kh], o[0], o[1 + kh]);
+                    else vmfma<T>(dp[kh], o[0], o[1 + kh]);
+                } else if constexpr (k < 24) {
+                    constexpr int c = (k - 16) >> 2, dt = (k - 16) & 3;
+                    acc256_mfma<T, 4 * kh + dt>(o[0], pb[kh].f[c]);
+                } else {
+                    constexpr int c = (k - 24) >> 2, dt = (k - 24) & 3;
+                    acc256_mfma<T, 8 + 4 * kh + dt>(o[0], sb[kh].f[c]);
+                }
+            };
+            // pair pi = 2 j + kh (j-major: the c = 0 operands of both halves are complete first): registers 2 j, 2 j + 1 =
+            // q rows q0 + 8 (j >> 1) + 4 lh + 2 (j & 1) + {0, 1}; their LSE2 (Delta: + 128 bytes) sit side by side
+            auto stat_pair = [&](auto pic, int delta) {
+                constexpr int j = decltype(pic)::value >> 1;
+                const f32x2a_t v = *(const lds_f32x2a*)(uintptr_t)(cs + (STAGE * 1024 + (j >> 1) * 32 + (j & 1) * 8) + delta);
+                return make_float2(v[0], v[1]);
+            };
+            auto p_pair = [&](auto pic, float2 l2) {
+                constexpr int pi = decltype(pic)::value, kh = pi & 1, j = pi >> 1;
+                const float lv[2] = {l2.x, l2.y};
+                float x[2];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kh][2 * j + e], p.scale_log2, -lv[e]));
+                    if (MASK) {
+                        const int r = 2 * j + e;
+                        const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key[kh] > q || q >= T_ || key[kh] >= T_ || q > hi_k[kh]) pv = 0.f;
+                    }
+                    x[e] = pv;
+                    sc[kh][2 * j + e] = pv;
+                }
+                pb[kh].w[j] = pack_pair2<T>(x[0], x[1]);
+                return pb[kh].w[j];
+            };
+            auto ds_pair = [&](auto pic, float2 dl) {            // masked entries have P = 0, hence dS' = 0
+                constexpr int pi = decltype(pic)::value, kh = pi & 1, j = pi >> 1;
+                const float x0 = sc[kh][2 * j] * (dp[kh][2 * j] - dl.x);
+                const float x1 = sc[kh][2 * j + 1] * (dp[kh][2 * j + 1] - dl.y);
+                sb[kh].w[j] = pack_pair2<T>(x0, x1);
+                return sb[kh].w[j];
+            };
+            // VALU work of chunk k, in two halves: `first` runs between the chunk's two MFMAs, the rest behind the second.
+            // 16 pairs over 7 chunks: 3 3 2 2 2 2 2 (slot -> first pair, count); one pair in the first half.
+            auto valu = [&](auto kc, auto half_c) {
+                constexpr int k = decltype(kc)::value;
+                constexpr bool FIRST = decltype(half_c)::value == 0;
+                if constexpr (k >= 9 && k < 16) {
+                    constexpr int slot = k - 9, first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2), count = slot < 2 ? 3 : 2;
+                    if constexpr (FIRST) {
+                        // S is complete (its last MFMA is >= 3 MFMA slots back): pin the reads of it BEHIND this point
+                        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));
+                        const uint32_t w0 = p_pair(std::integral_constant<int, first>{}, st2[k & 1][0]);
+                        asm volatile("" :: "v"(w0));
+                    } else {
+                        const uint32_t w1 = p_pair(std::integral_constant<int, first + 1>{}, st2[k & 1][1]);
+                        uint32_t w2 = w1;
+                        if constexpr (count == 3) w2 = p_pair(std::integral_constant<int, first + 2>{}, st2[k & 1][2]);
+                        asm volatile("" :: "v"(w1), "v"(w2));
+                    }
+                } else if constexpr (k >= 17 && k < 24) {
+                    constexpr int slot = k - 17, first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2), count = slot < 2 ? 3 : 2;
+                    if constexpr (FIRST) {
+                        asm volatile("" : "+v"(dp[0]), "+v"(dp[1]));
+                        const uint32_t w0 = ds_pair(std::integral_constant<int, first>{}, st2[k & 1][0]);
+                        asm volatile("" :: "v"(w0));
+                    } else {
+                        const uint32_t w1 = ds_pair(std::integral_constant<int, first + 1>{}, st2[k & 1][1]);
+                        uint32_t w2 = w1;
+                        if constexpr (count == 3) w2 = ds_pair(std::integral_constant<int, first + 2>{}, st2[k & 1][2]);
+                        asm volatile("" :: "v"(w1), "v"(w2));
+                    }
+                }
+                if constexpr (!FIRST) {
+                    // stats of the pairs chunk k + 1 will process (P: chunks 9-15, dS': 17-23)
+                    if constexpr ((k >= 8 && k < 15) || (k >= 16 && k < 23)) {
+                        constexpr int slot = (k >= 16 ? k - 16 : k - 8), first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2);
+                        constexpr int count = slot < 2 ? 3 : 2, dl = k >= 16 ? 128 : 0;
+                        st2[(k + 1) & 1][0] = stat_pair(std::integral_constant<int, first>{}, dl);
+                        st2[(k + 1) & 1][1] = stat_pair(std::integral_constant<int, first + 1>{}, dl);
+                        if constexpr (count == 3) st2[(k + 1) & 1][2] = stat_pair(std::integral_constant<int, first + 2>{}, dl);
+                    }
+                    if constexpr (k >= 8 && k < 13) issue(qn, STAGE ^ 1, k - 8, std::integral_constant<bool, !MASK>{});
+                }
+            };
+            reads(std::integral_constant<int, 0>{}, ob[0]);
+            reads(std::integral_constant<int, 1>{}, ob[1]);
+            static_for<32>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k + 2 < 32) reads(std::integral_constant<int, k + 2>{}, ob[(k + 2) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kc, ob[k % 3], std::integral_constant<int, 0>{});
+                valu(kc, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kc, ob[k % 3], std::integral_constant<int, 1>{});
+                valu(kc, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto run = [&](auto stage_c, int step) {
+            constexpr int STAGE = decltype(stage_c)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's tiles of `step` are in LDS
+            // the DMA issued DURING this step: the next step's tile, or -- last step -- this step's tile once more into the
+            // idle stage (unconditional: no branch inside the chunk stream; drained before the epilogue reuses the LDS)
+            const int qn = fetch_q0(step + 1 < nsteps ? step + 1 : step);
+            const int q0 = q0_of(step);
+            if (q0 >= T_ || q0 > hi_blk) {                        // idle slice / below the band
+                issue(qn, STAGE ^ 1, -1, std::false_type{});
+                return;
+            }
+            // slow body: some element of the tile is masked (diagonal / ragged / band edge) or the tile to fetch is ragged
+            const bool slow = (q0 < k0 + KT - 1) || (q0 + 32 > T_) || (k0 + KT > T_) || (q0 + 31 > hi_w0) || (qn + 32 > T_);
+            if (slow) body(std::true_type{}, stage_c, q0, qn); else body(std::false_type{}, stage_c, q0, qn);
+        };
+
+        if (nsteps > 0) issue(fetch_q0(0), 0, -1, std::false_type{});
+        for (int step = 0; step < nsteps; step += 2) {
+            run(std::integral_constant<int, 0>{}, step);
+            if (step + 1 < nsteps) run(std::integral_constant<int, 1>{}, step + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last step's spare DMA has landed
+    }
+
+    // ---- sum the 4 units through LDS (fixed order), store dV then dK (x softmax scale). red[unit][kh * 64 + dt * 16 + r][lane]
+    float* red = reinterpret_cast<float*>(smem);              // 4 x 128 x 64 floats = 128 KiB
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();                                       // every wave is out of the loop / done reading `red`
+        if (which == 0) {
+            acc256_to_lds<0>(red, unit, lane); acc256_to_lds<1>(red, unit, lane); acc256_to_lds<2>(red, unit, lane);
+            acc256_to_lds<3>(red, unit, lane); acc256_to_lds<4>(red, unit, lane); acc256_to_lds<5>(red, unit, lane);
+            acc256_to_lds<6>(red, unit, lane); acc256_to_lds<7>(red, unit, lane);
+        } else {
+            acc256_to_lds<8>(red, unit, lane); acc256_to_lds<9>(red, unit, lane); acc256_to_lds<10>(red, unit, lane);
+            acc256_to_lds<11>(red, unit, lane); acc256_to_lds<12>(red, unit, lane); acc256_to_lds<13>(red, unit, lane);
+            acc256_to_lds<14>(red, unit, lane); acc256_to_lds<15>(red, unit, lane);
+        }
+        __syncthreads();
+        T* outp = which ? (T*)p.dK : (T*)p.dV;
+        const int64_t o_sb = which ? p.dk_sb : p.dv_sb, o_st = which ? p.dk_st : p.dv_st, o_sh = which ? p.dk_sh : p.dv_sh;
+        const float mul = which ? p.scale : 1.0f;
+#pragma unroll
+        for (int okh = 0; okh < 2; ++okh) {
+            const int okey = k0 + okh * 32 + l31;
+            float v[16];                                       // this wave's d tile: dt = unit
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a += red[(u * 128 + okh * 64 + unit * 16 + r) * 64 + lane];
+                v[r] = a * mul;
+            }
+            if (okey < T_) {
+                T* op = outp + b * o_sb + (int64_t)okey * o_st + (int64_t)kvh * o_sh;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int d = unit * 32 + qd * 8 + lh * 4;
+                    uint2 o;
+                    o.x = pack_pair2<T>(v[4 * qd + 0], v[4 * qd + 1]);
+                    o.y = pack_pair2<T>(v[4 * qd + 2], v[4 * qd + 3]);
+                    *reinterpret_cast<uint2*>(op + d) = o;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef UAMD_ATTN_TRACE
@@ -1477,6 +1929,10 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     int rc;
+    // dK/dV kernel: one wave per SIMD x 64 keys (attn_bwd_dkdv4_kernel) unless UAMD_TUNE_ATTN_VAR bit 1 asks for the
+    // round-1 8-wave kernel
+    const bool dkdv4 = !(uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 2);
+    static bool attr4[2][64] = {{false}};
     if (dtype == UAMD_BF16) {
         if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<bf16_t>, KD_LDS, &attr_set[1][dev]))) return rc;
         if (lo) {
@@ -1487,7 +1943,12 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
             hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, false>), grid_q, dim3(512), ATTN_LDS, st, a);
         }
         if ((rc = uamd_launch_status())) return rc;
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), grid_k, dim3(512), KD_LDS, st, a);
+        if (dkdv4) {
+            if ((rc = set_lds_attr(&attn_bwd_dkdv4_kernel<bf16_t>, KD4_LDS, &attr4[0][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<bf16_t>), grid_k, dim3(256), KD4_LDS, st, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), grid_k, dim3(512), KD_LDS, st, a);
+        }
     } else if (dtype == UAMD_F16) {
         if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<f16_t>, KD_LDS, &attr_set[3][dev]))) return rc;
         if (lo) {
@@ -1498,7 +1959,12 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
             hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false>), grid_q, dim3(512), ATTN_LDS, st, a);
         }
         if ((rc = uamd_launch_status())) return rc;
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), grid_k, dim3(512), KD_LDS, st, a);
+        if (dkdv4) {
+            if ((rc = set_lds_attr(&attn_bwd_dkdv4_kernel<f16_t>, KD4_LDS, &attr4[1][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<f16_t>), grid_k, dim3(256), KD4_LDS, st, a);
+        } else {
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), grid_k, dim3(512), KD_LDS, st, a);
+        }
     } else {
         return UAMD_ERR_DTYPE;
     }

@@ -200,7 +200,9 @@ def _backward_native(do, q, k, v, o, lse, scale, band):
     dq = dqkv[..., :Hq * D].view(B, T, Hq, D)
     dk = dqkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
     dv = dqkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
-    delta = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
+    # scratch of the two launches: plane 0 = Delta = rowsum(dO * O), plane 1 = LSE * log2(e) (written by the dQ kernel,
+    # read by the dK/dV kernel's LDS-DMA)
+    delta = (torch.empty if Tp == T else torch.zeros)((2, B, Hq, Tp), dtype=torch.float32, device=q.device)
     lo, hi = _band_ptrs(band, B, T, q.device)
     with _lib.device_ctx(q):
         rc = _lib.lib().uamd_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do),

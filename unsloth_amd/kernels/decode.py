@@ -39,8 +39,19 @@ def lora_a_rows(A_list, dtype):
     # must not multiply the trained B by the pre-training A)
     vers = (_CAST_EPOCH[0],) + tuple((a._version, a.data_ptr()) for a in A_list)
     if ent is None or ent[0] != vers or ent[1].dtype != dtype or len(ent[2]) != len(A_list):
-        rows = torch.cat([a.detach().to(dtype) for a in A_list], dim=0).contiguous()
-        ent = (vers, rows, [a.shape[0] for a in A_list])
+        shapes = [a.shape[0] for a in A_list]
+        if (ent is not None and ent[1].dtype == dtype and ent[2] == shapes and ent[1].shape[1] == A_list[0].shape[1]
+                and ent[1].device == A_list[0].device):
+            # refresh IN PLACE: a captured hipGraph of the token step holds this buffer's address
+            r0 = 0
+            with torch.no_grad():
+                for a in A_list:
+                    ent[1][r0:r0 + a.shape[0]].copy_(a.detach())
+                    r0 += a.shape[0]
+            ent = (vers, ent[1], shapes)
+        else:
+            rows = torch.cat([a.detach().to(dtype) for a in A_list], dim=0).contiguous()
+            ent = (vers, rows, shapes)
         key._uamd_fast_lora_rows = ent
     return ent[1]
 

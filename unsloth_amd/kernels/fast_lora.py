@@ -259,13 +259,13 @@ class LoRA_QKV(torch.autograd.Function):
     def backward(ctx, dQ, dK, dV):
         QW, QW_quant, QS, KW, KW_quant, KS, VW, VW_quant, VS, Qb, Kb, Vb = ctx.custom_saved_tensors
         X, QA, QB, KA, KB, VA, VB = ctx.saved_tensors
-        nig = ctx.needs_input_grad
+        nig = tuple(ctx.needs_input_grad) + (False,) * 3          # (the bias arguments are optional)
         d_bias = (_bias_grad(dQ, Qb, nig[17]), _bias_grad(dK, Kb, nig[18]), _bias_grad(dV, Vb, nig[19]))
         dX, (d_QA, d_QB, d_KA, d_KB, d_VA, d_VB) = qkv_backward(
             dQ, dK, dV, X, ctx.xa, (QW, QW_quant, QA, QB, QS), (KW, KW_quant, KA, KB, KS), (VW, VW_quant, VA, VB, VS),
             ctx.inplace)
-        return (dX, None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None,
-                d_VA, d_VB, None, None, *d_bias)
+        grads = (dX, None, None, d_QA, d_QB, None, None, None, d_KA, d_KB, None, None, None, d_VA, d_VB, None, None)
+        return grads + d_bias if len(ctx.needs_input_grad) > 17 else grads
 
 
 def apply_lora_qkv(self, X, inplace=True):
@@ -295,9 +295,9 @@ class LoRA_W(torch.autograd.Function):
     def backward(ctx, dY):
         W, W_quant, S, bias = ctx.custom_saved_tensors
         A, B, X = ctx.saved_tensors
-        d_bias = _bias_grad(dY, bias, ctx.needs_input_grad[6])
+        d_bias = _bias_grad(dY, bias, len(ctx.needs_input_grad) > 6 and ctx.needs_input_grad[6])
         dX, (d_A, d_B) = w_backward(dY, X, ctx.xa, (W, W_quant, A, B, S))
-        return dX, None, None, d_A, d_B, None, d_bias
+        return (dX, None, None, d_A, d_B, None, d_bias) if len(ctx.needs_input_grad) > 6 else (dX, None, None, d_A, d_B, None)
 
 
 def apply_lora_o(self, X):

@@ -92,8 +92,21 @@ class DecodeEngine:
         # graph holds pointers to activation-dtype copies of the LoRA factors that are stale now -- capture again
         from ..kernels.utils import _CAST_EPOCH
         if getattr(self, "_epoch", None) != _CAST_EPOCH[0]:
-            self._graph = None
             self._epoch = _CAST_EPOCH[0]
+            # (a) the activation-dtype copies of the LoRA A factors are refreshed IN PLACE (the captured graph keeps
+            # their addresses); (b) if a parameter's storage moved (optim.FlatAdamW adopts the parameters into its flat
+            # arena, module.to(...)) the graph's pointers to the fp32 B factors dangle: capture again
+            sig = []
+            for P in self._params:
+                for grp in ("qkv", "o", "gu", "down"):
+                    As = [pr[2] for pr in P[grp] if pr[2] is not None]
+                    if As:
+                        _dk.lora_a_rows(As, self.dtype)
+                    sig += [t.data_ptr() for pr in P[grp] for t in pr[:4] if torch.is_tensor(t)]
+            sig = tuple(sig)
+            if getattr(self, "_ptr_sig", None) != sig:
+                self._graph = None
+                self._ptr_sig = sig
         core = self.core
         h = core.embed_tokens(input_ids.to(self.dev)).to(self.dtype)
         cos, sin = self.cos, self.sin
