@@ -225,9 +225,11 @@ def main():
             peak = int(pk)
         return dt, peak, [float(l) for l in losses], timer.summary()
 
+    # the PRIMARY measurement first, on the freshly initialised model (loss_first_last starts at ~ln V); the other operating
+    # points afterwards (their warm-up / timing steps keep training the same adapters, which no longer matters)
+    dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
     alt = None
     if a.alt_steps > 0:
-        # the other operating points, short, BEFORE the primary run (so the primary's timers / peak stand last):
         # the other checkpointing modes at the primary batch, then batch 1 and 2 without checkpointing
         alt = {}
 
@@ -286,7 +288,6 @@ def main():
             del eng
             torch.cuda.empty_cache()
             model.train()
-    dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
     rccl_ranks = None
     if dist.is_initialized():
         one = torch.ones(1, device=dev)
@@ -327,6 +328,9 @@ def main():
             from oracle.cpu_baseline import time_layer
             cpu = time_layer(n_layers=a.layers, budget_s=a.cpu_budget)
             cpu["value"] = round(cpu["value"], 2)
+            if os.environ.get("BENCH_CPU_CONFIG1", "1") == "1":
+                from oracle.cpu_baseline import time_config1
+                cpu["config1_tinyllama_direct"] = time_config1(budget_s=min(15.0, a.cpu_budget))
         rec = {
             "metric": "train tokens/sec, Llama-3-8B QLoRA (NF4) r=16 seq2048 bf16", "value": round(tokens / dt, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -70,6 +70,18 @@ int uamd_add_rms_layernorm_bwd(const void* dY, const void* dRes, void* dX, const
                                int64_t dres_row_stride, int64_t dx_row_stride, int64_t h_row_stride, int x_dtype,
                                int w_dtype, void* stream);
 
+/* LayerNorm (vision towers).  Replaces unsloth/kernels/layernorm.py:25-65 (layernorm_forward) and :68-104
+ * (layernorm_backward), as launched by Fast_Layernorm (:107-163) behind `fast_layernorm`:
+ *   fwd: mean, r = rsqrt(mean((x - mean)^2) + eps) in fp32; y = ((x - mean) r) W + b, ONE rounding to x's dtype; r and
+ *        mean (fp32 [n_rows]) are kept for the backward.
+ *   bwd: dX = (dY W - mean(dY W) - xhat mean(dY W xhat)) r, written IN PLACE over dY (:104); no dW / db (frozen norms).
+ * W and b share w_dtype (x's dtype or fp32). */
+int uamd_layernorm_fwd(const void* X, const void* W, const void* B, void* Y, float* r, float* mu, int64_t n_rows,
+                       int n_cols, int64_t x_row_stride, int64_t y_row_stride, float eps, int x_dtype, int w_dtype,
+                       void* stream);
+int uamd_layernorm_bwd(void* dY, const void* X, const void* W, const float* r, const float* mu, int64_t n_rows,
+                       int n_cols, int64_t dy_row_stride, int64_t x_row_stride, int x_dtype, int w_dtype, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * RoPE (rotate-half), IN PLACE.  backward != 0 negates sin (rope_embedding.py:140-142).
  * uamd_rope_embedding    replaces _rope_embedding    (rope_embedding.py:104-166) as launched by

@@ -68,13 +68,16 @@ def _vl_text_config(cfg):
 
 
 def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids=None, n_items=None, device="cpu",
-                                     return_model=False, loss_fn=None):
+                                     return_model=False, loss_fn=None, dtype=torch.float32):
     """Returns (loss fp32, {param_name: grad}) computed by a stock HF model in fp32 -- on the CPU by default; `device`
     = "cuda" runs the same stock-HF fp32 composition on the GPU (torch's own fp32 GEMMs and eager attention: still no
     kernel of the product) so that the BASELINE configurations can be checked at their stated sizes in seconds.
     position_ids [3, B, T] (multimodal RoPE): the backbone is transformers' Qwen2VLTextModel + an lm_head matmul.
     Biases of the base projections (Qwen2's q/k/v) are copied. `loss_fn(logits fp32 [B, T, V]) -> scalar` replaces the
-    causal-LM cross entropy (per-token log-prob objectives of the GRPO / DPO path)."""
+    causal-LM cross entropy (per-token log-prob objectives of the GRPO / DPO path). `dtype` = torch.bfloat16 runs the SAME
+    stock composition in bf16 (weights rounded once, activations in bf16, HF's own kernels): not an oracle but a
+    YARDSTICK -- the error stock HuggingFace itself has against the fp32 truth at that size, which bounds what any bf16
+    implementation can be asked for."""
     from transformers import AutoModelForCausalLM
     base = fast_model.get_base_model() if hasattr(fast_model, "get_base_model") else fast_model
     cfg = copy.deepcopy(base.config)
@@ -123,7 +126,7 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
                 eff[(li, parent, name)] = target.weight
     for p in backbone.parameters():
         p.requires_grad_(False)
-    (ref if ref is not None else backbone).to(dev)
+    (ref if ref is not None else backbone).to(device=dev, dtype=dtype)
     for k in eff:
         eff[k].requires_grad_(True)
     ids = input_ids.to(dev)
@@ -131,7 +134,7 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
     pos = None if position_ids is None else position_ids.to(dev).long()
     if mrope:
         h = backbone(input_ids=ids, position_ids=pos, use_cache=False).last_hidden_state
-        logits = h.float() @ lm_head_w.to(dev).t()
+        logits = (h @ lm_head_w.to(device=dev, dtype=dtype).t()).float()
     else:
         for p in ref.lm_head.parameters():
             p.requires_grad_(False)

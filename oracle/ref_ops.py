@@ -388,3 +388,25 @@ def lora_mlp_reference_grads(X, gate, up, down, dY, kind="swiglu"):
     i = lin(f * g, outs[2])
     grads = torch.autograd.grad(i, [Xf] + params, dY.to(F32))
     return i.detach(), grads
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm (unsloth/kernels/layernorm.py:25-104)
+def layernorm_forward(X, W, b, eps):
+    """y = ((x - mean) * rsqrt(mean((x - mean)^2) + eps)) * W + b, all in fp32, one rounding to X's dtype
+    (layernorm.py:47-65). Returns (Y, r fp32 [rows], mu fp32 [rows])."""
+    x = X.float()
+    mu = x.mean(dim=-1, keepdim=True)
+    xx = x - mu
+    r = torch.rsqrt((xx * xx).mean(dim=-1, keepdim=True) + eps)
+    y = (xx * r) * W.float() + b.float()
+    return y.to(X.dtype), r.squeeze(-1), mu.squeeze(-1)
+
+
+def layernorm_backward(dY, X, W, r, mu):
+    """dX = (g - mean(g) - normed * mean(g * normed)) * r with g = dY * W, normed = (x - mu) * r; fp32, one rounding
+    (layernorm.py:90-104). No dW / db (Fast_Layernorm.backward returns None for them, :163)."""
+    x, g = X.float(), dY.float() * W.float()
+    normed = (x - mu.unsqueeze(-1)) * r.unsqueeze(-1)
+    dx = (g - g.mean(dim=-1, keepdim=True) - normed * (g * normed).mean(dim=-1, keepdim=True)) * r.unsqueeze(-1)
+    return dx.to(dY.dtype)

@@ -19,6 +19,7 @@ ARCH = "gfx950"
 SOURCES = [
     "abi.hip",
     "rms_layernorm.hip",
+    "layernorm.hip",
     "rope_embedding.hip",
     "glu.hip",
     "cross_entropy_loss.hip",

@@ -60,6 +60,10 @@ SIGNATURES = {
                                        c_int64, c_float, c_int, c_int, c_int, c_void_p]),
     "uamd_rms_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                        c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "uamd_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64,
+                                   c_int64, c_float, c_int, c_int, c_void_p]),
+    "uamd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64,
+                                   c_int, c_int, c_void_p]),
     "uamd_rope_embedding": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "uamd_rope_embedding_qk": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64,

@@ -1455,6 +1455,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 // LDS tile formats and swizzles as the old kernel; same fixed-order reduction of the 4 units at the end.
 // LDS map: [V tile 16 KiB][stats 2 KiB: (stage, unit) x (32 LSE2 | 32 Delta)][ring: unit x stage x (Q 8 KiB | dO 8 KiB)]
 // -- the ring is unit-major so that stage / operand / k-step select an IMMEDIATE offset (< 64 KiB) on a per-lane constant.
+#ifndef UAMD_KD4_DMA_CHUNK
+#define UAMD_KD4_DMA_CHUNK 0      // first of the five chunks that carry the next step's LDS-DMA (0: beside the S MFMAs)
+#endif
+#ifndef UAMD_KD4_PF
+#define UAMD_KD4_PF 2             // operand prefetch distance in chunks (LDS round trip vs 64 MFMA cycles per chunk)
+#endif
 constexpr int KD4_STATS_OFF = TILE_B;                 // 16 KiB
 constexpr int KD4_RING_OFF = KD4_STATS_OFF + 2048;    // 18 KiB
 constexpr int KD4_LDS = KD4_RING_OFF + 4 * 32768;     // 149,504 B
@@ -1654,7 +1660,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // feeds), and the VALU work rides beside MFMAs that do not depend on it:
         //   chunks 9-15  P = exp2(S c - LSE2) and its packing, pair by pair (S is complete after chunk 7)
         //   chunks 17-23 dS' = P (dP - Delta) and its packing (dP is complete after chunk 15)
-        //   chunks 8-12  the next step's LDS-DMA (4 x 4 KiB of Q / dO + the stats line)
+        //   chunks 0-4   the next step's LDS-DMA (4 x 4 KiB of Q / dO + the stats line), beside the S MFMAs that have no VALU
+        //                work of their own (UAMD_KD4_DMA_CHUNK)
         // A VALU read of an MFMA result is always >= 2 MFMA issue slots behind the chain's last MFMA (the XDL write -> VALU
         // read wait states are covered by the MFMAs in between). Placement is pinned with EMPTY volatile asm statements
         // (volatile asms keep their order, and every MFMA is one): inputs are made opaque AFTER the chunk's MFMAs -- a pure
@@ -1667,7 +1674,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             constexpr int SO = STAGE * 16384;
             f32x16_t sc[2], dp[2];
             union { uint32_t w[8]; frag_t f[2]; } pb[2], sb[2];   // P / dS' as B operands: f[c] = rows 16 c .. 16 c + 15
-            frag_t ob[3][3];
+            constexpr int PF = UAMD_KD4_PF;
+            frag_t ob[PF + 1][3];
             float2 st2[2][3];                                     // stats of the pairs of the next chunk (ping-pong)
             auto rd128 = [&](unsigned addr) {
                 union { u32x4a_t r; frag_t f; } u;
@@ -1785,19 +1793,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                         st2[(k + 1) & 1][1] = stat_pair(std::integral_constant<int, first + 1>{}, dl);
                         if constexpr (count == 3) st2[(k + 1) & 1][2] = stat_pair(std::integral_constant<int, first + 2>{}, dl);
                     }
-                    if constexpr (k >= 8 && k < 13) issue(qn, STAGE ^ 1, k - 8, std::integral_constant<bool, !MASK>{});
+                    if constexpr (k >= UAMD_KD4_DMA_CHUNK && k < UAMD_KD4_DMA_CHUNK + 5)
+                        issue(qn, STAGE ^ 1, k - UAMD_KD4_DMA_CHUNK, std::integral_constant<bool, !MASK>{});
                 }
             };
-            reads(std::integral_constant<int, 0>{}, ob[0]);
-            reads(std::integral_constant<int, 1>{}, ob[1]);
+            static_for<PF>([&](auto kc) { reads(kc, ob[decltype(kc)::value]); });
             static_for<32>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                if constexpr (k + 2 < 32) reads(std::integral_constant<int, k + 2>{}, ob[(k + 2) % 3]);
+                if constexpr (k + PF < 32) reads(std::integral_constant<int, k + PF>{}, ob[(k + PF) % (PF + 1)]);
                 __builtin_amdgcn_sched_barrier(0);
-                mfmas(kc, ob[k % 3], std::integral_constant<int, 0>{});
+                mfmas(kc, ob[k % (PF + 1)], std::integral_constant<int, 0>{});
                 valu(kc, std::integral_constant<int, 0>{});
                 __builtin_amdgcn_sched_barrier(0);
-                mfmas(kc, ob[k % 3], std::integral_constant<int, 1>{});
+                mfmas(kc, ob[k % (PF + 1)], std::integral_constant<int, 1>{});
                 valu(kc, std::integral_constant<int, 1>{});
                 __builtin_amdgcn_sched_barrier(0);
             });

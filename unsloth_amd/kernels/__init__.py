@@ -12,6 +12,7 @@ from .rms_layernorm import (
     unpatch_rms_layernorm,
     Fast_RMS_Layernorm,
 )
+from .layernorm import fast_layernorm, patch_layernorm, unpatch_layernorm, Fast_Layernorm
 from .rope_embedding import (
     fast_rope_embedding,
     inplace_rope_embedding,

@@ -147,11 +147,13 @@ def _launch_gemm(X2d, groups, nf4, accumulate=False, nn=False):
     arr = (GemmGroup * len(groups))(*groups)
     L = _lib.lib()
     M, K = X2d.shape
+    # a LoRA term given as (fp32 XA, LB) -- no rank block -- is the register prologue of the 128 x 128 kernels only
+    prologue_lora = any(g.lora_xa and not g.lora_xk for g in groups)
     if nn:
         fn, name = L.uamd_gemm_nn_256, "uamd_gemm_nn_256"
     elif nf4:
         fn, name = L.uamd_gemm_nt_nf4, "uamd_gemm_nt_nf4"
-    elif _use_gemm256(M, K, [g.N for g in groups]):
+    elif _use_gemm256(M, K, [g.N for g in groups]) and not prologue_lora:
         fn, name = L.uamd_gemm_nt_256, "uamd_gemm_nt_256"
     else:
         fn, name = L.uamd_gemm_nt, "uamd_gemm_nt"
@@ -451,7 +453,28 @@ def _xa_and_rank_block(X2d, A_list, want_k, out=None):
     if Rt <= 64 and LORA_XA_V2 and X2d.shape[1] >= 8:
         xk = torch.empty((M, width), dtype=X2d.dtype, device=X2d.device)
         xa, offs = lora_xa(X2d, A_list, out=out, out_k=xk, k_cols=width)
-    else:                                   # total rank > 64: first-version kernel, then a padded cast
+    elif (LORA_XA_V2 and X2d.shape[1] >= 8 and Rt <= 192
+          and all(A.shape[0] % 8 == 0 and A.shape[0] <= 64 for A in A_list)):
+        # total rank 65 .. 192 (r = 32 on q|k|v, r = 64 on gate|up): the streaming kernel takes <= 64 rank columns per
+        # launch, so the factors go in groups, each launch writing its own columns of the shared XA / rank-block buffers
+        # (the last one zero-fills the padding)
+        xk = torch.empty((M, width), dtype=X2d.dtype, device=X2d.device)
+        xa = out if out is not None else torch.empty((M, Rt), dtype=torch.float32, device=X2d.device)
+        groups, cur, cur_r = [], [], 0
+        for A in A_list:
+            if cur and cur_r + A.shape[0] > 64:
+                groups.append((cur, cur_r))
+                cur, cur_r = [], 0
+            cur.append(A)
+            cur_r += A.shape[0]
+        groups.append((cur, cur_r))
+        offs, col = [], 0
+        for gi, (As, r) in enumerate(groups):
+            last = gi == len(groups) - 1
+            _, o = lora_xa(X2d, As, out=xa[:, col:col + r], out_k=xk[:, col:], k_cols=(width - col) if last else r)
+            offs += [(col + a, b) for a, b in o]
+            col += r
+    else:                                   # odd ranks / very wide: first-version kernel, then a padded cast
         xa, offs = lora_xa(X2d, A_list, out=out)
         xk = torch.zeros((M, width), dtype=X2d.dtype, device=X2d.device)
         xk[:, :Rt] = xa
@@ -572,7 +595,7 @@ def lora_dx_terms(dYs, projs):
         shared = torch.empty((M, sum(ranks)), dtype=torch.float32, device=dev)
     Rt = sum((r + 7) // 8 * 8 for r in with_lora)
     xk = None
-    if want_k and with_lora and Rt <= 64 and (shared is not None or len(with_lora) == 1):
+    if want_k and with_lora and Rt <= 192 and max(with_lora) <= 64 and (shared is not None or len(with_lora) == 1):
         xk = torch.empty((M, _rank_width(Rt)), dtype=dtype, device=dev)
     n_left = len(with_lora)
     for dY2d, (W, W_quant, A, B, s) in zip(dY2, projs):
