@@ -126,7 +126,13 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
                 eff[(li, parent, name)] = target.weight
     for p in backbone.parameters():
         p.requires_grad_(False)
-    (ref if ref is not None else backbone).to(device=dev, dtype=dtype)
+    top = ref if ref is not None else backbone
+    top.to(device=dev)
+    if dtype != torch.float32:
+        # PARAMETERS only: `module.to(bf16)` would also round the rotary `inv_freq` buffers (positions x 2^-9 of phase
+        # error: garbage from a few hundred tokens on), which no real bf16 run does (HF keeps them in fp32)
+        for p in top.parameters():
+            p.data = p.data.to(dtype)
     for k in eff:
         eff[k].requires_grad_(True)
     ids = input_ids.to(dev)

@@ -6,7 +6,7 @@ __version__ = "0.1.0"
 
 
 def __getattr__(name):          # lazy: importing the package must not pull transformers in
-    if name in ("FastLanguageModel", "FastModel", "is_bfloat16_supported"):
+    if name in ("FastLanguageModel", "FastModel", "FastVisionModel", "is_bfloat16_supported"):
         from . import models
         return getattr(models, name)
     if name in ("UnslothTrainer", "UnslothTrainingArguments", "unsloth_train"):

@@ -277,6 +277,23 @@ def load_language_tower_(model, directory):
     return [n for n, _ in model.named_parameters() if n not in seen and not (tied and n == "lm_head.weight")]
 
 
+def load_prefixed_(module, directory, prefixes):
+    """Fill `module` with the checkpoint tensors whose names start with one of `prefixes` (prefix stripped), e.g. the vision
+    tower of a VLM checkpoint ("model.visual." / "visual."). Returns the parameter names the checkpoint did not provide."""
+    own = dict(module.named_parameters())
+    own.update(dict(module.named_buffers()))
+    seen = set()
+    for name, t in iter_checkpoint_tensors(directory):
+        for prefix in prefixes:
+            if name.startswith(prefix) and name[len(prefix):] in own:
+                key = name[len(prefix):]
+                with torch.no_grad():
+                    own[key].copy_(t.to(device=own[key].device, dtype=own[key].dtype))
+                seen.add(key)
+                break
+    return [n for n, _ in module.named_parameters() if n not in seen]
+
+
 def reinit_rotary_buffers_(model, device):
     """Non-persistent rotary buffers (`inv_freq`, `original_inv_freq`) never travel in a checkpoint; after
     `to_empty` they are uninitialised memory, and HF's own forward (which the decode / generation path uses) reads

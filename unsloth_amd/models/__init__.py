@@ -1,4 +1,4 @@
-from .loader import FastLanguageModel, FastModel
+from .loader import FastLanguageModel, FastModel, FastVisionModel
 from .llama import FastLlamaModel
 
 

@@ -214,4 +214,4 @@ class FastModel(FastLanguageModel):
                                                  full_finetuning=full_finetuning, *args, **kwargs)
 
 
-FastVisionModel = FastModel        # loader.py:2187: the reference's alias
+from .vision import FastVisionModel    # noqa: E402  (loader.py:2187 aliases FastVisionModel = FastModel; here the VLM wrapper)
