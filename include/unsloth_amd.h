@@ -56,6 +56,14 @@ int uamd_rms_layernorm_bwd(const void* dY, void* dX, const void* X, const void* 
                            int64_t n_rows, int n_cols, int64_t dy_row_stride,
                            int64_t dx_row_stride, int64_t x_row_stride, int gemma, int x_dtype,
                            int w_dtype, void* stream);
+/* Weight gradient of the norm, dW[c] (+)= sum_rows dY[row, c] * X[row, c] * r[row] (the same for Llama's w and Gemma's
+ * 1 + w). The reference's backward returns none (rms_layernorm.py:218-240: norm weights are frozen under LoRA; with
+ * full_finetuning=True, vision.py:2206-2209 train_layernorms, HF's torch RMSNorm + autograd compute it). Deterministic
+ * two-stage column reduction; workspace: fp32 scratch, ws_elems >= n_cols (row chunks = ws_elems / n_cols, capped).
+ * Call BEFORE uamd_rms_layernorm_bwd when that one overwrites dY. X is the norm's input (H for the fused add form). */
+int uamd_rms_layernorm_dw(const void* dY, const void* X, const float* r, void* dW, float* workspace, int64_t ws_elems,
+                          int64_t n_rows, int n_cols, int64_t dy_row_stride, int64_t x_row_stride, int accumulate,
+                          int x_dtype, int w_dtype, void* stream);
 
 /* Residual add fused into the norm (llama.py:823-844 runs `residual + x` and the norm as two passes):
  *   fwd: h = X + Res -> H (one rounding to the activation dtype), Y = rmsnorm(h) * W, r as above. H may alias X / Res.
@@ -232,6 +240,14 @@ int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
  * through transposing LDS reads instead of a transposed copy of W. N_g % 8 == 0, ldb % 8 == 0. */
 int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
+/* uamd_gemm_tn_256: A given as [K, M] (M contiguous, lda = row stride) AND B_g as [K, N_g]: C_g (+)= A^T @ B_g. The
+ * weight gradient of a TRAINABLE dense projection (full fine-tuning, BASELINE config 3; the reference leaves it to
+ * torch.nn.Linear's autograd: loader.py:487-523 -> FastModel): dW[out, in] (+)= dY[T, out]^T @ X[T, in], both operands
+ * read where the backward left them (transposing LDS reads on both sides, no transposed copy). accumulate != 0 adds
+ * into C (gradient accumulation; the row-chunked lm_head gradient of the fused linear cross entropy).
+ * M % 8 == 0, N_g % 8 == 0, K % 64 == 0, lda % 8 == 0, ldb % 8 == 0; no LoRA fields. */
+int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                     int n_groups, int accumulate, int dtype, void* stream);
 /* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
  *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernel (L2 reuse) */
 #define UAMD_TUNE_GLU_VAR 0     /* (UAMD_GLU_VAR) gated-MLP activation kernels: 0 = 2048-block grid-stride, 1 = uncapped grid,
@@ -386,6 +402,14 @@ int uamd_lora_prepare(const uamd_lora_prep_desc* descs_dev, const int* tile_pref
 int uamd_adamw_flat(float* p, float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
                     double weight_decay, double bias_correction1, double bias_correction2_sqrt, double grad_scale,
                     int zero_grad, void* stream);
+/* uamd_adamw_shard: the same arithmetic for FULL fine-tuning (BASELINE config 3; reference: loader.py:487-523 hands
+ * full_finetuning to HF Trainer's optimizer over bf16 parameters). One rank's shard of a flat parameter bucket: fp32
+ * master copy p32 and moments m, v (updated in place), the reduce-scattered gradient shard g16 in `dtype` (bf16 / fp16),
+ * and the updated parameters rounded ONCE to `dtype` into p16 -- the slice of the bucket the all-gather broadcasts.
+ * p32 / m / v 16-byte aligned, g16 / p16 8-byte aligned. */
+int uamd_adamw_shard(float* p32, const void* g16, void* p16, float* m, float* v, int64_t n, double lr, double beta1,
+                     double beta2, double eps, double weight_decay, double bias_correction1,
+                     double bias_correction2_sqrt, double grad_scale, int dtype, void* stream);
 
 /* debug: (lane,reg) -> (row,col) map of v_mfma_f32_16x16x32_bf16; out = float[2][64][4] */
 int uamd_debug_mfma_probe(float* out, void* stream);

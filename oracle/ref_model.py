@@ -166,3 +166,34 @@ def hf_reference_loss_and_lora_grads(fast_model, input_ids, labels, position_ids
     if return_model:
         return loss.detach().cpu(), grads, (ref if ref is not None else backbone)
     return loss.detach().cpu(), grads
+
+
+def hf_reference_loss_and_all_grads(fast_model, input_ids, labels, position_ids=None, n_items=None, device="cpu",
+                                    dtype=torch.float32):
+    """Full fine-tuning (BASELINE config 3): (loss, {parameter name: gradient}) of a stock HF model holding the SAME
+    16-bit weights cast to fp32, every parameter trainable -- embeddings, norms, projections, lm_head -- HF's own forward,
+    torch autograd, no kernel of the product. `dtype` = bf16: the yardstick (see hf_reference_loss_and_lora_grads)."""
+    from transformers import AutoModelForCausalLM
+    cfg = copy.deepcopy(fast_model.config)
+    cfg.dtype = torch.float32
+    cfg._attn_implementation = "eager"
+    with _stock_hf_classes():
+        ref = AutoModelForCausalLM.from_config(cfg).to(torch.float32)
+    ref._unsloth_amd_fast = False
+    sd = {k: v.detach().float().cpu() for k, v in fast_model.state_dict().items()}
+    missing, unexpected = ref.load_state_dict(sd, strict=False)
+    assert not [k for k in missing if "inv_freq" not in k], missing
+    ref.to(torch.device(device))
+    if dtype != torch.float32:
+        for p in ref.parameters():
+            p.data = p.data.to(dtype)
+    dev = torch.device(device)
+    ids, lab = input_ids.to(dev), labels.to(dev)
+    pos = None if position_ids is None else position_ids.to(dev).long()
+    logits = ref(input_ids=ids, position_ids=pos, use_cache=False).logits.float()
+    shift = R.shift_labels(lab)
+    V = logits.shape[-1]
+    n = torch.count_nonzero(shift != -100) if n_items is None else n_items
+    loss = torch.nn.functional.cross_entropy(logits.view(-1, V), shift.view(-1), ignore_index=-100, reduction="sum") / n
+    loss.backward()
+    return loss.detach().cpu(), {k: p.grad.detach().float().cpu() for k, p in ref.named_parameters() if p.grad is not None}

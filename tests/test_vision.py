@@ -11,7 +11,7 @@ def _vl_config(hidden=256, heads=4, kv=2, inter=512, vocab=1200, layers=2, depth
     return Qwen2VLConfig(
         text_config=dict(hidden_size=hidden, intermediate_size=inter, num_hidden_layers=layers, num_attention_heads=heads,
                          num_key_value_heads=kv, vocab_size=vocab, max_position_embeddings=1024, rms_norm_eps=1e-6,
-                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [hidden // heads // 8, 3 * hidden // heads // 16, 3 * hidden // heads // 16]},
                          tie_word_embeddings=False),
         vision_config=dict(depth=depth, embed_dim=embed, hidden_size=hidden, num_heads=4, mlp_ratio=2, patch_size=14,
                            spatial_merge_size=2, temporal_patch_size=2, in_channels=3),

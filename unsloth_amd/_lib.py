@@ -60,6 +60,8 @@ SIGNATURES = {
                                        c_int64, c_float, c_int, c_int, c_int, c_void_p]),
     "uamd_rms_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                        c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "uamd_rms_layernorm_dw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64,
+                                      c_int64, c_int, c_int, c_int, c_void_p]),
     "uamd_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64,
                                    c_int64, c_float, c_int, c_int, c_void_p]),
     "uamd_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64,
@@ -98,6 +100,8 @@ SIGNATURES = {
                                  c_int, c_void_p]),
     "uamd_gemm_nn_256": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
                                  c_int, c_void_p]),
+    "uamd_gemm_tn_256": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
+                                 c_int, c_void_p]),
     "uamd_set_tuning": (c_int, [c_int, c_int]),
     "uamd_gemm_nt_nf4": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int,
                                  c_int, c_int, c_void_p]),
@@ -113,6 +117,8 @@ SIGNATURES = {
                                                              c_int, c_void_p]),
     "uamd_lora_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "uamd_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [ctypes.c_double] * 8 + [c_int, c_void_p]),
+    "uamd_adamw_shard": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [ctypes.c_double] * 8
+                         + [c_int, c_void_p]),
     "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int,
                               c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),

@@ -145,7 +145,11 @@ __device__ unsigned* g_trace256 = nullptr;
 //              lane 4 consecutive k of its column; semantics probed in profiles/r01_tr_probe.txt). Bank swizzle:
 //              32-byte granule ^= (k & 3) | ((k >> 3) & 1) << 2, applied on the DMA source column: the 8 rows a
 //              32-lane half of the transposing read touches land in 8 different granules of the 256-byte bank row.
-template <typename T, bool BNN>
+// ATN = true (with BNN): A is [K, M] (M contiguous, lda = row stride) as well -- C = A^T @ B, the weight-gradient
+//              product dW[out, in] = dY[T, out]^T @ X[T, in] of full fine-tuning: BOTH operands are read in the layout
+//              the forward / backward left them in, the A tile goes through the same [64 k][256 m] LDS image and
+//              transposing reads as B's. No rank block in this form.
+template <typename T, bool BNN, bool ATN = false>
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -213,11 +217,21 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
         int col = n0 + (((lane & 31) ^ (f << 1)) << 3);
         return col + 8 <= N ? col : N - 8;          // columns past N are never stored
     };
+    auto tn_col = [&](int krow) {                   // the same for A [K, M]
+        const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+        int col = m0 + (((lane & 31) ^ (f << 1)) << 3);
+        return col + 8 <= M ? col : M - 8;
+    };
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int ra = m0 + (c * 8 + wave) * 8 + sub_row;
-        ra = ra < M ? ra : M - 1;          // clamped rows are never stored
-        a_off[c] = (unsigned)(((int64_t)ra * p.lda + sub_slot * 8) * (int64_t)sizeof(T));
+        if (ATN) {
+            const int krow = (c * 8 + wave) * 2 + nn_krow;
+            a_off[c] = (unsigned)(((int64_t)krow * p.lda + tn_col(krow)) * (int64_t)sizeof(T));
+        } else {
+            int ra = m0 + (c * 8 + wave) * 8 + sub_row;
+            ra = ra < M ? ra : M - 1;          // clamped rows are never stored
+            a_off[c] = (unsigned)(((int64_t)ra * p.lda + sub_slot * 8) * (int64_t)sizeof(T));
+        }
         if (BNN) {
             const int krow = (c * 8 + wave) * 2 + nn_krow;
             b_off[c] = (unsigned)(((int64_t)krow * g.ldb + nn_col(krow)) * (int64_t)sizeof(T));
@@ -230,6 +244,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     // bytes from one K tile of B to the next: 64 columns (NT) or 64 rows (NN)
     const uint64_t b_tile_step = BNN ? (uint64_t)__builtin_amdgcn_readfirstlane((int)g.ldb) * (TK * sizeof(T))
                                      : (uint64_t)(TK * sizeof(T));
+    const uint64_t a_tile_step = ATN ? (uint64_t)__builtin_amdgcn_readfirstlane((int)p.lda) * (TK * sizeof(T))
+                                     : (uint64_t)(TK * sizeof(T));
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;    // LDS byte address of the dynamic region
     // K tiles: nk_main of the operands proper, then the rank block's. Both counts are wave-uniform by construction;
     // readfirstlane tells the compiler so (loop bounds and branches on them stay on the scalar unit).
@@ -238,7 +254,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     // issue_main: the hot path, branch-free (tiles of A / B proper). c, stage are compile-time at every call site.
     auto issue_main = [&](int c, int kt, int stage) {
         const unsigned dst = lds_base + stage * STAGE_BYTES + (c * 8 + wave) * 1024;
-        if (c < 4) dma16s(a_off[c & 3], a_gbase + (uint64_t)kt * (TK * sizeof(T)), dst);
+        if (c < 4) dma16s(a_off[c & 3], a_gbase + (uint64_t)kt * a_tile_step, dst);
         else dma16s(b_off[c & 3], b_gbase + (uint64_t)kt * b_tile_step, dst);
     };
     // issue_any: used only by the prologue and the last few tiles, where the tile being fetched may belong to the
@@ -276,19 +292,27 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     const int a_base = (grp * 8) * 2048;
     const int b_base = 32 * 1024 + (wn * 4) * 2048;
     frag_t af[4][2], bf[4][2];     // A: 4 m-tiles of the current 64-row half x 2 k-halves; B: 4 n-tiles x 2
+    // BNN fragment addresses: k-row ks*32 + l4*8 + (l15 >> 2) (+4 for the second read), logical granule wn*4 + t
+    const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
+    const int nn_lane = 32 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
     auto read_a = [&](int stage, int mq) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { uint4 r; frag_t f; } u;
-                u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + a_base + (mq * 4 + i) * 2048 + frag_off[ks]);
-                af[i][ks] = u.f;
+                if (ATN) {                       // [64 k][256 m] image at the start of the stage: m-tile grp*8 + mq*4 + i
+                    union { s16x4_t h[2]; frag_t f; } u;
+                    const int a0 = stage * STAGE_BYTES + (nn_lane - 32 * 1024) + ks * (32 * 512) + (((grp * 8 + mq * 4 + i) ^ nn_f) << 5);
+                    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + a0));
+                    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(smem + a0 + 4 * 512));
+                    af[i][ks] = u.f;
+                } else {
+                    union { uint4 r; frag_t f; } u;
+                    u.r = *reinterpret_cast<const uint4*>(smem + stage * STAGE_BYTES + a_base + (mq * 4 + i) * 2048 + frag_off[ks]);
+                    af[i][ks] = u.f;
+                }
             }
     };
-    // BNN fragment addresses: k-row ks*32 + l4*8 + (l15 >> 2) (+4 for the second read), logical granule wn*4 + t
-    const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
-    const int nn_lane = 32 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
     auto read_b = [&](int stage, int nq) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -952,18 +976,18 @@ int launch256h(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
-template <typename T, bool BNN>
+template <typename T, bool BNN, bool ATN = false>
 int launch256(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T, BNN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256_kernel<T, BNN, ATN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_nt256_kernel<T, BNN>), dim3((unsigned)a.total_tiles), dim3(512), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt256_kernel<T, BNN, ATN>), dim3((unsigned)a.total_tiles), dim3(512), LDS_BYTES, st, a);
     return uamd_launch_status();
 }
 
@@ -1007,13 +1031,19 @@ extern "C" int uamd_debug_g256_trace(unsigned* buf) {
 // Same contract as uamd_gemm_nt (dense B), 256x256x64 tiles. Requires K % 64 == 0. The LoRA term comes as the
 // rank block lora_xk / lora_bk (extra K tiles); a group that only carries lora_xa / lora_b is rejected.
 static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups, int n_groups,
-                         int accumulate, int dtype, void* stream, bool bnn) {
+                         int accumulate, int dtype, void* stream, bool bnn, bool atn = false) {
     if (M < 0 || K <= 0 || n_groups < 1 || n_groups > UAMD_G256_MAX_GROUPS || !groups) return UAMD_ERR_ARG;
     if (M == 0) return UAMD_OK;
     if ((K & 63) || (lda & 7) || !aligned16(A)) return UAMD_ERR_ALIGN;
     // per-lane addresses are 32-bit byte offsets from the matrix base: every operand must span < 4 GiB
     const int64_t kSpan = (int64_t)1 << 32;
-    if ((int64_t)M * lda * 2 >= kSpan) return UAMD_ERR_ARG;
+    if (atn) {                                  // A [K, M]: whole 16-byte slots of M, K rows x lda below 4 GiB
+        if (!bnn) return UAMD_ERR_ARG;
+        if ((M & 7) || M < 8) return UAMD_ERR_ALIGN;
+        if ((int64_t)K * lda * 2 >= kSpan || lda > 0x7fffffffLL / 128) return UAMD_ERR_ARG;
+    } else if ((int64_t)M * lda * 2 >= kSpan) {
+        return UAMD_ERR_ARG;
+    }
     G256Args a;
     a.A = A; a.lda = lda; a.M = M; a.K = K; a.n_groups = n_groups; a.accumulate = accumulate;
     // tile height: 256 rows when that tiling fills the chip, else 128 rows (twice the tiles; UAMD_TUNE_GEMM_HALF:
@@ -1021,7 +1051,7 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
     int tn_all = 0;
     for (int i = 0; i < n_groups; ++i) tn_all += (groups[i].N + TN - 1) / TN;
     const int half_mode = uamd_tuning_get(UAMD_TUNE_GEMM_HALF);
-    const bool half = half_mode == 2 || (half_mode == 1 && (int64_t)((M + TM - 1) / TM) * tn_all < 192);
+    const bool half = !atn && (half_mode == 2 || (half_mode == 1 && (int64_t)((M + TM - 1) / TM) * tn_all < 192));
     const int tile_m = half ? TMH : TM;
     a.tiles_m = (M + tile_m - 1) / tile_m;
     int tn = 0;
@@ -1038,6 +1068,7 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
                 return UAMD_ERR_ARG;
             }
             if (g.lora_xa && !g.lora_xk) return UAMD_ERR_ARG;     // this kernel takes the rank block as K tiles
+            if (atn && (g.lora_xk || g.lora_xa)) return UAMD_ERR_ARG;
             if (g.lora_xk) {
                 if (!g.lora_bk || g.Rk <= 0) return UAMD_ERR_ARG;
                 if ((g.Rk & 63) || (g.ld_xk & 7) || (g.ld_bk & 7) || !aligned16(g.lora_xk) || !aligned16(g.lora_bk))
@@ -1060,6 +1091,11 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
         a.group_m = gm < 1 ? 1 : (gm < a.tiles_m ? gm : a.tiles_m);
     }
     hipStream_t st = (hipStream_t)stream;
+    if (atn) {
+        if (dtype == UAMD_BF16) return launch256<bf16_t, true, true>(a, st);
+        if (dtype == UAMD_F16) return launch256<f16_t, true, true>(a, st);
+        return UAMD_ERR_DTYPE;
+    }
     if (half) {
         if (dtype == UAMD_BF16) return bnn ? launch256h<bf16_t, true>(a, st) : launch256h<bf16_t, false>(a, st);
         if (dtype == UAMD_F16) return bnn ? launch256h<f16_t, true>(a, st) : launch256h<f16_t, false>(a, st);
@@ -1092,4 +1128,13 @@ extern "C" int uamd_gemm_nt_256(const void* A, int64_t lda, int M, int K, const 
 extern "C" int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                                 int n_groups, int accumulate, int dtype, void* stream) {
     return gemm256_entry(A, lda, M, K, groups, n_groups, accumulate, dtype, stream, true);
+}
+
+// C_g[M, N_g] (+)= A[K, M]^T @ B_g[K, N_g]: both operands with the CONTRACTED dimension as rows. The weight gradient of
+// a trainable dense projection, dW[out, in] (+)= dY[T, out]^T @ X[T, in] (what torch.nn.Linear's backward computes as
+// grad_output.t().mm(input)); with accumulate != 0 it adds into the gradient buffer (gradient accumulation, and the
+// chunked lm_head gradient of the fused linear-CE path). M % 8 == 0, N_g % 8 == 0, K % 64 == 0; no rank block.
+extern "C" int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
+                                int n_groups, int accumulate, int dtype, void* stream) {
+    return gemm256_entry(A, lda, M, K, groups, n_groups, accumulate, dtype, stream, true, true);
 }

@@ -448,6 +448,92 @@ int launch_add_bwd(const void* dY, const void* dRes, void* dX, const void* X, co
     }                                                                                \
     return UAMD_ERR_DTYPE;
 
+// ---- weight gradient (full fine-tuning: the norm weights train; the reference's kernel returns no dW,
+//      rms_layernorm.py:218-240, and leaves trainable norms to HF's torch RMSNorm + autograd):
+//          dW[c] = sum_rows dY[row, c] * X[row, c] * r[row]          (Llama's w and Gemma's 1 + w alike)
+// Column sums over all rows, HBM-bound (reads dY and X once). Two deterministic stages: (1) a grid of
+// [column blocks] x [row chunks], thread = one 16-byte vector of columns, fp32 partial sums over the chunk's rows
+// -> workspace[chunk][col]; (2) one thread per column adds the chunks in order. No atomics: bit-stable.
+namespace {
+template <typename T>
+__global__ void __launch_bounds__(256)
+rms_dw_partial(const T* __restrict__ dY, const T* __restrict__ X, const float* __restrict__ R,
+               float* __restrict__ part, int64_t n_rows, int n_cols, int64_t dys, int64_t xs, int rows_per_chunk) {
+    constexpr int VEC = Vec16<T>::N;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (c >= n_cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t r1 = r0 + rows_per_chunk < n_rows ? r0 + rows_per_chunk : n_rows;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int64_t row = r0; row < r1; ++row) {
+        const Vec16<T> g = ld16(dY + row * dys + c);
+        const Vec16<T> x = ld16(X + row * xs + c);
+        const float inv = R[row];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += to_f32(g.e[j]) * (to_f32(x.e[j]) * inv);
+    }
+    float* out = part + (int64_t)blockIdx.y * n_cols + c;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = acc[j];
+}
+
+template <typename WT>
+__global__ void __launch_bounds__(256)
+rms_dw_reduce(const float* __restrict__ part, WT* __restrict__ dW, int n_cols, int n_chunks, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cols) return;
+    float s = 0.f;
+    for (int k = 0; k < n_chunks; ++k) s += part[(int64_t)k * n_cols + c];
+    if (accumulate) s += to_f32(dW[c]);
+    dW[c] = from_f32<WT>(s);
+}
+
+template <typename T, typename WT>
+int launch_dw(const void* dY, const void* X, const float* r, void* dW, float* ws, int64_t ws_elems, int64_t n_rows,
+              int n_cols, int64_t dys, int64_t xs, int accumulate, hipStream_t st) {
+    constexpr int VEC = Vec16<T>::N;
+    if ((n_cols % VEC) || (dys % VEC) || (xs % VEC) || !aligned16(dY) || !aligned16(X)) return UAMD_ERR_ALIGN;
+    const int col_blocks = (n_cols / VEC + 255) / 256;
+    // ~2048 blocks in flight (8 per CU), at least 8 rows per chunk, bounded by the workspace
+    int64_t chunks = (2048 + col_blocks - 1) / col_blocks;
+    if (chunks > (n_rows + 7) / 8) chunks = (n_rows + 7) / 8;
+    if (chunks > ws_elems / n_cols) chunks = ws_elems / n_cols;
+    if (chunks < 1) return UAMD_ERR_ARG;
+    const int rows_per_chunk = (int)((n_rows + chunks - 1) / chunks);
+    chunks = (n_rows + rows_per_chunk - 1) / rows_per_chunk;
+    hipLaunchKernelGGL((rms_dw_partial<T>), dim3(col_blocks, (unsigned)chunks), dim3(256), 0, st, (const T*)dY, (const T*)X, r,
+                       ws, n_rows, n_cols, dys, xs, rows_per_chunk);
+    hipLaunchKernelGGL((rms_dw_reduce<WT>), dim3((n_cols + 255) / 256), dim3(256), 0, st, ws, (WT*)dW, n_cols, (int)chunks,
+                       accumulate);
+    return uamd_launch_status();
+}
+}  // namespace
+
+// dW[n_cols] (+)= sum over rows of dY * X * r. `workspace`: fp32 scratch of ws_elems >= n_cols elements (more = more row
+// chunks in flight: 2048 / ceil(n_cols / (256 * vec)) chunks x n_cols saturates the chip). dW in w_dtype.
+extern "C" int uamd_rms_layernorm_dw(const void* dY, const void* X, const float* r, void* dW, float* workspace,
+                                     int64_t ws_elems, int64_t n_rows, int n_cols, int64_t dy_row_stride,
+                                     int64_t x_row_stride, int accumulate, int x_dtype, int w_dtype, void* stream) {
+    if (n_rows < 0 || n_cols <= 0 || !dY || !X || !r || !dW || !workspace) return UAMD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_rows == 0) {
+        if (!accumulate) return (int)hipMemsetAsync(dW, 0, (size_t)n_cols * (w_dtype == UAMD_F32 ? 4 : 2), st);
+        return UAMD_OK;
+    }
+#define DW_CASE(XT, XC, WT, WC) \
+    if (x_dtype == XC && w_dtype == WC) \
+        return launch_dw<XT, WT>(dY, X, r, dW, workspace, ws_elems, n_rows, n_cols, dy_row_stride, x_row_stride, accumulate, st);
+    DW_CASE(bf16_t, UAMD_BF16, bf16_t, UAMD_BF16)
+    DW_CASE(bf16_t, UAMD_BF16, float, UAMD_F32)
+    DW_CASE(f16_t, UAMD_F16, f16_t, UAMD_F16)
+    DW_CASE(f16_t, UAMD_F16, float, UAMD_F32)
+    DW_CASE(float, UAMD_F32, float, UAMD_F32)
+#undef DW_CASE
+    return UAMD_ERR_DTYPE;
+}
+
 extern "C" int uamd_rms_layernorm_fwd(const void* X, const void* W, void* Y, float* r,
                                       int64_t n_rows, int n_cols, int64_t x_row_stride,
                                       int64_t y_row_stride, float eps, int gemma, int x_dtype,

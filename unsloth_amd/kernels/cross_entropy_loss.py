@@ -188,13 +188,18 @@ class _FusedLinearCE(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, hidden2d, weight, weight_t, labels, n_items, softcap, scale, chunk_rows):
+    def forward(ctx, hidden2d, weight, weight_t, labels, n_items, softcap, scale, chunk_rows, weight_param=None):
+        """`weight_param`: the lm_head Parameter when it TRAINS (full fine-tuning; `weight` is its detached value): its
+        gradient dW = sum over chunks dlogits^T @ h is accumulated chunk by chunk (uamd_gemm_tn_256) -- like d(hidden),
+        inside the forward, while the chunk of dlogits exists."""
         T, H = hidden2d.shape
         V = weight.shape[0]
         dev = hidden2d.device
         loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
-        need_grad = hidden2d.requires_grad
+        train_w = weight_param is not None and weight_param.requires_grad
+        need_grad = hidden2d.requires_grad or train_w
         dh = torch.empty_like(hidden2d) if need_grad else None
+        dW = None
         inv_n = (1.0 / n_items) if not torch.is_tensor(n_items) else (1.0 / n_items.to(torch.float32))
         for r0 in range(0, T, chunk_rows):
             r1 = min(T, r0 + chunk_rows)
@@ -209,18 +214,41 @@ class _FusedLinearCE(torch.autograd.Function):
                 dl = torch.ones(r1 - r0, dtype=torch.float32, device=dev) * inv_n
                 _ce_backward_(logits, dl, lse, lab, softcap, scale)        # logits <- dlogits
                 _dhidden(chunk, logits, weight, weight_t, dh[r0:r1])
-        ctx.save_for_backward(dh)
+                if train_w:
+                    # the padded chunk (zero columns beyond V) keeps the GEMM's 8-column granularity for any vocabulary
+                    if dW is None:
+                        dW = torch.empty((chunk.shape[1], H), dtype=hidden2d.dtype, device=dev)
+                    _u.dense_dw(chunk, h, out=dW, accumulate=r0 > 0)
+        ctx.save_for_backward(dh, dW)
+        ctx.weight_param = weight_param if train_w else None
         return loss_sum * inv_n
 
     @staticmethod
     def backward(ctx, dloss):
-        (dh,) = ctx.saved_tensors
-        if dh is not None:
+        dh, dW = ctx.saved_tensors
+        scale = dloss.to(torch.float32)
+        d_weight = None
+        if dW is not None:
+            P = ctx.weight_param
+            V = P.shape[0]
+            sink = _u.grad_sink(P)
+            if sink is not None:
+                view = sink.grad_view(P)
+                if sink.first_write(P):
+                    torch.mul(dW[:V], scale.to(dW.dtype), out=view)
+                else:
+                    view.add_(dW[:V] * scale.to(dW.dtype))
+                sink.ready(P)
+            else:
+                d_weight = (dW[:V].to(torch.float32) * scale).to(P.dtype)
+        if dh is not None and ctx.needs_input_grad[0]:
             # the upstream scale (1/accumulation steps, a GradScaler factor, ...) is applied in fp32 and the
             # product rounded once: casting the scalar to bf16 first would put 2^-9 of relative error on every
             # gradient of the step
-            dh = (dh.to(torch.float32) * dloss.to(torch.float32)).to(dh.dtype)
-        return dh, None, None, None, None, None, None, None
+            dh = (dh.to(torch.float32) * scale).to(dh.dtype)
+        else:
+            dh = None
+        return (dh, None, None, None, None, None, None, None, d_weight)[:len(ctx.needs_input_grad)]
 
 
 _WT_CACHE = {}
@@ -251,8 +279,8 @@ def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, 
                           logit_softcapping=0, logit_scaling=0, chunk_rows=None, **kwargs):
     """Same call signature as the reference's import (llama.py:1497-1509): shifts labels
     internally, never materialises [T, V], returns the scalar mean loss over n_items."""
-    if lm_head_bias is not None or lm_head_weight.requires_grad:
-        raise NotImplementedError("fused linear-CE: frozen, bias-free lm_head only")
+    if lm_head_bias is not None:
+        raise NotImplementedError("fused linear-CE: bias-free lm_head only")
     _lib.require_gpu(hidden_states)
     H = hidden_states.shape[-1]
     shift = torch.empty_like(labels)
@@ -273,8 +301,14 @@ def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, 
         chunk_rows = fused_ce_chunk_rows(h2d.shape[0], W.shape[0], h2d.element_size(), h2d.device, target_gb)
     nn = _nn_ok(min(int(chunk_rows), h2d.shape[0]), W.shape[0], W.shape[1]) and W.stride(1) == 1 and W.stride(0) % 8 == 0
     Wt = None if nn else _transposed_weight(W)
-    loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
-                                int(chunk_rows))
+    if lm_head_weight.requires_grad:
+        if W.dtype != lm_head_weight.dtype:
+            raise NotImplementedError("fused linear-CE with a trainable lm_head: weight and activations in one dtype")
+        loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
+                                    int(chunk_rows), lm_head_weight)
+    else:
+        loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
+                                    int(chunk_rows))
     if scaling is not None:
         loss = loss * scaling
     return loss

@@ -1,8 +1,10 @@
 """RMSNorm through the HIP kernels; mirror of unsloth/kernels/rms_layernorm.py.
 
 Same autograd contract as the reference's Fast_RMS_Layernorm (:162-240): saves (X, W, r); the
-backward writes dX IN PLACE over dY for the non-Gemma case (:92-95, :218) and returns no dW
-(norm weights are frozen under LoRA).
+backward writes dX IN PLACE over dY for the non-Gemma case (:92-95, :218). The reference returns no dW
+(norm weights are frozen under LoRA; with full_finetuning=True it leaves trainable norms to HF's torch module).
+Here a weight that requires grad gets it from `uamd_rms_layernorm_dw` (csrc/rms_layernorm.hip), computed from dY
+before the in-place dX pass overwrites it.
 """
 import torch
 
@@ -47,6 +49,42 @@ def add_rms_fwd(X, residual, W, eps):
             _lib.dtype_code(W.dtype), _lib.stream_of(X2))
     _lib.check(rc, "uamd_add_rms_layernorm_fwd")
     return H, Y, r
+
+
+def rms_dw(dY, X, r, W, out=None, accumulate=False):
+    """dW[c] (+)= sum_rows dY[row, c] * X[row, c] * r[row] in W's dtype (X = the norm's input). Deterministic."""
+    from .. import nf4 as _nf4
+    dY2, X2 = _rows(dY), _rows(X)
+    n_rows, dim = dY2.shape
+    if out is None:
+        out = torch.empty(dim, dtype=W.dtype, device=W.device)
+        accumulate = False
+    assert out.is_contiguous() and out.numel() == dim and out.dtype == W.dtype
+    col_blocks = (dim // (16 // dY2.element_size()) + 255) // 256
+    chunks = max(1, min((2048 + col_blocks - 1) // col_blocks, (n_rows + 7) // 8))
+    ws = _nf4.scratch(dY2.device, chunks * dim, torch.float32, slot=41)
+    with _lib.device_ctx(dY2):
+        rc = _lib.lib().uamd_rms_layernorm_dw(
+            _lib.ptr(dY2), _lib.ptr(X2), _lib.ptr(r), _lib.ptr(out), _lib.ptr(ws), ws.numel(), n_rows, dim,
+            dY2.stride(0), X2.stride(0), int(bool(accumulate)), _lib.dtype_code(dY2.dtype), _lib.dtype_code(W.dtype),
+            _lib.stream_of(dY2))
+    _lib.check(rc, "uamd_rms_layernorm_dw")
+    return out
+
+
+def _weight_grad(dY, X, r, W, needed):
+    """The norm weight's gradient for autograd (None when the weight is frozen): added straight into the parameter's
+    gradient sink when it has one (full fine-tuning's flat gradient buckets), else returned."""
+    if not needed:
+        return None
+    from .utils import grad_sink
+    sink = grad_sink(W)
+    if sink is not None:
+        first = sink.first_write(W) if hasattr(sink, "first_write") else False
+        rms_dw(dY, X, r, W, out=sink.grad_view(W).view(-1), accumulate=not first)
+        sink.ready(W)
+        return None
+    return rms_dw(dY, X, r, W)
 
 
 def rms_bwd_(dY, H, W, r, dH=None):
@@ -105,6 +143,7 @@ class Fast_RMS_Layernorm(torch.autograd.Function):
             dY = dY.contiguous()
         X, W, r = ctx.saved_tensors
         n_rows, n_cols = dY.shape
+        dW = _weight_grad(dY, X, r, W, ctx.needs_input_grad[1])
         dX = torch.empty_like(dY) if ctx.GEMMA else dY      # rms_layernorm.py:218
         with _lib.device_ctx(dY):
             rc = _lib.lib().uamd_rms_layernorm_bwd(
@@ -112,7 +151,7 @@ class Fast_RMS_Layernorm(torch.autograd.Function):
                 dY.stride(0), dX.stride(0), X.stride(0), int(ctx.GEMMA), _lib.dtype_code(dY.dtype),
                 _lib.dtype_code(W.dtype), _lib.stream_of(dY))
         _lib.check(rc, "uamd_rms_layernorm_bwd")
-        return dX.view(*shape), None, None, None
+        return dX.view(*shape), dW, None, None
 
 
 class Fast_Add_RMS_Layernorm(torch.autograd.Function):
@@ -157,6 +196,7 @@ class Fast_Add_RMS_Layernorm(torch.autograd.Function):
         if dY.stride(1) != 1:
             dY = dY.contiguous()
         n_rows = dY.shape[0]
+        dW = _weight_grad(dY, H, r, W, ctx.needs_input_grad[2])
         with _lib.device_ctx(dY):
             if dH is None:
                 rc = _lib.lib().uamd_rms_layernorm_bwd(
@@ -173,7 +213,7 @@ class Fast_Add_RMS_Layernorm(torch.autograd.Function):
                     _lib.dtype_code(W.dtype), _lib.stream_of(dY))
         _lib.check(rc, "uamd_add_rms_layernorm_bwd")
         dX = dY.view(*shape)                       # written over dY, like rms_layernorm.py:218
-        return dX, dX, None, None
+        return dX, dX, dW, None
 
 
 def add_rms_supported(X, W):

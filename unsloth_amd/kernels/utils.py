@@ -849,6 +849,45 @@ def lora_tn(problems, targets=None):
     return outs
 
 
+def dense_dw(dY, X, out=None, accumulate=False):
+    """dW[out, in] (+)= dY[T, out]^T @ X[T, in]: the weight gradient of a trainable dense projection (full fine-tuning;
+    torch.nn.Linear's `grad_output.t().mm(input)`). `dY` may be several projections' gradients side by side in one buffer
+    ([T, sum out_g]: dQ | dK | dV as the attention backward writes them) -- then `out` is their stacked gradient
+    [sum out_g, in]. One uamd_gemm_tn_256 launch, both operands read in place; a token count that is not a multiple of
+    64 is zero-padded (zero rows add nothing)."""
+    dY2d, X2d = _rows2d(dY), _rows2d(X)
+    _lib.require_gpu(X2d)
+    T, N_out = dY2d.shape
+    assert X2d.shape[0] == T and X2d.dtype == dY2d.dtype
+    dtype = X2d.dtype
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise NotImplementedError("the MFMA GEMM path takes bf16/fp16 activations")
+    N_in = X2d.shape[1]
+    if N_out % 8 or N_in % 8:
+        raise NotImplementedError(f"dense_dw: out {N_out} / in {N_in} features must be multiples of 8")
+    if T % 64:
+        pad = 64 - T % 64
+        dY2d = torch.nn.functional.pad(dY2d, (0, 0, 0, pad))
+        X2d = torch.nn.functional.pad(X2d, (0, 0, 0, pad))
+        T += pad
+    if dY2d.stride(1) != 1 or dY2d.stride(0) % 8 or dY2d.data_ptr() % 16:
+        dY2d = dY2d.contiguous()
+    if X2d.stride(1) != 1 or X2d.stride(0) % 8 or X2d.data_ptr() % 16:
+        X2d = X2d.contiguous()
+    if out is None:
+        out = torch.empty((N_out, N_in), dtype=dtype, device=X2d.device)
+        accumulate = False
+    assert out.dtype == dtype and tuple(out.shape) == (N_out, N_in) and out.stride(1) == 1
+    g = _group(X2d, out, N_in, X2d.stride(0))
+    g.ldc = out.stride(0)
+    arr = (GemmGroup * 1)(g)
+    with _lib.device_ctx(X2d):
+        rc = _lib.lib().uamd_gemm_tn_256(_lib.ptr(dY2d), dY2d.stride(0), N_out, T, arr, 1, int(bool(accumulate)),
+                                        _lib.dtype_code(dtype), _lib.stream_of(X2d))
+    _lib.check(rc, "uamd_gemm_tn_256")
+    return out
+
+
 def matmul_lora(X, W, W_quant, A, B, s, out=None):
     """utils.py:1128-1170: out = X @ dequant(W).T (+ s * (X @ A.T) @ B.T).
     `W` may be the transposed packed storage (`W.t()`, shape [1, n/2]) or a transposed dense view,

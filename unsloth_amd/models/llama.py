@@ -396,8 +396,8 @@ def CausalLM_fast_forward(original_forward):
         n_items = kwargs.get("num_items_in_batch", None)
         if n_items is None:
             n_items = kwargs.get("n_items", None)
-        can_fuse = (labels is not None and not RETURN_LOGITS and not lm_head.requires_grad
-                    and self.lm_head.bias is None and not logit_scaling)
+        can_fuse = (labels is not None and not RETURN_LOGITS and self.lm_head.bias is None and not logit_scaling
+                    and (not lm_head.requires_grad or lm_head.dtype == hidden_states.dtype))
         if can_fuse:
             labels = mask_packed_boundary_labels(labels.to(hidden_states.device), kwargs.get("packed_seq_lengths"))
             loss = unsloth_fused_ce_loss(trainer=None, hidden_states=hidden_states, lm_head_weight=lm_head,
@@ -651,6 +651,37 @@ class FastLlamaModel:
             print(f"Unsloth (MI355X) patched {len(inner.layers)} layers with {n_qkv} QKV layers, "
                   f"{n_o} O layers and {n_mlp} MLP layers.")                        # :3774-3777
         model.for_training = MethodType(FastLlamaModel.for_training, model)          # :3811-3817
+        model.for_inference = MethodType(FastLlamaModel.for_inference, model)
+        return model
+
+    @staticmethod
+    def patch_full_finetune(model):
+        """`full_finetuning=True` (loader.py:487-523; the reference leaves such a model to torch.nn.Linear + autograd):
+        per layer install the dense manual-autograd blocks of kernels/fast_dense.py -- fused Q|K|V, o_proj, SwiGLU MLP,
+        each with its weight gradient (uamd_gemm_tn_256) -- when the projections are plain 16-bit Linear modules."""
+        from ..kernels.fast_dense import apply_dense_mlp_swiglu, apply_dense_o, apply_dense_qkv
+        inner = model.model
+        n_mlp = n_qkv = n_o = 0
+
+        def ok(m):
+            return (type(m) is torch.nn.Linear and m.weight.dtype in (torch.bfloat16, torch.float16)
+                    and m.weight.is_cuda and m.in_features % 8 == 0 and m.out_features % 8 == 0)
+
+        swiglu = getattr(model.config, "hidden_act", "silu") == "silu"
+        for layer in inner.layers:
+            mlp, attn = layer.mlp, layer.self_attn
+            if swiglu and all(hasattr(mlp, n) and ok(getattr(mlp, n)) and getattr(mlp, n).bias is None
+                              for n in ("gate_proj", "up_proj", "down_proj")):
+                mlp.forward = MethodType(apply_dense_mlp_swiglu, mlp)
+                n_mlp += 1
+            if all(ok(getattr(attn, n)) for n in ("q_proj", "k_proj", "v_proj")):
+                attn.apply_qkv = apply_dense_qkv
+                n_qkv += 1
+            if ok(attn.o_proj):
+                attn.apply_o = apply_dense_o
+                n_o += 1
+        model._unsloth_amd_patched = (n_qkv, n_o, n_mlp)
+        model.for_training = MethodType(FastLlamaModel.for_training, model)
         model.for_inference = MethodType(FastLlamaModel.for_inference, model)
         return model
 

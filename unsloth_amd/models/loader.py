@@ -45,10 +45,14 @@ class FastLanguageModel:
                         device_map="sequential", rope_scaling=None, fix_tokenizer=True,
                         trust_remote_code=False, use_gradient_checkpointing="unsloth", config=None,
                         device=None, random_state=3407, *args, **kwargs):
-        if load_in_8bit or full_finetuning:
+        if load_in_8bit:
             raise NotImplementedError(
-                "8-bit / full fine-tuning go through FastModel + the unsloth_zoo compiler in the reference "
+                "8-bit loading goes through FastModel + the unsloth_zoo compiler in the reference "
                 "(loader.py:487-523); outside the QLoRA hot path (SURVEY 8(f4)).")
+        if full_finetuning and (load_in_4bit or load_in_16bit):
+            # vision.py:1162-1168: "You selected full finetuning support, but 4bit / 8bit is enabled - disabling LoRA / QLoRA."
+            load_in_4bit = load_in_16bit = False
+        os.environ["UNSLOTH_ENABLE_FULL_FINETUNING"] = "1" if full_finetuning else "0"        # vision.py:1247-1268
         dtype = _resolve_dtype(dtype)
         if device is None:
             dm = prepare_device_map()
@@ -107,7 +111,9 @@ class FastLanguageModel:
                 torch.set_default_dtype(old)
             model.to(dtype)
         for p in model.parameters():
-            p.requires_grad_(False)
+            p.requires_grad_(bool(full_finetuning))        # vision.py:2206-2209: layernorms, embeddings and lm_head train too
+        if full_finetuning and prequantized:
+            raise ValueError("full_finetuning=True needs 16-bit weights; this checkpoint is pre-quantised to NF4")
         if load_in_4bit and not load_in_16bit and not prequantized:
             quantize_model_nf4_(model)
             torch.cuda.empty_cache()
@@ -116,10 +122,16 @@ class FastLanguageModel:
         from ..kernels import post_patch_loss_function
         post_patch_loss_function(model)
         FastLlamaModel.for_training(model, use_gradient_checkpointing)
+        model._unsloth_full_finetuning = bool(full_finetuning)                                  # _utils.py:2899-2908
+        if full_finetuning:
+            FastLlamaModel.patch_full_finetune(model)
         return model, tokenizer
 
     @staticmethod
     def get_peft_model(model, *args, **kwargs):
+        if getattr(model, "_unsloth_full_finetuning", False):
+            print("Unsloth: Full finetuning is enabled, so .get_peft_model has no effect")      # vision.py:1884-1889
+            return model
         return FastLlamaModel.get_peft_model(model, *args, **kwargs)
 
     @staticmethod

@@ -123,6 +123,12 @@ def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999), arena=
     gradients and moments in flat arenas, ONE launch per step (`arena`: the dp.LoRAGradArena of a data-parallel run, else
     the optimizer creates its own). `flat=False` (or UNSLOTH_AMD_FLAT_ADAMW=0) keeps torch's fused AdamW."""
     params = [p for p in model.parameters() if p.requires_grad]
+    base = model.get_base_model() if hasattr(model, "get_base_model") else model
+    if getattr(base, "_unsloth_full_finetuning", False) and params and all(p.is_cuda for p in params):
+        # full fine-tuning: flat per-layer buckets + AdamW sharded over the data-parallel group (full_finetune.py)
+        from .full_finetune import FullGradBuckets, ShardedAdamW
+        return ShardedAdamW(arena if isinstance(arena, FullGradBuckets) else model, lr=lr, betas=betas,
+                            weight_decay=weight_decay)
     if flat is None:
         flat = os.environ.get("UNSLOTH_AMD_FLAT_ADAMW", "1") != "0"
     if flat and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
@@ -157,6 +163,10 @@ def unsloth_train(model, batches, optimizer=None, arena=None, max_steps=None, lo
     model.train()
     if arena is None and optimizer is not None and getattr(optimizer, "arena", None) is not None:
         arena = optimizer.arena                    # FlatAdamW built over (or with) an arena: that one exchanges the gradients
+    base = model.get_base_model() if hasattr(model, "get_base_model") else model
+    if arena is None and optimizer is None and getattr(base, "_unsloth_full_finetuning", False):
+        optimizer = make_optimizer(model)          # ShardedAdamW owns its FullGradBuckets
+        arena = optimizer.arena
     if arena is None and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         arena = LoRAGradArena(model)               # BEFORE the optimizer: FlatAdamW adopts it instead of creating a second one
     if optimizer is None:
