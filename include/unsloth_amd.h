@@ -137,6 +137,20 @@ int uamd_geglu_exact_forward(const void* e, const void* g, void* h, int64_t n, i
 int uamd_geglu_exact_backward(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
 int uamd_geglu_approx_forward(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream);
 int uamd_geglu_approx_backward(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
+/* The gated activation fused with the skinny LoRA products that would re-read its output (fast_lora.py:93-96: h = f(e) * g,
+ * then h @ A_down^T; :157, :172-189: h, df, de, then df @ B_up and de @ B_gate). act: 0 SwiGLU, 1 GeGLU exact, 2 GeGLU tanh;
+ * element-wise results bit-identical to the plain entry points above. e / g / h (DW) are [M, K] with row stride ld;
+ * W* are the LoRA factors as [R, K] with K contiguous (A_down; B_up^T, B_gate^T), R <= 64. out*: fp32 [M, ld_out], columns
+ * [R, out_cols) zero-filled; out_k* (may be NULL): the same sums rounded to `dtype` -- the rank-block operand
+ * uamd_gemm_group.lora_xk at its column offset -- columns [R, k_cols) zero-filled. K % 8 == 0, ld % 8 == 0. */
+int uamd_glu_fwd_xa(int act, const void* e, const void* g, void* h, int M, int K, int64_t ld, const void* W, int64_t ldw,
+                    int R, float* out, int64_t ld_out, int out_cols, void* out_k, int64_t ld_k, int k_cols, int dtype,
+                    void* stream);
+int uamd_glu_bwd_xa(int act, void* DW, void* e, void* g, int M, int K, int64_t ld,
+                    const void* Wu, int64_t ldwu, int Ru, float* out_u, int64_t ld_out_u, int out_cols_u,
+                    void* out_k_u, int64_t ld_k_u, int k_cols_u,
+                    const void* Wg, int64_t ldwg, int Rg, float* out_g, int64_t ld_out_g, int out_cols_g,
+                    void* out_k_g, int64_t ld_k_g, int k_cols_g, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Cross entropy.  Replaces cross_entropy_loss.py:35-111 / :114-199 (+ host logsumexp :366-370) and

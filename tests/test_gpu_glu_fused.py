@@ -1,0 +1,91 @@
+"""-m gpu: the gated activation fused with the LoRA skinny products (uamd_glu_fwd_xa / uamd_glu_bwd_xa, csrc/glu.hip):
+element-wise outputs BIT-IDENTICAL to the plain activation kernels, the rank products equal to the separate
+uamd_lora_xa2 launches up to fp32 summation order, and the whole LoRA_MLP block unchanged within that."""
+import pytest
+import torch
+
+from tests._util import rel_fro
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda", 0)
+
+
+def _proj(n_out, n_in, r, g, dtype):
+    W = (torch.randn(n_out, n_in, generator=g) * 0.02).to(dtype).to(DEV)
+    A = (torch.randn(r, n_in, generator=g) * 0.02).to(DEV)
+    B = (torch.randn(n_out, r, generator=g) * 0.02).to(DEV)
+    return (W, None, A, B, 2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("act", ["swiglu", "geglu_exact", "geglu_approx"])
+@pytest.mark.parametrize("M,K,r", [(2048, 14336, 16), (300, 1024, 8), (17, 264, 32), (4096, 5632, 64)])
+def test_fused_activation_and_rank_products(M, K, r, act, dtype):
+    from unsloth_amd.kernels import geglu, swiglu, utils as U
+    fwd = {"swiglu": swiglu.swiglu_fg_kernel, "geglu_exact": geglu.geglu_exact_forward_kernel,
+           "geglu_approx": geglu.geglu_approx_forward_kernel}[act]
+    bwd = {"swiglu": swiglu.swiglu_DWf_DW_dfg_kernel, "geglu_exact": geglu.geglu_exact_backward_kernel,
+           "geglu_approx": geglu.geglu_approx_backward_kernel}[act]
+    g_ = torch.Generator().manual_seed(M + K)
+    e = torch.randn(M, K, generator=g_).to(dtype).to(DEV)
+    g = torch.randn(M, K, generator=g_).to(dtype).to(DEV)
+    DW = (torch.randn(M, K, generator=g_) * 0.1).to(dtype).to(DEV)
+    H = 512
+    down = _proj(H, K, r, g_, dtype)
+    up, gate = _proj(K, H, r, g_, dtype), _proj(K, H, r, g_, dtype)
+    # forward
+    out = U.glu_fwd_xa(act, e, g, down)
+    assert out is not None
+    h, (xa, offs, xk) = out
+    h_ref = fwd(e.clone(), g.clone())
+    assert torch.equal(h, h_ref)
+    xa_ref, offs_ref, xk_ref = U._xa_and_rank_block(h_ref, [down[2]], xk is not None)
+    assert offs == offs_ref
+    truth = h_ref.float() @ down[2].to(dtype).float().t()
+    assert rel_fro(xa, truth) <= 2 * rel_fro(xa_ref, truth) + 1e-6
+    assert rel_fro(xa, xa_ref) < 1e-5
+    if xk is not None:
+        assert xk.shape == xk_ref.shape and torch.all(xk[:, r:] == 0)
+        assert rel_fro(xk.float(), xk_ref.float()) < 2e-3
+    # backward
+    DW1, e1, g1 = DW.clone(), e.clone(), g.clone()
+    res = U.glu_bwd_terms(act, DW1, e1, g1, up, gate)
+    assert res is not None
+    h2, df, de, (pu, pg) = res
+    DW2, e2, g2 = bwd(DW.clone(), e.clone(), g.clone())
+    assert torch.equal(h2, DW2) and torch.equal(df, e2) and torch.equal(de, g2)
+    tu, tg = U.lora_dx_terms([e2, g2], [up, gate])
+    assert rel_fro(pu, tu) < 1e-5 and rel_fro(pg, tg) < 1e-5
+    ku, kg = getattr(pu, "_uamd_xk", None), getattr(pg, "_uamd_xk", None)
+    ru_, rg_ = getattr(tu, "_uamd_xk", None), getattr(tg, "_uamd_xk", None)
+    assert (ku is None) == (ru_ is None)
+    if ku is not None:
+        assert ku[0] is kg[0] and ku[1] == ru_[1] and kg[1] == rg_[1] and ku[0].shape == ru_[0].shape
+        assert torch.all(ku[0][:, 2 * r:] == 0)
+        assert rel_fro(ku[0].float(), ru_[0].float()) < 2e-3
+
+
+def test_lora_mlp_block_with_and_without_the_fusion():
+    from unsloth_amd.kernels import utils as U
+    from unsloth_amd.kernels.fast_lora import LoRA_MLP
+    from unsloth_amd.kernels.swiglu import swiglu_DWf_DW_dfg_kernel, swiglu_fg_kernel
+    g_ = torch.Generator().manual_seed(0)
+    T, H, I, r = 2048, 1024, 2816, 16
+    dtype = torch.bfloat16
+    gate, up, down = _proj(I, H, r, g_, dtype), _proj(I, H, r, g_, dtype), _proj(H, I, r, g_, dtype)
+    X = torch.randn(1, T, H, generator=g_).to(dtype).to(DEV)
+    dY = (torch.randn(1, T, H, generator=g_) * 0.1).to(dtype).to(DEV)
+    res = {}
+    for fused in (True, False):
+        U.GLU_FUSED = fused
+        try:
+            ps = [torch.nn.Parameter(t.clone()) for p in (gate, up, down) for t in (p[2], p[3])]
+            x = X.clone().requires_grad_(True)
+            out = LoRA_MLP.apply(x, gate[0], None, ps[0], ps[1], 2.0, up[0], None, ps[2], ps[3], 2.0, down[0], None, ps[4],
+                                 ps[5], 2.0, swiglu_fg_kernel, swiglu_DWf_DW_dfg_kernel, False)
+            out.backward(dY.clone())
+            res[fused] = [out.detach().float(), x.grad.float()] + [p.grad.float() for p in ps]
+        finally:
+            U.GLU_FUSED = True
+    for a, b in zip(res[True], res[False]):
+        assert rel_fro(a, b) < 3e-3

@@ -117,6 +117,11 @@ SIGNATURES = {
                                                              c_int, c_void_p]),
     "uamd_lora_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "uamd_adamw_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [ctypes.c_double] * 8 + [c_int, c_void_p]),
+    "uamd_glu_fwd_xa": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_int,
+                                c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "uamd_glu_bwd_xa": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]
+                        + [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int] * 2
+                        + [c_int, c_void_p]),
     "uamd_adamw_shard": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [ctypes.c_double] * 8
                          + [c_int, c_void_p]),
     "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),

@@ -257,7 +257,233 @@ int bwd(void* dw, void* e, void* g, int64_t n, int dtype, void* stream) {
     return UAMD_ERR_DTYPE;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The gated activation FUSED with the skinny LoRA products that would otherwise re-read its output (fast_lora.py:93-96:
+// `h = f(e) * g` then `h @ A_down^T`; :157, :172-189: `h, df, de` then `df @ B_up`, `de @ B_gate`): the activation kernel
+// already has every element of h / df / de in registers, and [T, 14336] is the widest activation of the layer (235 MB at
+// 8192 tokens) -- reading it again for a rank-16 product costs as much as the product's whole launch
+// (profiles/r03d_step_sequence.csv: lora_xa2 55 us forward, 64 + 69 us backward per layer, next to 105 / 216 us of the
+// activation kernels themselves).
+// Block = 16 rows x 8 waves; wave w of round `it` owns columns (it * 8 + w) * 128 .. + 127 of those rows: four k-steps of
+// 32, lane (l15, l4) holding row l15, columns + 8 l4 .. + 7 -- the 16x16x32 MFMA's A-operand layout, so the freshly
+// computed 16-bit values go straight into the matrix pipe. All loads of a round are issued before the first use
+// (256 contiguous bytes per row per wave, 2 KiB per row per block round: DRAM sees the same bursts as from the plain
+// streaming kernel). The LoRA factor (W[r, K], K-contiguous: A_down, B_up^T, B_gate^T -- L2-resident, <= 1.8 MB) is the
+// B operand, loaded per lane as 16 bytes of row nt * 16 + l15. The 8 partial [16 x R] tiles are summed through LDS in
+// fixed order; outputs: fp32 [M, ld_out] (columns R.. zero-filled up to out_cols) and, optionally, the same sums rounded
+// to the activation dtype into the GEMM's rank-block operand (uamd_gemm_group.lora_xk) at its column offset.
+typedef __attribute__((ext_vector_type(8))) __bf16 glu_bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 glu_f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float glu_f32x4_t;
+template <typename T> struct GluMfma;
+template <> struct GluMfma<bf16_t> {
+    typedef glu_bf16x8_t frag;
+    static __device__ __forceinline__ glu_f32x4_t run(frag a, frag b, glu_f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct GluMfma<f16_t> {
+    typedef glu_f16x8_t frag;
+    static __device__ __forceinline__ glu_f32x4_t run(frag a, frag b, glu_f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+struct GluXaOut {
+    float* out;          // fp32 [M, ld_out]: columns [0, R) = the product, [R, out_cols) = 0
+    int64_t ld_out;
+    int R, out_cols;
+    void* out_k;         // activation dtype [M, ld_k] or null: columns [0, R) = rounded product, [R, k_cols) = 0
+    int64_t ld_k;
+    int k_cols;
+    const void* W;       // [R, K] activation dtype, K contiguous
+    int64_t ldw;
+};
+
+// NS = number of products (1: forward, h x A_down; 2: backward, df x B_up^T and de x B_gate^T), NT = 16-rank tiles each
+template <typename T, int ACT, int NS, int NT>
+__global__ void __launch_bounds__(512)
+glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __restrict__ H, int M, int K, int64_t ld,
+              GluXaOut o0, GluXaOut o1) {
+    typedef typename GluMfma<T>::frag frag_t;
+    __shared__ float red[8 * 16 * NS * NT * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int m0 = blockIdx.x * 16;
+    const int row = min(m0 + l15, M - 1);                       // clamped rows are computed and never stored
+    const bool row_ok = m0 + l15 < M;
+    const int64_t roff = (int64_t)row * ld;
+    glu_f32x4_t acc[NS][NT];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[s][t] = glu_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const T* W0 = (const T*)o0.W;
+    const T* W1 = (const T*)o1.W;
+    // rank rows past R re-read the last valid row (their sums are never stored)
+    int wrow0[NT], wrow1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        wrow0[t] = min(t * 16 + l15, o0.R - 1);
+        wrow1[t] = NS > 1 ? min(t * 16 + l15, o1.R - 1) : 0;
+    }
+    for (int kb = wave * 128; kb < K; kb += 8 * 128) {
+        Vec16<T> e[4], g[4], dw[4];
+        bool ok[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = kb + s * 32 + l4 * 8;
+            ok[s] = c + 8 <= K;
+            const int cc = ok[s] ? c : 0;
+            e[s] = ld16_nt(E + roff + cc);
+            g[s] = ld16_nt(G + roff + cc);
+            if (NS > 1) dw[s] = ld16_nt(DW + roff + cc);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = kb + s * 32 + l4 * 8;
+            Vec16<T> v0, v1;
+            v1.raw = make_uint4(0, 0, 0, 0);
+            if (NS == 1) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f;
+                    act_fwd<ACT>(to_f32(e[s].e[j]), f);
+                    v0.e[j] = from_f32<T>(round_to<T>(f) * to_f32(g[s].e[j]));
+                }
+                if (ok[s] && row_ok) st16_nt(H + roff + c, v0);
+            } else {
+                Vec16<T> h;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bwd_one<T, ACT>(dw[s].e[j], e[s].e[j], g[s].e[j], h.e[j], v0.e[j], v1.e[j]);
+                if (ok[s] && row_ok) {
+                    st16_nt(DW + roff + c, h);
+                    st16_nt(E + roff + c, v0);
+                    st16_nt(G + roff + c, v1);
+                }
+            }
+            union { uint4 r; frag_t f; } a0, a1, w;
+            a0.r = ok[s] ? v0.raw : make_uint4(0, 0, 0, 0);      // columns past K contribute nothing
+            a1.r = ok[s] ? v1.raw : make_uint4(0, 0, 0, 0);
+            const int cw = ok[s] ? c : 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                w.r = *reinterpret_cast<const uint4*>(W0 + (int64_t)wrow0[t] * o0.ldw + cw);
+                acc[0][t] = GluMfma<T>::run(a0.f, w.f, acc[0][t]);
+                if (NS > 1) {
+                    w.r = *reinterpret_cast<const uint4*>(W1 + (int64_t)wrow1[t] * o1.ldw + cw);
+                    acc[1][t] = GluMfma<T>::run(a1.f, w.f, acc[1][t]);
+                }
+            }
+        }
+    }
+    // ---- 8 partial tiles -> LDS -> fixed-order sum. acc[s][t][i] = C[row 4 l4 + i][rank t * 16 + l15]
+    constexpr int RW = NS * NT * 16;                             // floats per row of the reduction buffer
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * l4 + i) * RW + (s * NT + t) * 16 + l15] = acc[s][t][i];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const GluXaOut& o = s == 0 ? o0 : o1;
+        for (int idx = tid; idx < 16 * o.out_cols; idx += 512) {
+            const int mm = idx / o.out_cols, c = idx - mm * o.out_cols;
+            if (m0 + mm >= M) continue;
+            float v = 0.f;
+            if (c < o.R) {
+                const float* q = red + mm * RW + s * NT * 16 + c;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += q[w * 16 * RW];
+            }
+            o.out[(int64_t)(m0 + mm) * o.ld_out + c] = v;
+        }
+        if (o.out_k != nullptr) {
+            for (int idx = tid; idx < 16 * o.k_cols; idx += 512) {
+                const int mm = idx / o.k_cols, c = idx - mm * o.k_cols;
+                if (m0 + mm >= M) continue;
+                float v = 0.f;
+                if (c < o.R) {
+                    const float* q = red + mm * RW + s * NT * 16 + c;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) v += q[w * 16 * RW];
+                }
+                ((T*)o.out_k)[(int64_t)(m0 + mm) * o.ld_k + c] = from_f32<T>(v);
+            }
+        }
+    }
+}
+
+template <typename T, int ACT, int NS>
+int launch_xa(void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, const GluXaOut& o0, const GluXaOut& o1,
+              hipStream_t st) {
+    const int R = NS > 1 ? (o0.R > o1.R ? o0.R : o1.R) : o0.R;
+    const dim3 grid((unsigned)((M + 15) / 16)), block(512);
+    if (R <= 16)
+        hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 1>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
+    else if (R <= 32)
+        hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 2>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
+    else
+        hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 4>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
+    return uamd_launch_status();
+}
+
+int check_xa_out(const GluXaOut& o, int K) {
+    if (!o.out || !o.W || o.R < 1 || o.R > 64 || o.out_cols < o.R) return UAMD_ERR_ARG;
+    if ((o.ldw & 7) || !aligned16(o.W)) return UAMD_ERR_ALIGN;
+    if (o.out_k && o.k_cols < o.R) return UAMD_ERR_ARG;
+    (void)K;
+    return UAMD_OK;
+}
+
+template <int NS>
+int glu_xa_entry(int act, void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, const GluXaOut& o0,
+                 const GluXaOut& o1, int dtype, void* stream) {
+    if (M < 0 || K <= 0 || !e || !g || (NS == 1 ? !h : !dw)) return UAMD_ERR_ARG;
+    if (M == 0) return UAMD_OK;
+    if ((K & 7) || (ld & 7) || !aligned16(e) || !aligned16(g) || (NS == 1 ? !aligned16(h) : !aligned16(dw))) return UAMD_ERR_ALIGN;
+    int rc = check_xa_out(o0, K);
+    if (rc) return rc;
+    if (NS > 1 && (rc = check_xa_out(o1, K))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+#define GLU_XA_CASE(TT, DC)                                                                          \
+    if (dtype == DC) {                                                                              \
+        if (act == ACT_SWIGLU) return launch_xa<TT, ACT_SWIGLU, NS>(dw, e, g, h, M, K, ld, o0, o1, st);          \
+        if (act == ACT_GEGLU_EXACT) return launch_xa<TT, ACT_GEGLU_EXACT, NS>(dw, e, g, h, M, K, ld, o0, o1, st); \
+        if (act == ACT_GEGLU_APPROX) return launch_xa<TT, ACT_GEGLU_APPROX, NS>(dw, e, g, h, M, K, ld, o0, o1, st); \
+        return UAMD_ERR_ARG;                                                                        \
+    }
+    GLU_XA_CASE(bf16_t, UAMD_BF16)
+    GLU_XA_CASE(f16_t, UAMD_F16)
+#undef GLU_XA_CASE
+    return UAMD_ERR_DTYPE;
+}
+
 }  // namespace
+
+// h[M, K] = act(e) * g  AND  XA[M, R] = h @ W^T (W = the down projection's LoRA A, [R, K]) in one pass over e and g.
+// act: 0 = SwiGLU, 1 = GeGLU exact, 2 = GeGLU tanh. e / g / h share the row stride `ld` (elements). out: fp32 [M, ld_out],
+// columns [R, out_cols) zero-filled; out_k (may be null): the sums rounded to `dtype`, columns [R, k_cols) zero-filled.
+extern "C" int uamd_glu_fwd_xa(int act, const void* e, const void* g, void* h, int M, int K, int64_t ld, const void* W,
+                               int64_t ldw, int R, float* out, int64_t ld_out, int out_cols, void* out_k, int64_t ld_k,
+                               int k_cols, int dtype, void* stream) {
+    GluXaOut o0{out, ld_out, R, out_cols, out_k, ld_k, k_cols, W, ldw};
+    return glu_xa_entry<1>(act, nullptr, const_cast<void*>(e), const_cast<void*>(g), h, M, K, ld, o0, o0, dtype, stream);
+}
+
+// The in-place backward (DW <- h, e <- df, g <- de) AND P_u[M, R_u] = df @ Wu^T, P_g[M, R_g] = de @ Wg^T (Wu = B_up^T,
+// Wg = B_gate^T, [R, K] K-contiguous) in one pass. Outputs as above, one set per product.
+extern "C" int uamd_glu_bwd_xa(int act, void* DW, void* e, void* g, int M, int K, int64_t ld,
+                               const void* Wu, int64_t ldwu, int Ru, float* out_u, int64_t ld_out_u, int out_cols_u,
+                               void* out_k_u, int64_t ld_k_u, int k_cols_u,
+                               const void* Wg, int64_t ldwg, int Rg, float* out_g, int64_t ld_out_g, int out_cols_g,
+                               void* out_k_g, int64_t ld_k_g, int k_cols_g, int dtype, void* stream) {
+    GluXaOut o0{out_u, ld_out_u, Ru, out_cols_u, out_k_u, ld_k_u, k_cols_u, Wu, ldwu};
+    GluXaOut o1{out_g, ld_out_g, Rg, out_cols_g, out_k_g, ld_k_g, k_cols_g, Wg, ldwg};
+    return glu_xa_entry<2>(act, DW, e, g, nullptr, M, K, ld, o0, o1, dtype, stream);
+}
 
 extern "C" int uamd_swiglu_fg(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream) {
     return fwd<ACT_SWIGLU>(e, g, h, n, dtype, stream);

@@ -19,6 +19,7 @@ the data-parallel gradient arena. Each block also exists as a pair of plain func
 """
 import torch
 
+from .utils import glu_bwd_terms, glu_fwd_xa
 from .utils import (
     GRAD_SINKS,
     grad_sink,
@@ -89,11 +90,24 @@ def _lora_grads_fused(items):
 # ---- the blocks as plain functions (forward returns what the backward needs; nothing here touches autograd), used by
 #      the autograd.Function wrappers below AND by the whole-layer Function of models/fast_layer.py, which decides
 #      per tensor whether to keep it or to recompute it in the backward.
+_ACT_NAMES = {swiglu_fg_kernel: "swiglu", swiglu_DWf_DW_dfg_kernel: "swiglu",
+              geglu_exact_forward_kernel: "geglu_exact", geglu_exact_backward_kernel: "geglu_exact",
+              geglu_approx_forward_kernel: "geglu_approx", geglu_approx_backward_kernel: "geglu_approx"}
+
+
 def mlp_forward(X, gate, up, down, act_fwd):
-    """gate/up/down = (W, W_quant, A, B, s). Returns (out, e, g, (xa_gate, xa_up, xa_down)); fast_lora.py:93-96."""
+    """gate/up/down = (W, W_quant, A, B, s). Returns (out, e, g, (xa_gate, xa_up, xa_down)); fast_lora.py:93-96.
+    The activation kernel also produces h @ A_down^T while h is in its registers (utils.glu_fwd_xa) when it can."""
     (e, g), xa_gu = lora_linear_forward(X, [gate, up], return_xa=True)
-    h = act_fwd(e, g)
-    (out,), xa_d = lora_linear_forward(h, [down], return_xa=True)
+    act = _ACT_NAMES.get(act_fwd)
+    fused = glu_fwd_xa(act, e.view(-1, e.shape[-1]), g.view(-1, g.shape[-1]), down) if (
+        act is not None and e.is_contiguous() and g.is_contiguous()) else None
+    if fused is not None:
+        h, pre = fused
+        (out,), xa_d = lora_linear_forward(h.view(e.shape), [down], return_xa=True, pre_xa=pre)
+    else:
+        h = act_fwd(e, g)
+        (out,), xa_d = lora_linear_forward(h, [down], return_xa=True)
     return out, e, g, (xa_gu[0], xa_gu[1], xa_d[0])
 
 
@@ -115,9 +129,14 @@ def mlp_backward(dY, X, e, g, xas, gate, up, down, act_bwd, inplace=True):
     # DW = dY @ W_down (+ LoRA)                                     fast_lora.py:156
     (p_d,) = lora_dx_terms([dY], [down])
     DW = lora_linear_dx([dY], [down], terms=[p_d])
-    DW, e, g = act_bwd(DW, e, g)                                   # in place (:157)
-    h, df, de = DW, e, g
-    p_u, p_g = lora_dx_terms([df, de], [up, gate])
+    act = _ACT_NAMES.get(act_bwd)
+    fused = glu_bwd_terms(act, DW, e, g, up, gate) if (act is not None and DW.dim() == 2) else None
+    if fused is not None:                                          # activation backward + df @ B_up, de @ B_gate in one pass
+        h, df, de, (p_u, p_g) = fused
+    else:
+        DW, e, g = act_bwd(DW, e, g)                               # in place (:157)
+        h, df, de = DW, e, g
+        p_u, p_g = lora_dx_terms([df, de], [up, gate])
     if lora_tn_supported([h, dY, X2, df, de]):
         (d_downA, d_downB), (d_upA, d_upB), (d_gateA, d_gateB) = _lora_grads_fused([
             (h, dY, down[2], down[3], down[4], xa_d, p_d), (X2, df, up[2], up[3], up[4], xa_u, p_u),

@@ -481,7 +481,7 @@ def _xa_and_rank_block(X2d, A_list, want_k, out=None):
     return xa, offs, xk
 
 
-def lora_linear_forward(X, projs, outs=None, return_xa=False):
+def lora_linear_forward(X, projs, outs=None, return_xa=False, pre_xa=None):
     """Y_g = X @ W_g^T + s_g * (X @ A_g^T) @ B_g^T for projections `projs` = [(W, W_quant, A, B, s)]
     that share X. Returns a list of [.., N_g] tensors. This is matmul_lora (utils.py:1128-1170)
     for q/k/v or gate/up at once."""
@@ -505,7 +505,13 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False):
     dense_Ns = [n for n, f in zip(Ns, fused_nf4) if not f]
     use256 = bool(dense_Ns) and _use_gemm256(M, K, dense_Ns)
     xa, offs, xk = None, [], None
-    if with_lora:
+    if with_lora and pre_xa is not None:
+        # X @ A^T already produced by the kernel that produced X (glu_fwd_xa: the gated activation computes h @ A_down^T
+        # while h is in its registers); the rank block must be there iff this launch wants it
+        xa, offs, xk = pre_xa
+        if (xk is not None) != use256:
+            xa, offs, xk = _xa_and_rank_block(X2d, [p[2] for p in with_lora], use256)
+    elif with_lora:
         xa, offs, xk = _xa_and_rank_block(X2d, [p[2] for p in with_lora], use256)
     results, dense_groups, nf4_groups, keep = [], [], [], []
     resident = None
@@ -847,6 +853,79 @@ def lora_tn(problems, targets=None):
             rc = L.uamd_lora_tn(arr, len(chunk), M, _lib.ptr(ws), need, _lib.dtype_code(dtype), _lib.stream_of(ws))
         _lib.check(rc, "uamd_lora_tn")
     return outs
+
+
+GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "1") != "0"
+_GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
+
+
+def _glu_fusable(dtype, tensors, ranks):
+    K = tensors[0].shape[-1]
+    return (GLU_FUSED and LORA_XA_V2 and dtype in (torch.bfloat16, torch.float16) and K % 8 == 0
+            and all(t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.dtype == dtype and t.shape == tensors[0].shape
+                    for t in tensors)
+            and all(r is not None and r % 8 == 0 and 0 < r <= 64 for r in ranks))
+
+
+def glu_fwd_xa(act, e, g, down, n_out_cols_hint=None):
+    """h = act(e) * g AND the down projection's X A^T (fp32 [M, r]) + rank block, in ONE pass over e and g
+    (uamd_glu_fwd_xa). `down` = (W, W_quant, A, B, s[, bias]). Returns (h, pre_xa) with pre_xa = (xa, offs, xk) as
+    lora_linear_forward(pre_xa=) takes it, or None when the shapes do not allow the fusion (the caller then runs the plain
+    activation kernel and lets lora_linear_forward compute X A^T itself)."""
+    A = down[2]
+    if A is None or not _glu_fusable(e.dtype, [e, g], [A.shape[0]]):
+        return None
+    M, K = e.shape
+    dtype = e.dtype
+    r = A.shape[0]
+    W, q = down[0], down[1]
+    N = q.shape[0] if q is not None else W.shape[0]
+    fused_nf4 = q is not None and FUSED_NF4 and M < FUSED_NF4_MAX_M and q.blocksize == 64 and K % 64 == 0
+    want_k = (not fused_nf4) and _use_gemm256(M, K, [N])
+    Ac = _cached_cast(A, "rowmajor", dtype, lambda: A.to(dtype).contiguous())
+    h = torch.empty_like(e)
+    xa = torch.empty((M, r), dtype=torch.float32, device=e.device)
+    xk = torch.empty((M, _rank_width(r)), dtype=dtype, device=e.device) if want_k else None
+    with _lib.device_ctx(e):
+        rc = _lib.lib().uamd_glu_fwd_xa(_GLU_ACTS[act], _lib.ptr(e), _lib.ptr(g), _lib.ptr(h), M, K, e.stride(0), _lib.ptr(Ac),
+                                        Ac.stride(0), r, _lib.ptr(xa), xa.stride(0), r,
+                                        _lib.ptr(xk) if xk is not None else None, xk.stride(0) if xk is not None else 0,
+                                        xk.shape[1] if xk is not None else 0, _lib.dtype_code(dtype), _lib.stream_of(e))
+    _lib.check(rc, "uamd_glu_fwd_xa")
+    return h, (xa, [(0, r)], xk)
+
+
+def glu_bwd_terms(act, DW, e, g, up, gate):
+    """The in-place activation backward (DW <- h, e <- df, g <- de) AND P_up = df @ B_up, P_gate = de @ B_gate -- the
+    lora_dx_terms([df, de], [up, gate]) of fast_lora.mlp_backward -- in ONE pass (uamd_glu_bwd_xa). Returns
+    (h, df, de, [p_up, p_gate]) or None when the shapes do not allow the fusion."""
+    (Au, Bu), (Ag, Bg) = (up[2], up[3]), (gate[2], gate[3])
+    if Au is None or Ag is None or not _glu_fusable(e.dtype, [DW, e, g], [Au.shape[0], Ag.shape[0]]):
+        return None
+    M, K = e.shape
+    dtype = e.dtype
+    ru, rg = Au.shape[0], Ag.shape[0]
+    Kin = [(p[1].shape[1] if p[1] is not None else p[0].shape[1]) for p in (up, gate)]
+    want_k = all(_use_gemm256(M, 64, [k]) for k in Kin)
+    But = _cached_cast(Bu, "T", dtype, lambda: Bu.to(dtype).t().contiguous())        # [r, K]
+    Bgt = _cached_cast(Bg, "T", dtype, lambda: Bg.to(dtype).t().contiguous())
+    shared = torch.empty((M, ru + rg), dtype=torch.float32, device=e.device)
+    xk = torch.empty((M, _rank_width(ru + rg)), dtype=dtype, device=e.device) if want_k else None
+    pu, pg = shared[:, :ru], shared[:, ru:]
+    null = None
+    with _lib.device_ctx(e):
+        rc = _lib.lib().uamd_glu_bwd_xa(
+            _GLU_ACTS[act], _lib.ptr(DW), _lib.ptr(e), _lib.ptr(g), M, K, e.stride(0),
+            _lib.ptr(But), But.stride(0), ru, _lib.ptr(pu), shared.stride(0), ru,
+            _lib.ptr(xk) if want_k else null, xk.stride(0) if want_k else 0, ru if want_k else 0,
+            _lib.ptr(Bgt), Bgt.stride(0), rg, _lib.ptr(pg), shared.stride(0), rg,
+            _lib.ptr(xk[:, ru:]) if want_k else null, xk.stride(0) if want_k else 0, (xk.shape[1] - ru) if want_k else 0,
+            _lib.dtype_code(dtype), _lib.stream_of(e))
+    _lib.check(rc, "uamd_glu_bwd_xa")
+    if want_k:
+        pu._uamd_xk = (xk, 0)
+        pg._uamd_xk = (xk, ru)
+    return DW, e, g, [pu, pg]
 
 
 def dense_dw(dY, X, out=None, accumulate=False):
