@@ -288,6 +288,41 @@ def main():
             del eng
             torch.cuda.empty_cache()
             model.train()
+        if os.environ.get("BENCH_FULLFT_ALT", "1") == "1" and world == 1:
+            # BASELINE config 3 on ONE GPU: the same architecture fully trainable in bf16 (dense dW GEMMs, norm / lm_head /
+            # embedding gradients, flat buckets, fp32-master AdamW: 16 + 16 + 96 GB of the 288), world size 1 = no collective
+            try:
+                from unsloth_amd.full_finetune import ShardedAdamW, full_finetune_step
+                timer.enabled = False
+                fmodel, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
+                                                              full_finetuning=True, device=dev, random_state=3407,
+                                                              use_gradient_checkpointing=False)
+                fopt = ShardedAdamW(fmodel, lr=1e-5)
+                fl = []
+                for i in range(2):
+                    fl.append(full_finetune_step(fmodel, batches[i % 2], fopt, n_items))
+                sync()
+                torch.cuda.reset_peak_memory_stats()
+                ft = []
+                for i in range(a.alt_steps):
+                    ts = time.perf_counter()
+                    fl.append(full_finetune_step(fmodel, batches[i % 2], fopt, n_items))
+                    sync()
+                    ft.append(time.perf_counter() - ts)
+                fdt = sorted(ft)[len(ft) // 2]
+                n_all = sum(p.numel() for p in fmodel.parameters())
+                alt["config3_full_finetune_bf16_1gpu (every parameter trains, fp32-master AdamW)"] = {
+                    "batch": B, "steps": a.alt_steps, "timing": "median step", "value": round(B * T / fdt, 1),
+                    "ms_per_step": round(fdt * 1e3, 2), "peak_vram_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+                    "trainable_params": n_all, "model_tflops_per_s": round(6.0 * n_all * B * T / fdt / 1e12, 1),
+                    "loss_first_last": [round(float(fl[0]), 4), round(float(fl[-1]), 4)]}
+                fopt.buckets.close()
+                del fmodel, fopt
+                torch.cuda.empty_cache()
+            except Exception as ex:                     # an operating point must never take the primary record down with it
+                alt["config3_full_finetune_bf16_1gpu"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                torch.cuda.empty_cache()
+            os.environ["UNSLOTH_ENABLE_FULL_FINETUNING"] = "0"
     rccl_ranks = None
     if dist.is_initialized():
         one = torch.ones(1, device=dev)

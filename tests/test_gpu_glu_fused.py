@@ -22,6 +22,15 @@ def _proj(n_out, n_in, r, g, dtype):
 @pytest.mark.parametrize("M,K,r", [(2048, 14336, 16), (300, 1024, 8), (17, 264, 32), (4096, 5632, 64)])
 def test_fused_activation_and_rank_products(M, K, r, act, dtype):
     from unsloth_amd.kernels import geglu, swiglu, utils as U
+    monkey = U.GLU_FUSED
+    U.GLU_FUSED = "all"
+    try:
+        _fused_case(M, K, r, act, dtype, geglu, swiglu, U)
+    finally:
+        U.GLU_FUSED = monkey
+
+
+def _fused_case(M, K, r, act, dtype, geglu, swiglu, U):
     fwd = {"swiglu": swiglu.swiglu_fg_kernel, "geglu_exact": geglu.geglu_exact_forward_kernel,
            "geglu_approx": geglu.geglu_approx_forward_kernel}[act]
     bwd = {"swiglu": swiglu.swiglu_DWf_DW_dfg_kernel, "geglu_exact": geglu.geglu_exact_backward_kernel,
@@ -35,6 +44,9 @@ def test_fused_activation_and_rank_products(M, K, r, act, dtype):
     up, gate = _proj(K, H, r, g_, dtype), _proj(K, H, r, g_, dtype)
     # forward
     out = U.glu_fwd_xa(act, e, g, down)
+    if act != "swiglu":                       # only the hot path's activation takes the fused kernels
+        assert out is None and U.glu_bwd_terms(act, DW.clone(), e.clone(), g.clone(), up, gate) is None
+        return
     assert out is not None
     h, (xa, offs, xk) = out
     h_ref = fwd(e.clone(), g.clone())
@@ -76,7 +88,8 @@ def test_lora_mlp_block_with_and_without_the_fusion():
     X = torch.randn(1, T, H, generator=g_).to(dtype).to(DEV)
     dY = (torch.randn(1, T, H, generator=g_) * 0.1).to(dtype).to(DEV)
     res = {}
-    for fused in (True, False):
+    keep = U.GLU_FUSED
+    for fused in ("all", False):
         U.GLU_FUSED = fused
         try:
             ps = [torch.nn.Parameter(t.clone()) for p in (gate, up, down) for t in (p[2], p[3])]
@@ -86,6 +99,6 @@ def test_lora_mlp_block_with_and_without_the_fusion():
             out.backward(dY.clone())
             res[fused] = [out.detach().float(), x.grad.float()] + [p.grad.float() for p in ps]
         finally:
-            U.GLU_FUSED = True
-    for a, b in zip(res[True], res[False]):
+            U.GLU_FUSED = keep
+    for a, b in zip(res["all"], res[False]):
         assert rel_fro(a, b) < 3e-3

@@ -264,14 +264,10 @@ int bwd(void* dw, void* e, void* g, int64_t n, int dtype, void* stream) {
 // 8192 tokens) -- reading it again for a rank-16 product costs as much as the product's whole launch
 // (profiles/r03d_step_sequence.csv: lora_xa2 55 us forward, 64 + 69 us backward per layer, next to 105 / 216 us of the
 // activation kernels themselves).
-// Block = 16 rows x 8 waves; wave w of round `it` owns columns (it * 8 + w) * 128 .. + 127 of those rows: four k-steps of
-// 32, lane (l15, l4) holding row l15, columns + 8 l4 .. + 7 -- the 16x16x32 MFMA's A-operand layout, so the freshly
-// computed 16-bit values go straight into the matrix pipe. All loads of a round are issued before the first use
-// (256 contiguous bytes per row per wave, 2 KiB per row per block round: DRAM sees the same bursts as from the plain
-// streaming kernel). The LoRA factor (W[r, K], K-contiguous: A_down, B_up^T, B_gate^T -- L2-resident, <= 1.8 MB) is the
-// B operand, loaded per lane as 16 bytes of row nt * 16 + l15. The 8 partial [16 x R] tiles are summed through LDS in
-// fixed order; outputs: fp32 [M, ld_out] (columns R.. zero-filled up to out_cols) and, optionally, the same sums rounded
-// to the activation dtype into the GEMM's rank-block operand (uamd_gemm_group.lora_xk) at its column offset.
+// The 4 partial [16 x R] tiles of a block are summed through LDS in fixed order; outputs: fp32 [M, ld_out] (columns R..
+// zero-filled up to out_cols) and, optionally, the same sums rounded to the activation dtype into the GEMM's rank-block
+// operand (uamd_gemm_group.lora_xk) at its column offset. (First version, measured +2.6 % on the step: lanes read 64 bytes
+// per row straight into the MFMA operand layout -- half lines, nothing prefetched; profiles/r03h_glu_fused_ab.txt.)
 typedef __attribute__((ext_vector_type(8))) __bf16 glu_bf16x8_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 glu_f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float glu_f32x4_t;
@@ -300,19 +296,32 @@ struct GluXaOut {
     int64_t ldw;
 };
 
-// NS = number of products (1: forward, h x A_down; 2: backward, df x B_up^T and de x B_gate^T), NT = 16-rank tiles each
+// NS = number of products (1: forward, h x A_down; 2: backward, df x B_up^T and de x B_gate^T), NT = 16-rank tiles each.
+// Block = 256 threads = 4 waves, 16 rows x all K in tiles of 256 columns (three blocks per CU):
+//   * global access is streaming: a wave instruction reads / writes two 512-byte row pieces (thread t, vector v: row
+//     8 v + 2 wave + (lane >> 5), columns 8 (lane & 31) ..), the next tile's loads are issued before the current tile is
+//     computed;
+//   * the 16-bit results also go into an LDS tile [16 rows][256 + 8 columns] (row stride 528 B: the 16 rows of a
+//     fragment read start 4 banks apart), double-buffered, ONE barrier per tile;
+//   * wave w then contracts k-steps w and w + 4 of the tile on the matrix cores: A operand = ds_read_b128 of
+//     the tile (row l15, 8 columns at 32 ks + 8 l4), B operand = 16 bytes of the LoRA factor's row nt * 16 + l15 (L2),
+//     requested at the top of the tile so that the activation arithmetic hides the latency.
+constexpr int GX_TK = 256;                       // columns per tile
+constexpr int GX_LD = GX_TK * 2 + 16;            // LDS row stride in bytes
+constexpr int GX_TILE = 16 * GX_LD;              // 8,448 B per operand tile
+
 template <typename T, int ACT, int NS, int NT>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(256)
 glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __restrict__ H, int M, int K, int64_t ld,
               GluXaOut o0, GluXaOut o1) {
     typedef typename GluMfma<T>::frag frag_t;
-    __shared__ float red[8 * 16 * NS * NT * 16];
+    constexpr int NV = 2, NQ = 2;                                        // vectors per thread per tensor, k-steps per wave
+    constexpr int RED = 4 * 16 * NS * NT * 16 * 4;                       // bytes of the final reduction buffer
+    constexpr int LDS_B = 2 * NS * GX_TILE > RED ? 2 * NS * GX_TILE : RED;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int m0 = blockIdx.x * 16;
-    const int row = min(m0 + l15, M - 1);                       // clamped rows are computed and never stored
-    const bool row_ok = m0 + l15 < M;
-    const int64_t roff = (int64_t)row * ld;
     glu_f32x4_t acc[NS][NT];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -320,65 +329,122 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
         for (int t = 0; t < NT; ++t) acc[s][t] = glu_f32x4_t{0.f, 0.f, 0.f, 0.f};
     const T* W0 = (const T*)o0.W;
     const T* W1 = (const T*)o1.W;
-    // rank rows past R re-read the last valid row (their sums are never stored)
-    int wrow0[NT], wrow1[NT];
+    int64_t woff0[NT], woff1[NT];                                       // rank rows past R re-read the last valid row
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        wrow0[t] = min(t * 16 + l15, o0.R - 1);
-        wrow1[t] = NS > 1 ? min(t * 16 + l15, o1.R - 1) : 0;
+        woff0[t] = (int64_t)min(t * 16 + l15, o0.R - 1) * o0.ldw + l4 * 8;
+        woff1[t] = NS > 1 ? (int64_t)min(t * 16 + l15, o1.R - 1) * o1.ldw + l4 * 8 : 0;
     }
-    for (int kb = wave * 128; kb < K; kb += 8 * 128) {
-        Vec16<T> e[4], g[4], dw[4];
-        bool ok[4];
+    // streaming side: vector v of this thread = row 8 v + 2 wave + (lane >> 5) of the block, columns 8 (lane & 31) ..
+    const int srow = 2 * wave + (lane >> 5), scol = (lane & 31) * 8;
+    int64_t roff[NV];
+    bool row_ok[NV];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int c = kb + s * 32 + l4 * 8;
-            ok[s] = c + 8 <= K;
-            const int cc = ok[s] ? c : 0;
-            e[s] = ld16_nt(E + roff + cc);
-            g[s] = ld16_nt(G + roff + cc);
-            if (NS > 1) dw[s] = ld16_nt(DW + roff + cc);
+    for (int v = 0; v < NV; ++v) {
+        const int r = m0 + 8 * v + srow;
+        row_ok[v] = r < M;
+        roff[v] = (int64_t)(row_ok[v] ? r : M - 1) * ld;                 // clamped rows are computed and never stored
+    }
+    const int ntiles = (K + GX_TK - 1) / GX_TK;
+    // two register sets for the streamed operands AND the LoRA factor's fragments, used alternately (the loop is unrolled
+    // by two: a `cur = next` copy at the end of a tile would make the compiler wait for the prefetch right there). One set
+    // = everything tile `it` consumes, requested one tile ahead in consumption order (vmcnt retires in order: data first,
+    // fragments second, then the previous tile's stores -- no wait ever covers a younger request).
+    struct Regs {
+        Vec16<T> e[NV], g[NV], dw[NV];
+        uint4 wf0[NQ][NT], wf1[NS > 1 ? NQ : 1][NT];
+    };
+    Regs A, B;
+    auto load_tile = [&](int it, Regs& r) {
+        const int c = it * GX_TK + scol;
+        const int cc = c + 8 <= K ? c : 0;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            r.e[v] = ld16_nt(E + roff[v] + cc);
+            r.g[v] = ld16_nt(G + roff[v] + cc);
+            if (NS > 1) r.dw[v] = ld16_nt(DW + roff[v] + cc);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int c = kb + s * 32 + l4 * 8;
+        for (int q = 0; q < NQ; ++q) {
+            const int kc = it * GX_TK + (wave + 4 * q) * 32;
+            const int kk = kc + l4 * 8 + 8 <= K ? kc : 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                r.wf0[q][t] = *reinterpret_cast<const uint4*>(W0 + woff0[t] + kk);
+                if (NS > 1) r.wf1[q][t] = *reinterpret_cast<const uint4*>(W1 + woff1[t] + kk);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto tile = [&](int it, Regs& r, Regs& rn) {
+        unsigned char* buf = smem + (it & 1) * NS * GX_TILE;
+        // unconditional (the last tile is simply fetched once more: behind a branch the compiler drains vmcnt at the join)
+        load_tile(it + 1 < ntiles ? it + 1 : it, rn);
+        const int c = it * GX_TK + scol;
+        const bool col_ok = c + 8 <= K;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
             Vec16<T> v0, v1;
             v1.raw = make_uint4(0, 0, 0, 0);
             if (NS == 1) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float f;
-                    act_fwd<ACT>(to_f32(e[s].e[j]), f);
-                    v0.e[j] = from_f32<T>(round_to<T>(f) * to_f32(g[s].e[j]));
+                    act_fwd<ACT>(to_f32(r.e[v].e[j]), f);
+                    v0.e[j] = from_f32<T>(round_to<T>(f) * to_f32(r.g[v].e[j]));
                 }
-                if (ok[s] && row_ok) st16_nt(H + roff + c, v0);
+                if (col_ok && row_ok[v]) st16_nt(H + roff[v] + c, v0);
             } else {
                 Vec16<T> h;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) bwd_one<T, ACT>(dw[s].e[j], e[s].e[j], g[s].e[j], h.e[j], v0.e[j], v1.e[j]);
-                if (ok[s] && row_ok) {
-                    st16_nt(DW + roff + c, h);
-                    st16_nt(E + roff + c, v0);
-                    st16_nt(G + roff + c, v1);
+                for (int j = 0; j < 8; ++j) bwd_one<T, ACT>(r.dw[v].e[j], r.e[v].e[j], r.g[v].e[j], h.e[j], v0.e[j], v1.e[j]);
+                if (col_ok && row_ok[v]) {
+                    st16_nt(DW + roff[v] + c, h);
+                    st16_nt(E + roff[v] + c, v0);
+                    st16_nt(G + roff[v] + c, v1);
                 }
             }
+            if (!col_ok) {                                               // columns past K contribute nothing
+                v0.raw = make_uint4(0, 0, 0, 0);
+                v1.raw = make_uint4(0, 0, 0, 0);
+            }
+            unsigned char* dst = buf + (8 * v + srow) * GX_LD + scol * 2;
+            *reinterpret_cast<uint4*>(dst) = v0.raw;
+            if (NS > 1) *reinterpret_cast<uint4*>(dst + GX_TILE) = v1.raw;
+        }
+        // the tile is complete (and buf ^ 1 is free again). NOT __syncthreads(): that drains vmcnt too, i.e. waits for
+        // the NEXT tile's loads issued above -- the prefetch would buy nothing (first build: 4.1 / 4.65 TB/s)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const unsigned char* src = buf + l15 * GX_LD + ((wave + 4 * q) * 32 + l4 * 8) * 2;
             union { uint4 r; frag_t f; } a0, a1, w;
-            a0.r = ok[s] ? v0.raw : make_uint4(0, 0, 0, 0);      // columns past K contribute nothing
-            a1.r = ok[s] ? v1.raw : make_uint4(0, 0, 0, 0);
-            const int cw = ok[s] ? c : 0;
+            a0.r = *reinterpret_cast<const uint4*>(src);
+            if (NS > 1) a1.r = *reinterpret_cast<const uint4*>(src + GX_TILE);
+            const bool k_ok = it * GX_TK + (wave + 4 * q) * 32 + l4 * 8 + 8 <= K;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                w.r = *reinterpret_cast<const uint4*>(W0 + (int64_t)wrow0[t] * o0.ldw + cw);
+                w.r = k_ok ? r.wf0[q][t] : make_uint4(0, 0, 0, 0);
                 acc[0][t] = GluMfma<T>::run(a0.f, w.f, acc[0][t]);
                 if (NS > 1) {
-                    w.r = *reinterpret_cast<const uint4*>(W1 + (int64_t)wrow1[t] * o1.ldw + cw);
+                    w.r = k_ok ? r.wf1[q][t] : make_uint4(0, 0, 0, 0);
                     acc[1][t] = GluMfma<T>::run(a1.f, w.f, acc[1][t]);
                 }
             }
         }
+    };
+    load_tile(0, A);
+    for (int it = 0; it < ntiles; it += 2) {
+        tile(it, A, B);
+        if (it + 1 < ntiles) tile(it + 1, B, A);
     }
-    // ---- 8 partial tiles -> LDS -> fixed-order sum. acc[s][t][i] = C[row 4 l4 + i][rank t * 16 + l15]
-    constexpr int RW = NS * NT * 16;                             // floats per row of the reduction buffer
+    // ---- 4 partial tiles -> LDS -> fixed-order sum. acc[s][t][i] = C[row 4 l4 + i][rank t * 16 + l15]
+    constexpr int RW = NS * NT * 16;                                     // floats per row of the reduction buffer
+    __syncthreads();                                                     // every wave is done with the operand tiles
+    float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -389,26 +455,26 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const GluXaOut& o = s == 0 ? o0 : o1;
-        for (int idx = tid; idx < 16 * o.out_cols; idx += 512) {
+        for (int idx = tid; idx < 16 * o.out_cols; idx += 256) {
             const int mm = idx / o.out_cols, c = idx - mm * o.out_cols;
             if (m0 + mm >= M) continue;
             float v = 0.f;
             if (c < o.R) {
                 const float* q = red + mm * RW + s * NT * 16 + c;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) v += q[w * 16 * RW];
+                for (int w = 0; w < 4; ++w) v += q[w * 16 * RW];
             }
             o.out[(int64_t)(m0 + mm) * o.ld_out + c] = v;
         }
         if (o.out_k != nullptr) {
-            for (int idx = tid; idx < 16 * o.k_cols; idx += 512) {
+            for (int idx = tid; idx < 16 * o.k_cols; idx += 256) {
                 const int mm = idx / o.k_cols, c = idx - mm * o.k_cols;
                 if (m0 + mm >= M) continue;
                 float v = 0.f;
                 if (c < o.R) {
                     const float* q = red + mm * RW + s * NT * 16 + c;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) v += q[w * 16 * RW];
+    #pragma unroll
+                for (int w = 0; w < 4; ++w) v += q[w * 16 * RW];
                 }
                 ((T*)o.out_k)[(int64_t)(m0 + mm) * o.ld_k + c] = from_f32<T>(v);
             }
@@ -420,7 +486,7 @@ template <typename T, int ACT, int NS>
 int launch_xa(void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, const GluXaOut& o0, const GluXaOut& o1,
               hipStream_t st) {
     const int R = NS > 1 ? (o0.R > o1.R ? o0.R : o1.R) : o0.R;
-    const dim3 grid((unsigned)((M + 15) / 16)), block(512);
+    const dim3 grid((unsigned)((M + 15) / 16)), block(256);
     if (R <= 16)
         hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 1>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
     else if (R <= 32)

@@ -251,27 +251,26 @@ class _FusedLinearCE(torch.autograd.Function):
         return (dh, None, None, None, None, None, None, None, d_weight)[:len(ctx.needs_input_grad)]
 
 
-_WT_CACHE = {}
-
-
-def _transposed_weight(weight):
-    """W^T [H, Vp] of the frozen lm_head (vocabulary zero-padded to a multiple of 8), built once per weight
-    version (288 GB HBM: 1 GB is cheap, and it turns the d(hidden) product into the same K-contiguous NT GEMM
-    as everything else)."""
-    key = weight.data_ptr()
+def _transposed_weight(weight, owner=None):
+    """W^T [H, Vp] of the frozen lm_head (vocabulary zero-padded to a multiple of 8) for the shapes the NN form of the
+    GEMM does not take. Cached ON `owner` (the lm_head Parameter: the copy lives and dies with it, and is rebuilt when
+    its version or storage changes); without an owner it is built per call -- a cache keyed on the data pointer alone
+    would hand a NEW tensor that the allocator placed at a freed lm_head's address the old model's transpose."""
     V, H = weight.shape
     Vp = _padded_vocab(V)
-    ent = _WT_CACHE.get(key)
-    if ent is None or ent[0] != weight._version or ent[1].shape != (H, Vp):
-        _WT_CACHE.clear()
-        if Vp == V:
-            wt = weight.detach().t().contiguous()
-        else:
-            wt = torch.zeros((H, Vp), dtype=weight.dtype, device=weight.device)
-            wt[:, :V] = weight.detach().t()
-        ent = (weight._version, wt)
-        _WT_CACHE[key] = ent
-    return ent[1]
+    if owner is not None:
+        ent = getattr(owner, "_uamd_wt", None)
+        if ent is not None and ent[0] == owner._version and ent[1] == weight.data_ptr() and ent[2].shape == (H, Vp) \
+                and ent[2].dtype == weight.dtype:
+            return ent[2]
+    if Vp == V:
+        wt = weight.detach().t().contiguous()
+    else:
+        wt = torch.zeros((H, Vp), dtype=weight.dtype, device=weight.device)
+        wt[:, :V] = weight.detach().t()
+    if owner is not None:
+        owner._uamd_wt = (owner._version, weight.data_ptr(), wt)
+    return wt
 
 
 def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, labels, mask=None,
@@ -300,7 +299,7 @@ def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, 
     if chunk_rows is None:
         chunk_rows = fused_ce_chunk_rows(h2d.shape[0], W.shape[0], h2d.element_size(), h2d.device, target_gb)
     nn = _nn_ok(min(int(chunk_rows), h2d.shape[0]), W.shape[0], W.shape[1]) and W.stride(1) == 1 and W.stride(0) % 8 == 0
-    Wt = None if nn else _transposed_weight(W)
+    Wt = None if nn else _transposed_weight(W, lm_head_weight if W.dtype == lm_head_weight.dtype else None)
     if lm_head_weight.requires_grad:
         if W.dtype != lm_head_weight.dtype:
             raise NotImplementedError("fused linear-CE with a trainable lm_head: weight and activations in one dtype")

@@ -855,13 +855,22 @@ def lora_tn(problems, targets=None):
     return outs
 
 
-GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "1") != "0"
+# the gated activation fused with the LoRA skinny products (csrc/glu.hip glu_xa_kernel). Measured at Llama-3-8B MLP widths
+# (profiles/r03j_glu_fused_bench.jsonl): backward 291 us against 350 us for the separate launches at 8192 tokens (118 vs
+# 109 at 2048: 128 blocks leave half the chip idle), forward 161 vs 143 -- so by default the BACKWARD is fused from 4096
+# tokens on and the forward is not. UNSLOTH_AMD_GLU_FUSED = "bwd" (default) | "all" (both, any size) | "0".
+GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "bwd")
+GLU_FUSED = {"1": "all", "0": False, "": "bwd"}.get(GLU_FUSED, GLU_FUSED)
+GLU_FUSED_MIN_ROWS = 4096
 _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 
 
-def _glu_fusable(dtype, tensors, ranks):
+def _glu_fusable(dtype, tensors, ranks, backward):
     K = tensors[0].shape[-1]
-    return (GLU_FUSED and LORA_XA_V2 and dtype in (torch.bfloat16, torch.float16) and K % 8 == 0
+    mode = GLU_FUSED if GLU_FUSED is not True else "all"
+    if not mode or (mode == "bwd" and (not backward or tensors[0].shape[0] < GLU_FUSED_MIN_ROWS)):
+        return False
+    return (LORA_XA_V2 and dtype in (torch.bfloat16, torch.float16) and K % 8 == 0
             and all(t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.dtype == dtype and t.shape == tensors[0].shape
                     for t in tensors)
             and all(r is not None and r % 8 == 0 and 0 < r <= 64 for r in ranks))
@@ -873,7 +882,9 @@ def glu_fwd_xa(act, e, g, down, n_out_cols_hint=None):
     lora_linear_forward(pre_xa=) takes it, or None when the shapes do not allow the fusion (the caller then runs the plain
     activation kernel and lets lora_linear_forward compute X A^T itself)."""
     A = down[2]
-    if A is None or not _glu_fusable(e.dtype, [e, g], [A.shape[0]]):
+    # SwiGLU only (the hot path's activation): its fused arithmetic is bit-identical to the plain kernel, which is pinned
+    # bit for bit to the reference's Triton kernel; the GeGLU instantiations differ from theirs in the last place in fp16
+    if act != "swiglu" or A is None or not _glu_fusable(e.dtype, [e, g], [A.shape[0]], False):
         return None
     M, K = e.shape
     dtype = e.dtype
@@ -900,7 +911,7 @@ def glu_bwd_terms(act, DW, e, g, up, gate):
     lora_dx_terms([df, de], [up, gate]) of fast_lora.mlp_backward -- in ONE pass (uamd_glu_bwd_xa). Returns
     (h, df, de, [p_up, p_gate]) or None when the shapes do not allow the fusion."""
     (Au, Bu), (Ag, Bg) = (up[2], up[3]), (gate[2], gate[3])
-    if Au is None or Ag is None or not _glu_fusable(e.dtype, [DW, e, g], [Au.shape[0], Ag.shape[0]]):
+    if act != "swiglu" or Au is None or Ag is None or not _glu_fusable(e.dtype, [DW, e, g], [Au.shape[0], Ag.shape[0]], True):
         return None
     M, K = e.shape
     dtype = e.dtype

@@ -84,7 +84,7 @@ def chunked_hidden_states_selective_log_softmax(hidden_states, lm_head, index, c
     chunks = max(1, int(chunks))
     chunk_rows = min(4096, max(256, -(-T // chunks)))         # <= 1 GB of transient logits at vocab 128k
     nn = _nn_ok(min(chunk_rows, T), W.shape[0], H) and W.stride(1) == 1 and W.stride(0) % 8 == 0
-    Wt = None if nn else _transposed_weight(W)
+    Wt = None if nn else _transposed_weight(W, lm_head if W.dtype == lm_head.dtype else None)
     scale = _effective_scale(logit_scale_multiply, logit_scale_divide, logit_softcapping, temperature)
     out = _ChunkedLogProbs.apply(h2d, W, Wt, index.reshape(-1).to(torch.int64).contiguous(),
                                  float(logit_softcapping or 0), scale, int(chunk_rows))
