@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "unsloth_amd.h"   // C ABI: error codes, dtype codes, entry-point prototypes
 
@@ -126,13 +127,15 @@ __device__ __forceinline__ void load_w(const WT* __restrict__ w, float* out) {
 // GEMM epilogue shared by the MFMA kernels (gemm.hip, gemm256.hip): a lane holds C[m][n .. n+3] in fp32; `bias` (the
 // base layer's bias, activation dtype, NULL = none) is added BEFORE the single rounding to the activation dtype and
 // `accumulate` adds the existing C (dX += ...).
-template <typename T>
+template <typename T, bool ACC, bool BIAS>
 __device__ __forceinline__ void store_c4(T* dst, float v0, float v1, float v2, float v3, int n, int N, bool vec_ok,
-                                         int accumulate, const T* bias) {
+                                         const T* bias) {
+    // ACC / BIAS are COMPILE-TIME: with run-time flags every one of a thread's 32 stores carried its own scalar loads of
+    // the kernel arguments + branches, and the 256-tile GEMM lost 12 % at K = 4096 (profiles/r03l_gemm_epilogue_ab.jsonl)
     float v[4] = {v0, v1, v2, v3};
     if (n + 3 < N && vec_ok) {
         union { uint2 raw; T e[4]; } o;
-        if (bias) {
+        if (BIAS) {
             union { uint2 raw; T e[4]; } bv;
             if ((reinterpret_cast<uintptr_t>(bias + n) & 7) == 0) {
                 bv.raw = *reinterpret_cast<const uint2*>(bias + n);
@@ -143,7 +146,7 @@ __device__ __forceinline__ void store_c4(T* dst, float v0, float v1, float v2, f
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += to_f32(bv.e[r]);
         }
-        if (accumulate) {
+        if (ACC) {
             o.raw = *reinterpret_cast<const uint2*>(dst);
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] += to_f32(o.e[r]);
@@ -154,12 +157,25 @@ __device__ __forceinline__ void store_c4(T* dst, float v0, float v1, float v2, f
     } else {
         for (int r = 0; r < 4 && n + r < N; ++r) {
             float x = v[r];
-            if (bias) x += to_f32(bias[n + r]);
-            if (accumulate) x += to_f32(dst[r]);
+            if (BIAS) x += to_f32(bias[n + r]);
+            if (ACC) x += to_f32(dst[r]);
             dst[r] = from_f32<T>(x);
         }
     }
 }
+
+// run `epi(acc_c, bias_c)` (two std::integral_constant<bool, ..> tags) for the launch's (accumulate, bias) combination:
+// ONE pair of uniform branches per tile instead of one per store
+#define UAMD_EPILOGUE_DISPATCH(epi, accumulate, bias_ptr)                                                        \
+    do {                                                                                                         \
+        if ((bias_ptr) == nullptr) {                                                                             \
+            if (accumulate) epi(std::integral_constant<bool, true>{}, std::integral_constant<bool, false>{});   \
+            else epi(std::integral_constant<bool, false>{}, std::integral_constant<bool, false>{});             \
+        } else {                                                                                                 \
+            if (accumulate) epi(std::integral_constant<bool, true>{}, std::integral_constant<bool, true>{});    \
+            else epi(std::integral_constant<bool, false>{}, std::integral_constant<bool, true>{});              \
+        }                                                                                                        \
+    } while (0)
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 

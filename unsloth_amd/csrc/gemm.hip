@@ -265,18 +265,22 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = ..+4*l4
     T* Cg = (T*)g.C;
     const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+    const T* bias = (const T*)g.bias;
+    auto epi = [&](auto acc_c, auto bias_c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
-        if (m >= M) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + l15;
+            if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l4 * 4;
-            if (n >= N) continue;
-            store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
-                        p.accumulate, (const T*)g.bias);
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+                if (n >= N) continue;
+                store_c4<T, decltype(acc_c)::value, decltype(bias_c)::value>(
+                    Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok, bias);
+            }
         }
-    }
+    };
+    UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -418,18 +418,22 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = ..+4*l4 (operands were passed swapped)
     T* Cg = (T*)g.C;
     const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+    const T* bias = (const T*)g.bias;
+    auto epi = [&](auto acc_c, auto bias_c) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + grp * 128 + i * 16 + l15;
-        if (m >= M) continue;
+        for (int i = 0; i < 8; ++i) {
+            const int m = m0 + grp * 128 + i * 16 + l15;
+            if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l4 * 4;
-            if (n >= N) continue;
-            store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
-                        p.accumulate, (const T*)g.bias);
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+                if (n >= N) continue;
+                store_c4<T, decltype(acc_c)::value, decltype(bias_c)::value>(
+                    Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok, bias);
+            }
         }
-    }
+    };
+    UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -642,18 +646,22 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
         T* Cg = (T*)g.C;
         const int N = g.N;
         const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+        const T* bias = (const T*)g.bias;
+        auto epi = [&](auto acc_c, auto bias_c) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = m0 + grp * 128 + i * 16 + l15;
-            if (m >= M) continue;
+            for (int i = 0; i < 8; ++i) {
+                const int m = m0 + grp * 128 + i * 16 + l15;
+                if (m >= M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + l4 * 4;
-                if (n >= N) continue;
-                store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
-                            p.accumulate, (const T*)g.bias);
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+                    if (n >= N) continue;
+                    store_c4<T, decltype(acc_c)::value, decltype(bias_c)::value>(
+                        Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok, bias);
+                }
             }
-        }
+        };
+        UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
     };
 
     int v = blockIdx.x;
@@ -947,18 +955,22 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256h_kernel(G256Args p) {
 
     T* Cg = (T*)g.C;
     const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+    const T* bias = (const T*)g.bias;
+    auto epi = [&](auto acc_c, auto bias_c) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + grp * 64 + i * 16 + l15;
-        if (m >= M) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + grp * 64 + i * 16 + l15;
+            if (m >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l4 * 4;
-            if (n >= N) continue;
-            store_c4<T>(Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok,
-                        p.accumulate, (const T*)g.bias);
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + l4 * 4;
+                if (n >= N) continue;
+                store_c4<T, decltype(acc_c)::value, decltype(bias_c)::value>(
+                    Cg + (int64_t)m * g.ldc + n, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3], n, N, vec_ok, bias);
+            }
         }
-    }
+    };
+    UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
 }
 
 template <typename T, bool BNN>
