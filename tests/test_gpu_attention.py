@@ -71,9 +71,10 @@ def test_attn_forward_matches_fp32_oracle(fwd_variant, dtype, B, T, Hq, Hk):
     assert torch.equal(o, o2)
 
 
-@pytest.fixture(params=[0, 2], ids=["dkdv_4waves_x64keys", "dkdv_8waves_x32keys"])
+@pytest.fixture(params=[0, 2, 4], ids=["dq_dkdv4", "dq_dkdv_8waves", "dq4_dkdv4"])
 def bwd_variant(request):
-    """UAMD_TUNE_ATTN_VAR bit 1: the dK/dV backward of round 1 (8 waves x 32 keys) instead of attn_bwd_dkdv4_kernel."""
+    """UAMD_TUNE_ATTN_VAR bit 1: the dK/dV backward of round 1 (8 waves x 32 keys) instead of attn_bwd_dkdv4_kernel; bit 2:
+    attn_bwd_dq4_kernel (4 waves x 64 query rows) instead of the 8-wave dQ kernel."""
     from unsloth_amd import _lib
     L = _lib.lib()
     L.uamd_set_tuning(4, request.param)

@@ -35,27 +35,28 @@ def timed(fn, n):
     return s.elapsed_time(e) / n
 
 
-res = {0: [], 2: []}
+ARMS = (0, 4, 2)
+res = {k_: [] for k_ in ARMS}
 outs = {}
-for knob in (0, 2):
+for knob in ARMS:
     L.uamd_set_tuning(4, knob)
     outs[knob] = A.attn_backward(do, q, k, v, o, lse)
     for _ in range(3):
         A.attn_backward(do, q, k, v, o, lse)
 torch.cuda.synchronize()
 for rnd in range(6):
-    for knob in (0, 2):
+    for knob in ARMS:
         L.uamd_set_tuning(4, knob)
         res[knob].append(timed(lambda: A.attn_backward(do, q, k, v, o, lse), 10))
 L.uamd_set_tuning(4, 0)
 t_f = timed(lambda: A.attn_forward(q, k, v), 20)
 print(json.dumps(dict(fwd_ms=round(t_f, 4), fwd_TF=round(fl / t_f / 1e9, 1))))
-for knob, name in ((0, "dkdv4 (4 waves x 64 keys)"), (2, "dkdv (8 waves x 32 keys)")):
+for knob, name in ((0, "dq (8 waves x 32 rows) + dkdv4"), (4, "dq4 + dkdv4 (one wave per SIMD)"), (2, "dq + dkdv (8 waves x 32 keys)")):
     ts = sorted(res[knob])
     print(json.dumps(dict(arm=name, bwd_ms_median=round(ts[len(ts) // 2], 4), bwd_ms_min=round(ts[0], 4),
                           bwd_TF_alg=round(2.5 * fl / ts[len(ts) // 2] / 1e9, 1))))
 # agreement of the two arms + fp64 truth on one (batch, kv head) slice
-d = {n: float((a.float() - b.float()).abs().max()) for n, a, b in zip(("dq", "dk", "dv"), outs[0], outs[2])}
+d = {n: float((a.float() - b.float()).abs().max()) for n, a, b in zip(("dq", "dk", "dv"), outs[0], outs[4])}
 print(json.dumps(dict(max_abs_diff_between_arms=d)))
 Tn = min(T, 512)
 qs, ks, vs = (x[:1, :Tn].double().detach().clone().requires_grad_(True) for x in (q[:, :, :Hq // Hk], k[:, :, :1], v[:, :, :1]))
@@ -64,7 +65,7 @@ s = s.masked_fill(~torch.ones(Tn, Tn, dtype=torch.bool, device=dev).tril(), floa
 oo = torch.einsum("bhts,bshd->bthd", torch.softmax(s, -1), vs.expand(-1, -1, Hq // Hk, -1))
 if Tn == T:
     oo.backward(do[:1, :Tn, :Hq // Hk].double())
-    for knob in (0, 2):
+    for knob in ARMS:
         dq_, dk_, dv_ = outs[knob]
         e = dict(dq=float((dq_[:1, :Tn, :Hq // Hk].double() - qs.grad).norm() / qs.grad.norm()),
                  dk=float((dk_[:1, :Tn, :1].double() - ks.grad).norm() / ks.grad.norm()),

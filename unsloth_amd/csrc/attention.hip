@@ -1878,6 +1878,318 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Backward, part 1, round-3 structure: dQ (+ Delta, LSE2) with ONE wave per SIMD -- attn_bwd_dkdv4_kernel with the roles of
+// Q and K swapped. What was wrong with attn_bwd_dq_kernel (8 waves x 32 query rows, 246 us in the step = 33 % MFMA-busy):
+// the compiler serialises `ds_read ; s_waitcnt lgkmcnt(0) ; v_mfma` under its register pressure (16 waits per 16 MFMAs in
+// the hot blocks) and every K / V / K^T fragment read from LDS feeds ONE MFMA.
+// Here a block = 4 waves = the 4 query heads of a KV head (G = 8: two passes; G < 4: query-tile slices), each wave owns
+// 64 query rows of its head and its SIMD's whole register file:
+//   * dQ^T [128 d x 64 q] lives in AGPRs a0..a127 (tuples 4 kh + dt of attn_acc256.inc, asm-owned); the Q^T and dO^T
+//     fragments of the wave's 64 rows (the B operands of S^T and dP^T) are parked in a128..a255 for the whole pass (MFMA
+//     source operands may come from the accumulator file): no register pressure, no LDS traffic for them. First version:
+//     Q^T in 64 VGPRs + dO read from an LDS tile -- 4 scratch reloads in every step's DMA preamble (the knock-out
+//     builds showed ~120 us of the kernel to be independent of MFMAs, VALU and LDS reads alike: profiles/r03o_dq4_knockout.jsonl);
+//   * K / V arrive in tiles of 32 keys through a double-buffered LDS ring SHARED by the four waves (each wave DMAs a
+//     quarter of a tile): one `vmcnt(0) + s_barrier` per step -- the four heads have identical masks, so they stay in step;
+//   * every K / V / K^T fragment read feeds TWO MFMAs (the two query halves); a step is a hand-pipelined stream of 24 chunks
+//     of two v_mfma_f32_32x32x16:  S^T = K Q^T (8) | dP^T = V dO^T (8, P = exp2(S^T c - LSE2[q]) beside them) |
+//     dQ^T += K^T dS' (8), dS' = P (dP^T - Delta[q]) -- the first half of dS' sits between the phases (dP must be complete), the
+//     second half beside the first dQ chunks; the softmax scale is applied once in the epilogue;
+//   * LSE2 and Delta are per-LANE scalars here (lane = query row): no statistics traffic at all.
+// Also writes Delta (plane 0) and LSE2 = LSE log2(e) (plane 1) for attn_bwd_dkdv4_kernel, like the old kernel.
+// LDS: only the ring, stage x (K tile 8 KiB | V tile 8 KiB) = 32 KiB.
+constexpr int DQ4_LDS = 2 * 16384;
+// -DUAMD_DQ4_KO=bits: knock-out builds for timing only (results are garbage): 1 = no softmax / dS arithmetic, 2 = operand
+// fragments are read from LDS once per step instead of once per chunk, 4 = no per-step barrier / DMA, 8 = no MFMAs
+#ifndef UAMD_DQ4_KO
+#define UAMD_DQ4_KO 0
+#endif
+#ifndef UAMD_DQ4_PF
+#define UAMD_DQ4_PF 2             // operand prefetch distance in chunks
+#endif
+
+template <typename T, bool BAND>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) attn_bwd_dq4_kernel(AttnBwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename MfmaA<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int unit = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = p.G, T_ = p.T;
+    const int hpp = G < 4 ? G : 4;                    // heads per pass
+    const int npass = G / hpp, nslice = 4 / hpp;
+    const int hin = unit % hpp, slice = unit / hpp;
+    const int npairs = p.Hk * p.B;
+    const int nq64 = (T_ + 63) / 64, nqb = (nq64 + nslice - 1) / nslice;
+    const int jb = nqb - 1 - (int)(blockIdx.x / npairs);               // the last query tiles see every key: heaviest first
+    const int pair_ = (int)(blockIdx.x % npairs);
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
+    const int q0 = (jb * nslice + slice) * 64;                          // this wave's query tile (>= T: an idle wave)
+    const bool active = q0 < T_;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    int qrow[2], q_ld[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        qrow[kh] = q0 + kh * 32 + l31;
+        q_ld[kh] = qrow[kh] < T_ ? qrow[kh] : T_ - 1;
+    }
+    // key-tile (32 keys) range of the block and of this wave
+    const int q0_first = min(jb * nslice * 64, T_ - 1), q0_last = min((jb * nslice + nslice - 1) * 64 + 63, T_ - 1);
+    const int t_first_blk = BAND ? p.lo[(int64_t)b * T_ + q0_first] / 32 : 0;
+    const int nsteps = q0_last / 32 - t_first_blk + 1;
+    const int t_first_w = BAND ? p.lo[(int64_t)b * T_ + min(q0, T_ - 1)] / 32 : 0;
+    const int t_last_w = min(q0 + 63, T_ - 1) / 32;
+    int lo_q[2] = {0, 0};
+    if (BAND) {
+        lo_q[0] = p.lo[(int64_t)b * T_ + q_ld[0]];
+        lo_q[1] = p.lo[(int64_t)b * T_ + q_ld[1]];
+    }
+    const int lo_max_w = BAND ? p.lo[(int64_t)b * T_ + min(q0 + 63, T_ - 1)] : 0;   // (lo is non-decreasing in q)
+
+    // ---- DMA plumbing. Piece i of a 16-row group: rows 4 i + (lane >> 4), source slot (lane & 15) ^ swz_c(row)
+    const int dsw0 = ((lane & 15) ^ ((lane >> 4) << 2)) << 4;
+    // ring: this wave fetches part `unit` of every K | V tile: unit 0 / 1 = K rows 0-15 / 16-31, 2 / 3 = V rows 0-15 / 16-31
+    const bool my_v = unit >= 2;
+    const int64_t t_st = my_v ? p.v_st : p.k_st;
+    const T* t_base = my_v ? (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh : (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
+    const int t_r0 = (unit & 1) * 16;                 // first tile row of this wave's part
+    unsigned to_[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        to_[i] = (unsigned)((int64_t)(t_r0 + i * 4 + (lane >> 4)) * t_st * 2) + (unsigned)(dsw0 ^ (i << 4));
+    auto issue = [&](int t, int stage) {
+        const int k0 = t * 32;
+        const unsigned d = lds_base + stage * 16384 + unit * 4096;
+        if (k0 + 32 <= T_) {
+            dma16x4g(t_base + (int64_t)k0 * t_st, to_[0], to_[1], to_[2], to_[3], d);
+        } else {                                                        // ragged last tile: rows past the end re-read the last row
+            unsigned o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = min(t_r0 + i * 4 + (lane >> 4), T_ - 1 - k0);
+                o[i] = (unsigned)((int64_t)r * t_st * 2) + (unsigned)(dsw0 ^ (i << 4));
+            }
+            dma16x4g(t_base + (int64_t)k0 * t_st, o[0], o[1], o[2], o[3], d);
+        }
+    };
+
+    // ---- per-lane ABSOLUTE LDS byte addresses (swizzle C), made opaque once: stage / operand / k-step are immediates
+    const int r_lane = l31 * 256 + ((swz_c(l31 & 15) ^ lh) << 4);
+    const int sg = lane & 15, gh = (lane >> 4) & 1;
+    const int t_lane = (4 * lh + (sg >> 2)) * 256 +
+                       ((((sg >> 2) << 2) | (((gh << 1) | ((sg >> 1) & 1)) ^ lh)) << 4) + (sg & 1) * 8;
+    unsigned ck[8], ct[4], ct2[4];                     // row reads / transposing reads of the ring
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        ck[ks] = lds_base + (unsigned)(r_lane ^ (ks * 32));
+        asm volatile("" : "+v"(ck[ks]));
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        ct[dt] = lds_base + (unsigned)(t_lane ^ (dt << 6));
+        ct2[dt] = lds_base + (unsigned)((t_lane ^ (dt << 6)) ^ 32) + 8 * 256;
+        asm volatile("" : "+v"(ct[dt]), "+v"(ct2[dt]));
+    }
+
+    for (int pass = 0; pass < npass; ++pass) {
+        const int head = kvh * G + pass * hpp + hin;
+        // ---- Q^T and dO^T fragments -> a128..a255 (fragment kh * 8 + ks and 16 + kh * 8 + ks), Delta / LSE2 per lane
+        acc256_zero();
+        float lse2[2], delta[2];
+        static_for<2>([&](auto khc) {
+            constexpr int kh = decltype(khc)::value;
+            const T* qp = (const T*)p.Q + b * p.q_sb + (int64_t)q_ld[kh] * p.q_st + (int64_t)head * p.q_sh + lh * 8;
+            const T* dp_ = (const T*)p.dO + b * p.do_sb + (int64_t)q_ld[kh] * p.do_st + (int64_t)head * p.do_sh + lh * 8;
+            const T* op = (const T*)p.O + b * p.o_sb + (int64_t)q_ld[kh] * p.o_st + (int64_t)head * p.o_sh + lh * 8;
+            float dl = 0.f;
+            static_for<8>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+                union { uint4 r; T e[8]; } u, d, o;
+                u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
+                d.r = *reinterpret_cast<const uint4*>(dp_ + ks * 16);
+                o.r = *reinterpret_cast<const uint4*>(op + ks * 16);
+                acc256_bset<kh * 8 + ks>(u.r.x, u.r.y, u.r.z, u.r.w);
+                acc256_bset<16 + kh * 8 + ks>(d.r.x, d.r.y, d.r.z, d.r.w);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dl += to_f32(d.e[j]) * to_f32(o.e[j]);
+            });
+            dl += __shfl_xor(dl, 32, 64);
+            const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld[kh];
+            lse2[kh] = p.LSE[stat_idx] * 1.4426950408889634f;
+            delta[kh] = dl;
+            if (lh == 0 && qrow[kh] < T_) {
+                p.Delta[stat_idx] = dl;
+                p.Delta[(int64_t)p.B * p.Hq * p.lse_st + stat_idx] = lse2[kh];
+            }
+        });
+
+        auto body = [&](auto masked, auto stage_c, int k0) {
+            constexpr bool MASK = decltype(masked)::value;
+            constexpr int STAGE = decltype(stage_c)::value;
+            constexpr int SO = STAGE * 16384;
+            f32x16_t sc[2], dp[2];
+            union { uint32_t w[8]; frag_t f[2]; } sb[2];          // dS' as B operands: f[c] = keys 16 c .. 16 c + 15
+            constexpr int PF = UAMD_DQ4_PF;
+            frag_t ob[PF + 1][1];
+            auto rd128 = [&](unsigned addr) {
+                union { u32x4a_t r; frag_t f; } u;
+                u.r = *(const lds_u32x4a*)(uintptr_t)addr;
+                return u.f;
+            };
+            auto rdtr = [&](unsigned a0, unsigned a1) {
+                union { s16x4_t h[2]; frag_t f; } t;
+                t.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a0);
+                t.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)a1);
+                return t.f;
+            };
+            auto reads = [&](auto kc, frag_t* o) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr ((UAMD_DQ4_KO & 2) != 0 && (k & 7) >= 3) {
+                    o[0] = ob[0][0];
+                } else if constexpr (k < 8) {
+                    o[0] = rd128(ck[k] + SO);                                 // K rows
+                } else if constexpr (k < 16) {
+                    o[0] = rd128(ck[k - 8] + (SO + 8192));                    // V rows
+                } else {
+                    constexpr int c = (k - 16) >> 2, dt = (k - 16) & 3;
+                    o[0] = rdtr(ct[dt] + (SO + c * 4096), ct2[dt] + (SO + c * 4096));   // K^T
+                }
+            };
+            auto mfmas = [&](auto kc, const frag_t* o, auto half_c) {        // half = query half
+                constexpr int k = decltype(kc)::value, kh = decltype(half_c)::value;
+                if constexpr ((UAMD_DQ4_KO & 8) != 0) {
+                    asm volatile("" :: "v"(o[0]));
+                } else if constexpr (k < 8) {
+                    acc256_vmfma_b<T, kh * 8 + k, k == 0>(sc[kh], o[0]);                    // x Q^T fragment (kh, ks = k)
+                } else if constexpr (k < 16) {
+                    acc256_vmfma_b<T, 16 + kh * 8 + (k - 8), k == 8>(dp[kh], o[0]);         // x dO^T fragment (kh, ks = k - 8)
+                } else {
+                    constexpr int c = (k - 16) >> 2, dt = (k - 16) & 3;
+                    acc256_mfma<T, 4 * kh + dt>(o[0], sb[kh].f[c]);
+                }
+            };
+            // pair pi = 2 j + kh: registers 2 j, 2 j + 1 of half kh = keys k0 + 8 (j >> 1) + 4 lh + 2 (j & 1) + {0, 1}
+            auto p_pair = [&](auto pic) {
+                constexpr int pi = decltype(pic)::value, kh = pi & 1, j = pi >> 1;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kh][2 * j + e], p.scale_log2, -lse2[kh]));
+                    if (MASK) {
+                        const int r = 2 * j + e;
+                        const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key > qrow[kh] || key >= T_ || qrow[kh] >= T_ || (BAND && key < lo_q[kh])) pv = 0.f;
+                    }
+                    sc[kh][2 * j + e] = pv;
+                }
+                return sc[kh][2 * j] + sc[kh][2 * j + 1];
+            };
+            auto ds_pair = [&](auto pic) {                        // masked entries have P = 0, hence dS' = 0
+                constexpr int pi = decltype(pic)::value, kh = pi & 1, j = pi >> 1;
+                const float x0 = sc[kh][2 * j] * (dp[kh][2 * j] - delta[kh]);
+                const float x1 = sc[kh][2 * j + 1] * (dp[kh][2 * j + 1] - delta[kh]);
+                sb[kh].w[j] = pack_pair2<T>(x0, x1);
+                return sb[kh].w[j];
+            };
+            // VALU work of chunk k: P pairs in chunks 9-15 (16 pairs: 3 3 2 2 2 2 2, one in the chunk's first half), the
+            // second half of the dS' pairs (8-15) in chunks 16-19 (two per chunk, one per half)
+            auto valu = [&](auto kc, auto half_c) {
+                constexpr int k = decltype(kc)::value;
+                constexpr bool FIRST = decltype(half_c)::value == 0;
+                if constexpr ((UAMD_DQ4_KO & 1) != 0) {
+                    if constexpr (k == 16 && FIRST) { sb[0].f[1] = ob[0][0]; sb[1].f[1] = ob[0][0]; }
+                } else if constexpr (k >= 9 && k < 16) {
+                    constexpr int slot = k - 9, first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2), count = slot < 2 ? 3 : 2;
+                    if constexpr (FIRST) {
+                        asm volatile("" : "+v"(sc[0]), "+v"(sc[1]));     // S is complete: pin the reads of it BEHIND this point
+                        const float w0 = p_pair(std::integral_constant<int, first>{});
+                        asm volatile("" :: "v"(w0));
+                    } else {
+                        const float w1 = p_pair(std::integral_constant<int, first + 1>{});
+                        float w2 = w1;
+                        if constexpr (count == 3) w2 = p_pair(std::integral_constant<int, first + 2>{});
+                        asm volatile("" :: "v"(w1), "v"(w2));
+                    }
+                } else if constexpr (k >= 16 && k < 20) {
+                    constexpr int first = 8 + 2 * (k - 16);
+                    if constexpr (FIRST) {
+                        const uint32_t w0 = ds_pair(std::integral_constant<int, first>{});
+                        asm volatile("" :: "v"(w0));
+                    } else {
+                        const uint32_t w1 = ds_pair(std::integral_constant<int, first + 1>{});
+                        asm volatile("" :: "v"(w1));
+                    }
+                }
+            };
+            static_for<PF>([&](auto kc) { reads(kc, ob[decltype(kc)::value]); });
+            static_for<24>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k + PF < 24) reads(std::integral_constant<int, k + PF>{}, ob[(k + PF) % (PF + 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (k == 16 && (UAMD_DQ4_KO & 1) != 0) {
+                    sb[0].f[0] = ob[0][0]; sb[1].f[0] = ob[0][0];
+                }
+                if constexpr (k == 16 && (UAMD_DQ4_KO & 1) == 0) {
+                    // dP is complete only now: the first half of dS' (pairs 0-7 = the c = 0 operands of both query halves)
+                    // cannot ride beside an MFMA that does not need it. The asm MFMAs are invisible to the hazard
+                    // recognizer: the XDL write -> VALU read wait states are spelled out.
+                    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+                    asm volatile("" : "+v"(dp[0]), "+v"(dp[1]));
+                    uint32_t w[8];
+                    static_for<8>([&](auto pc) { w[decltype(pc)::value] = ds_pair(pc); });
+                    asm volatile("s_nop 3" :: "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                mfmas(kc, ob[k % (PF + 1)], std::integral_constant<int, 0>{});
+                valu(kc, std::integral_constant<int, 0>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kc, ob[k % (PF + 1)], std::integral_constant<int, 1>{});
+                valu(kc, std::integral_constant<int, 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        auto run = [&](auto stage_c, int step) {
+            constexpr int STAGE = decltype(stage_c)::value;
+            if ((UAMD_DQ4_KO & 4) == 0 || step == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's piece of the tile landed
+            __builtin_amdgcn_s_barrier();                          // ... everybody's did; everybody is done with the other stage
+            asm volatile("" ::: "memory");
+            // the next tile into the other stage -- last step: this tile once more (unconditional: no branch around a DMA)
+            issue(t_first_blk + (step + 1 < nsteps ? step + 1 : step), STAGE ^ 1);
+            }
+            const int t = t_first_blk + step, k0 = t * 32;
+            if (!active || t < t_first_w || t > t_last_w) return;
+            const bool slow = (k0 + 31 > q0) || (k0 + 32 > T_) || (q0 + 64 > T_) || (BAND && k0 < lo_max_w);
+            if (slow) body(std::true_type{}, stage_c, k0); else body(std::false_type{}, stage_c, k0);
+        };
+        if (nsteps > 0) issue(t_first_blk, 0);
+        for (int step = 0; step < nsteps; step += 2) {
+            run(std::integral_constant<int, 0>{}, step);
+            if (step + 1 < nsteps) run(std::integral_constant<int, 1>{}, step + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last step's spare DMA has landed
+        // ---- dQ = scale * dQ^T: tuple 4 kh + dt = d rows dt * 32 + (r & 3) + 8 (r >> 2) + 4 lh of query qrow[kh]
+        auto store_dq = [&](auto ic) {
+            constexpr int I = decltype(ic)::value, kh = I >> 2, dt = I & 3;
+            float f[16];
+            acc256_read<I>(f);
+            if (active && qrow[kh] < T_) {
+                T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)qrow[kh] * p.dq_st + (int64_t)head * p.dq_sh;
+#pragma unroll
+                for (int qd = 0; qd < 4; ++qd) {
+                    const int d = dt * 32 + qd * 8 + lh * 4;
+                    uint2 o;
+                    o.x = pack_pair2<T>(f[4 * qd + 0] * p.scale, f[4 * qd + 1] * p.scale);
+                    o.y = pack_pair2<T>(f[4 * qd + 2] * p.scale, f[4 * qd + 3] * p.scale);
+                    *reinterpret_cast<uint2*>(op + d) = o;
+                }
+            }
+        };
+        static_for<8>(store_dq);
+        if (pass + 1 < npass) __syncthreads();                    // the ring is re-filled from the first key tile
+    }
+}
+
 }  // namespace
 
 #ifdef UAMD_ATTN_TRACE
@@ -1941,9 +2253,22 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     // round-1 8-wave kernel
     const bool dkdv4 = !(uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 2);
     static bool attr4[2][64] = {{false}};
+    // dQ kernel: bit 2 selects attn_bwd_dq4_kernel (one wave per SIMD x 64 query rows); default = the 8-wave kernel. Measured
+    // at parity (profiles/r03p_dq4_ab.jsonl): both are bound by instruction issue beside the MFMAs and by their per-block
+    // prologue / store tail, not by the matrix pipe (knock-out builds: profiles/r03p_dq4_knockout.jsonl)
+    const bool dq4 = (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 4) != 0;
+    static bool attrq4[4][64] = {{false}};
+    const int nslice4 = G < 4 ? 4 / G : 1;
+    dim3 grid_q4((unsigned)((((T + 63) / 64 + nslice4 - 1) / nslice4) * Hk * B));
     if (dtype == UAMD_BF16) {
         if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<bf16_t>, KD_LDS, &attr_set[1][dev]))) return rc;
-        if (lo) {
+        if (dq4 && lo) {
+            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<bf16_t, true>, DQ4_LDS, &attrq4[0][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq4_kernel<bf16_t, true>), grid_q4, dim3(256), DQ4_LDS, st, a);
+        } else if (dq4) {
+            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<bf16_t, false>, DQ4_LDS, &attrq4[1][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq4_kernel<bf16_t, false>), grid_q4, dim3(256), DQ4_LDS, st, a);
+        } else if (lo) {
             if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t, true>, ATTN_LDS, &attr_set[0][dev]))) return rc;
             hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, true>), grid_q, dim3(512), ATTN_LDS, st, a);
         } else {
@@ -1959,7 +2284,13 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
         }
     } else if (dtype == UAMD_F16) {
         if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<f16_t>, KD_LDS, &attr_set[3][dev]))) return rc;
-        if (lo) {
+        if (dq4 && lo) {
+            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<f16_t, true>, DQ4_LDS, &attrq4[2][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq4_kernel<f16_t, true>), grid_q4, dim3(256), DQ4_LDS, st, a);
+        } else if (dq4) {
+            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<f16_t, false>, DQ4_LDS, &attrq4[3][dev]))) return rc;
+            hipLaunchKernelGGL((attn_bwd_dq4_kernel<f16_t, false>), grid_q4, dim3(256), DQ4_LDS, st, a);
+        } else if (lo) {
             if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t, true>, ATTN_LDS, &attr_set[2][dev]))) return rc;
             hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, true>), grid_q, dim3(512), ATTN_LDS, st, a);
         } else {
