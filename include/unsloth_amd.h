@@ -359,6 +359,29 @@ typedef struct {
 } uamd_gemv_group;
 int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize, int dtype,
               void* stream);
+/* uamd_gemv_fused: the same launch with the token PRODUCED inside it and the LoRA `t = A x` computed by every block, so that
+ * one decoder layer of a decode step is 7 launches instead of 14 (LlamaModel_fast_forward_inference, llama.py:1249-1364:
+ * residual adds, fast_rms_layernorm_inference, fast_swiglu_inference and the `mv` of fast_linear_forward are separate
+ * torch / kernel launches there).
+ *   mode 0: x as given.   mode 1: x = (x * sigmoid(x)).to(T) * x2 (SwiGLU; x = gate, x2 = up).
+ *   mode 2: h = T(x + res) (x may be NULL: h = res), x' = rmsnorm(h; eps) * norm_w (norm_w in T, or fp32 when w_f32);
+ *           h is also written to h_out when non-NULL (by one block; h_out must not alias res or x).
+ *   a_rows: [Rt, K] stacked LoRA A rows in T (row stride ld_a), Rt <= 256; group g's t starts at row t_off[g]; a group
+ *           takes part when its lora_b / R / lora_scale are set (its lora_t is ignored). NULL: lora_t as in uamd_gemv. */
+typedef struct {
+    int mode, Rt, w_f32, _pad;
+    const void* x2;
+    const void* res;
+    const void* norm_w;
+    void* h_out;
+    const void* a_rows;
+    int64_t ld_a;
+    float eps;
+    int t_off[4];
+    int _pad2;
+} uamd_gemv_prologue;
+int uamd_gemv_fused(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize, int dtype,
+                    void* stream, const uamd_gemv_prologue* pro);
 /* RoPE (rotate-half; the training kernel's arithmetic and rounding points) on the new token's q and k in
  * place in the fused row qkv [B, (Hq + 2 Hk) D], and append of k, v to the cache [B, Hk, s_max, D] at position
  * kv_len[b] (a DEVICE array: the step is replayable as a hipGraph). rope_pos (device, NULL = kv_len) indexes the

@@ -316,3 +316,78 @@ def test_fast_generate_kwargs_follow_hf_semantics():
     assert len(calls) == 2 and calls[-1].get("attention_mask") is mask
     model.generate(input_ids=ids, max_new_tokens=3, attention_mask=torch.ones_like(ids), top_p=1.0)
     assert len(calls) == 2                                   # neutral values stay on the engine
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("wdtype", ["same", "fp32"])
+def test_gemv_fused_prologues_match_the_separate_launches(dtype, wdtype):
+    """uamd_gemv_fused: the token produced inside the launch (SwiGLU / residual add + RMSNorm, bit-identical x to the
+    separate kernels) and the LoRA t = A x computed by the launch's own blocks."""
+    from unsloth_amd.kernels import decode as D
+    from unsloth_amd.kernels.rms_layernorm import add_rms_fwd, rms_fwd
+    from unsloth_amd.kernels.swiglu import swiglu_fg_kernel
+    K, Ns, r = 1024, (512, 256, 256), 8
+    gen = g(77)
+    projs = []
+    for i, N in enumerate(Ns):
+        W, qs, _ = _nf4(N, K, 100 + i, dtype)
+        A = (torch.randn(r, K, generator=gen) * 0.05).to(DEV)
+        B = (torch.randn(N, r, generator=gen) * 0.05).to(DEV)
+        projs.append((W, qs, A, B, 2.0, None))
+    a = (torch.randn(K, generator=gen)).to(dtype).to(DEV)
+    res = (torch.randn(K, generator=gen)).to(dtype).to(DEV)
+    w = (1 + 0.1 * torch.randn(K, generator=gen)).to(torch.float32 if wdtype == "fp32" else dtype).to(DEV)
+    # mode 2: residual add + norm
+    h_ref, x_ref, _ = add_rms_fwd(a.view(1, K), res.view(1, K), w, 1e-5)
+    want = D.linear_group(x_ref.view(-1), projs)
+    h_out = torch.empty_like(res)
+    got = D.linear_group(a, projs, fused=dict(mode=2, res=res, norm_w=w, eps=1e-5, h_out=h_out))
+    assert torch.equal(h_out, h_ref.view(-1))
+    for y, yr in zip(got, want):
+        assert (y.float() - yr.float()).abs().max() <= 2e-2 * yr.float().abs().max()
+    # mode 2 without a delta (first layer): x = rmsnorm(res)
+    x0 = rms_fwd(res.view(1, K), w, 1e-5)[0]
+    want0 = D.linear_group(x0.view(-1), projs)
+    got0 = D.linear_group(None, projs, fused=dict(mode=2, res=res, norm_w=w, eps=1e-5, h_out=None))
+    for y, yr in zip(got0, want0):
+        assert (y.float() - yr.float()).abs().max() <= 2e-2 * yr.float().abs().max()
+    # mode 1: SwiGLU of two vectors
+    hh = swiglu_fg_kernel(a.view(1, 1, K), res.view(1, 1, K)).view(-1)
+    want1 = D.linear_group(hh, projs[:1])
+    got1 = D.linear_group(a, projs[:1], fused=dict(mode=1, x2=res))
+    assert (got1[0].float() - want1[0].float()).abs().max() <= 2e-2 * want1[0].float().abs().max()
+    # mode 0 with in-launch A x, and without any adapter
+    want2 = D.linear_group(a, projs)
+    got2 = D.linear_group(a, projs, fused=dict(mode=0))
+    for y, yr in zip(got2, want2):
+        assert (y.float() - yr.float()).abs().max() <= 2e-2 * yr.float().abs().max()
+    bare = [(p[0], p[1], None, None, None, None) for p in projs]
+    for y, yr in zip(D.linear_group(a, bare, fused=dict(mode=0)), D.linear_group(a, bare)):
+        assert torch.equal(y, yr)
+
+
+@pytest.mark.parametrize("load_in_4bit", [True, False])
+def test_fused_decode_step_matches_the_separate_launches(load_in_4bit):
+    """DecodeEngine with 7 launches per layer (uamd_gemv_fused) against the 14-launch step: same tokens, logits within the
+    fp32 summation-order noise of t = A x."""
+    from unsloth_amd.models import decode as MD
+    model = _tiny(load_in_4bit)
+    model.eval()
+    ids = torch.randint(0, 1000, (1, 19), generator=g(5)).to(DEV)
+    outs = {}
+    for fused in (True, False):
+        MD.FUSED_STEP = fused
+        try:
+            eng = MD.DecodeEngine(model, max_seq_len=128, batch=1, use_graph=fused)
+            lg = eng.prefill(ids)
+            seq = []
+            for _ in range(8):
+                nxt = torch.argmax(lg, dim=-1)
+                lg = eng.step(nxt).clone()
+                seq.append(lg)
+            outs[fused] = torch.stack(seq)
+        finally:
+            MD.FUSED_STEP = False
+    scale = outs[False].abs().max().item()
+    assert (outs[True] - outs[False]).abs().max().item() <= 2e-2 * scale
+    assert torch.equal(outs[True].argmax(-1), outs[False].argmax(-1))

@@ -46,6 +46,14 @@ class GemvGroup(ctypes.Structure):
     ]
 
 
+class GemvPrologue(ctypes.Structure):
+    """uamd_gemv_prologue (include/unsloth_amd.h)."""
+
+    _fields_ = [("mode", c_int), ("Rt", c_int), ("w_f32", c_int), ("_pad", c_int), ("x2", c_void_p), ("res", c_void_p),
+                ("norm_w", c_void_p), ("h_out", c_void_p), ("a_rows", c_void_p), ("ld_a", c_int64), ("eps", c_float),
+                ("t_off", c_int * 4), ("_pad2", c_int)]
+
+
 class LoraTnProblem(ctypes.Structure):
     """uamd_lora_tn_problem (include/unsloth_amd.h)."""
 
@@ -130,6 +138,8 @@ SIGNATURES = {
     "uamd_attn_bwd": (c_int, [c_void_p] * 10 + [ctypes.POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int,
                                                c_float, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "uamd_gemv": (c_int, [c_void_p, c_int, ctypes.POINTER(GemvGroup), c_int, c_int, c_int, c_int, c_void_p]),
+    "uamd_gemv_fused": (c_int, [c_void_p, c_int, ctypes.POINTER(GemvGroup), c_int, c_int, c_int, c_int, c_void_p,
+                                ctypes.POINTER(GemvPrologue)]),
     "uamd_rope_kv_append": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "uamd_attn_decode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p,

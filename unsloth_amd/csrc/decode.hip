@@ -86,6 +86,7 @@ struct GemvArgs {
     int K, n_groups, bs_shift, total_rows;         // blocksize = 1 << bs_shift
     int row_start[UAMD_GEMV_MAX_GROUPS + 1];
     uamd_gemv_group g[UAMD_GEMV_MAX_GROUPS];
+    uamd_gemv_prologue pro;                        // mode 0 / a_rows NULL = the plain kernel
 };
 
 // One block = 8 waves sharing the decode table and the token x in LDS; a wave takes RB ADJACENT rows per trip and
@@ -152,14 +153,84 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
     };
     int row0 = (blockIdx.x * (GEMV_THREADS / 64) + wave_u) * RB;
     if (row0 < p.total_rows) load_rows(row0);
-    // ---- block setup while those loads fly: x (zero-padded), the nested-absmax maps, the byte -> value-pair table
+    // ---- block setup while those loads fly: x (zero-padded; optionally PRODUCED here: SwiGLU of two vectors, or
+    //      residual add + RMSNorm), t = A x of the LoRA factors, the nested-absmax maps, the byte -> value-pair table
+    float* tl = reinterpret_cast<float*>(gemv_smem + NIT * 64 * ELEMS * sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 +
+                                          (NF4 ? 256 * 32 * 4 : 0));          // [64 ranks x 4 groups] + 8 reduction slots
     {
         const T* xp = (const T*)p.x;
         const int nvec = NIT * 64 * ELEMS / 8;
-        for (int v = tid; v < nvec; v += GEMV_THREADS) {
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (v * 8 < K) val = *reinterpret_cast<const uint4*>(xp + v * 8);        // K % 8 == 0 (host)
-            reinterpret_cast<uint4*>(xs)[v] = val;
+        const int mode = p.pro.mode;
+        if (mode == 0) {
+            for (int v = tid; v < nvec; v += GEMV_THREADS) {
+                uint4 val = make_uint4(0, 0, 0, 0);
+                if (v * 8 < K) val = *reinterpret_cast<const uint4*>(xp + v * 8);        // K % 8 == 0 (host)
+                reinterpret_cast<uint4*>(xs)[v] = val;
+            }
+        } else if (mode == 1) {
+            // x = (e * sigmoid(e)).to(T) * g: the SwiGLU of fast_swiglu_inference (llama.py:572-606), rounding points of
+            // the training kernel (csrc/glu.hip); p.x = e (gate), pro.x2 = g (up)
+            const T* gp = (const T*)p.pro.x2;
+            for (int v = tid; v < nvec; v += GEMV_THREADS) {
+                union { uint4 r; T e[8]; } a, b, o;
+                o.r = make_uint4(0, 0, 0, 0);
+                if (v * 8 < K) {
+                    a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
+                    b.r = *reinterpret_cast<const uint4*>(gp + v * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float e = to_f32(a.e[j]);
+                        const float f = e * (1.0f / (1.0f + __expf(-e)));
+                        o.e[j] = from_f32<T>(round_to<T>(f) * to_f32(b.e[j]));
+                    }
+                }
+                reinterpret_cast<uint4*>(xs)[v] = o.r;
+            }
+        } else {
+            // x = rmsnorm(h) * w, h = T(a + res) (a = p.x may be NULL: h = res): fast_rms_layernorm_inference after the
+            // residual add of the decoder layer (llama.py:352-606), rounding points of csrc/rms_layernorm.hip. Every block
+            // normalises the whole row for itself; block 0 also writes h (the next residual) to pro.h_out.
+            const T* rp = (const T*)p.pro.res;
+            T* hp = (T*)p.pro.h_out;
+            float ss = 0.f;
+            for (int v = tid; v < nvec; v += GEMV_THREADS) {
+                union { uint4 r; T e[8]; } a, b;
+                b.r = make_uint4(0, 0, 0, 0);
+                if (v * 8 < K) {
+                    b.r = *reinterpret_cast<const uint4*>(rp + v * 8);
+                    if (xp) {
+                        a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b.e[j] = from_f32<T>(to_f32(a.e[j]) + to_f32(b.e[j]));
+                    }
+                    if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = b.r;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = to_f32(b.e[j]); ss += f * f; }
+                }
+                reinterpret_cast<uint4*>(xs)[v] = b.r;                              // h for now
+            }
+            ss = wave_sum_dpp(ss);
+            if (lane == 0) tl[256 + wave_u] = ss;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < GEMV_THREADS / 64; ++w) tot += tl[256 + w];
+            const float inv = rsqrtf(tot / (float)K + p.pro.eps);
+            for (int v = tid; v < nvec; v += GEMV_THREADS) {
+                if (v * 8 >= K) continue;
+                union { uint4 r; T e[8]; } h;
+                h.r = reinterpret_cast<uint4*>(xs)[v];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float normed = to_f32(h.e[j]) * inv;
+                    if (p.pro.w_f32) {
+                        h.e[j] = from_f32<T>(normed * ((const float*)p.pro.norm_w)[v * 8 + j]);
+                    } else {                                        // (x * r).to(W.dtype) * W, product in W's dtype
+                        h.e[j] = from_f32<T>(round_to<T>(round_to<T>(normed) * to_f32(((const T*)p.pro.norm_w)[v * 8 + j])));
+                    }
+                }
+                reinterpret_cast<uint4*>(xs)[v] = h.r;
+            }
         }
         if (NF4) {
             for (int i = tid; i < UAMD_GEMV_MAX_GROUPS * 256; i += GEMV_THREADS) {
@@ -175,6 +246,25 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
         }
     }
     __syncthreads();
+    // ---- t = A x for the stacked LoRA A rows of the launch's projections ([Rt, K], activation dtype): every block
+    //      computes all of it (Rt <= 256 rows x K: L2-resident, 1-2 us) instead of a launch of its own in front of this one
+    if (p.pro.a_rows) {
+        const T* Ar = (const T*)p.pro.a_rows;
+        const int Rt = p.pro.Rt;
+        for (int r = wave_u; r < Rt; r += GEMV_THREADS / 64) {
+            float acc = 0.f;
+            for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+                union { uint4 r; uint32_t w[4]; } a, xv;
+                a.r = *reinterpret_cast<const uint4*>(Ar + (int64_t)r * p.pro.ld_a + k0);
+                xv.r = *reinterpret_cast<const uint4*>(xs + k0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = Dot2<T>::run(a.w[j], xv.w[j], acc);
+            }
+            acc = wave_sum_dpp(acc);
+            if (lane == 0) tl[r] = acc;
+        }
+        __syncthreads();
+    }
     const uint32_t* lut_lane = lut2 + (lane & 31);
     const uint4* x_lane = reinterpret_cast<const uint4*>(xs) + lane * (PAIRS / 4);
 
@@ -218,10 +308,12 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
                 if (NIT > 2) __builtin_amdgcn_sched_barrier(0);    // keep the table / x reads of later iterations from piling up in registers
             }
             // LoRA: lane j adds s * B[n][j] * t[j]  (t = A x, fp32, from the preceding GEMV launch over the A rows)
-            if (g.lora_t && lane < g.R) {
+            if (g.lora_b && g.R > 0 && lane < g.R) {
                 const float bv = g.lora_b_f32 ? ((const float*)g.lora_b)[(int64_t)ns[r] * g.ld_lb + lane]
                                               : to_f32(((const T*)g.lora_b)[(int64_t)ns[r] * g.ld_lb + lane]);
-                acc[r] += g.lora_scale * bv * g.lora_t[lane];
+                // t from the preceding launch (g.lora_t) or computed by this block (pro.a_rows: rows t_off[g] ..)
+                const float tv = p.pro.a_rows ? tl[p.pro.t_off[gis[r]] + lane] : g.lora_t[lane];
+                acc[r] += g.lora_scale * bv * tv;
             }
         }
         float tot[RB];
@@ -249,7 +341,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
 template <typename T, bool NF4, int NIT, int RB>
 int launch_gemv_n(const GemvArgs& a, hipStream_t st) {
     constexpr int ELEMS = NF4 ? 32 : 8;
-    const int lds = NIT * 64 * ELEMS * (int)sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 + (NF4 ? 256 * 32 * 4 : 0);
+    const int lds = NIT * 64 * ELEMS * (int)sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 + (NF4 ? 256 * 32 * 4 : 0) + (256 + 8) * 4;
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -450,10 +542,15 @@ __global__ void __launch_bounds__(128) attn_decode_combine_kernel(const float* _
 // given: all groups of a launch share code2). Replaces fast_gemv / the bsz == 1 branch of fast_linear_forward
 // (unsloth/kernels/utils.py:872-977, :1082-1125) in ONE launch instead of cdequantize_blockwise_fp32 +
 // cgemm_4bit_inference_naive + mv + addmv.
-extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize,
-                         int dtype, void* stream) {
-    if (!x || !groups || n_groups < 1 || n_groups > UAMD_GEMV_MAX_GROUPS || K <= 0) return UAMD_ERR_ARG;
-    if ((K & 7) || !aligned16(x)) return UAMD_ERR_ALIGN;
+static int gemv_entry(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize,
+                      int dtype, void* stream, const uamd_gemv_prologue* pro) {
+    const int mode = pro ? pro->mode : 0;
+    if (!groups || n_groups < 1 || n_groups > UAMD_GEMV_MAX_GROUPS || K <= 0 || mode < 0 || mode > 2) return UAMD_ERR_ARG;
+    if (!x && mode != 2) return UAMD_ERR_ARG;
+    if ((K & 7) || (x && !aligned16(x))) return UAMD_ERR_ALIGN;
+    if (mode == 1 && (!pro->x2 || !aligned16(pro->x2))) return UAMD_ERR_ARG;
+    if (mode == 2 && (!pro->res || !pro->norm_w || !aligned16(pro->res) || (pro->h_out && !aligned16(pro->h_out)))) return UAMD_ERR_ARG;
+    if (pro && pro->a_rows && (pro->Rt <= 0 || pro->Rt > 256 || (pro->ld_a & 7) || !aligned16(pro->a_rows))) return UAMD_ERR_ARG;
     if (nf4 && (blocksize < 32 || (blocksize & 31) || (K & 31))) return UAMD_ERR_ARG;
     GemvArgs a;
     auto log2_exact = [](int v) { int sft = 0; while ((1 << sft) < v) ++sft; return (1 << sft) == v ? sft : -1; };
@@ -471,8 +568,10 @@ extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, in
             } else if (g.ldw & 7) {
                 return UAMD_ERR_ALIGN;
             }
-            if (g.lora_t && (!g.lora_b || g.R <= 0 || g.R > 64)) return UAMD_ERR_ARG;
+            if ((g.lora_t || (pro && pro->a_rows && g.lora_b)) && (!g.lora_b || g.R <= 0 || g.R > 64)) return UAMD_ERR_ARG;
+            if (pro && pro->a_rows && g.lora_b && (pro->t_off[i] < 0 || pro->t_off[i] + g.R > pro->Rt)) return UAMD_ERR_ARG;
             a.g[i] = g;
+            if (!(g.lora_t || (pro && pro->a_rows))) a.g[i].lora_b = nullptr;      // (a B without any t: no LoRA term)
             if (nf4 && !g.absmax_f32) {
                 a.g[i].blocksize2 = log2_exact(g.blocksize2);
                 if (a.g[i].blocksize2 < 0) return UAMD_ERR_ARG;
@@ -484,10 +583,32 @@ extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, in
     }
     a.row_start[UAMD_GEMV_MAX_GROUPS] = rows;
     a.total_rows = rows;
+    if (pro) a.pro = *pro;
+    else {
+        a.pro.mode = 0; a.pro.x2 = nullptr; a.pro.res = nullptr; a.pro.norm_w = nullptr; a.pro.h_out = nullptr;
+        a.pro.a_rows = nullptr; a.pro.ld_a = 0; a.pro.Rt = 0; a.pro.w_f32 = 0; a.pro.eps = 0.f;
+        for (int i = 0; i < UAMD_GEMV_MAX_GROUPS; ++i) a.pro.t_off[i] = 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     if (dtype == UAMD_BF16) return nf4 ? launch_gemv<bf16_t, true>(a, st) : launch_gemv<bf16_t, false>(a, st);
     if (dtype == UAMD_F16) return nf4 ? launch_gemv<f16_t, true>(a, st) : launch_gemv<f16_t, false>(a, st);
     return UAMD_ERR_DTYPE;
+}
+
+extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize,
+                         int dtype, void* stream) {
+    return gemv_entry(x, K, groups, n_groups, nf4, blocksize, dtype, stream, nullptr);
+}
+
+// uamd_gemv with the token PRODUCED inside the launch (one decoder-layer step = 7 launches instead of 14):
+//   pro->mode 1: x = SwiGLU(x, x2)                       (fast_swiglu_inference, llama.py:572-606: down_proj's input)
+//   pro->mode 2: h = x + res (x may be NULL), x' = rmsnorm(h) * norm_w; block 0 writes h to h_out   (the residual add +
+//                fast_rms_layernorm_inference in front of q|k|v, gate|up and lm_head, llama.py:1249-1364)
+//   pro->a_rows: t = A x for the stacked LoRA A rows [Rt, K] computed by every block; group g reads t[t_off[g] ..]
+//                (the `mv` of fast_linear_forward, utils.py:1107-1117, without a launch of its own)
+extern "C" int uamd_gemv_fused(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize,
+                               int dtype, void* stream, const uamd_gemv_prologue* pro) {
+    return gemv_entry(x, K, groups, n_groups, nf4, blocksize, dtype, stream, pro);
 }
 
 // RoPE on the new token's q, k (in place in the fused qkv row) + append of k, v at cache position kv_len[b]

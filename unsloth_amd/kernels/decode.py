@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from .._lib import GemvGroup
+from .._lib import GemvGroup, GemvPrologue
 
 MAX_GROUPS = 4
 
@@ -56,11 +56,16 @@ def lora_a_rows(A_list, dtype):
     return ent[1]
 
 
-def gemv(x, groups, nf4, blocksize=64):
+def gemv(x, groups, nf4, blocksize=64, pro=None):
     """One launch. x: [K] (contiguous, 16-bit). groups: list of dicts with W, N and optionally qs (quant state),
-    y, y_f32, lora_t, lora_b, lora_scale, R, bias. Returns the list of outputs."""
-    _lib.require_gpu(x)
-    K = x.numel()
+    y, y_f32, lora_t, lora_b, lora_scale, R, bias. Returns the list of outputs.
+    `pro` (uamd_gemv_fused): dict(mode=0|1|2, x2=, res=, norm_w=, eps=, h_out=, a_rows=, t_off=[per group]) -- the token is
+    produced inside the launch (SwiGLU of x and x2 / residual add + RMSNorm; x may be None in mode 2) and the LoRA
+    t = A x is computed by every block from the stacked A rows instead of arriving from a launch of its own."""
+    ref = x if x is not None else pro["res"]
+    _lib.require_gpu(ref)
+    K = ref.numel()
+    dtype, dev = ref.dtype, ref.device
     assert 1 <= len(groups) <= MAX_GROUPS
     arr = (GemvGroup * len(groups))()
     outs, keep = [], []
@@ -69,7 +74,7 @@ def gemv(x, groups, nf4, blocksize=64):
         y_f32 = bool(g.get("y_f32", False))
         y = g.get("y")
         if y is None:
-            y = torch.empty(N, dtype=torch.float32 if y_f32 else x.dtype, device=x.device)
+            y = torch.empty(N, dtype=torch.float32 if y_f32 else dtype, device=dev)
         outs.append(y)
         W = g["W"]
         e = arr[i]
@@ -82,32 +87,62 @@ def gemv(x, groups, nf4, blocksize=64):
             e.absmax2 = absmax2.data_ptr() if absmax2 is not None else None
             e.offset, e.blocksize2, e.ldw = off, bs2, 0
         else:
-            assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == x.dtype and W.shape[1] == K
+            assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == dtype and W.shape[1] == K
             e.ldw = W.stride(0)
         e.y = y.data_ptr()
         t = g.get("lora_t")
-        if t is not None:
+        if t is not None or (pro is not None and pro.get("a_rows") is not None and g.get("lora_b") is not None):
             B = g["lora_b"]
-            assert t.dtype == torch.float32 and B.stride(1) == 1
-            e.lora_t, e.lora_b, e.ld_lb = t.data_ptr(), B.data_ptr(), B.stride(0)
+            assert (t is None or t.dtype == torch.float32) and B.stride(1) == 1
+            e.lora_t = t.data_ptr() if t is not None else None
+            e.lora_b, e.ld_lb = B.data_ptr(), B.stride(0)
             e.lora_scale, e.R = float(g["lora_scale"]), int(g["R"])
             e.lora_b_f32 = int(B.dtype == torch.float32)
-            assert B.dtype in (torch.float32, x.dtype)
+            assert B.dtype in (torch.float32, dtype)
             keep += [t, B]
         bias = g.get("bias")
         e.bias = bias.data_ptr() if bias is not None else None
         e.N, e.y_f32 = N, int(y_f32)
-    with _lib.device_ctx(x):
-        rc = _lib.lib().uamd_gemv(_lib.ptr(x), K, arr, len(groups), int(bool(nf4)), int(blocksize),
-                                  _lib.dtype_code(x.dtype), _lib.stream_of(x))
-    _lib.check(rc, "uamd_gemv")
+    if pro is None:
+        with _lib.device_ctx(ref):
+            rc = _lib.lib().uamd_gemv(_lib.ptr(x), K, arr, len(groups), int(bool(nf4)), int(blocksize),
+                                      _lib.dtype_code(dtype), _lib.stream_of(ref))
+        _lib.check(rc, "uamd_gemv")
+        return outs
+    P = GemvPrologue()
+    P.mode = int(pro.get("mode", 0))
+    for name in ("x2", "res", "norm_w", "h_out", "a_rows"):
+        tns = pro.get(name)
+        setattr(P, name, tns.data_ptr() if tns is not None else None)
+        keep.append(tns)
+    if P.mode == 1:
+        assert pro["x2"].dtype == dtype and pro["x2"].numel() == K and pro["x2"].is_contiguous()
+    if P.mode == 2:
+        w = pro["norm_w"]
+        assert w.numel() == K and w.is_contiguous() and w.dtype in (dtype, torch.float32) and pro["res"].is_contiguous()
+        P.w_f32 = int(w.dtype == torch.float32 and dtype != torch.float32)
+        P.eps = float(pro["eps"])
+    a_rows = pro.get("a_rows")
+    if a_rows is not None:
+        assert a_rows.dtype == dtype and a_rows.stride(1) == 1 and a_rows.shape[1] == K
+        P.Rt, P.ld_a = int(a_rows.shape[0]), int(a_rows.stride(0))
+        for i, off in enumerate(pro["t_off"]):
+            P.t_off[i] = int(off)
+    with _lib.device_ctx(ref):
+        rc = _lib.lib().uamd_gemv_fused(_lib.ptr(x) if x is not None else None, K, arr, len(groups), int(bool(nf4)),
+                                        int(blocksize), _lib.dtype_code(dtype), _lib.stream_of(ref), ctypes.byref(P))
+    _lib.check(rc, "uamd_gemv_fused")
     return outs
 
 
-def linear_group(x, projs, out=None):
+def linear_group(x, projs, out=None, fused=None):
     """y_i = W_i x + s_i B_i (A_i x) (+ bias_i) for projections sharing the token x [K]: at most two launches (the A rows
     of all members, then the weights). projs: (W, quant_state, A, B, s[, bias]) as get_lora_parameters(_bias) returns
-    them. `out`: optional preallocated [sum N_i] row the outputs are written into back to back. Returns the views."""
+    them. `out`: optional preallocated [sum N_i] row the outputs are written into back to back. Returns the views.
+    `fused` (dict: mode / x2 / res / norm_w / eps / h_out, see gemv): ONE launch -- the token is produced inside it (x may be
+    None in mode 2) and the A x products are computed by the launch's own blocks."""
+    if fused is not None:
+        return _linear_group_fused(x, projs, out, fused)
     x = x.reshape(-1)
     dtype = x.dtype
     nf4 = projs[0][1] is not None
@@ -135,6 +170,39 @@ def linear_group(x, projs, out=None):
     for i in range(0, len(groups), MAX_GROUPS):
         ys += gemv(x, groups[i:i + MAX_GROUPS], nf4=nf4, blocksize=blocksize)
     return ys
+
+
+def _linear_group_fused(x, projs, out, fused):
+    ref = x if x is not None else fused["res"]
+    if x is not None:
+        x = x.reshape(-1)
+    dtype, dev = ref.dtype, ref.device
+    nf4 = projs[0][1] is not None
+    assert all((p[1] is not None) == nf4 for p in projs), "a launch is all-NF4 or all-16-bit"
+    assert len(projs) <= MAX_GROUPS
+    Ns = [int(p[1].shape[0]) if p[1] is not None else int(p[0].shape[0]) for p in projs]
+    if out is None:
+        out = torch.empty(sum(Ns), dtype=dtype, device=dev)
+    with_lora = [p for p in projs if p[2] is not None]
+    pro = dict(fused)
+    pro.setdefault("mode", 0)
+    t_off = [0] * len(projs)
+    if with_lora:
+        pro["a_rows"] = lora_a_rows([p[2] for p in with_lora], dtype)
+    groups, col, r0 = [], 0, 0
+    for i, (p, N) in enumerate(zip(projs, Ns)):
+        W, qs, A, B, s = p[:5]
+        g = dict(W=W, N=N, qs=qs, y=out[col:col + N], bias=p[5] if len(p) > 5 else None)
+        if A is not None:
+            R = A.shape[0]
+            g.update(lora_b=B.detach(), lora_scale=s, R=R)
+            t_off[i] = r0
+            r0 += R
+        groups.append(g)
+        col += N
+    pro["t_off"] = t_off
+    blocksize = int(projs[0][1].blocksize) if nf4 else 64
+    return gemv(x, groups, nf4=nf4, blocksize=blocksize, pro=pro)
 
 
 def rope_kv_append(qkv, cos, sin, kv_len, k_cache, v_cache, Hq, Hk, D, rope_pos=None):

@@ -16,6 +16,7 @@ MI355X design: one `DecodeEngine` per (model, max_seq_len, batch):
 Batch > 1 decodes through the fused NF4 GEMM instead of the GEMV (as the reference does, utils.py:1095-1097).
 """
 import math
+import os
 
 import torch
 
@@ -31,6 +32,14 @@ SPLIT_KEYS = 128
 def _base(model):
     m = model.get_base_model() if hasattr(model, "get_base_model") else model
     return m
+
+
+# UNSLOTH_AMD_DECODE_FUSED=1: one token of one sequence as 7 launches per layer (uamd_gemv_fused: residual add + RMSNorm /
+# SwiGLU / the LoRA A x inside the GEMV launches) instead of 14. Measured SLOWER under the hipGraph (4.97 vs 4.13 ms per
+# token, profiles/r03r_decode_fused_ab.jsonl; eager 4.96 vs 6.79): every one of a launch's 200-500 blocks recomputes the
+# norm and t = A x (up to 48 rows x K from L2) on its own critical path, which costs more than the launches it removes --
+# a decode GEMV is bound by its fixed latencies (staging, one HBM round trip, reduction), not by launch gaps. Default off.
+FUSED_STEP = os.environ.get("UNSLOTH_AMD_DECODE_FUSED", "0") == "1"
 
 
 class DecodeEngine:
@@ -160,6 +169,54 @@ class DecodeEngine:
 
     @torch.no_grad()
     def _step_body(self):
+        if self.B == 1 and FUSED_STEP:
+            return self._step_body_fused()
+        return self._step_body_plain()
+
+    @torch.no_grad()
+    def _step_body_fused(self):
+        """One token of one sequence, 7 launches per decoder layer: the residual adds, both RMSNorms, SwiGLU and every
+        LoRA `A x` ride inside the GEMV launches (uamd_gemv_fused); RoPE + cache append, attention and its combine are
+        the other three."""
+        H = self.cfg.hidden_size
+        core = self.core
+        resid = core.embed_tokens(self.tok).to(self.dtype).view(H)
+        delta = None
+        I = self.cfg.intermediate_size
+        for li in range(len(core.layers)):
+            P = self._params[li]
+            qkv = torch.empty(1, (self.Hq + 2 * self.Hk) * self.D, dtype=self.dtype, device=self.dev)
+            h = torch.empty_like(resid) if delta is not None else None
+            _dk.linear_group(delta, P["qkv"], out=qkv.view(-1),
+                             fused=dict(mode=2, res=resid, norm_w=P["ln1"][0], eps=P["ln1"][1], h_out=h))
+            if h is not None:
+                resid = h
+            _dk.rope_kv_append(qkv, self.cos, self.sin, self.kv_len, self.k_cache[li], self.v_cache[li],
+                               self.Hq, self.Hk, self.D)
+            a_out = torch.empty(1, self.Hq * self.D, dtype=self.dtype, device=self.dev)
+            _dk.attn_decode(qkv[:, :self.Hq * self.D], self.k_cache[li], self.v_cache[li], self.kv_len, a_out,
+                            self.partials, SPLIT_KEYS, self.scale, len_add=1, window=self.window)
+            (o,) = _dk.linear_group(a_out.view(-1), P["o"], fused=dict(mode=0))
+            gu = torch.empty(2 * I, dtype=self.dtype, device=self.dev)
+            h = torch.empty_like(resid)
+            _dk.linear_group(o, P["gu"], out=gu, fused=dict(mode=2, res=resid, norm_w=P["ln2"][0], eps=P["ln2"][1], h_out=h))
+            resid = h
+            (delta,) = _dk.linear_group(gu[:I], P["down"], fused=dict(mode=1, x2=gu[I:]))
+        W = self._head
+        if W.dtype == self.dtype and W.shape[1] <= 16384:
+            (y,) = _dk.gemv(delta, [dict(W=W, N=W.shape[0], y_f32=True)], nf4=False,
+                            pro=dict(mode=2, res=resid, norm_w=core.norm.weight, eps=_eps(core.norm), h_out=None))
+            self.logits = y.view(1, -1)
+        else:
+            _, xn, _ = add_rms_fwd(delta.view(1, H), resid.view(1, H), core.norm.weight, _eps(core.norm))
+            self.logits = self._lm_head(xn)
+        self.kv_len.add_(1)
+        if self._sample is None:
+            self.next_tok.copy_(torch.argmax(self.logits, dim=-1))
+        return self.logits
+
+    @torch.no_grad()
+    def _step_body_plain(self):
         B, H = self.B, self.cfg.hidden_size
         core = self.core
         h = core.embed_tokens(self.tok).to(self.dtype).view(B, H)
