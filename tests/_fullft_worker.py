@@ -1,0 +1,67 @@
+"""Worker of tests/test_gpu_dp_rccl.py::test_full_finetune_*: full fine-tuning steps on real RCCL (1 forced rank, or N
+ranks with different batches): flat buckets, in-place reduce-scatter, sharded AdamW, in-place all-gather. Checks that
+every rank ends with identical parameters, that they moved, and -- one rank -- that the exchange changed nothing
+numerically against a run without any collective."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(int(os.environ["LOCAL_RANK"]))
+    dev = torch.device("cuda", int(os.environ["LOCAL_RANK"]))
+    dist.init_process_group("nccl", device_id=dev)
+    from transformers import LlamaConfig
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.full_finetune import ShardedAdamW, full_finetune_step
+    cfg = LlamaConfig(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4, num_key_value_heads=2,
+                      head_dim=128, vocab_size=2048, rms_norm_eps=1e-5, max_position_embeddings=1024,
+                      rope_parameters={"rope_type": "default", "rope_theta": 5e5}, tie_word_embeddings=False)
+
+    def build():
+        m, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=256, full_finetuning=True, device=dev,
+                                                 random_state=3407, use_gradient_checkpointing=False)
+        return m
+    model = build()
+    before = torch.cat([p.detach().float().flatten() for p in model.parameters()]).clone()
+    opt = ShardedAdamW(model, lr=1e-3)
+    assert opt.buckets._exchange, "the collectives must really be issued"
+    g = torch.Generator().manual_seed(100 + rank)
+    losses = []
+    for step in range(3):
+        ids = torch.randint(0, 2048, (2, 256), generator=g).to(dev)
+        pos = torch.arange(256, dtype=torch.int32, device=dev).unsqueeze(0).expand(2, 256).contiguous()
+        losses.append(float(full_finetune_step(model, dict(input_ids=ids, labels=ids.clone(), position_ids=pos), opt)))
+    after = torch.cat([p.detach().float().flatten() for p in model.parameters()])
+    assert torch.isfinite(after).all() and float((after - before).abs().max()) > 0
+    # replicas identical
+    mine = after.double().sum().reshape(1)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    assert all(torch.equal(allv[0], v) for v in allv), allv
+    if world == 1:
+        # the same three steps without any collective (the environment switch off): bit-identical parameters
+        opt.buckets.close()
+        os.environ["UNSLOTH_AMD_DP_FORCE"] = "0"
+        model2 = build()
+        opt2 = ShardedAdamW(model2, lr=1e-3)
+        assert not opt2.buckets._exchange
+        g2 = torch.Generator().manual_seed(100 + rank)
+        for step in range(3):
+            ids = torch.randint(0, 2048, (2, 256), generator=g2).to(dev)
+            pos = torch.arange(256, dtype=torch.int32, device=dev).unsqueeze(0).expand(2, 256).contiguous()
+            full_finetune_step(model2, dict(input_ids=ids, labels=ids.clone(), position_ids=pos), opt2)
+        after2 = torch.cat([p.detach().float().flatten() for p in model2.parameters()])
+        assert torch.equal(after, after2), float((after - after2).abs().max())
+    print(f"rank {rank}/{world} ok losses {losses}", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

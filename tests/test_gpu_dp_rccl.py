@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _run(world, extra_env):
+def _run(world, extra_env, worker="_dp_worker.py"):
     port = _free_port()
     procs = []
     for rank in range(world):
@@ -31,7 +31,7 @@ def _run(world, extra_env):
         # one node, no fabric: keep RCCL's bootstrap off interface / InfiniBand probing (seen to take 100 s on one box)
         env.setdefault("NCCL_SOCKET_IFNAME", "lo")
         env.setdefault("NCCL_IB_DISABLE", "1")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_dp_worker.py")], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -57,4 +57,17 @@ def test_forced_one_rank_rccl_group(gc):
 @pytest.mark.parametrize("gc,bucket", [("off", 1 << 16), ("unsloth", 1 << 30)])
 def test_two_rank_rccl_allreduce_matches_local_replay(gc, bucket):
     outs = _run(2, {"DP_TEST_GC": gc, "DP_TEST_BUCKET": str(bucket)})
+    assert "rank 0/2 ok" in outs[0] and "rank 1/2 ok" in outs[1]
+
+
+def test_full_finetune_forced_one_rank_rccl_group():
+    """BASELINE config 3's exchange on real RCCL (one forced rank): per-bucket in-place reduce-scatter launched from the
+    gradient sinks, sharded AdamW, in-place all-gather -- bit-identical to the same steps without any collective."""
+    outs = _run(1, {"UNSLOTH_AMD_DP_FORCE": "1"}, worker="_fullft_worker.py")
+    assert "rank 0/1 ok" in outs[0]
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
+def test_full_finetune_two_ranks_end_identical():
+    outs = _run(2, {}, worker="_fullft_worker.py")
     assert "rank 0/2 ok" in outs[0] and "rank 1/2 ok" in outs[1]

@@ -22,6 +22,7 @@ Works unchanged on gloo / CPU (all-reduce + slice instead of reduce-scatter; tor
 kernels), which is how tests/test_full_finetune_gloo.py covers the N > 1 path.
 """
 import math
+import os
 import re
 import weakref
 
@@ -61,6 +62,9 @@ class FullGradBuckets:
         self.world_size = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self._gloo = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
+        # UNSLOTH_AMD_DP_FORCE=1: issue the collectives even in a 1-rank group (exercises RCCL's in-place reduce-scatter /
+        # all-gather and the hook ordering on one GPU, tests/test_gpu_dp_rccl.py)
+        self._exchange = self.world_size > 1 or (os.environ.get("UNSLOTH_AMD_DP_FORCE", "0") == "1" and dist.is_initialized())
         layers = [l for l in (_layer_index(n) for n, _ in named) if l is not None]
         n_layers = (max(layers) + 1) if layers else 0
         groups = {}
@@ -151,7 +155,7 @@ class FullGradBuckets:
         b["pending"] += 1
         if b["pending"] == b["expected"]:
             b["pending"] = 0
-            if self._sync and self.overlap and self.world_size > 1:
+            if self._sync and self.overlap and self._exchange:
                 self._launch(bi)
 
     # ---- exchange ------------------------------------------------------------------------------------------------------
@@ -180,7 +184,7 @@ class FullGradBuckets:
             if id(p) not in self._written:
                 self._views[id(p)].zero_()
                 p.grad = self._views[id(p)]
-        if self.world_size > 1 and self._sync:
+        if self._exchange and self._sync:
             for bi, b in enumerate(self.buckets):
                 if not b["launched"]:
                     self._launch(bi)
@@ -194,7 +198,7 @@ class FullGradBuckets:
 
     def gather_params(self, bi, async_op=True):
         """All-gather the updated parameter slices of bucket `bi` back into its flat parameter buffer (in place)."""
-        if self.world_size == 1:
+        if not self._exchange:
             return None
         b = self.buckets[bi]
         return dist.all_gather_into_tensor(b["flat_p"], self.param_shard(bi), group=self.group, async_op=async_op)
@@ -334,7 +338,7 @@ class ShardedAdamW(torch.optim.Optimizer):
                     d.copy_(s_)
             for bi in range(len(self.buckets.buckets)):
                 self.buckets.param_shard(bi).copy_(self.master[bi])
-                h = self.buckets.gather_params(bi, async_op=False)
+                self.buckets.gather_params(bi, async_op=False)
 
 
 def full_finetune_step(model, batch, optimizer, num_items=None):
