@@ -214,10 +214,10 @@ class FastVisionModel:
             raise TypeError(f"Unsloth: Rank of {str(r)} must be an integer.")
         if r <= 0:
             raise TypeError(f"Unsloth: Rank of {str(r)} must be larger than 0.")
-        if isinstance(model.language, _lora.PeftModelForCausalLM):
-            raise RuntimeError("Unsloth: You already added LoRA adapters to your model!")
         if not isinstance(model, Qwen2VLFastModel):
             raise TypeError("FastVisionModel.get_peft_model expects the model FastVisionModel.from_pretrained returned")
+        if isinstance(model.language, _lora.PeftModelForCausalLM):
+            raise RuntimeError("Unsloth: You already added LoRA adapters to your model!")
         if target_modules == "all-linear":
             finetune_vision_layers = finetune_language_layers = finetune_attention_modules = finetune_mlp_modules = True
         if finetune_language_layers:
