@@ -197,3 +197,84 @@ def hf_reference_loss_and_all_grads(fast_model, input_ids, labels, position_ids=
     loss = torch.nn.functional.cross_entropy(logits.view(-1, V), shift.view(-1), ignore_index=-100, reduction="sum") / n
     loss.backward()
     return loss.detach().cpu(), {k: p.grad.detach().float().cpu() for k, p in ref.named_parameters() if p.grad is not None}
+
+
+def hf_vl_reference_loss_and_lora_grads(fast_vl, input_ids, attention_mask, pixel_values, image_grid_thw, labels,
+                                        device="cpu", dtype=torch.float32):
+    """BASELINE config 4 end to end (pixel_values -> patch-embed -> ViT -> merger -> scatter -> multimodal RoPE -> language
+    tower -> loss): (loss, {name: grad}) of transformers' own Qwen2VLForConditionalGeneration in fp32 holding the product's
+    weights -- NF4 decoded by the oracle, LoRA merged (W + s B A) on BOTH towers -- HF's forward, torch autograd. Gradient
+    names: "visual.<module>.lora_A|B" and "language.layers.<i>.<block>.<proj>.lora_A|B". `dtype` = bf16: the yardstick."""
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLForConditionalGeneration
+    from unsloth_amd import lora as _l
+    cfg = copy.deepcopy(fast_vl.config)
+    cfg.dtype = torch.float32
+    for c in (cfg, getattr(cfg, "text_config", None), getattr(cfg, "vision_config", None)):
+        if c is not None:
+            c._attn_implementation = "eager"
+    with _stock_hf_classes():
+        hf = Qwen2VLForConditionalGeneration(cfg).float()
+    hf_mods = dict(hf.named_modules())
+    lang = fast_vl.language.get_base_model() if hasattr(fast_vl.language, "get_base_model") else fast_vl.language
+    lora, eff = {}, {}
+
+    def place(fast_root, hf_prefix, tag):
+        for name, mod in fast_root.named_modules():
+            is_lora = isinstance(mod, _l.LoraLayer)
+            base = getattr(mod, "base_layer", mod)
+            if not (is_lora or (hasattr(base, "weight") and getattr(base.weight, "quant_state", None) is not None)
+                    or type(mod) is torch.nn.Linear):
+                continue
+            if ".base_layer" in name or name.endswith("base_layer") or ".lora_" in "." + name:
+                continue
+            tgt = hf_mods[hf_prefix + name]
+            W, A, B, s = _base_and_lora(mod)
+            with torch.no_grad():
+                tgt.weight.copy_((W + s * B @ A) if A is not None else W)
+                bias = getattr(base, "bias", None)
+                if bias is not None:
+                    tgt.bias.copy_(bias.detach().float().cpu())
+            if A is not None:
+                lora[tag + name] = (A, B, s)
+                eff[tag + name] = tgt.weight
+
+    place(fast_vl.visual, "model.visual.", "visual.")
+    place(lang.model, "model.language_model.", "language.")
+    with torch.no_grad():
+        hf.lm_head.weight.copy_(lang.lm_head.weight.detach().float().cpu())
+        # everything that is not a linear layer: norms, embeddings, the patch-embed convolution
+        hf_params = dict(hf.named_parameters())
+        for root, prefix in ((fast_vl.visual, "model.visual."), (lang.model, "model.language_model.")):
+            lin = {n for n, m in root.named_modules() if isinstance(m, (_l.LoraLayer, torch.nn.Linear)) or
+                   getattr(getattr(m, "weight", None), "quant_state", None) is not None}
+            for n, p in root.named_parameters():
+                owner = n.rsplit(".", 1)[0]
+                if any(owner == l or owner.startswith(l + ".") for l in lin) or ".lora_" in "." + n:
+                    continue
+                hf_params[prefix + n].copy_(p.detach().float().cpu())
+    for p in hf.parameters():
+        p.requires_grad_(False)
+    dev = torch.device(device)
+    hf.to(dev)
+    if dtype != torch.float32:
+        for p in hf.parameters():
+            p.data = p.data.to(dtype)
+    for k in eff:
+        eff[k].requires_grad_(True)
+    ids = input_ids.to(dev)
+    out = hf(input_ids=ids, attention_mask=None if attention_mask is None else attention_mask.to(dev),
+             pixel_values=pixel_values.to(dev).to(dtype), image_grid_thw=image_grid_thw.to(dev),
+             mm_token_type_ids=(ids == cfg.image_token_id).int())
+    logits = out.logits.float()
+    lab = labels.to(dev)
+    loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), lab[:, 1:].reshape(-1),
+                                             ignore_index=-100)
+    keys = list(eff)
+    dWs = torch.autograd.grad(loss, [eff[k] for k in keys])
+    grads = {}
+    for k, dW in zip(keys, dWs):
+        A, B, s = lora[k]
+        dW = dW.float().cpu()
+        grads[k + ".lora_A"] = s * B.t() @ dW
+        grads[k + ".lora_B"] = s * dW @ A.t()
+    return loss.detach().cpu(), grads

@@ -272,3 +272,61 @@ def test_config4_qwen2_vl_7b_tower_nf4_lora_r32_seq4096_mrope():
         L._fast_layer.decoder_layer_forward = real_layer
     assert calls["attn"] and all(g_ == 8 for g_ in calls["attn"])        # 7 query heads per KV head: padded onto the G = 8 kernels
     assert calls["layer_fn"] == 2, "multimodal positions must go through the whole-layer Function under 'unsloth'"
+
+
+def test_config4_qwen2_vl_7b_pixel_values_to_loss_real_widths_lora_on_both_towers():
+    """BASELINE config 4 END TO END at Qwen2-VL-7B's widths (ViT 1280 / 16 heads / patch 14 / merge 2 -> 3584; language
+    3584 / 18944 / 28:4 / vocab 152064, NF4), 2 + 2 layers, ONE 896 x 896 image (4096 patches -> 1024 merged tokens) inside a
+    4096-token sequence, LoRA r=32 on both towers: pixel_values -> patch-embed -> ViT (HIP LayerNorm, LoRA_W linears with
+    bias) -> merger -> scatter -> get_rope_index positions -> fused language tower -> loss, against transformers' own
+    Qwen2VLForConditionalGeneration in fp32 with the same (oracle-decoded, LoRA-merged) weights."""
+    from transformers import Qwen2VLConfig
+    from oracle.ref_model import hf_vl_reference_loss_and_lora_grads
+    from unsloth_amd import FastVisionModel
+    vocab = 152064
+    cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=2, num_attention_heads=28,
+                         num_key_value_heads=4, vocab_size=vocab, max_position_embeddings=32768, rms_norm_eps=1e-6,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+                         tie_word_embeddings=False),
+        vision_config=dict(depth=2, embed_dim=1280, hidden_size=3584, num_heads=16, mlp_ratio=4, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, in_channels=3),
+        image_token_id=151655, video_token_id=151656, vision_start_token_id=151652, vision_end_token_id=151653)
+    model, _ = FastVisionModel.from_pretrained(config=cfg, max_seq_length=4096, load_in_4bit=True, device="cuda",
+                                               use_gradient_checkpointing=False)
+    model = FastVisionModel.get_peft_model(model, r=32, lora_alpha=32, use_gradient_checkpointing=False)
+    g = torch.Generator().manual_seed(44)
+    for n, p in model.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
+    for p in model.visual.parameters():              # random-init leaves LayerNorm at (1, 0) and biases at 0: give them values
+        if p.dim() == 1 and not p.requires_grad:
+            p.data.copy_((torch.randn(p.shape, generator=g) * 0.1 + (1.0 if p.mean() > 0.5 else 0.0)).to(p.device, p.dtype))
+    grid = (1, 64, 64)
+    n_img = grid[0] * (grid[1] // 2) * (grid[2] // 2)                     # 1024 placeholder tokens
+    T, pre = 4096, 700
+    row = torch.cat([torch.randint(0, 150000, (pre,), generator=g), torch.tensor([cfg.vision_start_token_id]),
+                     torch.full((n_img,), cfg.image_token_id), torch.tensor([cfg.vision_end_token_id]),
+                     torch.randint(0, 150000, (T - pre - n_img - 2,), generator=g)])
+    ids = row.unsqueeze(0)
+    mask = torch.ones_like(ids)
+    thw = torch.tensor([grid])
+    pix = torch.randn(grid[0] * grid[1] * grid[2], 3 * 2 * 14 * 14, generator=g)
+    labels = ids.clone()
+    labels[ids == cfg.image_token_id] = -100
+    ref_loss, ref = hf_vl_reference_loss_and_lora_grads(model, ids, mask, pix, thw, labels, device="cuda")
+    torch.cuda.empty_cache()
+    _, yard = hf_vl_reference_loss_and_lora_grads(model, ids, mask, pix, thw, labels, device="cuda", dtype=torch.bfloat16)
+    torch.cuda.empty_cache()
+    out = model(input_ids=ids.cuda(), attention_mask=mask.cuda(), pixel_values=pix.cuda(), image_grid_thw=thw.cuda(),
+                labels=labels.cuda())
+    out.loss.backward()
+    got = {}
+    for n, p in model.visual.named_parameters():
+        if p.requires_grad:
+            got["visual." + n.replace(".default.weight", "")] = p.grad.detach().float().cpu()
+    for n, p in model.language.named_parameters():
+        if p.requires_grad:
+            got["language.layers." + n.split(".layers.", 1)[1].replace(".default.weight", "")] = p.grad.detach().float().cpu()
+    assert len([k for k in got if k.startswith("visual.")]) == 2 * 4 * 2      # A and B of qkv / proj / fc1 / fc2 in 2 blocks
+    _compare("config4_pixels_real_widths", out.loss, got, ref_loss, ref, yard)

@@ -166,3 +166,43 @@ def test_fast_vision_model_lora_on_both_towers_trains():
         opt.zero_grad(set_to_none=True)
         losses.append(float(loss))
     assert losses[-1] < losses[0] - 0.05, losses
+
+
+@pytest.mark.gpu
+def test_fast_vision_model_lora_gradients_on_both_towers_match_hf_fp32():
+    """pixel_values -> loss -> LoRA gradients of the ViT linears (LoRA_W with bias) and of the fused language tower, against
+    transformers' Qwen2VLForConditionalGeneration in fp32 with merged weights (oracle/ref_model.py)."""
+    from oracle.ref_model import hf_vl_reference_loss_and_lora_grads
+    from tests._util import rel_fro
+    from unsloth_amd import FastVisionModel
+    cfg = _vl_config()
+    model, _ = FastVisionModel.from_pretrained(config=cfg, max_seq_length=256, load_in_4bit=True, device="cuda",
+                                               use_gradient_checkpointing=False)
+    model = FastVisionModel.get_peft_model(model, r=8, lora_alpha=8, use_gradient_checkpointing=False)
+    gen = torch.Generator().manual_seed(6)
+    for n, p in model.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_((torch.randn(p.shape, generator=gen) * 0.05).to(p.device))
+    grids = [(1, 4, 6), (1, 8, 4)]
+    ids, mask = _sample(cfg, grids, gen=gen)
+    thw = torch.tensor(grids)
+    pix = torch.randn(int(sum(t * h * w for t, h, w in grids)), 3 * 2 * 14 * 14, generator=gen)
+    labels = ids.clone()
+    labels[mask == 0] = -100
+    labels[ids == cfg.image_token_id] = -100
+    ref_loss, ref = hf_vl_reference_loss_and_lora_grads(model, ids, mask, pix, thw, labels)
+    out = model(input_ids=ids.cuda(), attention_mask=mask.cuda(), pixel_values=pix.cuda(), image_grid_thw=thw.cuda(),
+                labels=labels.cuda())
+    out.loss.backward()
+    got = {}
+    for n, p in model.visual.named_parameters():
+        if p.requires_grad:
+            got["visual." + n.replace(".default.weight", "")] = p.grad.detach().float().cpu()
+    for n, p in model.language.named_parameters():
+        if p.requires_grad:
+            got["language.layers." + n.split(".layers.", 1)[1].replace(".default.weight", "")] = p.grad.detach().float().cpu()
+    assert set(got) == set(ref)
+    assert abs(float(out.loss) - float(ref_loss)) <= 2e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    worst = max((rel_fro(got[k], ref[k]), k) for k in got)
+    total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]), torch.cat([ref[k].flatten() for k in sorted(got)]))
+    assert worst[0] < 4e-2 and total < 2e-2, (worst, total)
