@@ -187,3 +187,47 @@ def test_config3_llama3_8b_widths_full_finetune_seq2048_step():
     opt.zero_grad()
     assert all(p.grad is None for p in model.parameters())
     opt.buckets.close()
+
+
+@pytest.mark.parametrize("arch,gc", [("qwen2", False), ("llama", True), ("qwen2", True)])
+def test_full_finetune_biased_projections_and_reentrant_checkpointing(arch, gc):
+    """Qwen2's q/k/v BIASES train too under full fine-tuning (column sums of dQ / dK / dV), and torch's reentrant per-layer
+    checkpointing (use_gradient_checkpointing=True: the reference's default for full fine-tuning through HF Trainer) re-runs
+    the dense blocks inside the backward with the gradient sinks attached."""
+    from oracle.ref_model import hf_reference_loss_and_all_grads
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.full_finetune import FullGradBuckets
+    if arch == "qwen2":
+        from transformers import Qwen2Config
+        cfg = Qwen2Config(hidden_size=512, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=4,
+                          num_key_value_heads=2, vocab_size=2048, rms_norm_eps=1e-6, max_position_embeddings=1024,
+                          rope_parameters={"rope_type": "default", "rope_theta": 1e6}, tie_word_embeddings=False)
+    else:
+        cfg = _llama_cfg(512, 1024, 4, 2, 2048, 2)
+    model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=512, full_finetuning=True, device=DEV,
+                                                 random_state=3407, use_gradient_checkpointing=gc)
+    assert model._unsloth_amd_patched == (2, 2, 2)
+    g = torch.Generator().manual_seed(9)
+    if arch == "qwen2":
+        for layer in model.model.layers:
+            for n in ("q_proj", "k_proj", "v_proj"):
+                b = getattr(layer.self_attn, n).bias
+                assert b is not None and b.requires_grad
+                b.data.copy_((torch.randn(b.shape, generator=g) * 0.1).to(b.device, b.dtype))
+    T = 320
+    ids = torch.randint(0, 2048, (2, T), generator=g)
+    pos = torch.arange(T, dtype=torch.int32).unsqueeze(0).expand(2, T).contiguous()
+    ref_loss, ref = hf_reference_loss_and_all_grads(model, ids, ids.clone(), pos)
+    _, yard = hf_reference_loss_and_all_grads(model, ids, ids.clone(), pos, dtype=torch.bfloat16)
+    buckets = FullGradBuckets(model)
+    try:
+        out = model(input_ids=ids.to(DEV), labels=ids.to(DEV), position_ids=pos.to(DEV))
+        out.loss.backward()
+        buckets.finish()
+        got = {n: p.grad.detach().float().cpu() for n, p in model.named_parameters()}
+        assert abs(float(out.loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
+        (worst, wk), total = _grad_errors(got, ref)
+        (yw, _), yt = _grad_errors(yard, ref)
+        assert worst < max(2.5e-2, 1.25 * yw) and total < max(1.5e-2, 1.25 * yt), (worst, wk, total, yw, yt)
+    finally:
+        buckets.close()

@@ -229,6 +229,34 @@ def test_return_logits_branch_and_n_items():
     assert abs(float(out2.loss) * 1000 / n - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
 
 
+def test_return_logits_branch_trains_like_the_fused_ce_branch():
+    """UNSLOTH_RETURN_LOGITS=1 materialises the logits; a loss computed from them -- the model's own, or the caller's --
+    must reach the LoRA factors exactly like the fused linear-CE branch does."""
+    model = _tiny()
+    ids, labels, pos = _batch(seed=4)
+    grads = {}
+    for branch in ("fused", "logits", "caller"):
+        for p in model.parameters():
+            p.grad = None
+        if branch != "fused":
+            os.environ["UNSLOTH_RETURN_LOGITS"] = "1"
+        try:
+            if branch == "caller":
+                lg = model(input_ids=ids.to(DEV), position_ids=pos.to(DEV)).logits
+                assert lg.requires_grad
+                loss = torch.nn.functional.cross_entropy(lg[:, :-1].float().reshape(-1, lg.shape[-1]),
+                                                         labels[:, 1:].reshape(-1).to(DEV), ignore_index=-100)
+            else:
+                loss = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV)).loss
+        finally:
+            os.environ.pop("UNSLOTH_RETURN_LOGITS", None)
+        loss.backward()
+        grads[branch] = (float(loss), torch.cat([p.grad.float().flatten() for p in model.parameters() if p.requires_grad]))
+    for branch in ("logits", "caller"):
+        assert abs(grads[branch][0] - grads["fused"][0]) <= 1e-3 * abs(grads["fused"][0])
+        assert rel_fro(grads[branch][1], grads["fused"][1]) < 1.5e-2, branch
+
+
 @pytest.mark.parametrize("head_dim", [32, 128])
 def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypatch):
     """position ids restart per document (indexed RoPE), attention is block-diagonal, boundary targets are

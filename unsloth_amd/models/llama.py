@@ -409,8 +409,19 @@ def CausalLM_fast_forward(original_forward):
             return CausalLMOutputWithPast(loss=loss, logits=EMPTY_LOGITS)
         keep = max(int(num_logits_to_keep or 0), int(logits_to_keep or 0) if isinstance(logits_to_keep, int) else 0)
         hs = hidden_states[:, -keep:, :] if keep else hidden_states
-        (logits,) = lora_linear_forward(hs, [(lm_head, None, None, None, None)]) \
-            if hs.dtype in (torch.bfloat16, torch.float16) else (self.lm_head(hs),)
+        if hs.dtype in (torch.bfloat16, torch.float16) and lm_head.dtype == hs.dtype:
+            # through autograd Functions (the MFMA GEMM forward, NN-form dX, dW for a trainable head): a bare kernel call
+            # here would cut the graph -- a loss computed from these logits must still train the model
+            from ..kernels.fast_dense import Dense_W
+            from ..kernels.fast_lora import LoRA_W
+            if lm_head.requires_grad or (self.lm_head.bias is not None and self.lm_head.bias.requires_grad):
+                logits = Dense_W.apply(hs, lm_head, self.lm_head.bias)
+            elif self.lm_head.bias is not None:
+                logits = LoRA_W.apply(hs, lm_head, None, None, None, None, self.lm_head.bias)
+            else:
+                logits = LoRA_W.apply(hs, lm_head, None, None, None, None)
+        else:
+            logits = self.lm_head(hs)
         loss = None
         if labels is not None:
             labels = labels.to(logits.device)
