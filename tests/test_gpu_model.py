@@ -229,6 +229,43 @@ def test_return_logits_branch_and_n_items():
     assert abs(float(out2.loss) * 1000 / n - float(ref_loss)) <= 1e-3 * abs(float(ref_loss))
 
 
+@pytest.mark.parametrize("load_in_4bit", [True, False])
+@pytest.mark.parametrize("targets", [("q_proj", "v_proj"), ("gate_proj", "up_proj", "down_proj"), ("q_proj", "k_proj", "v_proj"),
+                                     ("o_proj", "down_proj")])
+@pytest.mark.parametrize("gc", [False, "unsloth"])
+def test_lora_on_a_subset_of_the_projections(targets, load_in_4bit, gc):
+    """target_modules = a subset (the most common LoRA recipe is q_proj + v_proj): the projections without an adapter stay
+    frozen NF4 / 16-bit layers, the fused hooks are installed only where every member carries an adapter, and the gradient
+    still has to flow THROUGH the frozen ones. Loss and every LoRA gradient against the fp32 HF oracle."""
+    from transformers import LlamaConfig
+    from oracle.ref_model import hf_reference_loss_and_lora_grads
+    from unsloth_amd import FastLanguageModel
+    cfg = LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=2, head_dim=128, vocab_size=1000, rms_norm_eps=1e-5, max_position_embeddings=512,
+                      rope_parameters={"rope_type": "default", "rope_theta": 5e5}, tie_word_embeddings=False)
+    model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=256, load_in_4bit=load_in_4bit, device=DEV,
+                                                 random_state=3407, use_gradient_checkpointing=gc)
+    model = FastLanguageModel.get_peft_model(model, r=8, lora_alpha=16, target_modules=list(targets),
+                                             use_gradient_checkpointing=gc, random_state=3407)
+    g = torch.Generator().manual_seed(11)
+    n_lora = 0
+    for n, p in model.named_parameters():
+        if "lora_B" in n:
+            p.data.copy_((torch.randn(p.shape, generator=g) * 0.05).to(DEV))
+            n_lora += 1
+    assert n_lora == 2 * len(targets)
+    ids, labels, pos = _batch(seed=7)
+    out = model(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    out.loss.backward()
+    got = _grads(model)
+    ref_loss, ref = hf_reference_loss_and_lora_grads(model, ids, labels, pos)
+    assert set(got) == set(ref) and len(got) == 2 * 2 * len(targets)
+    assert abs(float(out.loss) - float(ref_loss)) <= 1e-3 * abs(float(ref_loss)), (float(out.loss), float(ref_loss))
+    worst = max((rel_fro(got[k], ref[k]), k) for k in got)
+    total = rel_fro(torch.cat([got[k].flatten() for k in sorted(got)]), torch.cat([ref[k].flatten() for k in sorted(got)]))
+    assert worst[0] < 2.5e-2 and total < 1.5e-2, (worst, total)
+
+
 def test_return_logits_branch_trains_like_the_fused_ce_branch():
     """UNSLOTH_RETURN_LOGITS=1 materialises the logits; a loss computed from them -- the model's own, or the caller's --
     must reach the LoRA factors exactly like the fused linear-CE branch does."""

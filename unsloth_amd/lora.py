@@ -109,10 +109,11 @@ class LoraLayer(nn.Module):
         W, q, A, B, s, bias = get_lora_parameters_bias(self)
         drop = self.lora_dropout[self._active_adapter[0]]
         if isinstance(drop, nn.Identity) or not self.training:
-            out = LoRA_W.apply(x, W, q, A, B, s)
-        else:
-            out = LoRA_W.apply(x, W, q, None, None, None)
-            out = out + (drop(x).to(A.dtype) @ A.t() @ B.t()).to(out.dtype) * s
+            if bias is not None:                     # (the bias rides in the GEMM epilogue: the ViT's qkv / proj / fc1 / fc2)
+                return LoRA_W.apply(x, W, q, A, B, s, bias)
+            return LoRA_W.apply(x, W, q, A, B, s)
+        out = LoRA_W.apply(x, W, q, None, None, None)
+        out = out + (drop(x).to(A.dtype) @ A.t() @ B.t()).to(out.dtype) * s
         return out if bias is None else out + bias
 
 

@@ -333,6 +333,15 @@ class Linear4bit(torch.nn.Module):
         return cls(linear.in_features, linear.out_features, packed, qs, linear.bias)
 
     def forward(self, x):
+        """A frozen NF4 projection on its own (LoRA on a subset of the projections -- target_modules=["q_proj", "v_proj"] --
+        leaves the others as this module). Through the autograd Function: the gradient must flow THROUGH a frozen layer
+        (dX = dY @ W, bitsandbytes' MatMul4Bit.backward); a bare kernel call would cut the graph and silently stop training
+        everything in front of it."""
+        if torch.is_grad_enabled() and x.requires_grad:
+            from .kernels.fast_lora import LoRA_W
+            if self.bias is not None:
+                return LoRA_W.apply(x, self.weight, self.weight.quant_state, None, None, None, self.bias)
+            return LoRA_W.apply(x, self.weight, self.weight.quant_state, None, None, None)
         from .kernels.utils import matmul_lora
         out = matmul_lora(x, self.weight, self.weight.quant_state, None, None, None)
         return out if self.bias is None else out + self.bias
