@@ -433,6 +433,8 @@ def test_training_reduces_loss_and_adapters_round_trip(tmp_path):
     from unsloth_amd import FastLanguageModel
     with _pt.raises(NotImplementedError):
         FastLanguageModel.get_peft_model(_tiny_base(), r=8, modules_to_save=["lm_head"])
+    with _pt.raises(NotImplementedError, match="lm_head"):
+        FastLanguageModel.get_peft_model(_tiny_base(), r=8, target_modules=["q_proj", "lm_head"])
 
 
 def test_bnb4bit_checkpoint_round_trip_and_merge(tmp_path):

@@ -616,6 +616,12 @@ class FastLlamaModel:
             raise TypeError(f"Unsloth: Rank of {str(r)} must be an integer larger than 0.")   # :3140-3143
         if bias != "none":
             raise NotImplementedError("bias != 'none' takes the slow PEFT path in the reference; not implemented")
+        extra = [t for t in target_modules if t in ("lm_head", "embed_tokens")]
+        if extra:
+            # the reference moves these into PEFT's modules_to_save (trainable fp32 copies, llama.py:3290-3330); this PEFT
+            # stand-in has no such wrapper -- refuse by name instead of wrapping them as LoRA layers
+            raise NotImplementedError(f"target_modules {extra}: training lm_head / embed_tokens next to LoRA needs PEFT's "
+                                      "modules_to_save (not in this build); full_finetuning=True trains them")
         torch.manual_seed(random_state)
         if torch.cuda.is_available():
             torch.cuda.manual_seed_all(random_state)
