@@ -55,6 +55,7 @@ class GemmTimer:
         self.orig = U._launch_gemm
         self.records = {}
         self.enabled = False
+        self.steps_sampled = 0         # timed steps whose launches carry event pairs (bench --roofline-every)
 
     def install(self):
         U, orig, recs = self.U, self.orig, self.records
@@ -78,6 +79,7 @@ class GemmTimer:
 
     def reset(self):
         self.records.clear()
+        self.steps_sampled = 0
 
     def summary(self):
         out = {}
@@ -86,7 +88,8 @@ class GemmTimer:
                 continue
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
             fl = sum(r[2] for r in recs)
-            out[name] = dict(launches=len(recs), total_ms=ms, avg_us=ms * 1e3 / len(recs), flops=fl,
+            out[name] = dict(launches=len(recs), steps_sampled=max(1, self.steps_sampled), total_ms=ms,
+                             avg_us=ms * 1e3 / len(recs), flops=fl,
                              tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                              alg_bytes=sum(r[3] for r in recs) / len(recs))
         return out
@@ -116,6 +119,11 @@ def main():
                     help="also time this many steps in the other checkpointing modes and at batch 1 / 2 "
                          "(reported under 'alt'); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-every", type=int, default=int(os.environ.get("BENCH_ROOFLINE_EVERY", 4)),
+                    help="HIP-event pairs around the GEMM launches on every Nth timed step (the first one always). An event "
+                         "pair drains the queue around its kernel: ~12 us per GEMM, 292 GEMMs per step = 1.4 %% of the step "
+                         "when every step is instrumented (profiles/r03final_step_sequence.csv: all 3.5 ms of idle gaps of a "
+                         "step sit before a GEMM or before the kernel that follows one). 1 = every step")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -205,12 +213,17 @@ def main():
             times = []
             for i in range(steps):
                 ts = time.perf_counter()
+                timer.enabled = (i == 0)                # the MEDIAN step is then one without event pairs
+                timer.steps_sampled += int(timer.enabled)
                 losses.append(training_step(model, bt[i % 2], opt, arena, ni))
                 sync()
                 times.append(time.perf_counter() - ts)
             dt = sorted(times)[len(times) // 2] * steps
         else:
+            every = max(1, a.roofline_every)
             for i in range(steps):
+                timer.enabled = (i % every == 0)        # roofline sample: the launches of every Nth timed step
+                timer.steps_sampled += int(timer.enabled)
                 losses.append(training_step(model, bt[i % 2], opt, arena, ni))
             sync()
             dt = time.perf_counter() - t0
@@ -353,10 +366,12 @@ def main():
                             unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                             traffic_unit="bytes per launch (mean)", traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(dom["alg_bytes"]),
-                            launches_per_step=dom["launches"] // a.steps, avg_launch_us=round(dom["avg_us"], 1),
-                            share_of_step=round(dom["total_ms"] / (dt * 1e3), 3),
+                            launches_per_step=dom["launches"] // dom["steps_sampled"], avg_launch_us=round(dom["avg_us"], 1),
+                            steps_sampled=dom["steps_sampled"],
+                            sampling=f"HIP-event pairs around every GEMM launch of every {max(1, a.roofline_every)}th timed step",
+                            share_of_step=round(dom["total_ms"] / dom["steps_sampled"] / (dt / a.steps * 1e3), 3),
                             other={k: dict(tflops=round(v["tflops"], 1), avg_us=round(v["avg_us"], 1),
-                                           share_of_step=round(v["total_ms"] / (dt * 1e3), 3))
+                                           share_of_step=round(v["total_ms"] / v["steps_sampled"] / (dt / a.steps * 1e3), 3))
                                    for k, v in gs.items() if k != dom_name})
         cpu = None
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the other ranks must not wait on it)
