@@ -8,6 +8,7 @@ import dataclasses
 import sys
 import types
 
+import pytest
 import torch
 
 
@@ -111,3 +112,43 @@ def test_recompute_policy_schedules():
     got = [policy_for_layer(sched, i) for i in range(8)]
     assert got[:3] == [POLICIES["all"]] * 3 and got[3:5] == [POLICIES["min"]] * 2 and got[5:] == [POLICIES["attn"]] * 3
     assert policy_for_layer(POLICIES["min"], 7) == POLICIES["min"]
+
+
+# ---- the PEFT plugin contract of get_lora_parameters(_bias): the reference's tests/test_fast_gemv_dispatch.py:38-63 ----
+def _proj(weight, weight_scale=None, **extra):
+    from types import SimpleNamespace
+    proj = SimpleNamespace(weight=weight, bias=None, merged=False, **extra)
+    if weight_scale is not None:
+        proj.weight_scale = weight_scale
+    return proj
+
+
+def test_bf16_weight_scale_is_not_a_quant_state():
+    """A bf16 weight that still carries a weight_scale (a decompressed compressed-tensors layer): quant state None, for
+    both accessors."""
+    from unsloth_amd.kernels.utils import get_lora_parameters, get_lora_parameters_bias
+    proj = _proj(torch.randn(4, 4, dtype=torch.bfloat16), torch.rand(2, 2))
+    assert get_lora_parameters_bias(proj)[1] is None
+    assert get_lora_parameters(proj)[1] is None
+    assert get_lora_parameters_bias(_proj(torch.randn(4, 4, dtype=torch.bfloat16)))[1] is None
+
+
+def test_fp8_weight_keeps_its_scale_and_the_kernels_refuse_it():
+    from unsloth_amd.kernels.utils import (get_lora_parameters, get_lora_parameters_bias, _FP8_WEIGHT_DTYPES, matmul_lora,
+                                           fast_dequantize)
+    if not _FP8_WEIGHT_DTYPES:
+        pytest.skip("no float8 dtype in this torch build")
+    scale = torch.rand(2, 2)
+    proj = _proj(torch.randn(4, 4).to(_FP8_WEIGHT_DTYPES[0]), scale)
+    W, q = get_lora_parameters_bias(proj)[:2]
+    assert q is scale and get_lora_parameters(proj)[1] is scale
+    # weight_scale_inv wins over weight_scale; quant_method "fp8" stamps the block size on weight and state (utils.py:351-366)
+    inv = torch.rand(2, 2)
+    proj2 = _proj(torch.randn(4, 4).to(_FP8_WEIGHT_DTYPES[0]), scale, weight_scale_inv=inv, quant_method="fp8")
+    W2, q2 = get_lora_parameters(proj2)[:2]
+    assert q2 is inv and W2.block_size == [128, 128] and q2.block_size == [128, 128]
+    # no fp8 GEMM on this backend: loud refusal instead of misreading the scale as an NF4 quant state
+    with pytest.raises(NotImplementedError, match="fp8"):
+        fast_dequantize(W, q)
+    with pytest.raises(NotImplementedError, match="fp8"):
+        matmul_lora(torch.randn(1, 3, 4, dtype=torch.bfloat16), W, q, None, None, None)

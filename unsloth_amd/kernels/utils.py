@@ -56,6 +56,38 @@ def QUANT_STATE(W):
     return getattr(W, "quant_state", None)
 
 
+# utils.py:325-332: the dtypes for which a layer's `weight_scale(_inv)` IS its quant state. A bf16 weight that still
+# carries a scale (a decompressed compressed-tensors layer) must NOT get one, or the NF4 path would read a missing absmax
+# (the reference's tests/test_fast_gemv_dispatch.py:38-63 pins exactly this resolution).
+_FP8_WEIGHT_DTYPES = tuple(d for d in (getattr(torch, "float8_e4m3fn", None), getattr(torch, "float8_e5m2", None))
+                           if d is not None)
+
+
+def _resolve_quant_state(base_layer, W):
+    """utils.py:351-366 / :407-422: bitsandbytes' quant_state off the weight; for a weight that is still fp8 the layer's
+    weight_scale_inv / weight_scale (block size stamped the way the reference passes it along). This backend has no fp8
+    GEMM: the resolution is kept for the plugin contract, the kernels refuse such a weight loudly (_refuse_fp8)."""
+    W_quant = getattr(W, "quant_state", None)
+    if W_quant is None and W.dtype in _FP8_WEIGHT_DTYPES:
+        W_quant = getattr(base_layer, "weight_scale_inv", None)
+        if W_quant is None:
+            W_quant = getattr(base_layer, "weight_scale", None)
+    if getattr(base_layer, "quant_method", None) == "fp8":
+        W.block_size = getattr(base_layer, "block_size", [128, 128])
+        if W_quant is not None:
+            W_quant.block_size = W.block_size
+    return W_quant
+
+
+def _refuse_fp8(projs):
+    for p in projs:
+        if p[0].dtype in _FP8_WEIGHT_DTYPES:
+            raise NotImplementedError(
+                "fp8 base weights (weight_scale / weight_scale_inv quant state) are outside this backend's scope: the MI355X "
+                "path takes NF4 (bitsandbytes layout) or 16-bit base weights. The reference routes them to "
+                "unsloth/kernels/fp8.py (utils.py:1146-1152).")
+
+
 def get_lora_parameters(proj):
     """(W, quant_state, A, B, scaling) of a PEFT-style LoRA layer; utils.py:335-397.
     Disabled / merged adapters -> (W, quant_state, None, None, None) (:369-370)."""
@@ -65,7 +97,7 @@ def get_lora_parameters(proj):
         fq = getattr(base_layer, "weight_fake_quantizer", None)
         if fq is not None:
             W = fq(W)
-    W_quant = getattr(W, "quant_state", None)
+    W_quant = _resolve_quant_state(base_layer, W)
     if getattr(proj, "disable_adapters", True) or proj.merged:
         return W, W_quant, None, None, None
     adapter = getattr(proj, "active_adapters", None)
@@ -87,7 +119,7 @@ def get_lora_parameters_bias(proj):
     """utils.py:400-440: same plus the base layer's bias."""
     base_layer = getattr(proj, "base_layer", proj)
     W = base_layer.weight
-    W_quant = getattr(W, "quant_state", None)
+    W_quant = _resolve_quant_state(base_layer, W)
     if getattr(proj, "disable_adapters", True) or proj.merged:
         return W, W_quant, None, None, None, base_layer.bias
     adapter = getattr(proj, "active_adapters", None)
@@ -106,6 +138,7 @@ def fast_dequantize(W, quant_state=None, out=None, use_global_buffer=False):
     per-device scratch buffer that the next call overwrites (:608-632)."""
     if quant_state is None:
         return W
+    _refuse_fp8([(W,)])
     is_transposed = W.shape[0] == 1
     packed = W.t() if is_transposed else W
     out = _nf4.dequantize_nf4(packed, quant_state, out=out, use_global_buffer=use_global_buffer)
@@ -485,6 +518,7 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False, pre_xa=None):
     """Y_g = X @ W_g^T + s_g * (X @ A_g^T) @ B_g^T for projections `projs` = [(W, W_quant, A, B, s)]
     that share X. Returns a list of [.., N_g] tensors. This is matmul_lora (utils.py:1128-1170)
     for q/k/v or gate/up at once."""
+    _refuse_fp8(projs)
     _lib.require_gpu(X)
     dtype = X.dtype
     if dtype not in (torch.bfloat16, torch.float16):
@@ -727,6 +761,7 @@ def lora_linear_dx(dYs, projs, out=None, terms=None):
     inplace=True) receives the result. `terms` = lora_dx_terms(dYs, projs) when the caller already has them."""
     dtype = dYs[0].dtype
     projs = [tuple(p[:5]) for p in projs]
+    _refuse_fp8(projs)
     if terms is None:
         terms = lora_dx_terms(dYs, projs)
     merged = _lora_linear_dx_merged(dYs, projs, out, terms) if MERGE_DX else None
@@ -1006,6 +1041,7 @@ def fast_linear_forward(proj, X, temp_lora=None, out=None):
     products of a launch land in one fp32 vector of their own)."""
     from . import decode as _dk
     W, W_quant, A, B, s, bias = get_lora_parameters_bias(proj)
+    _refuse_fp8([(W,)])
     bsz, q_len, in_dim = X.shape
     n_out = int(W_quant.shape[0]) if W_quant is not None else int(W.shape[0])
     if bsz == 1 and q_len == 1 and in_dim <= 16384 and X.dtype in (torch.bfloat16, torch.float16) \
@@ -1023,6 +1059,7 @@ def fast_gemv(X, W, quant_state, out=None):
     """utils.py:872-977: out[1, 1, N] = X[1, 1, K] @ W^T for an NF4 weight (or a plain matmul when quant_state is None,
     :880-881). One uamd_gemv launch; the nested absmax is decoded inside it."""
     from . import decode as _dk
+    _refuse_fp8([(W,)])
     if quant_state is None:
         return torch.matmul(X, W, out=out)
     N = int(quant_state.shape[0])
