@@ -283,7 +283,9 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_GEMM_PERSIST 7 /* (UAMD_GEMM_PERSIST) uamd_gemm_n{t,n}_256 with 256-row tiles: one persistent block per CU walks the tiles
                                  * and prefetches the next tile's first K tiles during the current one's last: 1 = when every CU gets
                                  * >= 4 tiles (default), 2 = whenever it gets more than one, 0 = never (one block per tile) */
-#define UAMD_TUNE_COUNT 8
+#define UAMD_TUNE_DEQUANT_X4 8  /* (UAMD_DEQUANT_X4) row-major NF4 dequant to a 16-bit dtype: 1 = four 8-element groups per lane per
+                                 * trip, loads issued ahead, shift instead of the 64-bit division (default), 0 = one group per lane */
+#define UAMD_TUNE_COUNT 9
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

@@ -204,7 +204,7 @@ def test_engine_logits_match_training_path_forward(load_in_4bit, monkeypatch):
     # a second prompt on the SAME engine (graph already captured): the replayed steps must return the graph's logits,
     # not the tensor prefill() produced
     lg2 = eng.prefill(ids)
-    assert torch.equal(lg2, lg_e.new_tensor(lg2))           # (finite, same device)
+    assert bool(torch.isfinite(lg2).all()) and lg2.device == lg_e.device
     first = torch.argmax(lg2, dim=-1)
     again = eng.step(first).clone()
     eng_f = DecodeEngine(model, max_seq_len=256, batch=1, use_graph=False)

@@ -110,6 +110,58 @@ nf4_dequant_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const float
     }
 }
 
+// The same arithmetic with FOUR groups per lane per trip (blocksize a power of two >= 8, 16-bit output). The one-group
+// kernel above keeps a single 4-byte load in flight per lane -- 8 waves x 64 lanes x 4 B x 4 SIMDs x 256 CUs = 2 MB over
+// the chip, which at ~2 us of loaded HBM latency is ~1 TB/s of packed codes = ~5 TB/s of total traffic: exactly where it
+// measured in the step (60-65 % of HBM, profiles/pmc_traffic.json). Here the four code loads and the four absmax loads of a
+// trip are issued before anything waits, every load / store instruction of a wave still covers one contiguous 256 B / 1 KB
+// piece, and the block index -> absmax index is a shift (the 64-bit division by a run-time blocksize was ~40 VALU
+// instructions per group).
+template <typename T>
+__global__ void __launch_bounds__(256)
+nf4_dequant_x4_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const float* __restrict__ lut_g,
+                      T* __restrict__ out, int64_t n, int shift /* log2(blocksize) - 3 */, int blocksize) {
+    __shared__ float lut[16];
+    __shared__ float code2[256];
+    if (threadIdx.x < 16) lut[threadIdx.x] = lut_g ? lut_g[threadIdx.x] : kNF4[threadIdx.x];
+    if (am.u8) code2[threadIdx.x] = am.code2[threadIdx.x];
+    __syncthreads();
+    const int64_t ngroups = n / 8;
+    const int64_t ntrips = ngroups / 1024;
+    const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(packed);
+    auto decode_store = [&](uint32_t w, float a0, int64_t g) {
+        Vec16<T> o;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t byte = (w >> (8 * b)) & 0xff;
+            o.e[2 * b] = from_f32<T>(lut[byte >> 4] * a0);          // high nibble first
+            o.e[2 * b + 1] = from_f32<T>(lut[byte & 15] * a0);
+        }
+        st16(out + g * 8, o);
+    };
+    for (int64_t t = blockIdx.x; t < ntrips; t += gridDim.x) {
+        const int64_t g0 = t * 1024 + threadIdx.x;
+        uint32_t w[4];
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = words[g0 + j * 256];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = absmax_at(am, code2, (g0 + j * 256) >> shift);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) decode_store(w[j], a[j], g0 + j * 256);
+    }
+    // the groups past the last whole trip, then the elements past the last whole group (as the one-group kernel)
+    for (int64_t g = ntrips * 1024 + (int64_t)blockIdx.x * 256 + threadIdx.x; g < ngroups; g += (int64_t)gridDim.x * 256)
+        decode_store(words[g], absmax_at(am, code2, g >> shift), g);
+    if (blockIdx.x == 0) {
+        for (int64_t e = ngroups * 8 + threadIdx.x; e < n; e += 256) {
+            const uint8_t byte = packed[e >> 1];
+            const int c = (e & 1) ? (byte & 15) : (byte >> 4);
+            out[e] = from_f32<T>(lut[c] * absmax_at(am, code2, e / blocksize));
+        }
+    }
+}
+
 // Transposed output: W is logically [rows, cols] (cols contiguous, packed); writes
 // out[c * ld_out + r].  Used to hand the backward GEMM (dX = dY @ W) a K-contiguous operand.
 // 64x64 tile through LDS; both the packed read and the transposed write are 16B/128B coalesced.
@@ -310,8 +362,21 @@ int launch_dequant(const uint8_t* packed, const AbsmaxSrc& am, const float* lut,
                    hipStream_t st) {
     const int64_t n = rows * cols;
     if (!transpose) {
-        hipLaunchKernelGGL((nf4_dequant_kernel<T>), dim3(grid_cap(n / 8)), dim3(256), 0, st, packed,
-                           am, lut, (T*)out, n, blocksize);
+        const bool pow2 = blocksize >= 8 && (blocksize & (blocksize - 1)) == 0;
+        if (sizeof(T) == 2 && pow2 && n >= 8192 && uamd_tuning_get(UAMD_TUNE_DEQUANT_X4) != 0) {
+            // whole trips spread EVENLY over at most 8 blocks per CU (7168 trips of a [14336, 4096] weight = 1792 blocks
+            // of 4 trips, not 2048 blocks of which half run a fourth trip alone)
+            const int64_t ntrips = n / 8192;
+            const int64_t per_block = (ntrips + 2047) / 2048;
+            const unsigned grid = (unsigned)((ntrips + per_block - 1) / per_block);
+            int shift = 0;
+            while ((8 << shift) < blocksize) ++shift;
+            hipLaunchKernelGGL((nf4_dequant_x4_kernel<T>), dim3(grid), dim3(256), 0, st, packed, am, lut, (T*)out, n,
+                               shift, blocksize);
+        } else {
+            hipLaunchKernelGGL((nf4_dequant_kernel<T>), dim3(grid_cap(n / 8)), dim3(256), 0, st, packed,
+                               am, lut, (T*)out, n, blocksize);
+        }
     } else {
         if (sizeof(T) != 2 || (cols & 7)) return UAMD_ERR_ARG;
         const int tv = uamd_tuning_get(UAMD_TUNE_DEQUANT_T);
