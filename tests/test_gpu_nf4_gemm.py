@@ -65,6 +65,35 @@ def test_nf4_dequantize_bit_exact(dtype, nested):
     assert err < 0.16 * W.float().abs().max()
 
 
+@pytest.mark.parametrize("blocksize", [32, 64, 256])
+@pytest.mark.parametrize("nested", [False, True])
+@pytest.mark.parametrize("rows,cols", [(128, 64), (192, 320), (520, 1032), (4096, 14336)])
+def test_nf4_dequantize_four_groups_per_lane_kernel_is_bit_identical(rows, cols, nested, blocksize):
+    """nf4_dequant_x4_kernel (knob 8, the default for 16-bit outputs of >= 8192 elements) against the one-group kernel
+    and, at the sizes the CPU restatement finishes quickly, the oracle: whole trips only (128 x 64 = one trip), trips + a
+    group remainder, absmax blocks that straddle trips (blocksize 256), nested and plain statistics, the [14336, 4096]
+    weight of the step (7168 trips over 1792 blocks)."""
+    from unsloth_amd import _lib
+    from unsloth_amd.nf4 import quantize_nf4, dequantize_nf4
+    if (rows * cols) % blocksize:
+        pytest.skip("numel not a multiple of the blocksize")
+    for dtype in (torch.bfloat16, torch.float16):
+        W = (torch.randn(rows, cols, generator=g(rows + cols)) * 0.02).to(dtype)
+        packed, qs = quantize_nf4(W.to(DEV), blocksize=blocksize, compress_statistics=nested)
+        L = _lib.lib()
+        try:
+            assert L.uamd_set_tuning(8, 0) == 0
+            one = dequantize_nf4(packed, qs, cache_absmax=False).clone()
+            assert L.uamd_set_tuning(8, 1) == 0
+            four = dequantize_nf4(packed, qs, cache_absmax=False).clone()
+            four_cached = dequantize_nf4(packed, qs, cache_absmax=True).clone()
+        finally:
+            L.uamd_set_tuning(8, 1)
+        assert torch.equal(one, four) and torch.equal(one, four_cached)
+        if rows * cols <= 600000:
+            assert torch.equal(four.cpu(), R.nf4_dequantize_state(packed, qs))
+
+
 @pytest.mark.parametrize("rows,cols", [(1024, 4096), (200, 264), (64, 256), (136, 1032)])
 @pytest.mark.parametrize("knob", [0, 1])
 def test_nf4_dequantize_transposed_kernels_bit_exact(rows, cols, knob):
