@@ -44,8 +44,7 @@ ce_fwd_kernel(const T* __restrict__ logits, int64_t row_stride, float* __restric
     float m = -INFINITY, s = 0.f;
     if (VECTOR) {
         const int nvec = vocab / VEC;
-        for (int i = threadIdx.x; i < nvec; i += 256) {
-            Vec16<T> v = ld16(x + (int64_t)i * VEC);
+        auto absorb = [&](const Vec16<T>& v) {
             float t[VEC];
             float lm = -INFINITY;
 #pragma unroll
@@ -61,7 +60,17 @@ ce_fwd_kernel(const T* __restrict__ logits, int64_t row_stride, float* __restric
                 s = acc;
                 m = M;
             }
+        };
+        // two vectors per trip, both loads issued before either is consumed (one 16-byte load in flight per thread left
+        // the kernel at 66 % of HBM); the vectors are absorbed in the same order as before: identical results
+        int i = threadIdx.x;
+        for (; i + 256 < nvec; i += 512) {
+            const Vec16<T> v0 = ld16(x + (int64_t)i * VEC);
+            const Vec16<T> v1 = ld16(x + (int64_t)(i + 256) * VEC);
+            absorb(v0);
+            absorb(v1);
         }
+        if (i < nvec) absorb(ld16(x + (int64_t)i * VEC));
         for (int c = nvec * VEC + threadIdx.x; c < vocab; c += 256) {
             const float t = ce_transform<SOFTCAP, SCALE>(to_f32(x[c]), softcap, scale);
             online_merge(m, s, t, 1.f);
@@ -127,12 +136,32 @@ ce_bwd_kernel(T* logits, int64_t row_stride, const float* __restrict__ dloss, in
     if (VECTOR) {
         // chunk is a multiple of VEC; the last chunk may end on a ragged tail
         const int cvec_end = c0 + ((c1 - c0) / VEC) * VEC;
-        for (int c = c0 + threadIdx.x * VEC; c < cvec_end; c += 256 * VEC) {
-            Vec16<T> v = ld16(x + c), o;
+        // a block's chunk is 4 vectors per thread (launch_bwd). A full chunk -- every block of a row but the last -- takes
+        // the branch-free form: four loads, then four computes + stores. (A load -> compute -> store loop waits for the
+        // previous trip's STORE before it can use the next load, vmcnt being in order; per-lane conditions around the
+        // loads make hipcc drain vmcnt at every join.)
+        if (c0 + 4 * 256 * VEC <= cvec_end) {
+            const int cb = c0 + threadIdx.x * VEC;
+            Vec16<T> v[4];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j)
-                o.e[j] = ce_grad<T, SOFTCAP, SCALE>(v.e[j], c + j, label, l, dl, softcap, scale);
-            st16(x + c, o);
+            for (int u = 0; u < 4; ++u) v[u] = ld16(x + cb + u * 256 * VEC);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cb + u * 256 * VEC;
+                Vec16<T> o;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    o.e[j] = ce_grad<T, SOFTCAP, SCALE>(v[u].e[j], c + j, label, l, dl, softcap, scale);
+                st16(x + c, o);
+            }
+        } else {
+            for (int c = c0 + threadIdx.x * VEC; c < cvec_end; c += 256 * VEC) {
+                Vec16<T> v = ld16(x + c), o;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    o.e[j] = ce_grad<T, SOFTCAP, SCALE>(v.e[j], c + j, label, l, dl, softcap, scale);
+                st16(x + c, o);
+            }
         }
         for (int c = cvec_end + threadIdx.x; c < c1; c += 256)
             x[c] = ce_grad<T, SOFTCAP, SCALE>(x[c], c, label, l, dl, softcap, scale);

@@ -437,9 +437,15 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
         }
     };
     load_tile(0, A);
-    for (int it = 0; it < ntiles; it += 2) {
-        tile(it, A, B);
-        if (it + 1 < ntiles) tile(it + 1, B, A);
+    {
+        // pairs of tiles in a branch-free body; an odd last tile after the loop (a conditional second tile inside the loop
+        // is a join at which hipcc drains vmcnt -- prefetched loads AND the previous tile's stores -- every iteration)
+        int it = 0;
+        for (; it + 1 < ntiles; it += 2) {
+            tile(it, A, B);
+            tile(it + 1, B, A);
+        }
+        if (it < ntiles) tile(it, A, B);
     }
     // ---- 4 partial tiles -> LDS -> fixed-order sum. acc[s][t][i] = C[row 4 l4 + i][rank t * 16 + l15]
     constexpr int RW = NS * NT * 16;                                     // floats per row of the reduction buffer

@@ -893,7 +893,8 @@ def lora_tn(problems, targets=None):
 # the gated activation fused with the LoRA skinny products (csrc/glu.hip glu_xa_kernel). Measured at Llama-3-8B MLP widths
 # (profiles/r03j_glu_fused_bench.jsonl): backward 291 us against 350 us for the separate launches at 8192 tokens (118 vs
 # 109 at 2048: 128 blocks leave half the chip idle), forward 161 vs 143 -- so by default the BACKWARD is fused from 4096
-# tokens on and the forward is not. UNSLOTH_AMD_GLU_FUSED = "bwd" (default) | "all" (both, any size) | "0".
+# tokens on and the forward is not. UNSLOTH_AMD_GLU_FUSED = "bwd" (default) | "both" (forward too, from 4096 tokens) | "all"
+# (both, any size) | "0".
 GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "bwd")
 GLU_FUSED = {"1": "all", "0": False, "": "bwd"}.get(GLU_FUSED, GLU_FUSED)
 GLU_FUSED_MIN_ROWS = 4096
@@ -903,7 +904,7 @@ _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 def _glu_fusable(dtype, tensors, ranks, backward):
     K = tensors[0].shape[-1]
     mode = GLU_FUSED if GLU_FUSED is not True else "all"
-    if not mode or (mode == "bwd" and (not backward or tensors[0].shape[0] < GLU_FUSED_MIN_ROWS)):
+    if not mode or (mode == "bwd" and not backward) or (mode in ("bwd", "both") and tensors[0].shape[0] < GLU_FUSED_MIN_ROWS):
         return False
     return (LORA_XA_V2 and dtype in (torch.bfloat16, torch.float16) and K % 8 == 0
             and all(t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.dtype == dtype and t.shape == tensors[0].shape
