@@ -2,6 +2,8 @@
 (Llama-3-8B MLP widths, 8192 and 2048 tokens, r = 16). Prints JSON lines."""
 import json
 import sys
+import os
+os.environ.setdefault("UNSLOTH_AMD_GLU_FUSED", "all")      # the direct calls below must not be refused by the size / direction policy
 import torch
 sys.path.insert(0, ".")
 from unsloth_amd.kernels import utils as U

@@ -890,13 +890,14 @@ def lora_tn(problems, targets=None):
     return outs
 
 
-# the gated activation fused with the LoRA skinny products (csrc/glu.hip glu_xa_kernel). Measured at Llama-3-8B MLP widths
-# (profiles/r03j_glu_fused_bench.jsonl): backward 291 us against 350 us for the separate launches at 8192 tokens (118 vs
-# 109 at 2048: 128 blocks leave half the chip idle), forward 161 vs 143 -- so by default the BACKWARD is fused from 4096
-# tokens on and the forward is not. UNSLOTH_AMD_GLU_FUSED = "bwd" (default) | "both" (forward too, from 4096 tokens) | "all"
-# (both, any size) | "0".
-GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "bwd")
-GLU_FUSED = {"1": "all", "0": False, "": "bwd"}.get(GLU_FUSED, GLU_FUSED)
+# the gated activation fused with the LoRA skinny products (csrc/glu.hip glu_xa_kernel). Measured at Llama-3-8B MLP widths,
+# 8192 tokens, in the step (profiles/r03ab_bench_kernel_stats.csv, after the tile loop lost its per-iteration vmcnt drain):
+# backward 281 us against 217 + 2 x ~65 us for the separate launches, forward 157 us against 108 + 57 us; whole step +0.3-0.5 %
+# with the forward fused too (profiles/r03ab_bench_ab.txt). At 2048 tokens 128 blocks leave half the chip idle (118 vs 109 us,
+# profiles/r03j_glu_fused_bench.jsonl), so both directions are fused from 4096 tokens on.
+# UNSLOTH_AMD_GLU_FUSED = "both" (default) | "bwd" (backward only, round 3's first default) | "all" (both, any size) | "0".
+GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "both")
+GLU_FUSED = {"1": "all", "0": False, "": "both"}.get(GLU_FUSED, GLU_FUSED)
 GLU_FUSED_MIN_ROWS = 4096
 _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 
