@@ -259,7 +259,7 @@ def main():
             torch.cuda.empty_cache()
         for tag, mode in (("gc_torch_reentrant (reference's True)", True),
                           ("gc_unsloth_selective_recompute (keep attention block, re-run gate/up)", "unsloth"),
-                          ("gc_unsloth_schedule (first 4 layers keep everything, rest as above)", "unsloth:all*4,attn"),
+                          ("gc_unsloth_auto (as many keep-everything layers as the free HBM holds)", "unsloth:auto"),
                           ("gc_unsloth_min (keep layer inputs only)", "unsloth:min"), ("gc_off", False)):
             if mode != GC_MODE[a.gc]:
                 alt_point(tag, mode, B)

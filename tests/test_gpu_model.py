@@ -89,7 +89,8 @@ def test_gradient_checkpointing_is_bitwise_neutral_and_run_to_run_deterministic(
             assert torch.equal(res[0][1][k], other[1][k]), k
 
 
-@pytest.mark.parametrize("policy", ["unsloth:min", "unsloth", "unsloth:all", "unsloth:qkv+eg", "unsloth:all*1,min*1,attn"])
+@pytest.mark.parametrize("policy", ["unsloth:min", "unsloth", "unsloth:all", "unsloth:qkv+eg", "unsloth:all*1,min*1,attn",
+                                    "unsloth:auto"])
 def test_selective_recompute_layer_function_is_bitwise_equal_to_no_checkpointing(policy):
     """use_gradient_checkpointing="unsloth" (models/fast_layer.py: one manual-autograd Function per decoder layer,
     keep-or-recompute per tensor): loss and every LoRA gradient are BITWISE those of the keep-everything autograd

@@ -47,6 +47,51 @@ def resolve_policy(policy):
     return frozenset(policy)
 
 
+AUTO = "auto"
+
+
+def auto_schedule(n_layers, tokens, hidden, inter, qkv_cols, elsize, free_bytes, vocab=0, headroom=0.15):
+    """"unsloth:auto": the least-recompute schedule `all*k,attn` that fits. The reference's "unsloth" mode is the same kind
+    of decision in the other direction (models/_utils.py:360-386 + unsloth_zoo: offload layer inputs to host RAM when VRAM is
+    short); with 288 GB of HBM the question is how many layers can simply KEEP everything. Pure arithmetic (tested on the CPU):
+      a layer under "attn" keeps  layer input + Q|K|V + attention output (+ fp32 LSE) + post-attention residual,
+      a layer under "all" keeps   that + both normed inputs + e and g ([tokens, 2 * inter]);
+    `free_bytes` = HBM that the step may use (driver-free + the allocator's cached blocks); the transient working set of one
+    layer (e, g, h, their gradients, decoded weight scratch) and of the loss (two logits chunks of <= 4096 rows) is set aside
+    first, `headroom` of the rest stays unused. Returns [(k, all), (None, attn)], or the uniform policy when k is 0 / n_layers."""
+    per_tok_attn = (hidden + qkv_cols + hidden + hidden) * elsize + 4 * (qkv_cols // 128 + 1)
+    per_tok_all_extra = (2 * hidden + 2 * inter) * elsize
+    transient = tokens * (6 * inter + 4 * hidden + 2 * qkv_cols) * elsize + 2 * min(tokens, 4096) * max(vocab, 1) * elsize \
+        + 3 * (hidden * inter) * elsize
+    budget = (free_bytes - transient - n_layers * tokens * per_tok_attn) * (1.0 - headroom)
+    k = int(budget // max(1, tokens * per_tok_all_extra))
+    k = max(0, min(n_layers, k))
+    if k == 0:
+        return POLICIES["attn"]
+    if k == n_layers:
+        return POLICIES["all"]
+    return [(k, POLICIES["all"]), (None, POLICIES["attn"])]
+
+
+def auto_policy(model, hidden_states):
+    """auto_schedule for this call: widths from the config, tokens from the batch, free HBM from the driver + torch's cache."""
+    cfg = model.config
+    dev = hidden_states.device
+    free, _total = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
+    qkv_cols = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * head_dim
+    tokens = hidden_states.shape[0] * hidden_states.shape[1]
+    key = (tokens, free >> 30)
+    hit = getattr(model, "_uamd_auto_policy", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    pol = auto_schedule(len(model.layers), tokens, cfg.hidden_size, cfg.intermediate_size, qkv_cols,
+                        hidden_states.element_size(), free, vocab=getattr(cfg, "vocab_size", 0))
+    model._uamd_auto_policy = (key, pol)
+    return pol
+
+
 def resolve_policy_spec(spec):
     """"attn" | "qkv+h1" | "all*3,attn": one policy, or a comma-separated schedule over the layers in order -- `name*count`
     covers `count` layers, a segment without a count covers all remaining ones (speed/memory dial between two policies:
@@ -55,6 +100,8 @@ def resolve_policy_spec(spec):
     def one(name):
         name = name.strip()
         return resolve_policy(name.split("+") if "+" in name else name)
+    if spec.strip() == AUTO:
+        return AUTO                     # decided per call from the batch size and the free HBM (auto_policy)
     if "," not in spec and "*" not in spec:
         return one(spec)
     out = []

@@ -307,6 +307,8 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
         band = None if (seq_info is None and window is None) else \
             _attention_band(seq_info, bsz, q_len, window, hidden_states.device)
         residual, delta = hidden_states, None
+        if policy == _fast_layer.AUTO:
+            policy = _fast_layer.auto_policy(self, hidden_states)
         for li, layer in enumerate(self.layers):
             residual, delta = _fast_layer.decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids,
                                                                 band, _fast_layer.policy_for_layer(policy, li))
@@ -713,8 +715,9 @@ class FastLlamaModel:
                        (the SwiGLU output and the down projection are never recomputed).
                        "unsloth:min" keeps only the layer input (the memory of `True`), "unsloth:all" keeps
                        everything (the speed of `False`); a schedule such as "unsloth:all*4,attn" keeps everything in
-                       the first 4 layers and applies "attn" to the rest (a dial between the two);
-                       UNSLOTH_AMD_GC_POLICY overrides the default "attn"."""
+                       the first 4 layers and applies "attn" to the rest (a dial between the two); "unsloth:auto"
+                       sets that dial per call from the batch size and the free HBM (fast_layer.auto_schedule: as many
+                       keep-everything layers as fit); UNSLOTH_AMD_GC_POLICY overrides the default "attn"."""
         base = model.get_base_model() if hasattr(model, "get_base_model") else model
         policy = None
         mode = use_gradient_checkpointing
