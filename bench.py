@@ -27,7 +27,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GC_MODE = {"on": True, "off": False, "unsloth": "unsloth", "unsloth:min": "unsloth:min", "unsloth:all": "unsloth:all"}
+GC_MODE = {"on": True, "off": False, "unsloth": "unsloth", "unsloth:min": "unsloth:min", "unsloth:all": "unsloth:all",
+           "unsloth:auto": "unsloth:auto"}
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 HBM_PEAK_GBPS = 8000.0
 
@@ -110,7 +111,7 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--gc", choices=["on", "off", "unsloth", "unsloth:min", "unsloth:all"],
+    ap.add_argument("--gc", choices=["on", "off", "unsloth", "unsloth:min", "unsloth:all", "unsloth:auto"],
                     default=os.environ.get("BENCH_GC", "off"),
                     help="gradient checkpointing for the primary number. off: activations stay in the 288 GB HBM "
                          "(no recompute); on: torch's reentrant per-layer checkpoint (layer inputs only, one extra "
