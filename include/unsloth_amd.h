@@ -285,7 +285,9 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * >= 4 tiles (default), 2 = whenever it gets more than one, 0 = never (one block per tile) */
 #define UAMD_TUNE_DEQUANT_X4 8  /* (UAMD_DEQUANT_X4) row-major NF4 dequant to a 16-bit dtype: 1 = four 8-element groups per lane per
                                  * trip, loads issued ahead, shift instead of the 64-bit division (default), 0 = one group per lane */
-#define UAMD_TUNE_COUNT 9
+#define UAMD_TUNE_GEMM_PLAIN 9  /* (UAMD_GEMM_PLAIN) persistent 256x256 GEMM without accumulate / bias: 1 = the kernel instance whose
+                                 * epilogue has no global loads (default: no vmcnt(0) in the K loop), 0 = the run-time-dispatch instance */
+#define UAMD_TUNE_COUNT 10
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""A/B of the persistent 256x256 GEMM with and without the per-iteration `s_waitcnt vmcnt(0)` hipcc put into its K loop
+(UAMD_TUNE_GEMM_PLAIN = knob 9: 1 = the kernel instance whose epilogue has no global loads, 0 = the run-time-dispatch
+instance), the persistence threshold (knob 7: 1 = from 4 tiles per CU, 2 = from 2, 0 = never) and torch.matmul (hipBLASLt) as
+the yardstick; one process, interleaved rounds, best of 5 x 10 launches. One JSON line per shape (TFLOP/s)."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from unsloth_amd import _lib  # noqa: E402
+from unsloth_amd.kernels import utils as U  # noqa: E402
+
+DEV = "cuda"
+
+
+def run(fn, iters):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+
+
+def main():
+    bf = torch.bfloat16
+    L = _lib.lib()
+    U.GEMM256_MODE = "on"
+    shapes = [(8192, 28672, 4096, "gate+up fwd"), (8192, 14336, 4096, "down dX (NT form of the same shape)"),
+              (8192, 6144, 4096, "q|k|v fwd"), (8192, 4096, 4096, "o fwd"), (8192, 4096, 14336, "down fwd"),
+              (4096, 128256, 4096, "lm_head chunk")]
+    for M, N, K, tag in shapes:
+        X = torch.randn(M, K, device=DEV, dtype=bf)
+        W = (torch.randn(N, K, device=DEV) * 0.02).to(bf)
+        ref = (X @ W.t()).float()
+
+        def mk(plain, persist):
+            def f():
+                L.uamd_set_tuning(9, plain)
+                L.uamd_set_tuning(7, persist)
+                return U.lora_linear_forward(X, [(W, None, None, None, None)])[0]
+            return f
+        cands = {"torch": lambda: X @ W.t(), "persist1_plain0": mk(0, 1), "persist1_plain1": mk(1, 1),
+                 "persist2_plain0": mk(0, 2), "persist2_plain1": mk(1, 2), "persist0": mk(1, 0)}
+        bit = {}
+        for name, f in cands.items():
+            y = f()
+            rel = float((y.float() - ref).norm() / ref.norm())
+            assert rel < 2e-2, (tag, name, rel)
+            bit[name] = y.clone()
+        same = bool(torch.equal(bit["persist1_plain0"], bit["persist1_plain1"]) and torch.equal(bit["persist2_plain0"], bit["persist2_plain1"])
+                    and torch.equal(bit["persist0"], bit["persist2_plain1"]))
+        del bit
+        for f in cands.values():
+            run(f, 3)
+        best = {k: 1e9 for k in cands}
+        for _ in range(5):
+            for name, f in cands.items():
+                best[name] = min(best[name], run(f, 10))
+        fl = 2.0 * M * N * K
+        print(json.dumps(dict(shape=tag, M=M, N=N, K=K, tiles_per_cu=round(-(-M // 256) * -(-N // 256) / 256, 2), bit_identical=same,
+                              **{k: round(fl / v / 1e12, 1) for k, v in best.items()})), flush=True)
+        L.uamd_set_tuning(9, 1)
+        L.uamd_set_tuning(7, 1)
+        del X, W, ref
+
+
+if __name__ == "__main__":
+    main()

@@ -448,7 +448,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(G256Args p) {
 // always numbers its stages 0, 1, so the two sets of LDS addresses (DMA destination base, fragment read offsets)
 // are held in registers and SWAPPED at such a boundary -- no address arithmetic enters the K loop.
 // Host contract (gemm256_entry): K >= 4 * 64, gridDim.x <= total_tiles.
-template <typename T, bool BNN>
+// PLAIN = no accumulate, no bias, known at LAUNCH: that instance's epilogue contains no global load at all. With the
+// run-time dispatch inside the kernel (PLAIN = false) the accumulate / bias paths' loads sit on the walk's back-edge, hipcc's
+// waitcnt pass cannot prove that none of them is still pending when the next output tile's K loop overwrites their registers,
+// and it puts `s_waitcnt vmcnt(0)` into the K LOOP'S HEADER -- executed every iteration, draining the three DMA pieces the
+// counted vmcnt(3) exists to keep in flight across the barrier (ISA: vmcnt sequence 0, 3, 3 per iteration; PLAIN: 3, 3).
+template <typename T, bool BNN, bool PLAIN>
 __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -661,7 +666,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
                 }
             }
         };
-        UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
+        if (PLAIN) epi(std::integral_constant<bool, false>{}, std::integral_constant<bool, false>{});
+        else UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
     };
 
     int v = blockIdx.x;
@@ -1003,20 +1009,27 @@ int launch256(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
-template <typename T, bool BNN>
-int launch256p(const G256Args& a, hipStream_t st, int n_cu) {
+template <typename T, bool BNN, bool PLAIN>
+int launch256p_(const G256Args& a, hipStream_t st, int n_cu) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256p_kernel<T, BNN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256p_kernel<T, BNN, PLAIN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
     const int grid = a.total_tiles < n_cu ? a.total_tiles : n_cu;
-    hipLaunchKernelGGL((gemm_nt256p_kernel<T, BNN>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt256p_kernel<T, BNN, PLAIN>), dim3((unsigned)grid), dim3(512), LDS_BYTES, st, a);
     return uamd_launch_status();
+}
+
+template <typename T, bool BNN>
+int launch256p(const G256Args& a, hipStream_t st, int n_cu) {
+    bool plain = !a.accumulate && uamd_tuning_get(UAMD_TUNE_GEMM_PLAIN) != 0;
+    for (int i = 0; i < a.n_groups; ++i) plain = plain && a.g[i].bias == nullptr;
+    return plain ? launch256p_<T, BNN, true>(a, st, n_cu) : launch256p_<T, BNN, false>(a, st, n_cu);
 }
 
 // compute units of the current device (one persistent block each: 128 KiB of the CU's 160 KiB LDS)
