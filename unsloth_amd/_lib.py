@@ -16,7 +16,8 @@ import torch
 c_void_p, c_int, c_int64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libunsloth_amd.so")
+# UNSLOTH_AMD_LIB: another build of the SAME C ABI (A/B of a kernel file on one box: tools/gpu_r03_ae.sh); default in-tree
+LIB_PATH = os.environ.get("UNSLOTH_AMD_LIB") or os.path.join(HERE, "lib", "libunsloth_amd.so")
 
 UAMD_F32, UAMD_F16, UAMD_BF16 = 0, 1, 2
 _DTYPE_CODE = {torch.float32: UAMD_F32, torch.float16: UAMD_F16, torch.bfloat16: UAMD_BF16}
