@@ -57,18 +57,6 @@ constexpr int NST = 3;
 constexpr int ATTN_LDS = NST * STAGE_B;  // 96 KiB
 
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
-
-// Operand fragments that a kernel loads from global memory ONCE and keeps in registers for its whole tile loop must be
-// "consumed" before that loop: hipcc's waitcnt pass tracks the loads per register and places the wait at the first USE -- which
-// is an MFMA inside the loop, where it stays for every iteration (the loop header merges the first entry's pending state).
-// The hardware counter it waits on is shared with the LDS-DMA the loop has in flight (inline asm, invisible to the pass): a
-// countdown `s_waitcnt vmcnt(7) ... vmcnt(0)` in front of the first eight MFMAs of EVERY tile step made each step wait for
-// the eight DMA pieces of the tile issued a few instructions earlier -- the prefetch bought nothing (found in the ISA of
-// attn_fwd_kernel and attn_bwd_dq_kernel, round 3). An empty asm that names the registers moves the wait to here.
-#define RESIDENT_FRAGS_LANDED(arr)                                              \
-    do {                                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" : "+v"((arr)[i_])); \
-    } while (0)
 typedef __attribute__((address_space(3))) s16x4_t lds_s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4a_t;
 typedef __attribute__((address_space(3))) u32x4a_t lds_u32x4a;
@@ -228,7 +216,6 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
             qf[ks] = u.f;
         }
-        RESIDENT_FRAGS_LANDED(qf);
     }
 
     // ---- DMA plan: a stage = K tile (64 rows x 256 B) then V tile. One DMA instruction = 4 rows. Wave w issues
@@ -682,7 +669,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
             qf[qb][ks] = u.f;
         }
-        RESIDENT_FRAGS_LANDED(qf[qb]);
     }
 
     // ---- DMA plan: stage = K tile (64 rows x 256 B) then V tile; one DMA instruction = 4 rows; wave w issues
@@ -1035,8 +1021,6 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) delta += to_f32(d.e[j]) * to_f32(o.e[j]);
         }
-        RESIDENT_FRAGS_LANDED(qf);
-        RESIDENT_FRAGS_LANDED(dof);
     }
     delta += __shfl_xor(delta, 32, 64);
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
