@@ -1,0 +1,58 @@
+"""Build-time invariants of two hand-pipelined loops, checked on the device assembly (no GPU): hipcc's waitcnt insertion
+must not put a full `s_waitcnt vmcnt(0)` into them. Both had one in round 3 (tools/isa_loop_waits.py tells the story):
+  * glu_xa_kernel (csrc/glu.hip): tile loop with register prefetch one tile ahead -- a conditional second tile inside the
+    loop body was a join at which the pass drained the prefetch and the previous tile's stores every iteration;
+  * gemm_nt256p_kernel<.., PLAIN = true> (csrc/gemm256.hip): the K loop of the persistent walk -- the epilogue's accumulate /
+    bias loads on the walk's back-edge put `vmcnt(0)` into the K loop's header, overriding the DMA ring's counted vmcnt(3)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = "/opt/rocm/bin/hipcc"
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+
+
+def _loops(tmp_path, source):
+    sys.path.insert(0, ROOT)
+    from unsloth_amd import _build
+    import isa_loop_waits
+    out = tmp_path / (source + ".s")
+    cmd = [HIPCC] + _build._flags(source) + ["--cuda-device-only", "-S", os.path.join(ROOT, "unsloth_amd", "csrc", source),
+                                             "-o", str(out)]
+    subprocess.run([c for c in cmd if c != "-fPIC"], check=True, capture_output=True)
+    return isa_loop_waits.loops_of(str(out))
+
+
+def test_glu_xa_tile_loop_keeps_its_prefetch_in_flight(tmp_path):
+    loops = _loops(tmp_path, "glu.hip")
+    kernels = {k: v for k, v in loops.items() if "glu_xa_kernel" in k}
+    assert len(kernels) >= 12                                   # {bf16, fp16} x 3 activations x {fwd, bwd} x rank tiles
+    for k, ls in kernels.items():
+        main = max(ls, key=lambda l: l[1])                      # the tile loop is the longest loop of the kernel
+        lab, n, nld, nst, waits, drains = main
+        assert nld >= 10 and nst >= 2, (k, main)
+        assert not drains, f"{k}: full vmcnt(0) inside the tile loop at body offsets {drains} (waits {waits})"
+        if re.search(r"glu_xa_kernelI\w+?Li0E", k):             # SwiGLU (the instances the training step launches):
+            assert all(int(w) >= 6 for w in waits), (k, waits)  # every wait leaves the next tile's loads in flight
+
+
+def test_persistent_gemm_k_loop_waits_are_the_counted_ones(tmp_path):
+    loops = _loops(tmp_path, "gemm256.hip")
+    plain = {k: v for k, v in loops.items() if re.search(r"gemm_nt256p_kernelI\w+Lb[01]ELb1E", k)}
+    general = {k: v for k, v in loops.items() if re.search(r"gemm_nt256p_kernelI\w+Lb[01]ELb0E", k)}
+    assert len(plain) == 4 and len(general) == 4                # {bf16, fp16} x {NT, NN}
+    for k, ls in plain.items():
+        k_loops = [l for l in ls if l[2] == 16 and l[3] == 0]   # the fast K loop: 2 K tiles = 16 LDS-DMA pieces, no stores
+        assert len(k_loops) == 1, (k, ls)
+        lab, n, nld, nst, waits, drains = k_loops[0]
+        assert waits == ["3", "3"] and not drains, (k, waits)
+    # the run-time-dispatch instance still carries the header wait: if hipcc ever stops inserting it this documents that
+    # PLAIN has become unnecessary (not an error)
+    carried = [k for k, ls in general.items() if any(l[2] == 16 and l[3] == 0 and l[5] for l in ls)]
+    assert len(carried) in (0, 4)
