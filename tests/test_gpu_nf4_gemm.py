@@ -416,10 +416,12 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
         L.uamd_set_tuning(6, 0)                  # 256-row tiles (the persistent walk exists for those)
         for accumulate in (False, True):
             ref = run(0, accumulate)
-            for _ in range(2):
+            for plain in (1, 0):                 # knob 9: the load-free-epilogue instance (default) / the run-time-dispatch one
+                L.uamd_set_tuning(9, plain)
                 got = run(1, accumulate)
                 for r, o in zip(ref, got):
                     assert torch.equal(r, o)
+            L.uamd_set_tuning(9, 1)
         # and against the fp32 product
         y = run(1, False)[0]
         Xf = X.float().cpu()
@@ -431,6 +433,7 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
         U.GEMM256_MODE = old
         L.uamd_set_tuning(6, 1)
         L.uamd_set_tuning(7, 1)
+        L.uamd_set_tuning(9, 1)
 
 
 def test_gemm256_transpose_detecting_and_k_order(force256):

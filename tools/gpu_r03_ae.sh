@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 SECONDS=0
 timeout 600 python -m pytest tests/test_gpu_attention.py -m gpu -q -x > $OUT/pytest_r03ae.log 2>&1
 echo "pytest rc=$? ($SECONDS s)"; tail -3 $OUT/pytest_r03ae.log
+# (build it first: the objects of unsloth_amd/lib/*.o with attention.o replaced by the previous attention.hip, `hipcc -shared`)
 PREV=$R/unsloth_amd/lib/libunsloth_amd_prevattn.so
 for i in 1 2; do
   echo "prev:"; UNSLOTH_AMD_LIB=$PREV timeout 200 python tools/attn_bench.py 2>/dev/null | tee -a $OUT/r03ae_attn_ab_prev.jsonl
