@@ -166,3 +166,37 @@ def test_load_reconciles_stamped_dtype_detects_missing_tensors_and_rebuilds_rota
     save_file(sd, fn, metadata={"format": "pt"})
     missing, _ = ck.load_prequantized_(fresh(), str(tmp_path), "cpu", torch.bfloat16)
     assert missing == [victim]
+
+
+def test_nf4_code_table_is_the_published_quantile_construction():
+    """The 16 NF4 levels are not free constants: bitsandbytes builds them (functional.create_normal_map, offset 0.9677083,
+    the QLoRA paper's "k-bit NormalFloat") from quantiles of N(0, 1) -- 8 positive levels norm.ppf(linspace(offset, 0.5, 9)[:-1]),
+    7 negative ones -norm.ppf(linspace(offset, 0.5, 8)[:-1]), an exact zero, normalised by the largest. Re-deriving them here
+    (torch.linspace in fp32, as bitsandbytes does) must give, BIT FOR BIT, the table of the oracle (oracle/ref_ops.py), of the
+    host module (unsloth_amd/nf4.py) and of the HIP kernels (csrc/nf4.hip kNF4): the one part of the third-party NF4 format
+    that can be pinned to its published algorithm without bitsandbytes installed."""
+    import re
+    import numpy as np
+    from scipy.stats import norm
+    from oracle.ref_ops import NF4_CODE as ORACLE_CODE
+    from unsloth_amd.nf4 import NF4_CODE as HOST_CODE
+    offset = 0.9677083
+    pos = norm.ppf(torch.linspace(offset, 0.5, 9)[:-1]).tolist()
+    neg = (-norm.ppf(torch.linspace(offset, 0.5, 8)[:-1])).tolist()
+    levels = torch.tensor(sorted(pos + [0.0] + neg))
+    levels = (levels / levels.max()).numpy().astype(np.float32)
+    assert levels.shape == (16,) and levels[7] == 0.0 and levels[0] == -1.0 and levels[15] == 1.0
+    assert np.array_equal(levels, np.asarray(ORACLE_CODE, dtype=np.float32))
+    assert np.array_equal(levels, np.asarray(HOST_CODE, dtype=np.float32))
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(ROOT, "unsloth_amd", "csrc", "nf4.hip")).read()
+    body = re.search(r"kNF4\[16\]\s*=\s*\{([^}]*)\}", src).group(1)
+    hip = np.array([float(t.strip().rstrip("f")) for t in body.split(",") if t.strip()], dtype=np.float32)
+    assert np.array_equal(levels, hip)
+    # the decode GEMV carries its own copy of the table (csrc/decode.hip)
+    dec = open(os.path.join(ROOT, "unsloth_amd", "csrc", "decode.hip")).read()
+    m = re.search(r"kNF4d\[16\]\s*=\s*\{([^}]*)\}", dec)
+    assert m is not None
+    if m:
+        dtab = np.array([float(t.strip().rstrip("f")) for t in m.group(1).split(",") if t.strip()], dtype=np.float32)
+        assert np.array_equal(levels, dtab)
