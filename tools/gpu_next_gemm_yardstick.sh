@@ -6,7 +6,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
+timeout ${YARDSTICK_TIMEOUT:-400} rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY \
     -d $OUT/pmc_gemm_yardstick -o pmc -- python $R/tools/gemm_plain_ab.py > $OUT/gemm_yardstick.log 2>&1
 tail -8 $OUT/gemm_yardstick.log | cut -c1-220
 cd $R
