@@ -11,6 +11,14 @@ A "step" = forward + backward + LoRA-grad exchange + AdamW step over one synthet
 bitsandbytes-format NF4 by our own quantiser; token ids ~ U[0, V), labels = ids, position_ids = arange
 (int32, exercising the indexed RoPE path). Nothing is skipped inside the timed region.
 
+The primary number runs under the API default `use_gradient_checkpointing="unsloth"` (the least-recompute schedule that
+fits the free HBM: on an idle 288 GB part every layer keeps everything). `alt` holds the other operating points of the
+reference: the checkpointing modes, batch 1 / 2, the PADDING-FREE PACKED step its SFT trainer runs by default
+(trainer.py:903-912, utils/packing.py:241-284), BASELINE config 3 (full fine-tuning), config 4 (Qwen2-VL-7B, one image in
+4096 tokens) and config 5 (Mistral-7B seq 4096: CE leg and the chunked GRPO log-prob leg), the DP path forced onto one
+rank, decode. `--only NAME` times ONE of them as the whole run (what the per-point rocprofv3 kernel stats under
+profiles/ are collected with).
+
 Rank 0 prints ONE JSON line. Besides the contract fields it carries
   roofline     : the dominant kernel (the MFMA GEMM), ALGORITHMIC flops of its launches / their HIP-event
                  durations measured live in the timed region, against the 2.5 PFLOP/s dense bf16 peak
@@ -28,9 +36,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GC_MODE = {"on": True, "off": False, "unsloth": "unsloth", "unsloth:min": "unsloth:min", "unsloth:all": "unsloth:all",
-           "unsloth:auto": "unsloth:auto"}
+           "unsloth:auto": "unsloth:auto", "unsloth:attn": "unsloth:attn"}
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 HBM_PEAK_GBPS = 8000.0
+ONLY_POINTS = ("primary", "packed", "config4", "config5_ce", "config5_logprob", "dp_force", "batch1", "fullft")
 
 
 def llama3_8b_config(n_layers=32, vocab=128256):
@@ -42,24 +51,50 @@ def llama3_8b_config(n_layers=32, vocab=128256):
         attention_bias=False, mlp_bias=False)
 
 
+def mistral_7b_config(n_layers=32):
+    """BASELINE config 5: Mistral-7B-v0.1 widths (sliding window 4096 == the sequence length: inactive, mistral.py:116-120)."""
+    from transformers import MistralConfig
+    return MistralConfig(hidden_size=4096, intermediate_size=14336, num_hidden_layers=n_layers, num_attention_heads=32,
+                         num_key_value_heads=8, head_dim=128, vocab_size=32000, rms_norm_eps=1e-5,
+                         max_position_embeddings=32768, sliding_window=4096,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e4}, tie_word_embeddings=False)
+
+
+def qwen2_vl_7b_config(n_layers=28, vit_depth=32):
+    """BASELINE config 4: Qwen2-VL-7B (language 3584 / 18944 / 28:4 heads / vocab 152064 with q/k/v bias; ViT 1280 / 16 heads,
+    patch 14, merge 2)."""
+    from transformers import Qwen2VLConfig
+    return Qwen2VLConfig(
+        text_config=dict(hidden_size=3584, intermediate_size=18944, num_hidden_layers=n_layers, num_attention_heads=28,
+                         num_key_value_heads=4, vocab_size=152064, max_position_embeddings=32768, rms_norm_eps=1e-6,
+                         rope_parameters={"rope_type": "default", "rope_theta": 1e6, "mrope_section": [16, 24, 24]},
+                         tie_word_embeddings=False),
+        vision_config=dict(depth=vit_depth, embed_dim=1280, hidden_size=3584, num_heads=16, mlp_ratio=4, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2, in_channels=3),
+        image_token_id=151655, video_token_id=151656, vision_start_token_id=151652, vision_end_token_id=151653)
+
+
 KERNEL_OF = {"uamd_gemm_nt_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nn_256": "gemm_nt256_kernel<bf16>", "uamd_gemm_nt": "gemm_nt_kernel<bf16,dense>",
              "uamd_gemm_nt_nf4": "gemm_nt_kernel<bf16,NF4>"}
 
 
 class GemmTimer:
-    """HIP-event pairs around every MFMA GEMM launch, recorded on the stream the kernel is launched on (torch's
-    current stream == the stream passed through the C ABI). One record per launch: (start, end, flops, kernel)."""
+    """HIP-event pairs around every MFMA GEMM launch and every flash-attention launch, recorded on the stream the kernel
+    is launched on (torch's current stream == the stream passed through the C ABI). One record per launch:
+    (start, end, algorithmic flops, algorithmic bytes)."""
 
     def __init__(self):
+        from unsloth_amd.kernels import attention as A
         from unsloth_amd.kernels import utils as U
-        self.U = U
+        self.U, self.A = U, A
         self.orig = U._launch_gemm
+        self.orig_fwd, self.orig_bwd = A.attn_forward, A.attn_backward
         self.records = {}
         self.enabled = False
         self.steps_sampled = 0         # timed steps whose launches carry event pairs (bench --roofline-every)
 
     def install(self):
-        U, orig, recs = self.U, self.orig, self.records
+        U, A, orig, recs = self.U, self.A, self.orig, self.records
 
         def timed(X2d, groups, nf4, accumulate=False, nn=False):
             if not self.enabled:
@@ -76,7 +111,39 @@ class GemmTimer:
             recs.setdefault(KERNEL_OF[name], []).append((s, e, flops, nbytes))
             return name
 
+        pair_cache = {}
+
+        def pairs(q, band):
+            """(query, key) pairs inside the mask, summed over the batch: T (T + 1) / 2 per row for plain causal attention,
+            sum_q (q - lo[q] + 1) under a packed / windowed band. A 0-d tensor (no host sync here) or a float."""
+            B, T = q.shape[0], q.shape[1]
+            if band is None:
+                return B * T * (T + 1) / 2.0
+            lo = band[0]
+            key = (lo.data_ptr(), B, T)
+            if key not in pair_cache:
+                pair_cache[key] = (torch.arange(T, device=lo.device, dtype=torch.int64).unsqueeze(0) - lo.to(torch.int64) + 1).sum()
+            return pair_cache[key]
+
+        def attn_timed(which, mult, fn):
+            def run(*args, **kw):
+                if not self.enabled:
+                    return fn(*args, **kw)
+                q = args[0] if which == "fwd" else args[1]
+                band = kw.get("band", args[-1] if len(args) == (5 if which == "fwd" else 8) else None)
+                Hq, D = q.shape[2], q.shape[3]
+                unit = mult * 4.0 * D * Hq            # forward: S = Q K^T and O = P V; backward 2.5x (S again + 4 products)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = fn(*args, **kw)
+                e.record()
+                recs.setdefault("attention_" + which, []).append((s, e, (unit, pairs(q, band)), 0.0))
+                return out
+            return run
+
         U._launch_gemm = timed
+        A.attn_forward = attn_timed("fwd", 1.0, self.orig_fwd)
+        A.attn_backward = attn_timed("bwd", 2.5, self.orig_bwd)
 
     def reset(self):
         self.records.clear()
@@ -88,12 +155,33 @@ class GemmTimer:
             if not recs:
                 continue
             ms = sum(r[0].elapsed_time(r[1]) for r in recs)
-            fl = sum(r[2] for r in recs)
+            fl = sum((r[2][0] * float(r[2][1])) if isinstance(r[2], tuple) else r[2] for r in recs)
             out[name] = dict(launches=len(recs), steps_sampled=max(1, self.steps_sampled), total_ms=ms,
                              avg_us=ms * 1e3 / len(recs), flops=fl,
                              tflops=fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
                              alg_bytes=sum(r[3] for r in recs) / len(recs))
         return out
+
+
+def fractions(gs, ms_per_step):
+    """GEMM / attention roofline fractions of one operating point from a GemmTimer.summary()."""
+    gem = {k: v for k, v in gs.items() if not k.startswith("attention_")}
+    dom = max(gem.values(), key=lambda r: r["total_ms"]) if gem else None
+    out = {"gemm_tflops": round(dom["tflops"], 1) if dom else None,
+           "gemm_frac_of_mfma_peak": round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4) if dom else None,
+           "gemm_share_of_step": round(dom["total_ms"] / dom["steps_sampled"] / ms_per_step, 3) if dom else None}
+    af, ab = gs.get("attention_fwd"), gs.get("attention_bwd")
+    if af:
+        out["attention_fwd_frac_of_mfma_peak"] = round(af["tflops"] / MFMA_PEAK_TFLOPS, 4)
+        out["attention_fwd_avg_us"] = round(af["avg_us"], 1)
+    if ab:
+        out["attention_bwd_frac_of_mfma_peak"] = round(ab["tflops"] / MFMA_PEAK_TFLOPS, 4)
+        out["attention_bwd_avg_us"] = round(ab["avg_us"], 1)
+    if af and ab:
+        ms = af["total_ms"] + ab["total_ms"]
+        out["attention_frac_of_mfma_peak"] = round((af["flops"] + ab["flops"]) / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)
+        out["attention_share_of_step"] = round(ms / af["steps_sampled"] / ms_per_step, 3)
+    return out
 
 
 def main():
@@ -111,14 +199,16 @@ def main():
     ap.add_argument("--seq", type=int, default=2048)
     ap.add_argument("--layers", type=int, default=32)
     ap.add_argument("--rank", type=int, default=16)
-    ap.add_argument("--gc", choices=["on", "off", "unsloth", "unsloth:min", "unsloth:all", "unsloth:auto"],
-                    default=os.environ.get("BENCH_GC", "off"),
-                    help="gradient checkpointing for the primary number. off: activations stay in the 288 GB HBM "
-                         "(no recompute); on: torch's reentrant per-layer checkpoint (layer inputs only, one extra "
-                         "forward per layer); unsloth[:policy]: selective recompute (models/fast_layer.py)")
+    ap.add_argument("--gc", choices=sorted(GC_MODE), default=os.environ.get("BENCH_GC", "unsloth"),
+                    help="gradient checkpointing for the primary number. unsloth (the API default of from_pretrained / "
+                         "get_peft_model): the least-recompute schedule that fits the free HBM (models/fast_layer.py "
+                         "auto_schedule); off: no checkpointing; on: torch's reentrant per-layer checkpoint (layer inputs only, "
+                         "one extra forward per layer); unsloth:<policy>: a fixed selective-recompute policy")
     ap.add_argument("--alt-steps", type=int, default=int(os.environ.get("BENCH_ALT_STEPS", 3)),
-                    help="also time this many steps in the other checkpointing modes and at batch 1 / 2 "
-                         "(reported under 'alt'); 0 = skip")
+                    help="also time this many steps at the other operating points (reported under 'alt'); 0 = skip")
+    ap.add_argument("--only", choices=ONLY_POINTS, default=os.environ.get("BENCH_ONLY", "primary"),
+                    help="time ONE operating point with --steps / --warmup as the whole run (per-point rocprofv3 profiles); "
+                         "the JSON line then describes that point. 'primary' (default) = the BASELINE metric + every alt point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-every", type=int, default=int(os.environ.get("BENCH_ROOFLINE_EVERY", 4)),
                     help="HIP-event pairs around the GEMM launches on every Nth timed step (the first one always). An event "
@@ -131,6 +221,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and os.environ.get("BENCH_ALT_MULTI", "0") != "1":
         a.alt_steps = 0            # the other operating points are a 1-GPU report; a scaling run times the primary only
+    if a.only != "primary":
+        a.alt_steps = 0
+        a.no_cpu_baseline = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -138,18 +231,23 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
+    if a.only == "dp_force":
+        os.environ["UNSLOTH_AMD_DP_FORCE"] = "1"
     force_dp = os.environ.get("UNSLOTH_AMD_DP_FORCE", "0") == "1"     # 1-rank RCCL group: exercises the DP path on one GPU
-    if world > 1 or force_dp:
+
+    def init_rccl():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # one node over xGMI: RCCL's bootstrap needs no NIC; keep it off interface / InfiniBand probing
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
-        if force_dp and world == 1:
+        if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29512")
             dist.init_process_group("nccl", device_id=dev, rank=0, world_size=1)
         else:
             dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
+    if world > 1 or force_dp:
+        init_rccl()
     if a.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
@@ -157,58 +255,34 @@ def main():
     from unsloth_amd.dp import LoRAGradArena
     from unsloth_amd.trainer import make_optimizer, training_step
 
-    cfg = llama3_8b_config(a.layers)
-    t_setup = time.time()
-    model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
-                                                 load_in_4bit=True, device=dev, random_state=3407,
-                                                 use_gradient_checkpointing=GC_MODE[a.gc])
-    # NOTE: for_training() below re-applies the checkpointing mode per measurement
-    model = FastLanguageModel.get_peft_model(model, r=a.rank, lora_alpha=a.rank, lora_dropout=0.0, bias="none",
-                                             use_gradient_checkpointing=GC_MODE[a.gc], random_state=3407)
-    g = torch.Generator(device="cpu").manual_seed(3407)
-    n_train = 0
-    for n, p in model.named_parameters():
-        if p.requires_grad:
-            n_train += p.numel()
-            if "lora_B" in n:           # non-zero B so every LoRA gradient is exercised with real numbers
-                p.data.copy_((torch.randn(p.shape, generator=g) * 0.02).to(p.device))
-    arena = LoRAGradArena(model) if (world > 1 or force_dp) else None
-    # optim.FlatAdamW: parameters / gradients / moments in flat arenas, one launch per step (the gradients live in the
-    # data-parallel arena when there is one; UNSLOTH_AMD_FLAT_ADAMW=0 = torch's fused AdamW)
-    opt = make_optimizer(model, lr=2e-4, arena=arena)
-    B, T, V = a.batch, a.seq, cfg.vocab_size
-    gi = torch.Generator(device="cpu").manual_seed(rank)       # different data per rank
-
-    def make_batches(bs):
-        out = []
-        for _ in range(2):
-            ids = torch.randint(0, V, (bs, T), generator=gi).to(dev)
-            pos = torch.arange(T, dtype=torch.int32, device=dev).unsqueeze(0).expand(bs, T).contiguous()
-            out.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
-        return out, torch.tensor((T - 1) * bs * world, device=dev)      # global non-ignored targets per step
-    batches, n_items = make_batches(B)
     timer = GemmTimer()
     timer.install()
-    setup_s = time.time() - t_setup
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(gc_mode, steps, warmup, data=None, per_step=False):
-        """W untimed + exactly K timed steps, barrier + synchronize on both sides, MAX over ranks.
+    def randomize_lora_b(model, seed=3407):
+        g_ = torch.Generator(device="cpu").manual_seed(seed)
+        n_train = 0
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                n_train += p.numel()
+                if "lora_B" in n:           # non-zero B so every LoRA gradient is exercised with real numbers
+                    p.data.copy_((torch.randn(p.shape, generator=g_) * 0.02).to(p.device))
+        return n_train
+
+    def timed_steps(step_fn, steps, warmup, per_step=False):
+        """W untimed + exactly K timed calls of step_fn(i), barrier + synchronize on both sides, MAX over ranks.
         per_step (the short `alt` points only, never the primary): every step is bracketed on its own and the MEDIAN step
         time x K is returned -- a 3-step point is otherwise at the mercy of one allocator stall after empty_cache()."""
-        bt, ni = data if data is not None else (batches, n_items)
-        model.for_training(use_gradient_checkpointing=gc_mode)
         losses = []
         for i in range(warmup):
-            losses.append(training_step(model, bt[i % 2], opt, arena, ni))
+            losses.append(step_fn(i))
         sync()
         torch.cuda.reset_peak_memory_stats()
         timer.reset()
-        timer.enabled = True
         t0 = time.perf_counter()
         if per_step:
             times = []
@@ -216,7 +290,7 @@ def main():
                 ts = time.perf_counter()
                 timer.enabled = (i == 0)                # the MEDIAN step is then one without event pairs
                 timer.steps_sampled += int(timer.enabled)
-                losses.append(training_step(model, bt[i % 2], opt, arena, ni))
+                losses.append(step_fn(i))
                 sync()
                 times.append(time.perf_counter() - ts)
             dt = sorted(times)[len(times) // 2] * steps
@@ -225,7 +299,7 @@ def main():
             for i in range(steps):
                 timer.enabled = (i % every == 0)        # roofline sample: the launches of every Nth timed step
                 timer.steps_sampled += int(timer.enabled)
-                losses.append(training_step(model, bt[i % 2], opt, arena, ni))
+                losses.append(step_fn(i))
             sync()
             dt = time.perf_counter() - t0
         timer.enabled = False
@@ -239,34 +313,277 @@ def main():
             peak = int(pk)
         return dt, peak, [float(l) for l in losses], timer.summary()
 
+    def point(tokens_per_step, dt, steps, peak, gs, **extra):
+        ms = dt / steps * 1e3
+        rec = {"steps": steps, "value": round(tokens_per_step * steps * world / dt, 1), "unit": "tokens/s",
+               "ms_per_step": round(ms, 2), "peak_vram_gb": round(peak / 2**30, 2)}
+        rec.update(fractions(gs, ms))
+        rec.update(extra)
+        return rec
+
+    # ------------------------------------------------------------------------------------------------------------
+    # the Llama-3-8B QLoRA model of the BASELINE metric (primary + the points that share it)
+    cfg = llama3_8b_config(a.layers)
+    B, T, V = a.batch, a.seq, cfg.vocab_size
+    gi = torch.Generator(device="cpu").manual_seed(rank)       # different data per rank
+    need_llama = a.only in ("primary", "packed", "dp_force", "batch1")
+    model = opt = arena = None
+    n_train = 0
+    setup_s = 0.0
+    if need_llama:
+        t_setup = time.time()
+        model, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=max(a.seq, 8192), dtype=torch.bfloat16,
+                                                     load_in_4bit=True, device=dev, random_state=3407,
+                                                     use_gradient_checkpointing=GC_MODE[a.gc])
+        # NOTE: for_training() below re-applies the checkpointing mode per measurement
+        model = FastLanguageModel.get_peft_model(model, r=a.rank, lora_alpha=a.rank, lora_dropout=0.0, bias="none",
+                                                 use_gradient_checkpointing=GC_MODE[a.gc], random_state=3407)
+        n_train = randomize_lora_b(model)
+        arena = LoRAGradArena(model) if (world > 1 or force_dp) else None
+        # optim.FlatAdamW: parameters / gradients / moments in flat arenas, one launch per step (the gradients live in the
+        # data-parallel arena when there is one; UNSLOTH_AMD_FLAT_ADAMW=0 = torch's fused AdamW)
+        opt = make_optimizer(model, lr=2e-4, arena=arena)
+        setup_s = time.time() - t_setup
+
+    def make_batches(bs, seq=None):
+        seq = seq or T
+        out = []
+        for _ in range(2):
+            ids = torch.randint(0, V, (bs, seq), generator=gi).to(dev)
+            pos = torch.arange(seq, dtype=torch.int32, device=dev).unsqueeze(0).expand(bs, seq).contiguous()
+            out.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
+        return out, torch.tensor((seq - 1) * bs * world, device=dev)      # global non-ignored targets per step
+
+    def make_packed_batches(total, vocab):
+        """The reference's default SFT batch (trainer.py:903-912: padding_free): documents of mixed length concatenated
+        into ONE row, `packed_seq_lengths` + position ids restarting per document (utils/packing.py:241-284), the first
+        token of every document unlabelled. Lengths ~ a chat-SFT mix: 64 ... 2048 tokens, mean ~ 640."""
+        from unsloth_amd.utils.packing import enable_padding_free_metadata
+        out = []
+        for _ in range(2):
+            lens, left = [], total
+            while left > 0:
+                n = int(torch.randint(64, 2049, (1,), generator=gi))
+                n = min(n if int(torch.randint(0, 3, (1,), generator=gi)) == 0 else max(64, n // 4), left)
+                lens.append(n)
+                left -= n
+            docs = [torch.randint(0, vocab, (n,), generator=gi).tolist() for n in lens]
+            out.append(enable_padding_free_metadata(docs, device=dev))
+        n_items = sum(int((b["labels"][:, 1:] != -100).sum()) for b in out) // 2
+        return out, torch.tensor(n_items * world, device=dev), [len(b["packed_seq_lengths"]) for b in out]
+
+    def measure(gc_mode, steps, warmup, data=None, per_step=False):
+        bt, ni = data if data is not None else (batches, n_items)
+        model.for_training(use_gradient_checkpointing=gc_mode)
+        return timed_steps(lambda i: training_step(model, bt[i % 2], opt, arena, ni), steps, warmup, per_step)
+
+    # ------------------------------------------------------------------------------------------------------------
+    # operating points that build their own model (BASELINE configs 3, 4, 5)
+    def run_config5(leg, steps, warmup, per_step):
+        """BASELINE config 5: Mistral-7B widths, NF4 + LoRA r=16, seq 4096, 2 rows per GPU. `ce`: the SFT / DPO-style CE step;
+        `logprob`: one GRPO policy step -- [left-padded prompt | right-padded completion] rows packed into one varlen forward
+        that returns hidden states, lm_head + log-softmax on the completion positions only in row chunks
+        (models/rl_replacements.py; ref rl_replacements.py:1517-1700), the clipped objective, backward, AdamW."""
+        from unsloth_amd.models.rl_replacements import grpo_accumulated_loss
+        mcfg = mistral_7b_config(a.layers)
+        m, _ = FastLanguageModel.from_pretrained(config=mcfg, max_seq_length=8192, dtype=torch.bfloat16, load_in_4bit=True,
+                                                 device=dev, random_state=3407, use_gradient_checkpointing=GC_MODE[a.gc])
+        m = FastLanguageModel.get_peft_model(m, r=16, lora_alpha=16, use_gradient_checkpointing=GC_MODE[a.gc], random_state=3407)
+        randomize_lora_b(m)
+        o = make_optimizer(m, lr=2e-4)
+        m.for_training(use_gradient_checkpointing=GC_MODE[a.gc])
+        rows, S = 2, 4096
+        try:
+            if leg == "ce":
+                bt = []
+                for _ in range(2):
+                    ids = torch.randint(0, 32000, (rows, S), generator=gi).to(dev)
+                    pos = torch.arange(S, dtype=torch.int32, device=dev).unsqueeze(0).expand(rows, S).contiguous()
+                    bt.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
+                ni = torch.tensor((S - 1) * rows, device=dev)
+                dt, peak, losses, gs = timed_steps(lambda i: training_step(m, bt[i % 2], o, None, ni), steps, warmup, per_step)
+                return point(rows * S, dt, steps, peak, gs, rows=rows, seq_len=S, lora_rank=16,
+                             loss_first_last=[round(losses[0], 4), round(losses[-1], 4)])
+            prompt, comp = 1024, 3072
+            data = []
+            for _ in range(2):
+                ids = torch.randint(0, 32000, (rows, S), generator=gi)
+                mask = torch.ones(rows, S, dtype=torch.int64)
+                p_len = torch.randint(prompt // 2, prompt + 1, (rows,), generator=gi)
+                c_len = torch.randint(comp // 2, comp + 1, (rows,), generator=gi)
+                for r_ in range(rows):
+                    mask[r_, :prompt - int(p_len[r_])] = 0                 # prompts are left-padded
+                    mask[r_, prompt + int(c_len[r_]):] = 0                 # completions right-padded
+                cmask = mask[:, prompt:].clone()
+                adv = torch.randn(rows, generator=gi)
+                old = -torch.rand(rows, comp, generator=gi) * 3.0
+                data.append(tuple(x.to(dev) for x in (ids, mask, cmask, adv, old)))
+            toks = sum(int(d[1].sum()) for d in data) / 2.0
+
+            def grpo_step(i):
+                ids, mask, cmask, adv, old = data[i % 2]
+                loss = grpo_accumulated_loss(m, ids, mask, comp, cmask, adv, old_logps=old, beta=0.0)[0]
+                loss.backward()
+                o.step()
+                o.zero_grad()
+                return loss.detach()
+            dt, peak, losses, gs = timed_steps(grpo_step, steps, warmup, per_step)
+            return point(toks, dt, steps, peak, gs, rows=rows, seq_len=S, lora_rank=16, logprob_chunks=4,
+                         tokens_counted="non-padding tokens of the packed forward (mean of the two batches): %d" % toks,
+                         completion_logprobs_per_step=int(sum(int(d[2].sum()) for d in data) / 2),
+                         objective_first_last=[round(losses[0], 5), round(losses[-1], 5)])
+        finally:
+            if hasattr(o, "close"):
+                o.close()
+            del m, o
+            torch.cuda.empty_cache()
+
+    def run_config4(steps, warmup, per_step):
+        """BASELINE config 4: FastVisionModel at Qwen2-VL-7B's widths (ViT depth 32 / 1280 wide; language tower 28 layers NF4),
+        LoRA r=32 on both towers, ONE 896 x 896 image (4096 patches -> 1024 merged tokens) inside a 4096-token row:
+        pixel_values -> patch-embed -> ViT -> merger -> scatter -> mrope positions -> fused tower -> loss -> backward -> AdamW."""
+        from unsloth_amd import FastVisionModel
+        vcfg = qwen2_vl_7b_config(28 if a.layers == 32 else a.layers, 32 if a.layers == 32 else 2)
+        m, _ = FastVisionModel.from_pretrained(config=vcfg, max_seq_length=4096, load_in_4bit=True, device=dev,
+                                               use_gradient_checkpointing=GC_MODE[a.gc])
+        m = FastVisionModel.get_peft_model(m, r=32, lora_alpha=32, use_gradient_checkpointing=GC_MODE[a.gc])
+        randomize_lora_b(m)
+        o = make_optimizer(m, lr=2e-4)
+        m.for_training(use_gradient_checkpointing=GC_MODE[a.gc])
+        grid, S, pre = (1, 64, 64), 4096, 700
+        n_img = grid[0] * (grid[1] // 2) * (grid[2] // 2)
+        bt = []
+        for _ in range(2):
+            row = torch.cat([torch.randint(0, 150000, (pre,), generator=gi), torch.tensor([vcfg.vision_start_token_id]),
+                             torch.full((n_img,), vcfg.image_token_id), torch.tensor([vcfg.vision_end_token_id]),
+                             torch.randint(0, 150000, (S - pre - n_img - 2,), generator=gi)])
+            ids = row.unsqueeze(0)
+            labels = ids.clone()
+            labels[ids == vcfg.image_token_id] = -100
+            pix = torch.randn(grid[0] * grid[1] * grid[2], 3 * 2 * 14 * 14, generator=gi)
+            bt.append({k: v.to(dev) for k, v in dict(input_ids=ids, attention_mask=torch.ones_like(ids), labels=labels,
+                                                     pixel_values=pix, image_grid_thw=torch.tensor([grid])).items()})
+        ni = torch.tensor(int((bt[0]["labels"][:, 1:] != -100).sum()), device=dev)
+        try:
+            dt, peak, losses, gs = timed_steps(lambda i: training_step(m, bt[i % 2], o, None, ni), steps, warmup, per_step)
+            return point(S, dt, steps, peak, gs, rows=1, seq_len=S, image="896x896 -> 4096 patches -> 1024 tokens", lora_rank=32,
+                         vit="depth %d, torch SDPA attention + HIP LayerNorm + LoRA_W linears" % vcfg.vision_config.depth,
+                         trainable_params=sum(p.numel() for p in m.parameters() if p.requires_grad),
+                         loss_first_last=[round(losses[0], 4), round(losses[-1], 4)])
+        finally:
+            if hasattr(o, "close"):
+                o.close()
+            del m, o
+            torch.cuda.empty_cache()
+
+    def run_fullft(steps, warmup):
+        # BASELINE config 3 on ONE GPU: the same architecture fully trainable in bf16 (dense dW GEMMs, norm / lm_head /
+        # embedding gradients, flat buckets, fp32-master AdamW: 16 + 16 + 96 GB of the 288), world size 1 = no collective
+        from unsloth_amd.full_finetune import ShardedAdamW, full_finetune_step
+        fmodel, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
+                                                      full_finetuning=True, device=dev, random_state=3407,
+                                                      use_gradient_checkpointing=False)
+        fopt = ShardedAdamW(fmodel, lr=1e-5)
+        fb, fni = make_batches(B)
+        try:
+            dt, peak, fl, gs = timed_steps(lambda i: full_finetune_step(fmodel, fb[i % 2], fopt, fni), steps, warmup, True)
+            n_all = sum(p.numel() for p in fmodel.parameters())
+            return point(B * T, dt, steps, peak, gs, batch=B, timing="median step", trainable_params=n_all,
+                         model_tflops_per_s=round(6.0 * n_all * B * T * steps / dt / 1e12, 1),
+                         loss_first_last=[round(float(fl[0]), 4), round(float(fl[-1]), 4)])
+        finally:
+            fopt.buckets.close()
+            del fmodel, fopt
+            torch.cuda.empty_cache()
+            os.environ["UNSLOTH_ENABLE_FULL_FINETUNING"] = "0"
+
+    def guarded(alt, tag, fn):
+        try:
+            alt[tag] = fn()
+        except Exception as ex:                     # an operating point must never take the primary record down with it
+            alt[tag] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            torch.cuda.empty_cache()
+
+    PACKED_TAG = "packed_padding_free_1x8192 (the reference's default SFT batch: mixed-length documents in one row)"
+    C4_TAG = "config4_qwen2_vl_7b_nf4_r32_seq4096_one_image"
+    C5CE_TAG = "config5_mistral_7b_nf4_r16_seq4096_ce_leg"
+    C5LP_TAG = "config5_mistral_7b_nf4_r16_seq4096_grpo_logprob_leg"
+
+    # ------------------------------------------------------------------------------------------------------------
+    if a.only != "primary":
+        # ONE operating point as the whole run (rocprofv3 kernel stats per point)
+        if a.only == "packed":
+            pdata, pni, ndocs = make_packed_batches(B * T, V)
+            dt, peak, losses, gs = measure(GC_MODE[a.gc], a.steps, a.warmup, (pdata, pni))
+            rec = point(B * T, dt, a.steps, peak, gs, documents_per_batch=ndocs, gradient_checkpointing=GC_MODE[a.gc])
+        elif a.only in ("dp_force", "batch1"):
+            bs = 1 if a.only == "batch1" else B
+            data = make_batches(bs)
+            dt, peak, losses, gs = measure(GC_MODE[a.gc], a.steps, a.warmup, data)
+            rec = point(bs * T, dt, a.steps, peak, gs, batch=bs, gradient_checkpointing=GC_MODE[a.gc],
+                        dp_buckets=len(arena.buckets) if arena is not None else None)
+        elif a.only == "config4":
+            rec = run_config4(a.steps, a.warmup, False)
+        elif a.only == "fullft":
+            rec = run_fullft(a.steps, a.warmup)
+        else:
+            rec = run_config5("ce" if a.only == "config5_ce" else "logprob", a.steps, a.warmup, False)
+        rec = dict({"metric": "operating point '%s' of bench.py (not the BASELINE headline)" % a.only, "n_gpus": world,
+                    "warmup": a.warmup, "higher_is_better": True, "dtype": "bf16", "data": "synthetic"}, **rec)
+        if rank == 0:
+            os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # the PRIMARY measurement first, on the freshly initialised model (loss_first_last starts at ~ln V); the other operating
     # points afterwards (their warm-up / timing steps keep training the same adapters, which no longer matters)
+    batches, n_items = make_batches(B)
     dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
+    base_ = model.get_base_model().model
+    sched = getattr(base_, "_uamd_auto_policy", None)
+    primary_policy = None
+    if sched is not None:
+        from unsloth_amd.models import fast_layer as _fl
+        pol = sched[1]
+        primary_policy = ("all (every layer keeps everything)" if pol == _fl.POLICIES["all"] else
+                          "attn (every layer re-runs norm2 + gate/up)" if pol == _fl.POLICIES["attn"] else
+                          "all*%d,attn" % pol[0][0])
     alt = None
     if a.alt_steps > 0:
         # the other checkpointing modes at the primary batch, then batch 1 and 2 without checkpointing
         alt = {}
 
-        def alt_point(tag, gc_mode, bs):
-            data = None if bs == B else make_batches(bs)
+        def alt_point(tag, gc_mode, bs, data=None, **extra):
+            if data is None and bs != B:
+                data = make_batches(bs)
             adt, apeak, _, ags = measure(gc_mode, a.alt_steps, 3, data, per_step=True)     # 3 warm-up steps: allocator growth after empty_cache(), decoded mirrors
-            dom_ = max(ags.values(), key=lambda r: r["total_ms"]) if ags else None
-            alt[tag] = {"gradient_checkpointing": gc_mode, "batch": bs, "steps": a.alt_steps, "timing": "median step x steps",
-                        "value": round(bs * T * a.alt_steps * world / adt, 1),
-                        "ms_per_step": round(adt / a.alt_steps * 1e3, 2), "peak_vram_gb": round(apeak / 2**30, 2),
-                        "gemm_tflops": round(dom_["tflops"], 1) if dom_ else None,
-                        "gemm_frac_of_mfma_peak": round(dom_["tflops"] / MFMA_PEAK_TFLOPS, 4) if dom_ else None}
+            alt[tag] = point(bs * T, adt, a.alt_steps, apeak, ags, gradient_checkpointing=gc_mode, batch=bs,
+                             timing="median step x steps", **extra)
             del data
             torch.cuda.empty_cache()
         for tag, mode in (("gc_torch_reentrant (reference's True)", True),
-                          ("gc_unsloth_selective_recompute (keep attention block, re-run gate/up)", "unsloth"),
-                          ("gc_unsloth_auto (as many keep-everything layers as the free HBM holds)", "unsloth:auto"),
+                          ("gc_unsloth (API default: least-recompute schedule that fits the free HBM)", "unsloth"),
+                          ("gc_unsloth_attn (fixed: keep attention block, re-run gate/up)", "unsloth:attn"),
                           ("gc_unsloth_min (keep layer inputs only)", "unsloth:min"), ("gc_off", False)):
             if mode != GC_MODE[a.gc]:
                 alt_point(tag, mode, B)
+        # the default spelling on a CROWDED GPU: 10.5 GB of HBM left for the step beyond the resident weights
+        os.environ["UNSLOTH_AMD_GC_FREE_GB"] = "10.5"
+        base_._uamd_auto_policy = None
+        alt_point("gc_unsloth_with_10.5_GB_free (UNSLOTH_AMD_GC_FREE_GB=10.5: the same spelling falls back to 'attn')", "unsloth", B)
+        del os.environ["UNSLOTH_AMD_GC_FREE_GB"]
+        base_._uamd_auto_policy = None
         for bs in (1, 2):
             if bs != B:
                 alt_point(f"batch_{bs}_gc_off", False, bs)
+        # the reference's DEFAULT SFT step: padding-free packed row (band attention + indexed RoPE with restarting positions)
+        pdata, pni, ndocs = make_packed_batches(B * T, V)
+        alt_point(PACKED_TAG, GC_MODE[a.gc], 1, (pdata, pni), documents_per_batch=ndocs, tokens_per_row=B * T)
+        alt[PACKED_TAG]["value"] = round(alt[PACKED_TAG]["value"] * B, 1)         # alt_point counted bs * T tokens with bs = 1
+        alt[PACKED_TAG]["batch"] = "1 x %d" % (B * T)
+        del pdata
         if os.environ.get("BENCH_RESIDENT_ALT", "1") == "1":
             # opt-in mode: decoded bf16 mirrors of the NF4 weights stay in HBM (+2 B/param), no decode launches
             from unsloth_amd import nf4 as _nf4
@@ -275,6 +592,27 @@ def main():
             alt_point("weights_resident_bf16_batch_1", False, 1)
             _nf4.set_resident(False)
             torch.cuda.empty_cache()
+        if os.environ.get("BENCH_DP_FORCE_ALT", "1") == "1" and world == 1 and arena is None:
+            # the data-parallel path on ONE rank: gradient arena owned by dp.LoRAGradArena, the post-accumulate hooks, the 11
+            # bucketed RCCL all-reduces issued from inside the backward (a 1-rank group: the collective is a device copy, its
+            # launch / stream-dependency cost is real) -- what DP adds to the step before any xGMI traffic
+            def dp_force():
+                os.environ["UNSLOTH_AMD_DP_FORCE"] = "1"
+                try:
+                    if not dist.is_initialized():
+                        init_rccl()
+                    farena = opt.arena
+                    farena._force = True
+                    model.for_training(use_gradient_checkpointing=GC_MODE[a.gc])
+                    ddt, dpeak, _, dgs = timed_steps(lambda i: training_step(model, batches[i % 2], opt, farena, n_items),
+                                                     a.alt_steps, 3, True)
+                    farena._force = False
+                    return point(B * T, ddt, a.alt_steps, dpeak, dgs, batch=B, timing="median step x steps",
+                                 buckets=len(farena.buckets), bucket_mb=[round((e - s) * 4 / 2**20, 1) for s, e, _ in farena.buckets],
+                                 collectives_per_step=len(farena.buckets), rccl_group_size=1)
+                finally:
+                    os.environ["UNSLOTH_AMD_DP_FORCE"] = "0"
+            guarded(alt, "dp_path_forced_on_one_rank (UNSLOTH_AMD_DP_FORCE=1: hooks + bucketed RCCL all-reduce inside backward)", dp_force)
         if os.environ.get("BENCH_DECODE_ALT", "1") == "1":
             # single-stream KV-cache decode of the same model through the GEMV kernels, one hipGraph per token
             from unsloth_amd.models.decode import DecodeEngine
@@ -302,41 +640,14 @@ def main():
             del eng
             torch.cuda.empty_cache()
             model.train()
+        if world == 1 and os.environ.get("BENCH_CONFIGS_ALT", "1") == "1":
+            # the primary model's 20 GB of decode scratch / caches are not needed below: the other BASELINE configurations
+            guarded(alt, C5CE_TAG, lambda: run_config5("ce", a.alt_steps, 3, True))
+            guarded(alt, C5LP_TAG, lambda: run_config5("logprob", a.alt_steps, 3, True))
+            guarded(alt, C4_TAG, lambda: run_config4(a.alt_steps, 3, True))
         if os.environ.get("BENCH_FULLFT_ALT", "1") == "1" and world == 1:
-            # BASELINE config 3 on ONE GPU: the same architecture fully trainable in bf16 (dense dW GEMMs, norm / lm_head /
-            # embedding gradients, flat buckets, fp32-master AdamW: 16 + 16 + 96 GB of the 288), world size 1 = no collective
-            try:
-                from unsloth_amd.full_finetune import ShardedAdamW, full_finetune_step
-                timer.enabled = False
-                fmodel, _ = FastLanguageModel.from_pretrained(config=cfg, max_seq_length=a.seq, dtype=torch.bfloat16,
-                                                              full_finetuning=True, device=dev, random_state=3407,
-                                                              use_gradient_checkpointing=False)
-                fopt = ShardedAdamW(fmodel, lr=1e-5)
-                fl = []
-                for i in range(2):
-                    fl.append(full_finetune_step(fmodel, batches[i % 2], fopt, n_items))
-                sync()
-                torch.cuda.reset_peak_memory_stats()
-                ft = []
-                for i in range(a.alt_steps):
-                    ts = time.perf_counter()
-                    fl.append(full_finetune_step(fmodel, batches[i % 2], fopt, n_items))
-                    sync()
-                    ft.append(time.perf_counter() - ts)
-                fdt = sorted(ft)[len(ft) // 2]
-                n_all = sum(p.numel() for p in fmodel.parameters())
-                alt["config3_full_finetune_bf16_1gpu (every parameter trains, fp32-master AdamW)"] = {
-                    "batch": B, "steps": a.alt_steps, "timing": "median step", "value": round(B * T / fdt, 1),
-                    "ms_per_step": round(fdt * 1e3, 2), "peak_vram_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2),
-                    "trainable_params": n_all, "model_tflops_per_s": round(6.0 * n_all * B * T / fdt / 1e12, 1),
-                    "loss_first_last": [round(float(fl[0]), 4), round(float(fl[-1]), 4)]}
-                fopt.buckets.close()
-                del fmodel, fopt
-                torch.cuda.empty_cache()
-            except Exception as ex:                     # an operating point must never take the primary record down with it
-                alt["config3_full_finetune_bf16_1gpu"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
-                torch.cuda.empty_cache()
-            os.environ["UNSLOTH_ENABLE_FULL_FINETUNING"] = "0"
+            guarded(alt, "config3_full_finetune_bf16_1gpu (every parameter trains, fp32-master AdamW)",
+                    lambda: run_fullft(a.alt_steps, 2))
     rccl_ranks = None
     if dist.is_initialized():
         one = torch.ones(1, device=dev)
@@ -345,9 +656,11 @@ def main():
 
     if rank == 0:
         tokens = B * T * a.steps * world
-        dom = max(gs.values(), key=lambda r: r["total_ms"]) if gs else None
-        dom_name = [k for k, v in gs.items() if v is dom][0] if dom else None
+        gem = {k: v for k, v in gs.items() if not k.startswith("attention_")}
+        dom = max(gem.values(), key=lambda r: r["total_ms"]) if gem else None
+        dom_name = [k for k, v in gem.items() if v is dom][0] if dom else None
         roofline = None
+        ms_step = dt / a.steps * 1e3
         if dom:
             # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json,
             # tools/gpu_pmc_bench.sh): counters cannot be collected inside a timed run
@@ -363,17 +676,19 @@ def main():
                     traffic_src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
             except (OSError, ValueError, KeyError):
                 pass
+            fr = fractions(gs, ms_step)
             roofline = dict(bound="mfma", kernel=dom_name, achieved=round(dom["tflops"], 1), peak=MFMA_PEAK_TFLOPS,
                             unit="TFLOP/s", frac=round(dom["tflops"] / MFMA_PEAK_TFLOPS, 4), traffic=traffic,
                             traffic_unit="bytes per launch (mean)", traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(dom["alg_bytes"]),
                             launches_per_step=dom["launches"] // dom["steps_sampled"], avg_launch_us=round(dom["avg_us"], 1),
                             steps_sampled=dom["steps_sampled"],
-                            sampling=f"HIP-event pairs around every GEMM launch of every {max(1, a.roofline_every)}th timed step",
-                            share_of_step=round(dom["total_ms"] / dom["steps_sampled"] / (dt / a.steps * 1e3), 3),
+                            sampling=f"HIP-event pairs around every GEMM and attention launch of every {max(1, a.roofline_every)}th timed step",
+                            share_of_step=round(dom["total_ms"] / dom["steps_sampled"] / ms_step, 3),
+                            attention={k: v for k, v in fr.items() if k.startswith("attention")},
                             other={k: dict(tflops=round(v["tflops"], 1), avg_us=round(v["avg_us"], 1),
-                                           share_of_step=round(v["total_ms"] / v["steps_sampled"] / (dt / a.steps * 1e3), 3))
-                                   for k, v in gs.items() if k != dom_name})
+                                           share_of_step=round(v["total_ms"] / v["steps_sampled"] / ms_step, 3))
+                                   for k, v in gem.items() if k != dom_name})
         cpu = None
         if not a.no_cpu_baseline and world == 1:      # rank 0 at N=1 only (the other ranks must not wait on it)
             from oracle.cpu_baseline import time_layer
@@ -385,13 +700,14 @@ def main():
         rec = {
             "metric": "train tokens/sec, Llama-3-8B QLoRA (NF4) r=16 seq2048 bf16", "value": round(tokens / dt, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init Llama-3-8B-shaped weights -> NF4, "
             "uniform random token ids)",
             "config": {"workload": "Llama-3-8B QLoRA NF4 r=16 (q,k,v,o,gate,up,down) seq2048 bf16, fwd+bwd+AdamW",
                        "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
-                       "gradient_checkpointing": GC_MODE[a.gc], "trainable_params": n_train,
+                       "gradient_checkpointing": GC_MODE[a.gc], "gc_schedule_chosen": primary_policy,
+                       "trainable_params": n_train,
                        "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": type(opt).__name__ + " fp32 on LoRA params"},
             "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T, "rccl_ranks": rccl_ranks,
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),

@@ -127,3 +127,104 @@ def test_sharded_full_finetune_world2(tied):
     assert all(r[2] for r in res), res             # replicas identical after the all-gather
     assert all(r[3] for r in res), res             # parameters live in the flat buckets
     assert all(r[4] == 5 for r in res), res        # head, 3 layers, embeddings
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class TinyPos(Tiny):
+    """Tiny + a second '*embed*' parameter (a learned position embedding): the embedding bucket then holds TWO parameters,
+    one of them the tied lm_head / embed_tokens weight."""
+
+    def __init__(self, tied=True):
+        super().__init__(tied)
+        self.model.embed_positions = torch.nn.Parameter(torch.randn(8, 16) * 0.1)
+
+    def forward(self, ids, use_pos=True):
+        h = self.model.embed_tokens(ids)
+        if use_pos:
+            h = h + self.model.embed_positions
+        for blk in self.model.layers:
+            h = h + torch.tanh(blk.q_proj(blk.norm(h)))
+        return self.lm_head(self.model.norm(h))
+
+
+def _worker_accum(rank, world, port, q):
+    """Tied weights + a second embedding parameter + gradient accumulation under no_sync():
+      (1) the post-accumulate hook of the tied weight fires ONCE per backward (autograd sums lm_head's and the lookup's
+          gradient first), so the embedding bucket is complete after 2 arrivals, not 3;
+      (2) micro-batch 1 gives `embed_positions` no gradient: the bucket stays one arrival short, and that leftover must not
+          complete the bucket in the middle of micro-batch 2 (a reduce of half-accumulated gradients, with the late hook
+          writing under the in-flight collective);
+      (3) every bucket's exchange is launched exactly once per optimizer step, from the hook of its last gradient."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unsloth_amd.full_finetune import ShardedAdamW
+    torch.manual_seed(0)
+    m = TinyPos(True).to(torch.bfloat16)
+    opt = ShardedAdamW(m, lr=3e-2, weight_decay=0.0)
+    B = opt.buckets
+    emb = B.buckets[-1]
+    assert sorted(emb["names"]) == ["model.embed_positions", "model.embed_tokens.weight"], emb["names"]
+    assert emb["expected"] == 2
+    fires = {"n": 0}
+    tied_w = m.model.embed_tokens.weight
+    tied_w.register_post_accumulate_grad_hook(lambda p: fires.__setitem__("n", fires["n"] + 1))
+    launches = []
+    real_launch = B._launch
+
+    def counting_launch(bi):
+        # at launch time the bucket must already hold EVERYTHING this step accumulates into it
+        launches.append((bi, set(B._written)))
+        return real_launch(bi)
+    B._launch = counting_launch
+    ok = True
+    for step in range(2):
+        ids = [[torch.randint(0, 40, (2, 8), generator=torch.Generator().manual_seed(100 * step + 10 * r + mb)) for mb in range(2)]
+               for r in range(world)]
+        want = {n: torch.zeros_like(p, dtype=torch.float32) for n, p in m.named_parameters()}
+        for r in range(world):
+            rep = TinyPos(True).to(torch.bfloat16)
+            rep.load_state_dict(m.state_dict())
+            (rep(ids[r][0], use_pos=False).float().logsumexp(-1).sum() / 64.0 * 0.5).backward()
+            (rep(ids[r][1], use_pos=True).float().logsumexp(-1).sum() / 64.0 * 0.5).backward()
+            for n, p in rep.named_parameters():
+                want[n] += p.grad.float()
+        launches.clear()
+        fires["n"] = 0
+        with B.no_sync():
+            (m(ids[rank][0], use_pos=False).float().logsumexp(-1).sum() / 64.0 * 0.5).backward()
+        (m(ids[rank][1], use_pos=True).float().logsumexp(-1).sum() / 64.0 * 0.5).backward()
+        ok = ok and fires["n"] == 2                                     # (1): one hook call per backward
+        ok = ok and sorted(bi for bi, _ in launches) == list(range(len(B.buckets)))          # (3) all launched by hooks, once
+        emb_launch = [w for bi, w in launches if bi == len(B.buckets) - 1][0]
+        ok = ok and {id(tied_w), id(m.model.embed_positions)} <= emb_launch
+        B.finish()
+        ok = ok and len(launches) == len(B.buckets)                     # finish() had nothing left to send
+        for bi in range(len(B.buckets)):
+            B.wait(bi)
+        # (2): the reduced gradient of every parameter is the sum over ranks of the two accumulated micro-batches
+        for n, p in m.named_parameters():
+            bi, o = B._where[id(p)]
+            lo, hi = B.rank * B.buckets[bi]["shard"], (B.rank + 1) * B.buckets[bi]["shard"]
+            got = B.buckets[bi]["flat_g"][o:o + p.numel()].float()
+            ref = want[n].flatten()
+            a, b_ = max(o, lo), min(o + p.numel(), hi)                  # gloo all-reduces the whole bucket; compare all of it
+            err = (got - ref).abs().max().item()
+            ok = ok and err <= 2 ** -7 * max(1.0, ref.abs().max().item())
+        opt.step()
+        opt.zero_grad()
+    q.put((rank, bool(ok), fires["n"], len(launches)))
+    dist.destroy_process_group()
+
+
+def test_tied_embedding_bucket_counts_one_arrival_and_never_leaks_across_micro_batches():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_accum, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res

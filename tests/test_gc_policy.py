@@ -55,3 +55,44 @@ def test_auto_schedule_never_plans_beyond_the_free_memory():
     ka = 32 if a == F.POLICIES["all"] else 0 if a == F.POLICIES["attn"] else a[0][0]
     kb = 32 if b == F.POLICIES["all"] else 0 if b == F.POLICIES["attn"] else b[0][0]
     assert kb < ka
+
+
+def test_bare_unsloth_spelling_is_the_fit_to_memory_schedule(monkeypatch):
+    """`use_gradient_checkpointing="unsloth"` (the API default, reference models/loader.py:407-441) resolves to the
+    least-recompute schedule that fits (the reference's own "unsloth" is a fit-to-memory decision, models/_utils.py:360-386);
+    the fixed keep-attention policy is "unsloth:attn"; UNSLOTH_AMD_GC_POLICY re-binds the bare spelling."""
+    import torch
+    from unsloth_amd.models.llama import FastLlamaModel
+
+    class _Inner(torch.nn.Module):
+        gradient_checkpointing = False
+
+    class _Base(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.model = _Inner()
+
+    def policy_of(mode):
+        b = _Base()
+        FastLlamaModel.for_training(b, mode)
+        return b.model._unsloth_amd_layer_policy, b.model.gradient_checkpointing
+
+    monkeypatch.delenv("UNSLOTH_AMD_GC_POLICY", raising=False)
+    assert policy_of("unsloth") == (F.AUTO, True)
+    assert policy_of("unsloth:auto") == (F.AUTO, True)
+    assert policy_of("unsloth:attn") == (F.POLICIES["attn"], True)
+    assert policy_of("unsloth:min") == (F.POLICIES["min"], True)
+    assert policy_of(True) == (None, True) and policy_of(False) == (None, False)
+    monkeypatch.setenv("UNSLOTH_AMD_GC_POLICY", "attn")
+    assert policy_of("unsloth") == (F.POLICIES["attn"], True)
+    assert policy_of("unsloth:all") == (F.POLICIES["all"], True)      # an explicit name beats the environment
+
+
+def test_auto_schedule_on_an_idle_and_on_a_crowded_mi355x():
+    """The two operating points bench.py reports for the default spelling: an idle 288 GB part keeps everything in all 32
+    layers (the speed of gradient_checkpointing=False); with 10 GB free beyond the 8.5 GB of resident weights and optimizer
+    state (a 19 GB total footprint, what the fixed "attn" policy measures) it is the keep-attention policy everywhere."""
+    assert F.auto_schedule(free_bytes=270 * GiB, **LLAMA3_8B) == F.POLICIES["all"]
+    assert F.auto_schedule(free_bytes=10 * GiB, **LLAMA3_8B) == F.POLICIES["attn"]
+    # batch 1 (2048 tokens) needs a quarter of the activations: the same 10 GB are plenty for keep-everything
+    assert F.auto_schedule(free_bytes=10 * GiB, **dict(LLAMA3_8B, tokens=2048)) == F.POLICIES["all"]

@@ -139,6 +139,68 @@ def test_config2_llama3_8b_qlora_r16_seq2048_every_checkpointing_mode(llama3_8b_
     _zero(model)
 
 
+def test_default_unsloth_spelling_fits_the_free_hbm(llama3_8b_two_layers):
+    """`use_gradient_checkpointing="unsloth"` (the API default) = the least-recompute schedule that fits (ref: the mode is a
+    fit-to-memory decision, models/_utils.py:360-386). On the idle GPU it keeps everything: the peak of `False`. With most of
+    the HBM held by somebody else (a reserved dummy tensor, no environment switch) the same spelling falls back to the
+    keep-attention policy: the peak of "unsloth:attn". auto_schedule's transient estimate must be conservative -- the largest
+    free size at which it still answers "attn" has to cover what the "attn" step really takes, or the fallback would OOM."""
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.models import fast_layer as F
+    model = llama3_8b_two_layers
+    T = 2048
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, 128256, (4, T), generator=g).to(DEV)
+    pos = torch.arange(T, dtype=torch.int32, device=DEV).unsqueeze(0).expand(4, T).contiguous()
+    seen = {}
+
+    def step(mode):
+        FastLanguageModel.for_training(model, use_gradient_checkpointing=mode)
+        model.get_base_model().model._uamd_auto_policy = None
+        _zero(model)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = model(input_ids=ids, labels=ids, position_ids=pos)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        pol = model.get_base_model().model._uamd_auto_policy
+        return torch.cuda.max_memory_allocated() - base, float(out.loss), _grads(model), (pol[1] if pol else None)
+
+    step("unsloth:attn")                                       # warm-up: per-device scratch is allocated on first use
+    for mode in (False, "unsloth:attn", "unsloth"):
+        seen[mode] = step(mode)
+    assert seen["unsloth"][3] == F.POLICIES["all"], "an idle 288 GB part must keep everything"
+    assert seen["unsloth"][0] <= 1.05 * seen[False][0] and seen["unsloth:attn"][0] < 0.8 * seen[False][0], seen
+    # the largest free size at which the arithmetic still says "attn everywhere" for this model and batch
+    kw = dict(n_layers=2, tokens=4 * T, hidden=4096, inter=14336, qkv_cols=6144, elsize=2, vocab=128256)
+    lo, hi = 0, 64 << 30
+    while hi - lo > (1 << 20):
+        mid = (lo + hi) // 2
+        lo, hi = (mid, hi) if F.auto_schedule(free_bytes=mid, **kw) == F.POLICIES["attn"] else (lo, mid)
+    assert lo > seen["unsloth:attn"][0] + (64 << 20), ("auto_schedule would plan an 'attn' step into less memory than it takes",
+                                                        lo, seen["unsloth:attn"][0])
+    _zero(model)
+    torch.cuda.empty_cache()
+    free = F.free_hbm_bytes(DEV)
+    dummy = torch.empty(free - lo + (8 << 20), dtype=torch.uint8, device=DEV)       # somebody else's memory
+    try:
+        assert F.free_hbm_bytes(DEV) <= lo
+        crowded = step("unsloth")
+    finally:
+        del dummy
+        torch.cuda.empty_cache()
+    assert crowded[3] == F.POLICIES["attn"]
+    assert crowded[0] <= 1.02 * seen["unsloth:attn"][0], (crowded[0], seen["unsloth:attn"][0])
+    # and it is the same step: every gradient bitwise (the loss itself is summed over fused-CE row chunks whose size follows
+    # the free memory too -- another summation order, the last bit of the fp32 sum may differ)
+    assert abs(crowded[1] - seen[False][1]) <= 1e-6 * abs(seen[False][1])
+    assert all(torch.equal(crowded[2][k], seen[False][2][k]) for k in crowded[2])
+    _report("default_unsloth_spelling", idle_peak_gb=seen["unsloth"][0] / 2**30, no_gc_peak_gb=seen[False][0] / 2**30,
+            attn_peak_gb=seen["unsloth:attn"][0] / 2**30, crowded_peak_gb=crowded[0] / 2**30, largest_attn_free_gb=lo / 2**30)
+    _zero(model)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def test_config5_mistral_7b_lora_r16_seq4096_loss_and_logprob_leg():
     from transformers import MistralConfig

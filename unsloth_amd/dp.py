@@ -160,12 +160,15 @@ class LoRAGradArena:
 
     @contextmanager
     def no_sync(self):
-        """Gradient accumulation: skip the exchange on all but the last micro-step."""
+        """Gradient accumulation: skip the exchange on all but the last micro-step (one micro-batch per block). Arrival
+        counts are dropped at the exit: a bucket that stayed incomplete (some factor received no gradient) must not be
+        completed -- and all-reduced half-accumulated -- by the first arrivals of the next micro-batch."""
         old, self._sync = self._sync, False
         try:
             yield
         finally:
             self._sync = old
+            self._pending = [0] * len(self.buckets)
 
     def zero_grad(self):
         """Keeps the views: the arena is zeroed in one memset instead of N small ones."""

@@ -87,11 +87,12 @@ class FullGradBuckets:
                 padded = (off + quantum - 1) // quantum * quantum
                 flat_p = torch.zeros(padded, dtype=self.dtype, device=self.device)
                 flat_g = torch.zeros(padded, dtype=self.dtype, device=self.device)
-                # gradient arrivals that complete the bucket: one per parameter, two for tied embeddings (lm_head's
-                # gradient and the embedding lookup's both accumulate into the one shared weight)
+                # gradient arrivals that complete the bucket: ONE per parameter and backward. A tied embedding has two
+                # producers (lm_head's gradient and the embedding lookup's), but autograd sums them before AccumulateGrad:
+                # the post-accumulate hook fires once (tests/test_full_finetune_gloo.py counts it)
                 b = dict(names=[n for n, _ in items], params=[p for _, p in items], offsets=offs, numel=padded,
                          flat_p=flat_p, flat_g=flat_g, shard=padded // self.world_size, pending=0, handle=None,
-                         launched=False, expected=sum(2 if id(p) in tied else 1 for _, p in items))
+                         launched=False, expected=len(items))
                 bi = len(self.buckets)
                 for (n, p), o in zip(items, offs):
                     k = p.numel()
@@ -188,6 +189,15 @@ class FullGradBuckets:
             for bi, b in enumerate(self.buckets):
                 if not b["launched"]:
                     self._launch(bi)
+        self._reset_arrivals()
+
+    def _reset_arrivals(self):
+        """Arrival counts never leak from one backward into the next: a bucket some parameter of which received no gradient
+        stays below `expected`, and the leftover would complete it in the MIDDLE of the next micro-batch's backward -- a
+        reduce-scatter of half-accumulated gradients. Called where a backward is known to be over: finish(), the exit of a
+        no_sync() block (one micro-batch per block, the accelerate / HF Trainer pattern), zero_grad()."""
+        for b in self.buckets:
+            b["pending"] = 0
 
     def wait(self, bi):
         b = self.buckets[bi]
@@ -208,10 +218,10 @@ class FullGradBuckets:
         self._written.clear()
         for p in self.params:
             p.grad = None
-        for b in self.buckets:
-            b["pending"] = 0
+        self._reset_arrivals()
 
     def no_sync(self):
+        """Gradient accumulation: no exchange for the backward(s) inside the block -- wrap ONE micro-batch per block."""
         from contextlib import contextmanager
 
         @contextmanager
@@ -221,6 +231,7 @@ class FullGradBuckets:
                 yield
             finally:
                 self._sync = old
+                self._reset_arrivals()
         return ctx()
 
     def close(self):

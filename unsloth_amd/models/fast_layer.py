@@ -23,7 +23,8 @@ Recomputed tensors come from the same deterministic kernels on the same inputs, 
 gradients of the keep-everything path (tests/test_gpu_model.py).
 
 Policies: "min" = {} (memory of plain checkpointing, ~30 % less recompute), "attn" = {qkv, h1} (re-runs only
-norm2 + gate/up), "all" = everything (no recompute; equals use_gradient_checkpointing=False).
+norm2 + gate/up), "all" = everything (no recompute; equals use_gradient_checkpointing=False). The bare spelling
+"unsloth" = "unsloth:auto": `all` for as many layers as the free HBM holds, `attn` for the rest (auto_schedule).
 """
 import torch
 
@@ -51,7 +52,7 @@ AUTO = "auto"
 
 
 def auto_schedule(n_layers, tokens, hidden, inter, qkv_cols, elsize, free_bytes, vocab=0, headroom=0.15):
-    """"unsloth:auto": the least-recompute schedule `all*k,attn` that fits. The reference's "unsloth" mode is the same kind
+    """"unsloth" (= "unsloth:auto"): the least-recompute schedule `all*k,attn` that fits. The reference's "unsloth" mode is the same kind
     of decision in the other direction (models/_utils.py:360-386 + unsloth_zoo: offload layer inputs to host RAM when VRAM is
     short); with 288 GB of HBM the question is how many layers can simply KEEP everything. Pure arithmetic (tested on the CPU):
       a layer under "attn" keeps  layer input + Q|K|V + attention output (+ fp32 LSE) + post-attention residual,
@@ -73,12 +74,23 @@ def auto_schedule(n_layers, tokens, hidden, inter, qkv_cols, elsize, free_bytes,
     return [(k, POLICIES["all"]), (None, POLICIES["attn"])]
 
 
+def free_hbm_bytes(dev):
+    """HBM this step may still take: what the driver reports free + the blocks torch's allocator holds but has not handed
+    out. UNSLOTH_AMD_GC_FREE_GB caps it (a share of a GPU that other jobs use; the capped operating point of bench.py)."""
+    import os
+    free, _total = torch.cuda.mem_get_info(dev)
+    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    cap = os.environ.get("UNSLOTH_AMD_GC_FREE_GB", "")
+    if cap:
+        free = min(free, int(float(cap) * (1 << 30)))
+    return free
+
+
 def auto_policy(model, hidden_states):
     """auto_schedule for this call: widths from the config, tokens from the batch, free HBM from the driver + torch's cache."""
     cfg = model.config
     dev = hidden_states.device
-    free, _total = torch.cuda.mem_get_info(dev)
-    free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    free = free_hbm_bytes(dev)
     head_dim = getattr(cfg, "head_dim", None) or cfg.hidden_size // cfg.num_attention_heads
     qkv_cols = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * head_dim
     tokens = hidden_states.shape[0] * hidden_states.shape[1]

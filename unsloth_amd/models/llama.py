@@ -709,20 +709,21 @@ class FastLlamaModel:
         """llama.py:3824-3885 + the mode selection of models/_utils.py:360-386.
           False      : every activation stays in HBM (288 GB), no recompute.
           True       : torch's reentrant per-layer checkpoint, what the reference gives for `True` (llama.py:1169-1193).
-          "unsloth"  : the reference offloads layer inputs to host RAM and re-runs whole layers; here: selective
-                       recompute (models/fast_layer.py) -- per layer keep the layer input, Q/K/V + attention output
-                       and the post-attention residual, re-run only norm2 + the gate/up GEMM in the backward
-                       (the SwiGLU output and the down projection are never recomputed).
-                       "unsloth:min" keeps only the layer input (the memory of `True`), "unsloth:all" keeps
-                       everything (the speed of `False`); a schedule such as "unsloth:all*4,attn" keeps everything in
-                       the first 4 layers and applies "attn" to the rest (a dial between the two); "unsloth:auto"
-                       sets that dial per call from the batch size and the free HBM (fast_layer.auto_schedule: as many
-                       keep-everything layers as fit); UNSLOTH_AMD_GC_POLICY overrides the default "attn"."""
+          "unsloth"  : the reference's smart mode is a fit-to-memory decision (models/_utils.py:360-386: offload layer
+                       inputs to host RAM and re-run whole layers when VRAM is short). Here the same spelling resolves,
+                       per call, to the LEAST-RECOMPUTE schedule that fits the free HBM (fast_layer.auto_schedule from the
+                       batch size and the free memory: keep everything in as many layers as fit -- all 32 on an idle
+                       288 GB part, i.e. the speed of `False` -- and fall back layer by layer to "attn" as memory gets
+                       short). Fixed policies stay reachable by name: "unsloth:attn" (per layer keep the layer input,
+                       Q/K/V + attention output and the post-attention residual, re-run only norm2 + the gate/up GEMM),
+                       "unsloth:min" (layer input only: the memory of `True`), "unsloth:all" (everything), schedules
+                       such as "unsloth:all*4,attn"; "unsloth:auto" is the explicit name of the default.
+                       UNSLOTH_AMD_GC_POLICY overrides what the bare spelling means."""
         base = model.get_base_model() if hasattr(model, "get_base_model") else model
         policy = None
         mode = use_gradient_checkpointing
         if isinstance(mode, str) and mode.split(":")[0] == "unsloth":
-            name = mode.split(":", 1)[1] if ":" in mode else os.environ.get("UNSLOTH_AMD_GC_POLICY", "attn")
+            name = mode.split(":", 1)[1] if ":" in mode else os.environ.get("UNSLOTH_AMD_GC_POLICY", "auto")
             policy = _fast_layer.resolve_policy_spec(name)
         gc = bool(mode)
         base.model.gradient_checkpointing = gc
