@@ -71,7 +71,28 @@ struct AttnArgs {
     int nqt;                             // number of q tiles
     int lse_st;                          // row stride of LSE [B, Hq, lse_st] (T rounded up to 32)
     float scale_log2;                    // softmax scale * log2(e)
+    int xcd_map;                         // block -> (tile, pair) mapping: 1 = one (batch, KV head) pair at a time per XCD
 };
+
+// Block index -> (rank of the tile in heaviest-first order, (batch, KV head) pair).
+// All q tiles of one pair stream the SAME K / V (1 MiB at 2048 tokens): 7 B / cycle / CU in the tile loop, two thirds of what a CU
+// gets from the fabric when every CU streams (MI355X_MICROARCH.md: ~10 B/cyc/CU) -- the three forward kernels of rounds 1-4,
+// as different as they are, all ran 4,500 cycles per tile step (profiles/r04_attn_fwd_slope.md). Workgroups go to the 8 XCDs
+// round-robin by block index, each XCD has its own 4 MiB L2. map 0 (rounds 1-3): tile-major, pair-minor -- the 32 blocks an XCD
+// runs at a time cover EVERY pair it owns (4 MiB of K / V + the Q / O streams: the L2 thrashes). map 1: XCD x takes its pairs
+// x, x + 8, ... ONE AFTER THE OTHER, each with its tiles heaviest first: the 32 CUs of an XCD share one or two pairs' K / V
+// (1-2 MiB) out of L2, and the short tiles of a pair finish while the next pair's heavy ones start (the load balance of the
+// heaviest-first order is kept within every XCD's own stream).
+__device__ __forceinline__ void block_to_work(int bid, int ntiles, int npairs, int map, int& rank, int& pair) {
+    if (map == 1) {
+        const int x = bid & 7, j = bid >> 3;
+        pair = (j / ntiles) * 8 + x;
+        rank = j % ntiles;
+    } else {
+        rank = bid / npairs;
+        pair = bid % npairs;
+    }
+}
 
 // two LDS-DMA wave-instructions (2 x 1 KiB) from one wave-uniform base: lane l copies 16 B from
 // base + voff_i to LDS [dst_i + 16 l). Inline asm: see gemm256.hip / cdna guide 5.7.
@@ -180,7 +201,36 @@ __device__ unsigned* g_attn_trace = nullptr;
 #define ASTAMP(TI, I) do { } while (0)
 #endif
 
+// Row-per-lane epilogue store of a 32 x 128 accumulator block (lane = row l31; lane half lh holds columns 8 g + 4 lh .. + 3
+// of every 8-column group g): 16 x 8-byte stores per lane are store-ISSUE-bound (cdna_hip_programming.md T21). One
+// v_permlane32_swap per dword of a group pair (g, g + 1) hands the lower half 16 contiguous bytes of group g and the upper
+// half 16 of group g + 1: 8 x dwordx4 per lane, same bytes, same addresses.
+template <typename T>
+__device__ __forceinline__ void store_rows_x4(T* row, const f32x16_t (&acc)[4], float mul, int lh, bool live) {
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int qd = 0; qd < 4; qd += 2) {
+            uint32_t ax = pack_pair2<T>(acc[dt][qd * 4 + 0] * mul, acc[dt][qd * 4 + 1] * mul);
+            uint32_t ay = pack_pair2<T>(acc[dt][qd * 4 + 2] * mul, acc[dt][qd * 4 + 3] * mul);
+            uint32_t bx = pack_pair2<T>(acc[dt][qd * 4 + 4] * mul, acc[dt][qd * 4 + 5] * mul);
+            uint32_t by = pack_pair2<T>(acc[dt][qd * 4 + 6] * mul, acc[dt][qd * 4 + 7] * mul);
+#ifdef UAMD_ATTN_NARROW_STORE
+            if (live) {
+                *reinterpret_cast<uint2*>(row + dt * 32 + qd * 8 + lh * 4) = make_uint2(ax, ay);
+                *reinterpret_cast<uint2*>(row + dt * 32 + qd * 8 + 8 + lh * 4) = make_uint2(bx, by);
+            }
+#else
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            if (live) *reinterpret_cast<uint4*>(row + dt * 32 + qd * 8 + lh * 8) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+#endif
+        }
+}
+
 // BAND = false: plain causal attention, the band bookkeeping folds away at compile time (it costs ~50 VGPRs).
+// (A 2-stage ring = 64 KiB = two blocks per CU was tried in round 4: the kernel needs ~240 registers per lane -- O 64, S 32, Q^T 32,
+// operand fragments -- so the 128-register cap of 4 waves per SIMD spills 126-256 registers. Not built.)
 template <typename T, bool BAND>
 __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -193,8 +243,9 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     // longest-processing-time-first over the WHOLE grid: all (batch, kv head) pairs of the heaviest q tile are
     // dispatched first, the one-tile blocks fill the tail
     const int npairs = p.Hk * p.B;
-    const int qtile = p.nqt - 1 - (int)(blockIdx.x / npairs);
-    const int pair_ = (int)(blockIdx.x % npairs);
+    int rank_, pair_;
+    block_to_work((int)blockIdx.x, p.nqt, npairs, p.xcd_map, rank_, pair_);
+    const int qtile = p.nqt - 1 - rank_;                              // heaviest q tiles first
     const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int head = kvh * G + (wave % G);
     const int qs = qtile * QT + (wave / G) * 32;                      // first q position of this wave
@@ -432,20 +483,323 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     // ---- epilogue: O = O^T / l, LSE = ln2 * (m + log2 l)
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_pos < T_) {
-        T* op = (T*)p.O + b * p.o_sb + (int64_t)q_pos * p.o_st + (int64_t)head * p.o_sh;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int d = dt * 32 + qd * 8 + lh * 4;
-                uint2 o;
-                o.x = pack_pair2<T>(o_acc[dt][qd * 4 + 0] * inv, o_acc[dt][qd * 4 + 1] * inv);
-                o.y = pack_pair2<T>(o_acc[dt][qd * 4 + 2] * inv, o_acc[dt][qd * 4 + 3] * inv);
-                *reinterpret_cast<uint2*>(op + d) = o;
-            }
-        if (lh == 0) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    {
+        T* op = (T*)p.O + b * p.o_sb + (int64_t)q_ld * p.o_st + (int64_t)head * p.o_sh;
+        store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_);
+        if (lh == 0 && q_pos < T_) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Forward, PING-PONG schedule (round 4; the default). Same tiling, LDS image, swizzles and DMA ring as attn_fwd_kernel --
+// what changes is WHEN each wave does what. In the lockstep kernel all 8 waves run [K reads + S MFMAs | softmax | V reads +
+// PV MFMAs] behind one barrier per tile: the two waves of a SIMD want the matrix pipe in the same phases and leave it idle
+// in the same phases, and every MFMA waits for its own LDS read (profiles/r01_attn_fwd_trace.txt: tile period 5,800 cycles
+// against 2,048 cycles of MFMA issue). Here a tile is four phases separated by block barriers,
+//     P1  K rows of the tile LDS -> 64 registers (16 ds_read_b128), LDS-DMA of the tile two ahead
+//     P2  S^T = K Q^T: 16 MFMAs on registers only
+//     P3  V^T fragments LDS -> the SAME 64 registers (32 ds_read_b64_tr_b16), online softmax on S^T, P packed
+//     P4  O^T += V^T P^T: 16 MFMAs on registers only
+// and waves 4-7 (the second wave of every SIMD: a workgroup's waves go to the SIMDs in cyclic order) run ONE PHASE BEHIND
+// waves 0-3: a matrix phase (P2, P4) of one wave always sits beside a load / VALU phase (P1, P3) of its SIMD partner -- the
+// regime MI355X_MICROARCH.md "Two waves per SIMD" describes (matrix beside memory, never matrix beside matrix). The ring
+// stays safe under the skew: the stage of tile t is last read in the trailing group's P3(t), which ends at the barrier
+// before the leading group's P1(t + 1) -- the first phase that issues a DMA (tile t + 3) into that stage; every wave waits
+// for ITS pieces of tile t + 1 at the end of its P3(t), one barrier before anybody reads them.
+template <typename T, bool BAND>
+__global__ void __launch_bounds__(512, 2) attn_fwd_pp_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename MfmaA<T>::frag frag_t;
+#ifdef UAMD_ATTN_TRACE
+    const unsigned long long tb_start = __builtin_amdgcn_s_memtime();
+    unsigned long long tb_loop0 = 0, tb_loop1 = 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int G = p.G, T_ = p.T;
+    const int QT = 32 * p.nsub;
+    const int npairs = p.Hk * p.B;
+    int rank_, pair_;
+    block_to_work((int)blockIdx.x, p.nqt, npairs, p.xcd_map, rank_, pair_);
+    const int qtile = p.nqt - 1 - rank_;                              // heaviest q tiles first
+    const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
+    const int head = kvh * G + (wave % G);
+    const int qs = qtile * QT + (wave / G) * 32;
+    const int q_pos = qs + l31;
+    const int q_ld = q_pos < T_ ? q_pos : T_ - 1;
+    const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
+    const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
+    const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
+
+    const int nkv_blk = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);
+    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
+    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh;
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
+    const unsigned dst_w = lds_base + wave * 2048;
+    // DMA plan: a stage = K tile (64 rows x 256 B) then V tile; one instruction = 4 rows; wave w issues pieces 2w, 2w + 1
+    // (rows 8w .. 8w + 7) of K and of V; lane -> (row = 4 piece + (lane >> 4), stored slot = lane & 15), the stored slot
+    // holds logical slot s ^ (row & 15) (K) / s ^ ((row & 3) << 2) (V). The four per-lane source offsets are RECOMPUTED at
+    // every issue from an opaque copy of the lane id (a dozen VALU instructions per tile): kept in registers across the tile
+    // loop they are the first thing hipcc spills, and a scratch reload in front of the DMA drains vmcnt (= the ring)
+    auto issue = [&](int t, int stage) {
+#if defined(UAMD_ATTN_DBG) && UAMD_ATTN_DBG == 1
+        if (t >= 0) return;                        // timing experiment: no K / V traffic at all (results are garbage)
+        const int k0 = 0;
+#elif defined(UAMD_ATTN_DBG) && UAMD_ATTN_DBG == 2
+        const int k0 = 0;                          // timing experiment: every tile is tile 0 (L2-resident)
+#else
+        const int k0 = t * KT;
+#endif
+        const unsigned d = dst_w + stage * STAGE_B;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int rmax = T_ - 1 - k0;                                  // ragged last tile: rows past the end re-read the last key
+        unsigned ko[2], vo[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 4 + (ln >> 4);
+            const int r = min(row, rmax);
+            ko[i] = (unsigned)(r * (int)p.k_st * 2 + ((ln & 15) ^ (row & 15)) * 16);
+            vo[i] = (unsigned)(r * (int)p.v_st * 2 + ((ln & 15) ^ ((row & 3) << 2)) * 16);
+        }
+        dma16x2(kbase + (int64_t)k0 * p.k_st, ko[0], ko[1], d, d + 1024);
+        dma16x2(vbase + (int64_t)k0 * p.v_st, vo[0], vo[1], d + TILE_B, d + TILE_B + 1024);
+    };
+    const int kx = l31 & 15;
+    const int k_lane = l31 * 256 + (((kx & 14) | (lh ^ (kx & 1))) << 4);
+    const int sg = lane & 15, gh = (lane >> 4) & 1;
+    const int v_lane = (4 * lh + (sg >> 2)) * 256 + ((((sg >> 2) << 2) | (gh << 1) | ((sg >> 1) & 1)) << 4) + (sg & 1) * 8;
+
+    f32x16_t o_acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = nkv_blk - t_first;
+    const int last_tile_wave = min(qs + 31, T_ - 1) / KT;
+    const int first_tile_wave = lo_w0 / KT;
+    const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);       // tiles that start below the band edge
+    const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
+    const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
+
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed for everybody; the trailing group then drops one phase behind
+    issue(t_first, 0);
+    if (nt > 1) issue(t_first + 1, 1);
+    // Q^T operand fragments (B operand: lane -> q = l31, 8 d at 16 ks + 8 lh), resident for the whole tile loop. Loaded
+    // AFTER the first tiles' DMA was issued and waited for with a wait the COMPILER can see (the builtin, not asm): hipcc
+    // counts only its own loads, and would otherwise thread a vmcnt(11) ... vmcnt(4) countdown through the first S MFMAs of
+    // every tile -- which on the hardware's single counter also waits for LDS-DMA pieces that are meant to stay in flight
+    frag_t qf[8];
+    {
+        const T* qp = (const T*)p.Q + b * p.q_sb + (int64_t)q_ld * p.q_st + (int64_t)head * p.q_sh + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            union { uint4 r; frag_t f; } u;
+            u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
+            qf[ks] = u.f;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): Q fragments + tiles 0 and 1 (tile 1 is needed four phases on)
+    bar();
+    if (wave >= 4) bar();
+#ifdef UAMD_ATTN_TRACE
+    tb_loop0 = __builtin_amdgcn_s_memtime();
+#endif
+
+#ifdef UAMD_ATTN_TRACE
+    // deferred stamps (tile 8 only): s_memtime lands in SGPRs and is consumed after the phase's own waits, so a stamp
+    // between "reads issued" and "reads waited for" does not itself wait for the reads
+    unsigned long long tsx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tsx[i] = 0;
+#define PSTAMP(I) do { __builtin_amdgcn_sched_barrier(0); if (ti == 8) tsx[I] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(I) do { } while (0)
+#endif
+    frag_t kv[16];                       // P1 -> P2: K rows (kt * 8 + ks);  P3 -> P4: V^T fragments (u * 4 + dt)
+    f32x16_t st[2];
+    frag_t pb[4];
+    // P^T fragment of 16-key step u = 2 kt + c (registers 8 c .. 8 c + 7 of st[kt]): exp2, partial row sums, packing
+    auto softmax_piece = [&](int u, float m_ref, float& ls0, float& ls1) {
+        const int kt = u >> 1, c = u & 1;
+        union { uint32_t w[4]; frag_t f; } w_;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][8 * c + 2 * jj], p.scale_log2, -m_ref));
+            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kt][8 * c + 2 * jj + 1], p.scale_log2, -m_ref));
+            ls0 += e0;
+            ls1 += e1;
+            w_.w[jj] = pack_pair2<T>(e0, e1);
+        }
+        pb[u] = w_.f;
+    };
+    for (int ti = 0; ti < nt; ++ti) {
+        const int t = t_first + ti;
+        const bool live = !(t > last_tile_wave || t < first_tile_wave);         // wave-uniform
+        const unsigned char* sk = smem + (ti % NST) * STAGE_B;
+        const unsigned char* sv = sk + TILE_B;
+        // ---------------- P1 (load): K rows -> 64 registers
+        PSTAMP(0);
+        if (live) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    union { uint4 r; frag_t f; } u;
+                    u.r = *reinterpret_cast<const uint4*>(sk + kt * 32 * 256 + (k_lane ^ (ks * 32)));
+                    kv[kt * 8 + ks] = u.f;
+                }
+            PSTAMP(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        PSTAMP(2);
+        bar();
+        PSTAMP(3);
+        // ---------------- P2 (matrix): S^T[key][q] = K Q^T on registers; the LDS-DMA of tile t + 2 rides in the MFMA shadow
+        //                  (its stage was last read two barriers ago; an issue costs ~60 cycles among bare MFMAs, 100-185 in a
+        //                  phase that also carries LDS reads -- MI355X_MICROARCH.md)
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) st[0] = MfmaA<T>::run(kv[ks], qf[ks], st[0]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);
+        if (live) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 4; ks < 8; ++ks) st[0] = MfmaA<T>::run(kv[ks], qf[ks], st[0]);
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) st[1] = MfmaA<T>::run(kv[8 + ks], qf[ks], st[1]);
+        }
+        PSTAMP(4);
+        bar();
+        PSTAMP(5);
+        // ---------------- P3 (load + row statistics): V^T fragments -> the same 64 registers; mask, row max (a TREE: a serial
+        //                  fmax chain is 32 dependent VALU latencies), rescale test; P^T of the first 16-key step
+        float m_ref = 0.f, ls0 = 0.f, ls1 = 0.f;
+        if (live) {
+            const int k0 = t * KT;
+            const bool need_mask = BAND ? (t < t_pre_end || t >= t_suf) : (t >= t_suf);
+            if (need_mask) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (key > q_pos || key >= T_ || key < lo_q) st[kt][r] = -INFINITY;
+                    }
+            }
+            float m8[8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const int a0 = (u * 16) * 256 + (v_lane ^ (dt << 6));
+                    union { s16x4_t h[2]; frag_t f; } va;
+                    va.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0));
+                    va.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0 + 8 * 256));
+                    kv[u * 4 + dt] = va.f;
+                }
+                // leaves of the max tree for 8 scores, issued between the read bursts
+                const int kt = u >> 1, c = u & 1;
+                m8[2 * u] = fmaxf(fmaxf(st[kt][8 * c], st[kt][8 * c + 1]), fmaxf(st[kt][8 * c + 2], st[kt][8 * c + 3]));
+                m8[2 * u + 1] = fmaxf(fmaxf(st[kt][8 * c + 4], st[kt][8 * c + 5]), fmaxf(st[kt][8 * c + 6], st[kt][8 * c + 7]));
+            }
+            PSTAMP(6);
+            float mt = fmaxf(fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3])), fmaxf(fmaxf(m8[4], m8[5]), fmaxf(m8[6], m8[7])));
+            mt = max_across_halves(mt) * p.scale_log2;
+            if (__builtin_amdgcn_ballot_w64(mt > m_run) != 0) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - (m_new == -INFINITY ? 0.f : m_new));
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o_acc[i] *= alpha;
+            }
+            m_ref = m_run == -INFINITY ? 0.f : m_run;
+            softmax_piece(0, m_ref, ls0, ls1);
+            __builtin_amdgcn_sched_barrier(0);       // (nothing above may sink below the wait: it is what hides the reads)
+            PSTAMP(7);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        PSTAMP(8);
+        // this wave's pieces of tile t + 1 have landed before anybody reads them (one barrier from now)
+        if (ti + 2 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PSTAMP(9);
+        bar();
+        PSTAMP(10);
+        // ---------------- P4 (matrix): O^T[d][q] += V^T P^T on registers; the exponentials of step u + 1 ride in the shadow
+        //                  of step u's four MFMAs (one wave hides <= 5 single-issue instructions per 32x32x16 MFMA)
+        if (live) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) o_acc[dt] = MfmaA<T>::run(kv[u * 4 + dt], pb[u], o_acc[dt]);
+                if (u < 3) softmax_piece(u + 1, m_ref, ls0, ls1);
+#pragma unroll
+                for (int g_ = 0; g_ < 4; ++g_) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // 1 MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);       // 7 VALU (28 per step: 8 fma, 8 exp2, 8 add, 4 cvt)
+                }
+            }
+            l_run += ls0 + ls1;
+        }
+        PSTAMP(11);
+        bar();
+#ifdef UAMD_ATTN_TRACE
+        if (ti == 8) tsx[12] = __builtin_amdgcn_s_memtime();
+#endif
+    }
+#ifdef UAMD_ATTN_TRACE
+    if (g_attn_trace && lane == 0 && blockIdx.x < 256) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) g_attn_trace[(blockIdx.x * 8 + wave) * 16 + i] = (unsigned)tsx[i];
+    }
+#endif
+    if (wave < 4) bar();                 // the leading group's extra barrier = the trailing group's last phase
+#ifdef UAMD_ATTN_TRACE
+    tb_loop1 = __builtin_amdgcn_s_memtime();
+#endif
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    {
+        // the row address is formed HERE (an opaque copy of the row index): hoisted to the kernel entry, the 64-bit pointer
+        // pair is spilled around the tile loop and its reload's vmcnt(0) drains the LDS-DMA ring
+        int qr = q_ld;
+        asm volatile("" : "+v"(qr));
+        T* op = (T*)p.O + b * p.o_sb + (int64_t)qr * p.o_st + (int64_t)head * p.o_sh;
+        store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_);
+        if (lh == 0 && q_pos < T_) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + qr] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
+    }
+#ifdef UAMD_ATTN_TRACE
+    // block timeline (second region of the trace buffer): entry | tile loop start | tile loop end | stores issued | stores
+    // done | HW_ID | XCC_ID, per wave -- tools/attn_trace.py rebuilds every CU's sequence of blocks from it
+    if (g_attn_trace) {
+        const unsigned long long tb_issued = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tb_done = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && blockIdx.x < 4096) {
+            unsigned* o_ = g_attn_trace + 32768 + (blockIdx.x * 8 + wave) * 8;
+            o_[0] = (unsigned)tb_start; o_[1] = (unsigned)tb_loop0; o_[2] = (unsigned)tb_loop1; o_[3] = (unsigned)tb_issued;
+            o_[4] = (unsigned)tb_done;
+            o_[5] = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID
+            o_[6] = __builtin_amdgcn_s_getreg(20 | (31 << 11));       // HW_REG_XCC_ID
+            o_[7] = (unsigned)nt;
+        }
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -649,8 +1003,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int G = p.G, T_ = p.T;
     const int QT = 64 * (4 / G);
     const int npairs = p.Hk * p.B;
-    const int qtile = p.nqt - 1 - (int)(blockIdx.x / npairs);           // heaviest q tiles first
-    const int pair_ = (int)(blockIdx.x % npairs);
+    int rank_, pair_;
+    block_to_work((int)blockIdx.x, p.nqt, npairs, p.xcd_map, rank_, pair_);
+    const int qtile = p.nqt - 1 - rank_;                              // heaviest q tiles first
     const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int head = kvh * G + (wave % G);
     const int qs = qtile * QT + (wave / G) * 64;                        // first q position of this wave
@@ -982,6 +1337,7 @@ struct AttnBwdArgs {
     int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
     int B, T, Hq, Hk, G, nsub, lse_st, nqt;
     float scale, scale_log2;
+    int xcd_map;                         // see block_to_work
 };
 
 __device__ __forceinline__ int swz_c(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -996,8 +1352,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int G = p.G, T_ = p.T;
     const int QT = 32 * p.nsub;
     const int npairs = p.Hk * p.B;
-    const int qtile = p.nqt - 1 - (int)(blockIdx.x / npairs);
-    const int pair_ = (int)(blockIdx.x % npairs);
+    int rank_, pair_;
+    block_to_work((int)blockIdx.x, p.nqt, npairs, p.xcd_map, rank_, pair_);
+    const int qtile = p.nqt - 1 - rank_;                              // heaviest q tiles first
     const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int head = kvh * G + (wave % G);
     const int qs = qtile * QT + (wave / G) * 32;
@@ -1158,18 +1515,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
             for (int ti = 0; ti < nt; ++ti) step(ti, std::integral_constant<int, 2>{}, ti >= t_suf);
         }
     }
-    if (q_pos < T_) {
-        T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)q_pos * p.dq_st + (int64_t)head * p.dq_sh;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int d = dt * 32 + qd * 8 + lh * 4;
-                uint2 o;
-                o.x = pack_pair2<T>(dq_acc[dt][qd * 4 + 0], dq_acc[dt][qd * 4 + 1]);
-                o.y = pack_pair2<T>(dq_acc[dt][qd * 4 + 2], dq_acc[dt][qd * 4 + 3]);
-                *reinterpret_cast<uint2*>(op + d) = o;
-            }
+    {
+        T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)q_ld * p.dq_st + (int64_t)head * p.dq_sh;
+        store_rows_x4<T>(op, dq_acc, 1.0f, lh, q_pos < T_);
     }
 }
 
@@ -1201,8 +1549,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     const int hin = unit % hpp, slice = unit / hpp;
     // key tile 0 sees every q tile (causal): heaviest first over the whole grid
     const int npairs = p.Hk * p.B;
-    const int jt = (int)(blockIdx.x / npairs);
-    const int pair_ = (int)(blockIdx.x % npairs);
+    int jt, pair_;
+    block_to_work((int)blockIdx.x, (T_ + KT - 1) / KT, npairs, p.xcd_map, jt, pair_);
     const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int k0 = jt * KT;
     const int key = k0 + kh * 32 + l31;               // this lane's key (C-layout column)
@@ -1526,8 +1874,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int npass = G / hpp, nslice = 4 / hpp;
     const int hin = unit % hpp, slice = unit / hpp;
     const int npairs = p.Hk * p.B;
-    const int jt = (int)(blockIdx.x / npairs);        // key tile 0 sees every q tile (causal): heaviest first
-    const int pair_ = (int)(blockIdx.x % npairs);
+    int jt, pair_;                                    // key tile 0 sees every q tile (causal): heaviest first
+    block_to_work((int)blockIdx.x, (T_ + KT - 1) / KT, npairs, p.xcd_map, jt, pair_);
     const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int k0 = jt * KT;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
@@ -1922,8 +2270,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int hin = unit % hpp, slice = unit / hpp;
     const int npairs = p.Hk * p.B;
     const int nq64 = (T_ + 63) / 64, nqb = (nq64 + nslice - 1) / nslice;
-    const int jb = nqb - 1 - (int)(blockIdx.x / npairs);               // the last query tiles see every key: heaviest first
-    const int pair_ = (int)(blockIdx.x % npairs);
+    int rank_, pair_;
+    block_to_work((int)blockIdx.x, nqb, npairs, p.xcd_map, rank_, pair_);
+    const int jb = nqb - 1 - rank_;                                     // the last query tiles see every key: heaviest first
     const int kvh = pair_ % p.Hk, b = pair_ / p.Hk;
     const int q0 = (jb * nslice + slice) * 64;                          // this wave's query tile (>= T: an idle wave)
     const bool active = q0 < T_;
@@ -2240,6 +2589,8 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     a.dv_sb = strides[21]; a.dv_st = strides[22]; a.dv_sh = strides[23];
     a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    // UAMD_TUNE_ATTN_VAR bit 4: one pair at a time per XCD (block_to_work map 1; measured 6 % SLOWER, default off)
+    a.xcd_map = ((Hk * B) % 8 == 0 && (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 16)) ? 1 : 0;
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
     dim3 grid_q((unsigned)(a.nqt * Hk * B));
@@ -2260,53 +2611,44 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     static bool attrq4[4][64] = {{false}};
     const int nslice4 = G < 4 ? 4 / G : 1;
     dim3 grid_q4((unsigned)((((T + 63) / 64 + nslice4 - 1) / nslice4) * Hk * B));
-    if (dtype == UAMD_BF16) {
-        if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<bf16_t>, KD_LDS, &attr_set[1][dev]))) return rc;
-        if (dq4 && lo) {
-            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<bf16_t, true>, DQ4_LDS, &attrq4[0][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq4_kernel<bf16_t, true>), grid_q4, dim3(256), DQ4_LDS, st, a);
-        } else if (dq4) {
-            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<bf16_t, false>, DQ4_LDS, &attrq4[1][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq4_kernel<bf16_t, false>), grid_q4, dim3(256), DQ4_LDS, st, a);
+    auto run = [&](auto tag) -> int {
+        typedef decltype(tag) T;
+        constexpr int ti = std::is_same<T, bf16_t>::value ? 0 : 1;
+        int rc_;
+        if ((rc_ = set_lds_attr(&attn_bwd_dkdv_kernel<T>, KD_LDS, &attr_set[ti][dev]))) return rc_;
+        auto dq = [&](auto kernel, int lds, bool* done) -> int {
+            int r_;
+            if ((r_ = set_lds_attr(kernel, lds, done))) return r_;
+            hipLaunchKernelGGL(kernel, grid_q, dim3(512), lds, st, a);
+            return 0;
+        };
+        static bool done_dq[2][2][64] = {};
+        if (dq4) {
+            if (lo) {
+                if ((rc_ = set_lds_attr(&attn_bwd_dq4_kernel<T, true>, DQ4_LDS, &attrq4[2 * ti][dev]))) return rc_;
+                hipLaunchKernelGGL((attn_bwd_dq4_kernel<T, true>), grid_q4, dim3(256), DQ4_LDS, st, a);
+            } else {
+                if ((rc_ = set_lds_attr(&attn_bwd_dq4_kernel<T, false>, DQ4_LDS, &attrq4[2 * ti + 1][dev]))) return rc_;
+                hipLaunchKernelGGL((attn_bwd_dq4_kernel<T, false>), grid_q4, dim3(256), DQ4_LDS, st, a);
+            }
         } else if (lo) {
-            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t, true>, ATTN_LDS, &attr_set[0][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, true>), grid_q, dim3(512), ATTN_LDS, st, a);
+            if ((rc_ = dq(&attn_bwd_dq_kernel<T, true>, ATTN_LDS, &done_dq[ti][1][dev]))) return rc_;
         } else {
-            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<bf16_t, false>, ATTN_LDS, &attr_set[4][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<bf16_t, false>), grid_q, dim3(512), ATTN_LDS, st, a);
+            if ((rc_ = dq(&attn_bwd_dq_kernel<T, false>, ATTN_LDS, &done_dq[ti][0][dev]))) return rc_;
         }
-        if ((rc = uamd_launch_status())) return rc;
+        if ((rc_ = uamd_launch_status())) return rc_;
         if (dkdv4) {
-            if ((rc = set_lds_attr(&attn_bwd_dkdv4_kernel<bf16_t>, KD4_LDS, &attr4[0][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<bf16_t>), grid_k, dim3(256), KD4_LDS, st, a);
+            if ((rc_ = set_lds_attr(&attn_bwd_dkdv4_kernel<T>, KD4_LDS, &attr4[ti][dev]))) return rc_;
+            hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<T>), grid_k, dim3(256), KD4_LDS, st, a);
         } else {
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<bf16_t>), grid_k, dim3(512), KD_LDS, st, a);
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<T>), grid_k, dim3(512), KD_LDS, st, a);
         }
-    } else if (dtype == UAMD_F16) {
-        if ((rc = set_lds_attr(&attn_bwd_dkdv_kernel<f16_t>, KD_LDS, &attr_set[3][dev]))) return rc;
-        if (dq4 && lo) {
-            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<f16_t, true>, DQ4_LDS, &attrq4[2][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq4_kernel<f16_t, true>), grid_q4, dim3(256), DQ4_LDS, st, a);
-        } else if (dq4) {
-            if ((rc = set_lds_attr(&attn_bwd_dq4_kernel<f16_t, false>, DQ4_LDS, &attrq4[3][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq4_kernel<f16_t, false>), grid_q4, dim3(256), DQ4_LDS, st, a);
-        } else if (lo) {
-            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t, true>, ATTN_LDS, &attr_set[2][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, true>), grid_q, dim3(512), ATTN_LDS, st, a);
-        } else {
-            if ((rc = set_lds_attr(&attn_bwd_dq_kernel<f16_t, false>, ATTN_LDS, &attr_set[5][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<f16_t, false>), grid_q, dim3(512), ATTN_LDS, st, a);
-        }
-        if ((rc = uamd_launch_status())) return rc;
-        if (dkdv4) {
-            if ((rc = set_lds_attr(&attn_bwd_dkdv4_kernel<f16_t>, KD4_LDS, &attr4[1][dev]))) return rc;
-            hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<f16_t>), grid_k, dim3(256), KD4_LDS, st, a);
-        } else {
-            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<f16_t>), grid_k, dim3(512), KD_LDS, st, a);
-        }
-    } else {
-        return UAMD_ERR_DTYPE;
-    }
+        return 0;
+    };
+    if (dtype == UAMD_BF16) rc = run(bf16_t{});
+    else if (dtype == UAMD_F16) rc = run(f16_t{});
+    else return UAMD_ERR_DTYPE;
+    if (rc) return rc;
     return uamd_launch_status();
 }
 
@@ -2332,6 +2674,7 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     a.o_sb = strides[9]; a.o_st = strides[10]; a.o_sh = strides[11];
     a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale_log2 = scale * 1.4426950408889634f;
+    a.xcd_map = ((Hk * B) % 8 == 0 && (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 16)) ? 1 : 0;
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
     dim3 grid((unsigned)(a.nqt * Hk * B));
@@ -2354,24 +2697,26 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
         }
         return uamd_launch_status();
     }
-    if (dtype == UAMD_BF16) {
-        if (lo) {
-            if ((rc = set_lds_attr(&attn_fwd_kernel<bf16_t, true>, ATTN_LDS, &attr_set[0][dev]))) return rc;
-            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, true>), grid, dim3(512), ATTN_LDS, st, a);
-        } else {
-            if ((rc = set_lds_attr(&attn_fwd_kernel<bf16_t, false>, ATTN_LDS, &attr_set[1][dev]))) return rc;
-            hipLaunchKernelGGL((attn_fwd_kernel<bf16_t, false>), grid, dim3(512), ATTN_LDS, st, a);
-        }
-    } else if (dtype == UAMD_F16) {
-        if (lo) {
-            if ((rc = set_lds_attr(&attn_fwd_kernel<f16_t, true>, ATTN_LDS, &attr_set[2][dev]))) return rc;
-            hipLaunchKernelGGL((attn_fwd_kernel<f16_t, true>), grid, dim3(512), ATTN_LDS, st, a);
-        } else {
-            if ((rc = set_lds_attr(&attn_fwd_kernel<f16_t, false>, ATTN_LDS, &attr_set[3][dev]))) return rc;
-            hipLaunchKernelGGL((attn_fwd_kernel<f16_t, false>), grid, dim3(512), ATTN_LDS, st, a);
-        }
-    } else {
-        return UAMD_ERR_DTYPE;
-    }
+    // UAMD_TUNE_ATTN_VAR bit 3: the ping-pong forward kernel instead of the lockstep kernel
+    const bool lockstep = (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 8) == 0;
+    auto run = [&](auto tag) -> int {
+        typedef decltype(tag) T;
+        constexpr int ti = std::is_same<T, bf16_t>::value ? 0 : 1;
+        static bool done[2][2][2][64] = {};
+        auto go = [&](auto kernel, int lds, bool* d) -> int {
+            int r_;
+            if ((r_ = set_lds_attr(kernel, lds, d))) return r_;
+            hipLaunchKernelGGL(kernel, grid, dim3(512), lds, st, a);
+            return 0;
+        };
+        if (lo) return lockstep ? go(&attn_fwd_kernel<T, true>, ATTN_LDS, &done[ti][1][1][dev])
+                                : go(&attn_fwd_pp_kernel<T, true>, ATTN_LDS, &done[ti][1][0][dev]);
+        return lockstep ? go(&attn_fwd_kernel<T, false>, ATTN_LDS, &done[ti][0][1][dev])
+                        : go(&attn_fwd_pp_kernel<T, false>, ATTN_LDS, &done[ti][0][0][dev]);
+    };
+    if (dtype == UAMD_BF16) rc = run(bf16_t{});
+    else if (dtype == UAMD_F16) rc = run(f16_t{});
+    else return UAMD_ERR_DTYPE;
+    if (rc) return rc;
     return uamd_launch_status();
 }
