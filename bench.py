@@ -663,7 +663,7 @@ def main():
         ms_step = dt / a.steps * 1e3
         if dom:
             # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/pmc_traffic.json,
-            # tools/gpu_pmc_bench.sh): counters cannot be collected inside a timed run
+            # tools/gpu.sh pmc:primary): counters cannot be collected inside a timed run
             traffic, traffic_src = None, None
             try:
                 with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")) as f:

@@ -270,12 +270,12 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_STREAM_NT 2   /* (UAMD_STREAM_NT) streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
 #define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64, 2 = 64x256 with
                                  * the row tile as the fastest grid index (adjacent output segments written together) */
-#define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention: bit 0 = forward with 64 q rows per wave (attn_fwd64_kernel: 4 waves x 512 registers, hidden
-                                 * AGPR accumulators) for plain causal, G <= 4; default 0 (measured at parity with the 8-wave kernel);
-                                 * bit 1 = dK/dV backward with the round-1 kernel (8 waves x 32 keys) instead of attn_bwd_dkdv4_kernel
-                                 * (4 waves x 64 keys, one per SIMD, hidden AGPR accumulators); bit 2 = dQ backward with
-                                 * attn_bwd_dq4_kernel (4 waves x 64 query rows, Q^T / dO^T fragments parked in AGPRs) instead of the
-                                 * 8-wave kernel; measured at parity, default off */
+#define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention forward: 0 = by shape (plain causal batches with >= 2 work items per CU take
+                                 * attn_fwd_ps_kernel -- one persistent workgroup per CU, ping-pong wave groups -- everything else
+                                 * attn_fwd_kernel, one block per work item); bit 0 = attn_fwd_kernel always; bit 1 = attn_fwd_ps_kernel
+                                 * always. (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
+                                 * round-1 dK/dV kernel, a 4-wave dQ kernel -- all measured at parity or slower: removed in round 4,
+                                 * tools/experiments/attention_removed_r04.hip) */
 #define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
 #define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has

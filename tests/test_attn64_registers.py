@@ -1,6 +1,7 @@
-"""Build-time invariant of attn_fwd64_kernel (csrc/attention.hip): its O accumulators live in AGPRs a0..a127 that the
-compiler does not know about (every instruction touching them is inline asm naming the physical registers). The kernel is
-only correct if NO compiler-generated instruction uses those registers -- checked on the device assembly."""
+"""Build-time invariants of the attention kernels (csrc/attention.hip), checked on the device assembly: attn_bwd_dkdv4_kernel's
+accumulators live in AGPRs the compiler does not know about (every instruction touching them is inline asm naming the physical
+registers) -- no compiler-generated instruction may use them; and the kernels whose tile loops count their own `vmcnt` must not
+reload spilled registers there."""
 import os
 import re
 import shutil
@@ -62,26 +63,23 @@ def test_dkdv4_accumulators_are_asm_owned_and_step_bodies_do_not_spill(tmp_path)
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_compiler_never_touches_the_hidden_accumulators(tmp_path):
+def test_forward_and_dq_kernels_do_not_spill(tmp_path):
+    """The tile loops of the forward kernels and of the dQ kernel carry hand-counted `vmcnt` waits that keep LDS-DMA pieces in
+    flight across barriers; a scratch reload is a VMEM load whose compiler-inserted wait drains that ring (round 4 found the
+    persistent kernel's DMA offsets and its epilogue pointer spilled exactly there). The plain-causal instances must not touch
+    scratch at all; the band instances (50 more live registers) may spill a handful outside the hot loop."""
     lines = _device_asm(tmp_path)
-    kernels = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*attn_fwd64_kernel.*:", l)]
-    assert len(kernels) == 2                                    # bf16 and fp16
-    for start in kernels:
-        end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
-        in_asm, managed, scratch = False, set(), 0
-        for l in lines[start:end + 1]:
-            t = l.strip()
-            if t.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if t.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            if t.startswith("scratch_"):
-                scratch += 1
-            if in_asm or t.startswith(";"):
-                continue
-            for m in re.finditer(r"\ba(\d+)\b|\ba\[(\d+):(\d+)\]", t):
-                managed.update([int(m.group(1))] if m.group(1) is not None else range(int(m.group(2)), int(m.group(3)) + 1))
-        assert managed and min(managed) >= 128, f"compiler-managed AGPRs overlap the hidden accumulators: {sorted(managed)[:8]}"
-        assert scratch == 0, "attn_fwd64_kernel spills"
+    seen = 0
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN.*(attn_fwd_kernel|attn_fwd_ps_kernel|attn_bwd_dq_kernel)\w*):", l)
+        if not m:
+            continue
+        end = next(j for j in range(i, len(lines)) if lines[j].strip().startswith("s_endpgm"))
+        scratch = sum(1 for t in lines[i:end + 1] if t.strip().startswith("scratch_"))
+        band = "Lb1E" in m.group(1)
+        seen += 1
+        if m.group(2) == "attn_fwd_ps_kernel" or not band:
+            assert scratch == 0, (m.group(1), scratch)
+        else:
+            assert scratch <= 24, (m.group(1), scratch)
+    assert seen == 12                 # 3 kernels x {bf16, fp16} x {plain, band}

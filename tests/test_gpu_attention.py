@@ -29,9 +29,10 @@ def ref_attention(q, k, v, scale, allowed=None):
     return o, lse
 
 
-@pytest.fixture(params=[0, 1], ids=["rows32x8waves", "rows64x4waves"])
+@pytest.fixture(params=[1, 2], ids=["one_block_per_item", "persistent_pingpong"])
 def fwd_variant(request):
-    """UAMD_TUNE_ATTN_VAR bit 0: the forward with 64 q rows per wave (attn_fwd64_kernel; G <= 4, plain causal)."""
+    """UAMD_TUNE_ATTN_VAR bit 0: attn_fwd_kernel always (one block per work item); bit 1: attn_fwd_ps_kernel always (one
+    persistent workgroup per CU, ping-pong wave groups) -- the default picks by shape, here every shape runs on both."""
     from unsloth_amd import _lib
     L = _lib.lib()
     L.uamd_set_tuning(4, request.param)
@@ -71,10 +72,9 @@ def test_attn_forward_matches_fp32_oracle(fwd_variant, dtype, B, T, Hq, Hk):
     assert torch.equal(o, o2)
 
 
-@pytest.fixture(params=[0, 2, 4], ids=["dq_dkdv4", "dq_dkdv_8waves", "dq4_dkdv4"])
+@pytest.fixture(params=[1, 2], ids=["fwd_one_block_per_item", "fwd_persistent"])
 def bwd_variant(request):
-    """UAMD_TUNE_ATTN_VAR bit 1: the dK/dV backward of round 1 (8 waves x 32 keys) instead of attn_bwd_dkdv4_kernel; bit 2:
-    attn_bwd_dq4_kernel (4 waves x 64 query rows) instead of the 8-wave dQ kernel."""
+    """The backward (dQ kernel + attn_bwd_dkdv4_kernel) behind either forward kernel (the LSE it reads comes from there)."""
     from unsloth_amd import _lib
     L = _lib.lib()
     L.uamd_set_tuning(4, request.param)

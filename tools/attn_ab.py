@@ -1,6 +1,6 @@
 """Interleaved A/B of attention kernel variants (UAMD_TUNE_ATTN_VAR knob values) in ONE process, forward and backward, over the
 shapes of the bench's operating points; error of every arm against an fp64 oracle on a slice.
-    python tools/attn_ab.py [knob,knob,...]      default "0,8" (8 = the lockstep forward kernel of rounds 1-3)
+    python tools/attn_ab.py [knob,knob,...] [fwd|bwd|fwd,bwd]      default "1,2": attn_fwd_kernel vs attn_fwd_ps_kernel
 Prints one JSON line per (shape, arm): ms (median of 6 rounds x 10 launches), algorithmic TFLOP/s, fraction of the 2.5 PFLOP/s peak."""
 import json
 import math
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unsloth_amd import _lib  # noqa: E402
 from unsloth_amd.kernels import attention as A  # noqa: E402
 
-ARMS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,8").split(",")]
+ARMS = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,2").split(",")]
 WHAT = sys.argv[2] if len(sys.argv) > 2 else "fwd,bwd"
 dev, bf = "cuda", torch.bfloat16
 L = _lib.lib()
