@@ -521,7 +521,8 @@ def main():
             data = make_batches(bs)
             dt, peak, losses, gs = measure(GC_MODE[a.gc], a.steps, a.warmup, data)
             rec = point(bs * T, dt, a.steps, peak, gs, batch=bs, gradient_checkpointing=GC_MODE[a.gc],
-                        dp_buckets=len(arena.buckets) if arena is not None else None)
+                        dp_buckets=len(arena.buckets) if arena is not None else None,
+                        collectives_issued_per_step=(arena.collectives / (a.steps + a.warmup)) if arena is not None else None)
         elif a.only == "config4":
             rec = run_config4(a.steps, a.warmup, False)
         elif a.only == "fullft":
@@ -604,12 +605,13 @@ def main():
                     farena = opt.arena
                     farena._force = True
                     model.for_training(use_gradient_checkpointing=GC_MODE[a.gc])
+                    c0 = farena.collectives
                     ddt, dpeak, _, dgs = timed_steps(lambda i: training_step(model, batches[i % 2], opt, farena, n_items),
                                                      a.alt_steps, 3, True)
                     farena._force = False
                     return point(B * T, ddt, a.alt_steps, dpeak, dgs, batch=B, timing="median step x steps",
                                  buckets=len(farena.buckets), bucket_mb=[round((e - s) * 4 / 2**20, 1) for s, e, _ in farena.buckets],
-                                 collectives_per_step=len(farena.buckets), rccl_group_size=1)
+                                 collectives_issued_per_step=(farena.collectives - c0) / (a.alt_steps + 3), rccl_group_size=1)
                 finally:
                     os.environ["UNSLOTH_AMD_DP_FORCE"] = "0"
             guarded(alt, "dp_path_forced_on_one_rank (UNSLOTH_AMD_DP_FORCE=1: hooks + bucketed RCCL all-reduce inside backward)", dp_force)

@@ -62,10 +62,23 @@ def main():
     mine = batch_of(rank, dev)
     n = global_num_items(mine["labels"])
     assert int(n) == n_global, (int(n), n_global)
+    # every bucket is all-reduced exactly ONCE per step and only when all its gradients are in (round 4: the sink report plus
+    # torch's post-accumulate hook counted every parameter twice -- two exchanges per bucket, the first one half complete)
+    real_launch = arena._launch
+
+    def checked_launch(b):
+        members = [p for p in arena.params if arena._bucket_of[id(p)] == b]
+        assert all(id(p) in arena._arrived for p in members) or not arena.overlap, f"bucket {b} exchanged while incomplete"
+        return real_launch(b)
+    arena._launch = checked_launch
     for step in range(2):                     # second step: the arena was zeroed, views kept
+        c0 = arena.collectives
         out = model(**mine, num_items_in_batch=n)
         out.loss.backward()
+        hooked = arena.collectives - c0       # launched from the gradient hooks, inside the backward
         arena.finish()
+        assert arena.collectives - c0 == len(arena.buckets), (arena.collectives - c0, len(arena.buckets))
+        assert hooked == len(arena.buckets), "every bucket's exchange starts inside the backward, from its last gradient"
         worst = 0.0
         for name, p in model.named_parameters():
             if p.requires_grad:

@@ -34,10 +34,22 @@ def main():
     assert opt.buckets._exchange, "the collectives must really be issued"
     g = torch.Generator().manual_seed(100 + rank)
     losses = []
+    # every bucket is exchanged exactly ONCE per step, and only when every gradient that belongs to it has been produced
+    # (round 4: counted twice -- sink report + torch's hook -- a bucket was reduce-scattered when half complete, then again)
+    FB = opt.buckets
+    real_launch = FB._launch
+
+    def checked_launch(bi):
+        missing = [n for n, p in zip(FB.buckets[bi]["names"], FB.buckets[bi]["params"]) if id(p) not in FB._written]
+        assert not missing, f"bucket {bi} exchanged before the gradients of {missing[:3]} were produced"
+        return real_launch(bi)
+    FB._launch = checked_launch
     for step in range(3):
         ids = torch.randint(0, 2048, (2, 256), generator=g).to(dev)
         pos = torch.arange(256, dtype=torch.int32, device=dev).unsqueeze(0).expand(2, 256).contiguous()
+        c0 = FB.collectives
         losses.append(float(full_finetune_step(model, dict(input_ids=ids, labels=ids.clone(), position_ids=pos), opt)))
+        assert FB.collectives - c0 == len(FB.buckets), (FB.collectives - c0, len(FB.buckets))
     after = torch.cat([p.detach().float().flatten() for p in model.parameters()])
     assert torch.isfinite(after).all() and float((after - before).abs().max()) > 0
     # replicas identical

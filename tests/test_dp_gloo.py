@@ -114,3 +114,82 @@ def test_lora_grad_arena_allreduce_world2(overlap):
     assert [r[1] for r in res] == [True, True], res
     assert [r[2] for r in res] == [4, 4], res        # rank0 shifted targets {2,4}; rank1 {3,5} -> global 4
     assert all(r[3] for r in res)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+class _SinkLinear(torch.autograd.Function):
+    """y = x W^T whose weight gradient goes the way the HIP kernels' gradients go (kernels/utils.py GRAD_SINKS): ADDED straight
+    into the arena's view of the parameter, reported through arena.ready(), and autograd is handed None for it."""
+
+    @staticmethod
+    def forward(ctx, x, w, arena):
+        ctx.save_for_backward(x, w)
+        ctx.arena = arena
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        ctx.arena.grad_view(w).add_(g.t() @ x)
+        ctx.arena.ready(w)
+        return g @ w, None, None
+
+
+class TinySink(Tiny):
+    def forward(self, x, arena):
+        for blk in self.model.layers:
+            x = blk.frozen(x) + _SinkLinear.apply(_SinkLinear.apply(x, blk.lora_A.weight, arena), blk.lora_B.weight, arena)
+        return x
+
+
+def _worker_sinks(rank, world, port, q):
+    """A parameter whose gradient was sunk is reported twice: by ready(), and by torch's post-accumulate hook, which runs even
+    though the Function returned None for it (torch 2.10). Counted twice, a bucket is 'complete' when half its gradients are in
+    and is all-reduced twice -- the partial sums of the first exchange are summed over the ranks AGAIN by the second. One bucket
+    over two layers makes that visible: at the first (wrong) completion the second layer has not produced anything yet."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unsloth_amd.dp import LoRAGradArena
+    torch.manual_seed(0)
+    m = TinySink()
+    arena = LoRAGradArena(m, bucket_bytes=1 << 20)
+    assert len(arena.buckets) == 1
+    fired = []
+    first = arena.params[0]
+    first.register_post_accumulate_grad_hook(lambda p: fired.append(1))
+    ok = True
+    for step in range(2):
+        x = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + rank + 10 * step))
+        c0 = arena.collectives
+        m(x, arena).square().sum().backward()
+        arena.finish()
+        ok = ok and arena.collectives - c0 == 1                          # ONE exchange per bucket and step
+        want = [torch.zeros_like(p) for p in arena.params]
+        for r in range(world):
+            m2 = Tiny()
+            m2.load_state_dict(m.state_dict())
+            xr = torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + r + 10 * step))
+            m2(xr).square().sum().backward()
+            named = dict(m2.named_parameters())
+            for w, name in zip(want, arena.names):
+                w += named[name].grad
+        ok = ok and all(torch.allclose(p.grad, w, rtol=1e-5, atol=1e-6) for p, w in zip(arena.params, want))
+        arena.zero_grad()
+    q.put((rank, bool(ok), len(fired)))
+    dist.destroy_process_group()
+
+
+def test_sunk_gradients_are_counted_once_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sinks, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    # (documenting the torch behaviour the fix guards against: the hook of a parameter whose Function returned None does run)
+    assert all(r[2] >= 0 for r in res)

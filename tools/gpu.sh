@@ -59,7 +59,7 @@ for step in "$@"; do
     prof|trace)
       P=${arg%%:*}; K=3; [ "$P" != "$arg" ] && K=${arg#*:}
       cd /tmp
-      EXTRA=""; [ $kind = trace ] && EXTRA="--rccl-trace"
+      EXTRA=""; [ $kind = trace ] && EXTRA="--rccl-trace --hip-runtime-trace"
       timeout 900 rocprofv3 --kernel-trace $EXTRA -d $OUT/prof_${TAG}_$P -o bench -- python $R/bench.py --only $P --steps $K --warmup 1 \
           --no-cpu-baseline --alt-steps 0 > $OUT/prof_${TAG}_$P.log 2>&1
       echo "[$step] rc=$? ($SECONDS s)"

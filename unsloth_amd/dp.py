@@ -70,7 +70,9 @@ class LoRAGradArena:
             last_layer = layer
         self.buckets.append([b_start, off, b_count])
         self._pending = [0] * len(self.buckets)
+        self._arrived = set()                              # ids of the parameters whose gradient arrived in this backward
         self._launched = [False] * len(self.buckets)      # per step: which buckets already have a collective in flight
+        self.collectives = 0                               # all-reduces issued so far (telemetry: bench.py, tests)
         self.writes = 0                                    # gradients accumulated so far (optim.FlatAdamW: "is the arena dirty?")
         self._handles = []
         self._sync = True
@@ -129,12 +131,21 @@ class LoRAGradArena:
             # zero_grad(set_to_none=True)): move it into the arena, which is what gets reduced and stepped on
             v.copy_(p.grad)
             p.grad = v
+        # One arrival per parameter and backward, whoever reports it. With the direct sinks (kernels/utils.py GRAD_SINKS) the
+        # fused gradient kernel reports through ready() and hands autograd None -- and torch (2.10) STILL runs the parameter's
+        # post-accumulate hook: counted twice, every bucket "completed" when half its gradients were in and was all-reduced
+        # twice per step, the first time over partial sums that the second reduction then summed over the ranks AGAIN
+        # (found in round 4 on the rocprofv3 trace: 16 collectives for 8 buckets; invisible at one rank, and the CPU tests
+        # have no sinks). tests/_dp_worker.py now checks, at one rank too, that a bucket is launched once and complete.
+        if id(p) in self._arrived:
+            return
+        self._arrived.add(id(p))
         b = self._bucket_of[id(p)]
         self.writes += 1
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
             self._pending[b] = 0
-            if self._sync and self.overlap and (self.world_size > 1 or self._force):
+            if self._sync and self.overlap and (self.world_size > 1 or self._force) and not self._launched[b]:
                 self._launch(b)
 
     def _launch(self, b):
@@ -142,6 +153,7 @@ class LoRAGradArena:
         h = dist.all_reduce(self.arena[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._handles.append(h)
         self._launched[b] = True
+        self.collectives += 1
 
     def finish(self):
         """Call after backward, before optimizer.step(): launches every bucket that has no collective in flight
@@ -157,6 +169,7 @@ class LoRAGradArena:
         self._handles = []
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._arrived.clear()
 
     @contextmanager
     def no_sync(self):
@@ -169,9 +182,12 @@ class LoRAGradArena:
         finally:
             self._sync = old
             self._pending = [0] * len(self.buckets)
+            self._arrived.clear()
 
     def zero_grad(self):
         """Keeps the views: the arena is zeroed in one memset instead of N small ones."""
+        self._arrived.clear()
+        self._pending = [0] * len(self.buckets)
         self.arena.zero_()
         for p in self.params:
             v = self._views[id(p)]

@@ -105,7 +105,9 @@ class FullGradBuckets:
         self._views = {id(p): self.buckets[bi]["flat_g"][o:o + p.numel()].view(p.shape)
                        for p in self.params for (bi, o) in [self._where[id(p)]]}
         self._written = set()                  # ids whose gradient view holds THIS step's gradient
+        self._arrived = set()                  # ids counted towards their bucket in THIS backward
         self._sync = True
+        self.collectives = 0                   # reduce-scatters issued so far (telemetry: tests, bench)
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         # direct sinks (kernels/utils.GRAD_SINKS): the weight-gradient GEMM / the norm dW kernel / the chunked lm_head
         # gradient write into the bucket themselves. Tied embeddings keep the autograd path (two producers).
@@ -151,12 +153,18 @@ class FullGradBuckets:
         self._count(p)
 
     def _count(self, p):
+        # one arrival per parameter and backward: a sink reports through ready() AND torch still runs the post-accumulate hook of
+        # a parameter whose Function returned None (see dp.LoRAGradArena._hook: every bucket was exchanged twice, the first time
+        # half complete)
+        if id(p) in self._arrived:
+            return
+        self._arrived.add(id(p))
         bi, _ = self._where[id(p)]
         b = self.buckets[bi]
         b["pending"] += 1
         if b["pending"] == b["expected"]:
             b["pending"] = 0
-            if self._sync and self.overlap and self._exchange:
+            if self._sync and self.overlap and self._exchange and not b["launched"]:
                 self._launch(bi)
 
     # ---- exchange ------------------------------------------------------------------------------------------------------
@@ -176,6 +184,7 @@ class FullGradBuckets:
             b["handle"] = dist.reduce_scatter_tensor(self.grad_shard(bi), b["flat_g"], op=dist.ReduceOp.SUM,
                                                      group=self.group, async_op=True)
         b["launched"] = True
+        self.collectives += 1
 
     def finish(self):
         """After backward, before the optimizer: parameters that received no gradient this step count as zero; buckets
@@ -198,6 +207,7 @@ class FullGradBuckets:
         no_sync() block (one micro-batch per block, the accelerate / HF Trainer pattern), zero_grad()."""
         for b in self.buckets:
             b["pending"] = 0
+        self._arrived.clear()
 
     def wait(self, bi):
         b = self.buckets[bi]
