@@ -63,7 +63,9 @@ def _worker(rank, world, port, tied, q):
     ref = Tiny(tied).to(torch.float32)                      # fp32 masters of a single-process run
     ref.load_state_dict({k: v.float() for k, v in m.state_dict().items()})
     opt = ShardedAdamW(m, lr=3e-2, weight_decay=0.1)
-    ropt = torch.optim.AdamW(ref.parameters(), lr=3e-2, weight_decay=0.1)
+    # HF Trainer's rule for the reference's full_finetuning path: no decay on 1-D parameters (norm weights, biases)
+    ropt = torch.optim.AdamW([dict(params=[p for p in ref.parameters() if p.dim() > 1], weight_decay=0.1),
+                              dict(params=[p for p in ref.parameters() if p.dim() <= 1], weight_decay=0.0)], lr=3e-2)
     B = opt.buckets
     n_buckets = len(B.buckets)
     views_ok = all(p.data_ptr() == B.buckets[B._where[id(p)][0]]["flat_p"].data_ptr() + 2 * B._where[id(p)][1] for p in B.params)

@@ -180,7 +180,8 @@ def test_config3_llama3_8b_widths_full_finetune_seq2048_step():
     for n, p in model.named_parameters():
         m32 = torch.nn.Parameter(masters[n])
         m32.grad = grads[n]
-        torch.optim.AdamW([m32], lr=1e-3, weight_decay=0.01).step()
+        # HF Trainer's rule (get_decay_parameter_names): no decay on biases and norm weights, i.e. on 1-D parameters
+        torch.optim.AdamW([m32], lr=1e-3, weight_decay=0.01 if m32.dim() > 1 else 0.0).step()
         assert torch.equal(p.detach(), m32.detach().to(torch.bfloat16)) or \
             (p.detach().float() - m32.detach().to(torch.bfloat16).float()).abs().max() <= 2 ** -8 * m32.abs().max(), n
         worst_p = max(worst_p, (p.detach().float() - m32.detach()).abs().max().item())

@@ -266,8 +266,11 @@ class FullGradBuckets:
 
 class ShardedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW's arithmetic on fp32 master weights, sharded over the data-parallel group (see module docstring).
-    One parameter group; LR schedulers / state_dict work through the usual Optimizer interface (the state of the flat
-    shards is exposed under the first parameter)."""
+    One parameter group; LR schedulers work through the usual Optimizer interface (they scale the group's `lr`); the state of
+    the flat shards (step count, fp32 masters, both moments) is saved and loaded under the extra `uamd_sharded` key of
+    state_dict(), per rank. Weight decay follows HF Trainer's rule for the reference's full_finetuning path
+    (`get_decay_parameter_names`: no decay on biases and on LayerNorm / RMSNorm weights): one-dimensional parameters are
+    updated with decay 0 -- they sit at the end of every per-layer bucket, so a bucket is two launches instead of one."""
 
     def __init__(self, model_or_buckets, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, process_group=None):
         self.buckets = model_or_buckets if isinstance(model_or_buckets, FullGradBuckets) else \
@@ -279,6 +282,24 @@ class ShardedAdamW(torch.optim.Optimizer):
             self.master.append(B.param_shard(bi).to(torch.float32))            # (a copy: the shard changes dtype)
             self.exp_avg.append(torch.zeros(b["shard"], dtype=torch.float32, device=B.device))
             self.exp_avg_sq.append(torch.zeros(b["shard"], dtype=torch.float32, device=B.device))
+        # [start, end, decays) runs of this rank's shard of every bucket, in shard-local elements
+        self._runs = []
+        for bi, b in enumerate(B.buckets):
+            lo, hi = B.rank * b["shard"], (B.rank + 1) * b["shard"]
+            marks = []                                   # (offset in the bucket, decays) per parameter, in layout order
+            for p, o in zip(b["params"], b["offsets"]):
+                marks.append((o, p.dim() > 1))
+            runs = []
+            for i, (o, dec) in enumerate(marks):
+                end = marks[i + 1][0] if i + 1 < len(marks) else b["numel"]
+                a, e = max(o, lo), min(end, hi)
+                if a >= e:
+                    continue
+                if runs and runs[-1][2] == dec and runs[-1][1] == a - lo:
+                    runs[-1][1] = e - lo
+                else:
+                    runs.append([a - lo, e - lo, dec])
+            self._runs.append(runs)
         self._t = 0
 
     @property
@@ -313,21 +334,24 @@ class ShardedAdamW(torch.optim.Optimizer):
             B.wait(bi)
             g16, p16 = B.grad_shard(bi), B.param_shard(bi)
             p32, m, v = self.master[bi], self.exp_avg[bi], self.exp_avg_sq[bi]
-            if p32.is_cuda:
-                from . import _lib
-                with _lib.device_ctx(p32):
-                    rc = _lib.lib().uamd_adamw_shard(
-                        p32.data_ptr(), g16.data_ptr(), p16.data_ptr(), m.data_ptr(), v.data_ptr(), p32.numel(),
-                        float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), float(grp["weight_decay"]), bc1,
-                        bc2_sqrt, float(grad_scale), _lib.dtype_code(g16.dtype), _lib.stream_of(p32))
-                _lib.check(rc, "uamd_adamw_shard")
-            else:                                        # host arithmetic of the gloo tests: the same formula in torch
-                g = g16.to(torch.float32) * grad_scale
-                p32.mul_(1.0 - grp["lr"] * grp["weight_decay"])
-                m.mul_(b1).add_(g, alpha=1.0 - b1)
-                v.mul_(b2).addcmul_(g, g, value=1.0 - b2)
-                p32.addcdiv_(m, v.sqrt() / bc2_sqrt + grp["eps"], value=-grp["lr"] / bc1)
-                p16.copy_(p32)
+            for a, e, decays in self._runs[bi]:
+                wd = float(grp["weight_decay"]) if decays else 0.0
+                if p32.is_cuda:
+                    from . import _lib
+                    es = g16.element_size()
+                    with _lib.device_ctx(p32):
+                        rc = _lib.lib().uamd_adamw_shard(
+                            p32.data_ptr() + 4 * a, g16.data_ptr() + es * a, p16.data_ptr() + es * a, m.data_ptr() + 4 * a,
+                            v.data_ptr() + 4 * a, e - a, float(grp["lr"]), float(b1), float(b2), float(grp["eps"]), wd, bc1,
+                            bc2_sqrt, float(grad_scale), _lib.dtype_code(g16.dtype), _lib.stream_of(p32))
+                    _lib.check(rc, "uamd_adamw_shard")
+                else:                                    # host arithmetic of the gloo tests: the same formula in torch
+                    g = g16[a:e].to(torch.float32) * grad_scale
+                    p32[a:e].mul_(1.0 - grp["lr"] * wd)
+                    m[a:e].mul_(b1).add_(g, alpha=1.0 - b1)
+                    v[a:e].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+                    p32[a:e].addcdiv_(m[a:e], v[a:e].sqrt() / bc2_sqrt + grp["eps"], value=-grp["lr"] / bc1)
+                    p16[a:e].copy_(p32[a:e])
             h = B.gather_params(bi)
             if h is not None:
                 handles.append(h)

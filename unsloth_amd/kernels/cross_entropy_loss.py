@@ -188,7 +188,7 @@ class _FusedLinearCE(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, hidden2d, weight, weight_t, labels, n_items, softcap, scale, chunk_rows, weight_param=None):
+    def forward(ctx, hidden2d, weight, weight_t, labels, n_items, softcap, scale, chunk_rows, weight_param=None, grad_on=True):
         """`weight_param`: the lm_head Parameter when it TRAINS (full fine-tuning; `weight` is its detached value): its
         gradient dW = sum over chunks dlogits^T @ h is accumulated chunk by chunk (uamd_gemm_tn_256) -- like d(hidden),
         inside the forward, while the chunk of dlogits exists."""
@@ -196,8 +196,11 @@ class _FusedLinearCE(torch.autograd.Function):
         V = weight.shape[0]
         dev = hidden2d.device
         loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
-        train_w = weight_param is not None and weight_param.requires_grad
-        need_grad = hidden2d.requires_grad or train_w
+        # `grad_on`: torch.is_grad_enabled() of the CALLER (inside Function.forward grad mode is always off): an evaluation
+        # pass under no_grad() must not pay the CE backward, the d(hidden) GEMM and the chunked dW GEMMs (3x the compute and a
+        # [T, H] + [Vp, H] pair of buffers for a full fine-tuning model)
+        train_w = grad_on and weight_param is not None and weight_param.requires_grad
+        need_grad = grad_on and (hidden2d.requires_grad or train_w)
         dh = torch.empty_like(hidden2d) if need_grad else None
         dW = None
         inv_n = (1.0 / n_items) if not torch.is_tensor(n_items) else (1.0 / n_items.to(torch.float32))
@@ -234,10 +237,12 @@ class _FusedLinearCE(torch.autograd.Function):
             sink = _u.grad_sink(P)
             if sink is not None:
                 view = sink.grad_view(P)
+                # the upstream scale in fp32, ONE rounding (like d(hidden) below and like the non-sink branch): the scalar rounded
+                # to bf16 first would bias the lm_head gradient by up to 2^-9 against every other parameter's
                 if sink.first_write(P):
-                    torch.mul(dW[:V], scale.to(dW.dtype), out=view)
+                    view.copy_(dW[:V].to(torch.float32) * scale)
                 else:
-                    view.add_(dW[:V] * scale.to(dW.dtype))
+                    view.add_((dW[:V].to(torch.float32) * scale).to(view.dtype))
                 sink.ready(P)
             else:
                 d_weight = (dW[:V].to(torch.float32) * scale).to(P.dtype)
@@ -248,7 +253,7 @@ class _FusedLinearCE(torch.autograd.Function):
             dh = (dh.to(torch.float32) * scale).to(dh.dtype)
         else:
             dh = None
-        return (dh, None, None, None, None, None, None, None, d_weight)[:len(ctx.needs_input_grad)]
+        return (dh, None, None, None, None, None, None, None, d_weight, None)[:len(ctx.needs_input_grad)]
 
 
 def _transposed_weight(weight, owner=None):
@@ -304,10 +309,10 @@ def unsloth_fused_ce_loss(trainer, hidden_states, lm_head_weight, lm_head_bias, 
         if W.dtype != lm_head_weight.dtype:
             raise NotImplementedError("fused linear-CE with a trainable lm_head: weight and activations in one dtype")
         loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
-                                    int(chunk_rows), lm_head_weight)
+                                    int(chunk_rows), lm_head_weight if torch.is_grad_enabled() else None, torch.is_grad_enabled())
     else:
         loss = _FusedLinearCE.apply(h2d, W, Wt, shift, n_items, logit_softcapping or 0, logit_scaling or 0,
-                                    int(chunk_rows))
+                                    int(chunk_rows), None, torch.is_grad_enabled())
     if scaling is not None:
         loss = loss * scaling
     return loss

@@ -349,14 +349,31 @@ def unsloth_fast_generate(model, input_ids=None, max_new_tokens=None, max_seq_le
     pad = kwargs.get("pad_token_id", None)
     if pad is None and gen_cfg is not None:
         pad = getattr(gen_cfg, "pad_token_id", None)
+    # Sampling defaults come from the model's generation_config like in HF's generate (a checkpoint that ships
+    # do_sample=True / temperature / top_k / top_p samples without the caller saying so); explicit keywords win. A
+    # generation_config top_p below 1 (the engine has no nucleus filter) goes to HF's own generate.
+    def gen_default(name, fallback):
+        if name in kwargs and kwargs[name] is not None:
+            return kwargs[name]
+        v = getattr(gen_cfg, name, None) if gen_cfg is not None else None
+        return fallback if v is None else v
+    do_sample = bool(gen_default("do_sample", False))
+    temperature = float(gen_default("temperature", 1.0))
+    top_k = int(gen_default("top_k", 0) or 0) if do_sample else 0
+    top_p = float(gen_default("top_p", 1.0))
+    if do_sample and top_p < 1.0:
+        old = getattr(model, "_old_generate", None)
+        if old is None:
+            raise NotImplementedError("unsloth_fast_generate: nucleus sampling (top_p < 1) needs HF's generate")
+        return old(input_ids, max_new_tokens=max_new_tokens, **kwargs)
     need = input_ids.shape[1] + max_new_tokens
     eng = getattr(model, "_uamd_decode_engine", None)
     if eng is None or eng.B != input_ids.shape[0] or eng.S < need:
         eng = DecodeEngine(model, max_seq_len=max(need, max_seq_len or 0), batch=input_ids.shape[0])
         model._uamd_decode_engine = eng
     return eng.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=eos,
-                        do_sample=kwargs.get("do_sample", False), temperature=kwargs.get("temperature", 1.0),
-                        top_k=kwargs.get("top_k", 0) or 0, generator=kwargs.get("generator", None), pad_token_id=pad)
+                        do_sample=do_sample, temperature=temperature, top_k=top_k,
+                        generator=kwargs.get("generator", None), pad_token_id=pad)
 
 
 # ---- the reference's function names, for code written against unsloth/models/llama.py ----------------------------------------

@@ -87,8 +87,11 @@ def mrope_position_ids(input_ids, image_grid_thw=None, video_grid_thw=None, atte
 
 # ------------------------------------------------------------------------------------------------------------------
 class Qwen2VLFastModel(nn.Module):
-    """vision tower + language tower (fused path). Parameter names follow HF's Qwen2VLForConditionalGeneration
-    (`model.visual.*`, `model.language_model.*`, `lm_head.*`) through state_dict hooks, so checkpoints interchange."""
+    """vision tower + language tower (fused path). LOADING takes HF's Qwen2VLForConditionalGeneration names (`model.visual.*`
+    through checkpoint.load_prefixed_, the language tower through the text loader). state_dict() of THIS module emits its own
+    tree -- `visual.*`, `language.model.*` / `language.lm_head.*` (`language.base_model.model.*` once LoRA is attached) -- and
+    is not an HF checkpoint: save adapters with the language tower's PEFT model and the ViT's LoRA factors by name; a merged HF
+    export of the VLM is the reference's save pipeline, out of scope (GGUF / save paths)."""
 
     def __init__(self, config, visual, language):
         super().__init__()

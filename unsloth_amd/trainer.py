@@ -118,12 +118,14 @@ def _patch_trl_trainer():
     return done
 
 
-def make_optimizer(model, lr=2e-4, weight_decay=0.01, betas=(0.9, 0.999), arena=None, flat=None):
+def make_optimizer(model, lr=None, weight_decay=0.01, betas=(0.9, 0.999), arena=None, flat=None):
     """AdamW on the trainable (LoRA) parameters. On the GPU with fp32 parameters: optim.FlatAdamW -- parameters,
     gradients and moments in flat arenas, ONE launch per step (`arena`: the dp.LoRAGradArena of a data-parallel run, else
     the optimizer creates its own). `flat=False` (or UNSLOTH_AMD_FLAT_ADAMW=0) keeps torch's fused AdamW."""
     params = [p for p in model.parameters() if p.requires_grad]
     base = model.get_base_model() if hasattr(model, "get_base_model") else model
+    if lr is None:             # LoRA factors: 2e-4 (the reference notebooks' rate); every weight of the model: 2e-5
+        lr = 2e-5 if getattr(base, "_unsloth_full_finetuning", False) else 2e-4
     if getattr(base, "_unsloth_full_finetuning", False) and params and all(p.is_cuda for p in params):
         # full fine-tuning: flat per-layer buckets + AdamW sharded over the data-parallel group (full_finetune.py)
         from .full_finetune import FullGradBuckets, ShardedAdamW
