@@ -33,9 +33,10 @@ def _layer_index(name):
 class LoRAGradArena:
     def __init__(self, model, process_group=None, bucket_bytes=None, overlap=True, direct=True):
         if bucket_bytes is None:
-            # 16 MB = 3 decoder layers of Llama-3-8B r=16 factors (5.24 MB per layer): 11 buckets, so that the LAST one --
-            # layers 2..0, the only exchange nothing can overlap -- is 16 MB, not the 64+ MB of a 3-bucket split; still
-            # far above the size where an xGMI ring is latency-bound (per-layer buckets)
+            # a bucket closes at the first decoder-layer boundary past this size: Llama-3-8B r=16 factors are 5.24 MB per
+            # layer, so 16 MB means FOUR layers = 20 MB per bucket, 8 buckets; the LAST one (layers 3..0) is the only exchange
+            # nothing can overlap (runnable 0.4 ms before the optimizer kernel) -- still far above the size where an
+            # xGMI ring is latency-bound
             bucket_bytes = int(float(os.environ.get("UNSLOTH_AMD_DP_BUCKET_MB", "16")) * (1 << 20))
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
