@@ -68,6 +68,8 @@ for step in "$@"; do
       if [ -n "$DB" ]; then
         python tools/rocpd_stats.py $DB > $OUT/${TAG}_${P}_kernel_stats.csv 2> $OUT/${TAG}_${P}_stats.err
         head -14 $OUT/${TAG}_${P}_kernel_stats.csv | cut -c1-150
+        python tools/rocpd_sequence.py $DB > $OUT/${TAG}_${P}_step_sequence.csv 2> $OUT/${TAG}_${P}_seq.err
+        grep "^# kernels" $OUT/${TAG}_${P}_step_sequence.csv
         if [ $kind = trace ]; then
           python tools/rocpd_overlap.py $DB > $OUT/${TAG}_${P}_overlap.md 2> $OUT/${TAG}_${P}_overlap.err
           head -40 $OUT/${TAG}_${P}_overlap.md | cut -c1-170
