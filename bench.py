@@ -467,7 +467,7 @@ def main():
         try:
             dt, peak, losses, gs = timed_steps(lambda i: training_step(m, bt[i % 2], o, None, ni), steps, warmup, per_step)
             return point(S, dt, steps, peak, gs, rows=1, seq_len=S, image="896x896 -> 4096 patches -> 1024 tokens", lora_rank=32,
-                         vit="depth %d, torch SDPA attention + HIP LayerNorm + LoRA_W linears" % vcfg.vision_config.depth,
+                         vit="depth %d: HIP 2-D RoPE + non-causal flash attention + QuickGELU + LayerNorm, LoRA_W linears (models/vision_tower.py)" % vcfg.vision_config.depth,
                          trainable_params=sum(p.numel() for p in m.parameters() if p.requires_grad),
                          loss_first_last=[round(losses[0], 4), round(losses[-1], 4)])
         finally:

@@ -137,6 +137,10 @@ int uamd_geglu_exact_forward(const void* e, const void* g, void* h, int64_t n, i
 int uamd_geglu_exact_backward(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
 int uamd_geglu_approx_forward(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream);
 int uamd_geglu_approx_backward(void* DW, void* e, void* g, int64_t n, int dtype, void* stream);
+/* QuickGELU y = x * sigmoid(1.702 x) (Qwen2-VL vision MLP; BASELINE config 4): forward y from x; backward dx written IN PLACE
+ * over dy (dy_dx), x unchanged. fp32 arithmetic, one rounding. */
+int uamd_quick_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream);
+int uamd_quick_gelu_backward(const void* x, void* dy_dx, int64_t n, int dtype, void* stream);
 /* The gated activation fused with the skinny LoRA products that would re-read its output (fast_lora.py:93-96: h = f(e) * g,
  * then h @ A_down^T; :157, :172-189: h, df, de, then df @ B_up and de @ B_gate). act: 0 SwiGLU, 1 GeGLU exact, 2 GeGLU tanh;
  * element-wise results bit-identical to the plain entry points above. e / g / h (DW) are [M, K] with row stride ld;
@@ -336,6 +340,14 @@ int uamd_attn_bwd(const void* Q, const void* K, const void* V, const void* O, co
                   void* dQ, void* dK, void* dV, float* Delta, const int64_t* strides, int B, int T, int Hq, int Hk,
                   int D, int lse_stride, float scale, int causal, const int* lo, const int* hi, int dtype,
                   void* stream);
+/* NON-CAUSAL attention inside documents (round 4; the vision tower of BASELINE config 4: Qwen2-VL's ViT attends all patches of
+ * an image / frame, `cu_seqlens` windows): uamd_attn_fwd_band with causal = 0 and uamd_attn_bwd with causal = 0 take the band as
+ * DOCUMENT edges -- query q and key k attend each other iff lo[q] <= k <= hi[q], lo / hi = first / last position of q's document
+ * (intervals: equivalently lo[k] <= q <= hi[k]); both arrays are required. With causal != 0 uamd_attn_fwd_band is uamd_attn_fwd
+ * (hi ignored). Same kernels: the upper edge of a query is a per-lane value instead of the query's own position. */
+int uamd_attn_fwd_band(const void* Q, const void* K, const void* V, void* O, float* LSE, const int64_t* strides,
+                       int B, int T, int Hq, int Hk, int D, int lse_stride, float scale, int causal, const int* lo,
+                       const int* hi, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Single-token decode: csrc/decode.hip.

@@ -251,3 +251,53 @@ def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
         e = (got.float().cpu() - want).abs().max().item()
         ref = want.abs().max().item()
         assert e <= 3e-2 * max(ref, 1.0), (name, e, ref)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Non-causal attention inside documents (round 4): the vision tower of BASELINE config 4 (Qwen2-VL's ViT: every patch of an
+# image attends every patch of the same image, `cu_seqlens` windows; reference: run_attention, attention_dispatch.py:298-617).
+def _doc_mask(T, lengths):
+    doc = torch.repeat_interleave(torch.arange(len(lengths)), torch.tensor(lengths))
+    doc = torch.cat([doc, torch.full((T - doc.numel(),), len(lengths))]) if doc.numel() < T else doc[:T]
+    return doc[:, None] == doc[None, :]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,T,Hq,Hk,D,lengths", [
+    (1, 256, 4, 4, 128, None), (2, 200, 8, 2, 128, None), (1, 1024, 16, 16, 80, None),          # one document per row; the ViT's head_dim 80
+    (1, 640, 4, 4, 128, [100, 37, 300, 203]), (1, 777, 2, 1, 128, [64, 64, 500]),               # windows, ragged tail document
+    (1, 4096, 16, 16, 80, [1024, 3072])])
+def test_noncausal_document_attention_forward_and_backward(dtype, B, T, Hq, Hk, D, lengths):
+    from unsloth_amd.kernels.attention import attn_backward, attn_forward, document_band
+    qkv = (torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(11)) * 1.0).to(dtype)
+    do = torch.randn(B, T, Hq, D, generator=g(12)).to(dtype)
+    scale = 1.0 / math.sqrt(D)
+    qr = qkv[..., :Hq * D].view(B, T, Hq, D).float().requires_grad_(True)
+    kr = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D).float().requires_grad_(True)
+    vr = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D).float().requires_grad_(True)
+    allowed = torch.ones(T, T, dtype=torch.bool) if lengths is None else _doc_mask(T, lengths)
+    o_ref, lse_ref = ref_attention(qr, kr, vr, scale, allowed)
+    o_ref.backward(do.float())
+    qd = qkv.to(DEV)
+    q = qd[..., :Hq * D].view(B, T, Hq, D)
+    k = qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qd[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    band = None if lengths is None else document_band(T, batch=B, seq_lengths=lengths, device=DEV)
+    o, lse = attn_forward(q, k, v, scale, band, causal=False)
+    torch.testing.assert_close(lse.cpu(), lse_ref, rtol=1e-4, atol=2e-3)
+    d = o.float().cpu() - o_ref.detach()
+    assert (d.norm() / o_ref.norm()).item() <= (4e-3 if dtype == torch.bfloat16 else 5e-4)
+    assert d.abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3)
+    dq, dk, dv = attn_backward(do.to(DEV), q, k, v, o, lse, scale, band, causal=False)
+    for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        err = (got.float().cpu() - want).norm() / want.norm()
+        assert err <= (6e-3 if dtype == torch.bfloat16 else 8e-4), (name, float(err))
+        assert (got.float().cpu() - want).abs().max().item() <= (3e-2 if dtype == torch.bfloat16 else 6e-3) * max(want.abs().max().item(), 1.0), name
+
+
+def test_document_band_is_the_cu_seqlens_window():
+    from unsloth_amd.kernels.attention import document_band
+    lo, hi = document_band(10, batch=1, seq_lengths=[3, 5])
+    assert lo.tolist() == [[0, 0, 0, 3, 3, 3, 3, 3, 8, 8]] and hi.tolist() == [[2, 2, 2, 7, 7, 7, 7, 7, 9, 9]]
+    lo, hi = document_band(4, batch=2)
+    assert lo.tolist() == [[0] * 4] * 2 and hi.tolist() == [[3] * 4] * 2

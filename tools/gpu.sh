@@ -45,8 +45,8 @@ for step in "$@"; do
       echo "[$step] rc=$? ($SECONDS s)"; tail -6 $OUT/pytest_$TAG.log ;;
     testfile)
       n=$(basename ${arg%%:*} .py)
-      timeout 1200 python -m pytest $(unplus "$arg") -m gpu -q -x > $OUT/pytest_${TAG}_$n.log 2>&1
-      echo "[$step] rc=$? ($SECONDS s)"; tail -6 $OUT/pytest_${TAG}_$n.log ;;
+      timeout 1200 python -m pytest $(unplus "$arg") -m gpu -q -x --durations=6 > $OUT/pytest_${TAG}_$n.log 2>&1
+      echo "[$step] rc=$? ($SECONDS s)"; tail -12 $OUT/pytest_${TAG}_$n.log ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 ;;
     bench)

@@ -89,6 +89,8 @@ SIGNATURES = {
     "uamd_geglu_exact_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_geglu_approx_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_geglu_approx_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_quick_gelu_forward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "uamd_quick_gelu_backward": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_cross_entropy_forward": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_int, c_float, c_float, c_int, c_void_p]),
     "uamd_cross_entropy_backward": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p,
@@ -136,6 +138,8 @@ SIGNATURES = {
     "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "uamd_attn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int,
                               c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_int, c_void_p]),
+    "uamd_attn_fwd_band": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_int64), c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "uamd_attn_bwd": (c_int, [c_void_p] * 10 + [ctypes.POINTER(c_int64), c_int, c_int, c_int, c_int, c_int, c_int,
                                                c_float, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "uamd_gemv": (c_int, [c_void_p, c_int, ctypes.POINTER(GemvGroup), c_int, c_int, c_int, c_int, c_void_p]),

@@ -66,6 +66,8 @@ typedef __attribute__((address_space(3))) f32x2a_t lds_f32x2a;
 struct AttnArgs {
     const void* Q; const void* K; const void* V; void* O; float* LSE;
     const int* lo;                       // [B, T] first key each query may attend (NULL: 0), non-decreasing in t
+    const int* hi;                       // [B, T] LAST key each query may attend, >= t, non-decreasing (NULL: t itself = causal).
+                                         // Non-causal (bidirectional) attention inside documents: lo = document start, hi = its end
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
     int B, T, Hq, Hk, G, nsub;          // G = Hq / Hk, nsub = 8 / G q-subtiles of 32 rows per block
     int nqt;                             // number of q tiles
@@ -242,6 +244,12 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
     const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
     const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
+    // upper edge: the query itself (causal) or the band's `hi` (non-causal attention inside documents; BAND builds only)
+    const bool full = BAND && p.hi != nullptr;
+    const int lim_q = full ? p.hi[(int64_t)b * T_ + q_ld] : q_pos;
+    const int lim_w0 = full ? __builtin_amdgcn_readfirstlane(lim_q) : qs;
+    const int lim_w1 = full ? __builtin_amdgcn_readlane(lim_q, 31) : min(qs + 31, T_ - 1);
+    const int lim_blk = full ? p.hi[(int64_t)b * T_ + min(qtile * QT + QT - 1, T_ - 1)] : qtile * QT + QT - 1;
 
     // ---- Q^T operand fragments (B operand: lane -> q = l31, 8 d at 16 ks + 8 lh), kept for the whole tile loop
     frag_t qf[8];
@@ -258,7 +266,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     // ---- DMA plan: a stage = K tile (64 rows x 256 B) then V tile. One DMA instruction = 4 rows. Wave w issues
     //      pieces 2w, 2w+1 (rows 8w .. 8w+7) of K and of V. lane -> (row = 4 piece + (lane>>4), stored slot =
     //      lane & 15); the stored slot holds logical slot  s ^ (row & 15)  (K)  /  s ^ ((row & 3) << 2)  (V).
-    const int nkv_blk = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);      // causal: keys <= last q
+    const int nkv_blk = min(lim_blk / KT + 1, (T_ + KT - 1) / KT);                     // keys <= the last row's upper edge
     int drow[2], dks[2], dvs[2];
     unsigned koff[2], voff[2];
 #pragma unroll
@@ -320,7 +328,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     issue(t_first, 0);
     if (nt > 1) issue(t_first + 1, 1);
 
-    const int last_tile_wave = min(qs + 31, T_ - 1) / KT;            // tiles beyond are fully masked for this wave
+    const int last_tile_wave = lim_w1 / KT;                          // tiles beyond are fully masked for this wave
     const int first_tile_wave = lo_w0 / KT;                          // ... and tiles before
     // One tile step; MASKED is compile-time and the tile range is split by hand (see attn_bwd_dq_kernel).
     auto step = [&](int ti, auto mode_c, bool rt_mask) {       // mode 0: no mask, 1: mask, 2: mask iff rt_mask
@@ -388,7 +396,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             for (int r = 0; r < 16; ++r) {
                 if (MODE == 1 || (MODE == 2 && rt_mask)) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key > q_pos || key >= T_ || key < lo_q) st[kt][r] = -INFINITY;
+                    if (key > lim_q || key >= T_ || key < lo_q) st[kt][r] = -INFINITY;
                 }
                 mt = fmaxf(mt, st[kt][r]);
             }
@@ -446,7 +454,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     };
     {
         const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);       // tiles that start below the band edge
-        const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
+        const int t_diag = (lim_w0 + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
         const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
         if constexpr (BAND) {
             int ti = 0;
@@ -813,6 +821,8 @@ struct AttnBwdArgs {
     int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
     int B, T, Hq, Hk, G, nsub, lse_st, nqt;
     float scale, scale_log2;
+    int noncausal;                       // 1: bidirectional inside documents -- query q and key k attend iff lo[q] <= k <= hi[q]
+                                         // (documents are intervals, so equivalently lo[k] <= q <= hi[k]); needs lo AND hi
 };
 
 __device__ __forceinline__ int swz_c(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -865,8 +875,13 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
     const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
     const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
+    const bool full = BAND && p.noncausal;           // non-causal inside documents: keys lo[q] .. hi[q]
+    const int lim_q = full ? p.hi[(int64_t)b * T_ + q_ld] : q_pos;
+    const int lim_w0 = full ? __builtin_amdgcn_readfirstlane(lim_q) : qs;
+    const int lim_w1 = full ? __builtin_amdgcn_readlane(lim_q, 31) : min(qs + 31, T_ - 1);
+    const int lim_blk = full ? p.hi[(int64_t)b * T_ + min(qtile * QT + QT - 1, T_ - 1)] : qtile * QT + QT - 1;
 
-    const int nkv_blk = min((qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT);
+    const int nkv_blk = min(lim_blk / KT + 1, (T_ + KT - 1) / KT);
     int drow[2], dsw[2];
     unsigned koff[2], voff[2];
 #pragma unroll
@@ -916,7 +931,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int nt = nkv_blk - t_first;
     issue(t_first, 0);
     if (nt > 1) issue(t_first + 1, 1);
-    const int last_tile_wave = min(qs + 31, T_ - 1) / KT;
+    const int last_tile_wave = lim_w1 / KT;
     const int first_tile_wave = lo_w0 / KT;
     // One tile step. MASKED is a compile-time flag and the tile range is split by hand into
     // [band-edge tiles | interior tiles | diagonal / ragged tiles]: with a run-time `need_mask` that depends on
@@ -952,7 +967,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], p.scale_log2, -lse2));
                 if (MODE == 1 || (MODE == 2 && rt_mask)) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (key > q_pos || key >= T_ || key < lo_q) pv = 0.f;
+                    if (key > lim_q || key >= T_ || key < lo_q) pv = 0.f;
                 }
                 st[r] = pv * __builtin_fmaf(dp[r], p.scale, -delta_s);        // (dP - Delta) * scale in one fma
             }
@@ -977,7 +992,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         // tiles whose first key lies below the wave's largest band edge: a prefix; tiles that touch the diagonal
         // or run past T: a suffix
         const int t_pre_end = min(nkv_blk, (lo_w1 + KT - 1) / KT);
-        const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
+        const int t_diag = (lim_w0 + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
         const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
         if constexpr (BAND) {
             int ti = 0;
@@ -1110,6 +1125,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     const int hi_w0 = __builtin_amdgcn_readfirstlane(hi_k[0]);                   // smallest edge of the tile
     const int hi_blk = p.hi ? p.hi[(int64_t)b * T_ + min(k0 + KT - 1, T_ - 1)] : T_ - 1;
+    // lower edge: the key itself (causal: queries before the key do not see it) or -- non-causal attention inside documents --
+    // the first query of the key's document
+    const bool full = p.noncausal != 0;
+    int qlo_k[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        const int key_ld = key[kh] < T_ ? key[kh] : T_ - 1;
+        qlo_k[kh] = full ? p.lo[(int64_t)b * T_ + key_ld] : key[kh];
+    }
+    const int qlo_blk = full ? p.lo[(int64_t)b * T_ + k0] : k0;                                  // smallest lower edge of the tile
+    const int qlo_w1 = full ? p.lo[(int64_t)b * T_ + min(k0 + KT - 1, T_ - 1)] : k0 + KT - 1;    // largest
 
     // ---- V tile -> LDS (swizzle C), 16 pieces of 1 KiB, 4 per wave
     {
@@ -1145,7 +1171,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         doo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.do_st * 2) + (unsigned)(dsw0 ^ (i << 4));
     }
     const int nq32 = (T_ + 31) / 32;
-    const int q32_first = k0 / 32;
+    const int q32_first = qlo_blk / 32;
     const int nsteps = (min(nq32, hi_blk / 32 + 1) - q32_first + nslice - 1) / nslice;
 
     // ---- per-lane ABSOLUTE LDS byte addresses (swizzle C; the dynamic region's base included), made opaque once:
@@ -1307,7 +1333,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     if (MASK) {
                         const int r = 2 * j + e;
                         const int q = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (key[kh] > q || q >= T_ || key[kh] >= T_ || q > hi_k[kh]) pv = 0.f;
+                        if (q < qlo_k[kh] || q >= T_ || key[kh] >= T_ || q > hi_k[kh]) pv = 0.f;
                     }
                     x[e] = pv;
                     sc[kh][2 * j + e] = pv;
@@ -1391,7 +1417,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 return;
             }
             // slow body: some element of the tile is masked (diagonal / ragged / band edge) or the tile to fetch is ragged
-            const bool slow = (q0 < k0 + KT - 1) || (q0 + 32 > T_) || (k0 + KT > T_) || (q0 + 31 > hi_w0) || (qn + 32 > T_);
+            const bool slow = (q0 < qlo_w1) || (q0 + 32 > T_) || (k0 + KT > T_) || (q0 + 31 > hi_w0) || (qn + 32 > T_);
             if (slow) body(std::true_type{}, stage_c, q0, qn); else body(std::false_type{}, stage_c, q0, qn);
         };
 
@@ -1474,7 +1500,8 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;                     // empty batch: nothing to read (pointers may be null)
     if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !Delta || !strides) return UAMD_ERR_ARG;
-    if (D != AD || !causal || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
+    if (D != AD || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
+    if (!causal && !(lo && hi)) return UAMD_ERR_ARG;          // non-causal: the (lo, hi) band of the documents is required
     const int G = Hq / Hk;
     if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
     for (int i = 0; i < 24; ++i)
@@ -1497,6 +1524,7 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     a.dv_sb = strides[21]; a.dv_st = strides[22]; a.dv_sh = strides[23];
     a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
+    a.noncausal = causal ? 0 : 1;
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
     dim3 grid_q((unsigned)(a.nqt * Hk * B));
@@ -1530,13 +1558,15 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     return uamd_launch_status();
 }
 
-extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
-                             const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
-                             float scale, int causal, const int* lo, int dtype, void* stream) {
+static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                         const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
+                         float scale, int causal, const int* lo, const int* hi, int dtype, void* stream) {
     if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;                     // empty batch: nothing to read (pointers may be null)
     if (!Q || !K || !V || !O || !LSE || !strides) return UAMD_ERR_ARG;
-    if (D != AD || !causal || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
+    if (D != AD || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
+    if (!causal && !(lo && hi)) return UAMD_ERR_ARG;          // non-causal: the (lo, hi) band of the documents is required
+    if (causal) hi = nullptr;
     const int G = Hq / Hk;
     if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
     for (int i = 0; i < 12; ++i)
@@ -1545,7 +1575,7 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     // 32-bit per-lane byte offsets inside a 64-key tile
     if (strides[4] > (1 << 22) || strides[7] > (1 << 22)) return UAMD_ERR_ARG;
     AttnArgs a;
-    a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE; a.lo = lo;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.LSE = LSE; a.lo = lo; a.hi = hi;
     a.q_sb = strides[0]; a.q_st = strides[1]; a.q_sh = strides[2];
     a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
     a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];
@@ -1594,4 +1624,21 @@ extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* 
     else return UAMD_ERR_DTYPE;
     if (rc) return rc;
     return uamd_launch_status();
+}
+
+extern "C" int uamd_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                             const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
+                             float scale, int causal, const int* lo, int dtype, void* stream) {
+    if (!causal) return UAMD_ERR_ARG;                         // (non-causal: uamd_attn_fwd_band)
+    return attn_fwd_impl(Q, K, V, O, LSE, strides, B, T, Hq, Hk, D, lse_stride, scale, 1, lo, nullptr, dtype, stream);
+}
+
+// The same with both edges of the band: query t attends keys lo[t] .. hi[t]. causal != 0: hi is ignored (the upper edge is t).
+// causal == 0: BIDIRECTIONAL attention inside documents (lo = start, hi = end of the query's document): the vision tower of
+// BASELINE config 4 (Qwen2-VL's ViT attends all patches of an image / frame, `cu_seqlens` windows; the reference hands it to
+// flash-attn / SDPA through the same run_attention, utils/attention_dispatch.py:298-617).
+extern "C" int uamd_attn_fwd_band(const void* Q, const void* K, const void* V, void* O, float* LSE,
+                                  const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
+                                  float scale, int causal, const int* lo, const int* hi, int dtype, void* stream) {
+    return attn_fwd_impl(Q, K, V, O, LSE, strides, B, T, Hq, Hk, D, lse_stride, scale, causal, lo, hi, dtype, stream);
 }

@@ -557,6 +557,61 @@ extern "C" int uamd_glu_bwd_xa(int act, void* DW, void* e, void* g, int M, int K
     return glu_xa_entry<2>(act, DW, e, g, nullptr, M, K, ld, o0, o1, dtype, stream);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// QuickGELU, y = x * sigmoid(1.702 x): the activation of Qwen2-VL's vision MLP (fc1 -> act -> fc2; BASELINE config 4). The
+// reference leaves it to the zoo compiler's fused graph (unsloth/models/vision.py:881-1990); here one streaming kernel each way,
+// fp32 arithmetic, one rounding: forward y from x; backward dx = dy * (s + 1.702 x s (1 - s)), s = sigmoid(1.702 x), written IN
+// PLACE over dy (x is kept: fc1's output is what autograd saved anyway).
+namespace {
+template <typename T, bool BWD>
+__global__ void __launch_bounds__(256) quick_gelu_kernel(const T* __restrict__ X, T* __restrict__ Y, int64_t n) {
+    constexpr int VEC = Vec16<T>::N;
+    const int64_t nvec = n / VEC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        Vec16<T> x = ld16_m(X + i * VEC, 0), y;
+        if (BWD) y = ld16_m(Y + i * VEC, 0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float v = to_f32(x.e[j]);
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * v));
+            if (BWD) y.e[j] = from_f32<T>(to_f32(y.e[j]) * (sg + 1.702f * v * sg * (1.0f - sg)));
+            else y.e[j] = from_f32<T>(v * sg);
+        }
+        st16_m(Y + i * VEC, y, 0);
+    }
+    if (blockIdx.x == 0) {
+        for (int64_t k = nvec * VEC + threadIdx.x; k < n; k += 256) {
+            const float v = to_f32(X[k]);
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * v));
+            Y[k] = from_f32<T>(BWD ? to_f32(Y[k]) * (sg + 1.702f * v * sg * (1.0f - sg)) : v * sg);
+        }
+    }
+}
+template <typename T, bool BWD>
+int launch_quick_gelu(const void* x, void* y, int64_t n, hipStream_t st) {
+    if (!aligned16(x) || !aligned16(y)) return UAMD_ERR_ALIGN;
+    const int64_t nvec = n / Vec16<T>::N;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL((quick_gelu_kernel<T, BWD>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)y, n);
+    return uamd_launch_status();
+}
+}  // namespace
+
+extern "C" int uamd_quick_gelu_forward(const void* x, void* y, int64_t n, int dtype, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !y))) return UAMD_ERR_ARG;
+    if (n == 0) return UAMD_OK;
+    UAMD_DISPATCH_FLOAT(dtype, return (launch_quick_gelu<T, false>(x, y, n, (hipStream_t)stream)))
+    return UAMD_ERR_DTYPE;
+}
+extern "C" int uamd_quick_gelu_backward(const void* x, void* dy_dx, int64_t n, int dtype, void* stream) {
+    if (n < 0 || (n > 0 && (!x || !dy_dx))) return UAMD_ERR_ARG;
+    if (n == 0) return UAMD_OK;
+    UAMD_DISPATCH_FLOAT(dtype, return (launch_quick_gelu<T, true>(x, dy_dx, n, (hipStream_t)stream)))
+    return UAMD_ERR_DTYPE;
+}
+
 extern "C" int uamd_swiglu_fg(const void* e, const void* g, void* h, int64_t n, int dtype, void* stream) {
     return fwd<ACT_SWIGLU>(e, g, h, n, dtype, stream);
 }

@@ -98,6 +98,28 @@ def attention_band(T, batch=1, seq_lengths=None, sliding_window=None, device="cp
     return lo.to(torch.int32).view(batch, T).contiguous(), hi.to(torch.int32).view(batch, T).contiguous()
 
 
+def document_band(T, batch=1, seq_lengths=None, device="cpu"):
+    """(lo, hi) int32 [batch, T] of NON-CAUSAL attention inside documents: position t attends every position of its own document,
+    lo[t] = first, hi[t] = last position of it. `seq_lengths`: document lengths back to back over the flattened batch (the
+    `cu_seqlens` windows of a vision tower: one entry per image / frame); None = every batch row is one document. Documents are
+    cut at row boundaries like attention_band's. Integer work with torch ops; exact."""
+    total = batch * T
+    g = torch.arange(total, dtype=torch.int64, device=device)
+    row0 = (g // T) * T
+    if seq_lengths is not None:
+        lens = torch.as_tensor(seq_lengths, dtype=torch.int64, device=device).flatten()
+        lens = lens[lens > 0]
+        ends = torch.cumsum(lens, 0).clamp_(max=total)
+        doc = torch.searchsorted(ends, g, right=True)
+        ends = torch.cat([ends, ends.new_full((1,), total)])
+        starts = torch.cat([ends.new_zeros(1), ends[:-1]])
+        lo = torch.maximum(starts[doc], row0) - row0
+        hi = torch.minimum(ends[doc] - 1, row0 + (T - 1)) - row0
+    else:
+        lo, hi = torch.zeros_like(g), torch.full_like(g, T - 1)
+    return lo.to(torch.int32).view(batch, T).contiguous(), hi.to(torch.int32).view(batch, T).contiguous()
+
+
 def padding_mask_documents(attention_mask):
     """A key-padding mask [B, T] (non-zero = real token) whose real tokens are CONTIGUOUS in every row (right padding,
     left padding, or both) as packed-document lengths over the flattened batch: per row [pad_left, real, pad_right].
@@ -126,9 +148,10 @@ def _band_ptrs(band, B, T, dev):
     return _lib.ptr(lo), _lib.ptr(hi)
 
 
-def attn_forward(q, k, v, scale=None, band=None):
+def attn_forward(q, k, v, scale=None, band=None, causal=True):
     """q [B,T,Hq,128], k/v [B,T,Hk,128] (strided views are fine) -> (o [B,T,Hq,128] contiguous, lse [B,Hq,T] fp32).
-    `band` = (lo, hi) from attention_band() restricts the causal mask to packed documents / a sliding window."""
+    `band` = (lo, hi) from attention_band() restricts the causal mask to packed documents / a sliding window.
+    causal=False: bidirectional attention inside the documents of `band` = document_band(...) (None: each row one document)."""
     _lib.require_gpu(q, k, v)
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
@@ -137,31 +160,38 @@ def attn_forward(q, k, v, scale=None, band=None):
     if not native(q, k, v):
         assert supported(q, k, v), "head_dim <= 128 and at most 8 query heads per KV head"
         qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
-        op, lsep = _forward_native(qp, kp, vp, scale, band)
+        op, lsep = _forward_native(qp, kp, vp, scale, band) if causal else _forward_native(qp, kp, vp, scale, band, False)
         o = op.view(B, T, Hk, Gp, 128)[:, :, :, :G, :D].reshape(B, T, Hq, D)
         Tp = _pad32(T)
         lse = torch.as_strided(lsep, (B, Hk, Gp, Tp), (Hk * Gp * Tp, Gp * Tp, Tp, 1))[:, :, :G].reshape(B, Hq, Tp)
         return o, lse[:, :, :T]
-    return _forward_native(q, k, v, scale, band)
+    return _forward_native(q, k, v, scale, band) if causal else _forward_native(q, k, v, scale, band, False)
 
 
-def _forward_native(q, k, v, scale, band):
+def _forward_native(q, k, v, scale, band, causal=True):
     """The launch itself: head_dim 128, G in {1, 2, 4, 8}."""
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
     o = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
     Tp = _pad32(T)
     lse = (torch.empty if Tp == T else torch.zeros)((B, Hq, Tp), dtype=torch.float32, device=q.device)
-    lo, _ = _band_ptrs(band, B, T, q.device)
+    if not causal and band is None:
+        band = document_band(T, batch=B, device=q.device)
+    lo, hi = _band_ptrs(band, B, T, q.device)
     with _lib.device_ctx(q):
-        rc = _lib.lib().uamd_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(lse),
-                                      _strides(q, k, v, o), B, T, Hq, Hk, D, Tp, float(scale), 1, lo,
-                                      _lib.dtype_code(q.dtype), _lib.stream_of(q))
+        if causal:
+            rc = _lib.lib().uamd_attn_fwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(lse),
+                                          _strides(q, k, v, o), B, T, Hq, Hk, D, Tp, float(scale), 1, lo,
+                                          _lib.dtype_code(q.dtype), _lib.stream_of(q))
+        else:
+            rc = _lib.lib().uamd_attn_fwd_band(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(lse),
+                                               _strides(q, k, v, o), B, T, Hq, Hk, D, Tp, float(scale), 0, lo, hi,
+                                               _lib.dtype_code(q.dtype), _lib.stream_of(q))
     _lib.check(rc, "uamd_attn_fwd")
     return o, lse[:, :, :T]
 
 
-def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
+def attn_backward(do, q, k, v, o, lse, scale=None, band=None, causal=True):
     """Gradients of attn_forward: (dq [B,T,Hq,D], dk, dv [B,T,Hk,D]) in q's dtype, column blocks of one buffer. `lse` is the view
     attn_forward returned (its storage is padded to a multiple of 32 positions). Two launches, deterministic."""
     _lib.require_gpu(do, q, k, v, o)
@@ -175,7 +205,9 @@ def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
         qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
         lse_full = torch.as_strided(lse, (B, Hq, Tp), (Hq * Tp, Tp, 1))
         lsep = torch.nn.functional.pad(lse_full.view(B, Hk, G, Tp), (0, 0, 0, Gp - G)).view(B, Hk * Gp, Tp)
-        dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, _pad_like_q(o, G, Gp), lsep[:, :, :T], scale, band)
+        extra = () if causal else (False,)
+        dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, _pad_like_q(o, G, Gp), lsep[:, :, :T], scale, band,
+                                         *extra)
         # same contract as below: dQ | dK | dV as column blocks of ONE buffer
         dqkv = torch.empty((B, T, (Hq + 2 * Hk) * D), dtype=q.dtype, device=q.device)
         dq = dqkv[..., :Hq * D].view(B, T, Hq, D)
@@ -185,10 +217,10 @@ def attn_backward(do, q, k, v, o, lse, scale=None, band=None):
         dk.copy_(dkp[..., :D])
         dv.copy_(dvp[..., :D])
         return dq, dk, dv
-    return _backward_native(do, q, k, v, o, lse, scale, band)
+    return _backward_native(do, q, k, v, o, lse, scale, band) if causal else _backward_native(do, q, k, v, o, lse, scale, band, False)
 
 
-def _backward_native(do, q, k, v, o, lse, scale, band):
+def _backward_native(do, q, k, v, o, lse, scale, band, causal=True):
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
     Tp = _pad32(T)
@@ -203,12 +235,14 @@ def _backward_native(do, q, k, v, o, lse, scale, band):
     # scratch of the two launches: plane 0 = Delta = rowsum(dO * O), plane 1 = LSE * log2(e) (written by the dQ kernel,
     # read by the dK/dV kernel's LDS-DMA)
     delta = (torch.empty if Tp == T else torch.zeros)((2, B, Hq, Tp), dtype=torch.float32, device=q.device)
+    if not causal and band is None:
+        band = document_band(T, batch=B, device=q.device)
     lo, hi = _band_ptrs(band, B, T, q.device)
     with _lib.device_ctx(q):
         rc = _lib.lib().uamd_attn_bwd(_lib.ptr(q), _lib.ptr(k), _lib.ptr(v), _lib.ptr(o), _lib.ptr(do),
                                       _lib.ptr(lse), _lib.ptr(dq), _lib.ptr(dk), _lib.ptr(dv), _lib.ptr(delta),
-                                      _strides(q, k, v, o, do, dq, dk, dv), B, T, Hq, Hk, D, Tp, float(scale), 1,
-                                      lo, hi, _lib.dtype_code(q.dtype), _lib.stream_of(q))
+                                      _strides(q, k, v, o, do, dq, dk, dv), B, T, Hq, Hk, D, Tp, float(scale),
+                                      1 if causal else 0, lo, hi, _lib.dtype_code(q.dtype), _lib.stream_of(q))
     _lib.check(rc, "uamd_attn_bwd")
     return dq, dk, dv
 
@@ -217,18 +251,18 @@ class FlashAttention(torch.autograd.Function):
     """o = causal_attention(q, k, v) on [B,T,H,D] views; saves (q, k, v, o, lse) like flash-attention."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale, band):
-        o, lse = attn_forward(q, k, v, scale, band)
+    def forward(ctx, q, k, v, scale, band, causal=True):
+        o, lse = attn_forward(q, k, v, scale, band, causal)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale, ctx.band = scale, band
+        ctx.scale, ctx.band, ctx.causal = scale, band, causal
         return o
 
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band)
-        return dq, dk, dv, None, None
+        dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band, ctx.causal)
+        return dq, dk, dv, None, None, None
 
 
-def flash_attention(q, k, v, scale=None, band=None):
-    return FlashAttention.apply(q, k, v, scale, band)
+def flash_attention(q, k, v, scale=None, band=None, causal=True):
+    return FlashAttention.apply(q, k, v, scale, band, causal)

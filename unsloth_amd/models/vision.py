@@ -9,10 +9,11 @@ tower on the fused path".
 MI355X composition:
   * language tower = the Qwen2 causal LM on the hand-kernel path (models/loader.py FastModel: NF4, LoRA through the
     grouped MFMA GEMMs with the q/k/v bias in the epilogue, multimodal RoPE kernel, flash attention, fused linear-CE);
-  * vision tower = transformers' Qwen2VisionTransformerPretrainedModel (patch-embed, ViT blocks with 2-D RoPE, patch
-    merger) -- its frozen LayerNorms run through `fast_layernorm` (csrc/layernorm.hip, kernels/layernorm.patch_layernorm)
-    and, once LoRA is attached, its linear layers (qkv / proj / fc1 / fc2 / merger MLP) through LoRA_W, i.e. the same
-    MFMA GEMM kernels with bias in the epilogue;
+  * vision tower = transformers' Qwen2VisionTransformerPretrainedModel's modules and parameters (patch-embed, ViT blocks,
+    patch merger) with the blocks' forwards replaced (models/vision_tower.py, round 4): 2-D RoPE through
+    csrc/rope_embedding.hip, NON-CAUSAL attention inside the `cu_seqlens` windows through csrc/attention.hip, QuickGELU
+    through csrc/glu.hip; the frozen LayerNorms run through `fast_layernorm` (csrc/layernorm.hip) and, once LoRA is
+    attached, the linear layers (qkv / proj / fc1 / fc2) through LoRA_W, i.e. the MFMA GEMM kernels with bias in the epilogue;
   * glue (this file): image features scattered over the image placeholder tokens (`masked_scatter`, as HF), and the
     [3, B, T] multimodal position ids -- INTEGER work, restated from transformers' `get_rope_index` /
     `get_vision_position_ids` and tested bit-exact against them (tests/test_vision.py).
@@ -201,6 +202,8 @@ class FastVisionModel:
                 raise RuntimeError(f"{model_name}: no tensors for {missing[:8]} ... in the checkpoint's vision tower")
         for p in visual.parameters():
             p.requires_grad_(False)
+        from .vision_tower import patch_vision_tower
+        patch_vision_tower(visual)                  # ViT attention (2-D RoPE + non-causal flash) and QuickGELU on the HIP kernels
         model = Qwen2VLFastModel(config, visual, language)
         model.max_seq_length = max_seq_length
         return model, tok

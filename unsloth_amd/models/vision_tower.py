@@ -1,0 +1,76 @@
+"""Qwen2-VL's vision tower on the hand kernels (BASELINE config 4).
+
+transformers' Qwen2VLVisionBlock = LayerNorm -> VisionAttention (qkv Linear, 2-D RoPE, NON-CAUSAL attention inside every image /
+frame's `cu_seqlens` window, proj Linear) -> LayerNorm -> VisionMlp (fc1, QuickGELU, fc2). The reference hands that module tree to
+the unsloth_zoo compiler (unsloth/models/vision.py:881-1990; third party). Here the blocks keep HF's modules and parameters, and
+their forwards are replaced per instance (the way the language tower's attention / MLP forwards are, models/llama.py):
+
+  * attention: q | k | v stay where the qkv GEMM wrote them ([S, 3, H, D] -> three strided [1, S, H, D] views), the rotary
+    embedding (fp32 tables of the 2-D patch positions, row = patch) rotates q and k IN PLACE through csrc/rope_embedding.hip,
+    and csrc/attention.hip runs the bidirectional attention inside the `cu_seqlens` windows (kernels/attention.document_band;
+    head_dim 80 and 16 : 16 heads go through the zero-padding of kernels/attention._pad_qkv) -- in round 3 this was torch SDPA:
+    aotriton's flash kernels at 14 % (forward) and 6 % (backward) of the MFMA peak, 20 % of the config-4 step
+    (profiles/r04m_config4_kernel_stats.csv: bwd_kernel_dk_dv 1.07 ms, bwd_kernel_dq 0.38 ms, attn_fwd 0.24 ms per block);
+  * MLP: fc1 / fc2 are the module's own linears (LoRA_W on the MFMA GEMM once adapters are attached), QuickGELU is one streaming
+    HIP kernel each way (kernels/quick_gelu.py) instead of three torch elementwise kernels forward and more backward.
+CPU tensors / fp32 activations fall through to transformers' forward (the CPU tests of tests/test_vision.py)."""
+from types import MethodType
+
+import torch
+
+from ..kernels import attention as _flash
+from ..kernels.quick_gelu import fast_quick_gelu
+from ..kernels.rope_embedding import fast_rope_embedding
+
+_BAND_CACHE = {}
+
+
+def _band_of(cu_seqlens, S, device):
+    """(lo, hi) of the `cu_seqlens` windows, built once per forward (every block of the tower passes the same tensor)."""
+    key = (cu_seqlens.data_ptr(), int(cu_seqlens.numel()), S, device)
+    hit = _BAND_CACHE.get("last")
+    if hit is not None and hit[0] == key and hit[1] is cu_seqlens:
+        return hit[2]
+    lengths = (cu_seqlens[1:] - cu_seqlens[:-1]).to(torch.int64)
+    band = None if lengths.numel() == 1 else _flash.document_band(S, batch=1, seq_lengths=lengths, device=device)
+    _BAND_CACHE["last"] = (key, cu_seqlens, band)
+    return band
+
+
+def vision_attention_fast_forward(self, hidden_states, cu_seqlens, position_embeddings=None, max_seqlen=None, **kwargs):
+    """Qwen2-VL VisionAttention.forward on the HIP kernels (see the module docstring)."""
+    if (not hidden_states.is_cuda) or hidden_states.dtype not in (torch.bfloat16, torch.float16) or position_embeddings is None \
+            or self.head_dim > 128 or (self.head_dim & 1):
+        return self._uamd_hf_forward(hidden_states, cu_seqlens, position_embeddings=position_embeddings, max_seqlen=max_seqlen,
+                                     **kwargs)
+    S = hidden_states.shape[0]
+    H, D = self.num_heads, self.head_dim
+    qkv = self.qkv(hidden_states).view(1, S, 3, H, D)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                         # [1, S, H, D] views of the GEMM output
+    cos, sin = position_embeddings                                             # [S, D] fp32: row = patch, first D/2 columns used
+    qr, kr = fast_rope_embedding(q.transpose(1, 2), k.transpose(1, 2), cos.float(), sin.float(), None)
+    o = _flash.flash_attention(qr.transpose(1, 2), kr.transpose(1, 2), v, float(self.scaling), _band_of(cu_seqlens, S, qkv.device),
+                               False)
+    return self.proj(o.reshape(S, H * D))
+
+
+def vision_mlp_fast_forward(self, x):
+    if (not x.is_cuda) or x.dtype not in (torch.bfloat16, torch.float16) or not getattr(self, "_uamd_quick_gelu", False):
+        return self._uamd_hf_forward(x)
+    return self.fc2(fast_quick_gelu(self.fc1(x)))
+
+
+def patch_vision_tower(visual):
+    """Install the fast forwards on every block of a Qwen2VisionTransformerPretrainedModel. Returns the number of blocks patched."""
+    n = 0
+    for blk in getattr(visual, "blocks", []):
+        attn, mlp = getattr(blk, "attn", None), getattr(blk, "mlp", None)
+        if attn is not None and hasattr(attn, "qkv") and hasattr(attn, "proj") and not hasattr(attn, "_uamd_hf_forward"):
+            attn._uamd_hf_forward = attn.forward
+            attn.forward = MethodType(vision_attention_fast_forward, attn)
+            n += 1
+        if mlp is not None and hasattr(mlp, "fc1") and hasattr(mlp, "fc2") and not hasattr(mlp, "_uamd_hf_forward"):
+            mlp._uamd_quick_gelu = type(getattr(mlp, "act", None)).__name__ == "QuickGELUActivation"
+            mlp._uamd_hf_forward = mlp.forward
+            mlp.forward = MethodType(vision_mlp_fast_forward, mlp)
+    return n
