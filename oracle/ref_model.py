@@ -262,9 +262,12 @@ def hf_vl_reference_loss_and_lora_grads(fast_vl, input_ids, attention_mask, pixe
     for k in eff:
         eff[k].requires_grad_(True)
     ids = input_ids.to(dev)
-    out = hf(input_ids=ids, attention_mask=None if attention_mask is None else attention_mask.to(dev),
-             pixel_values=pixel_values.to(dev).to(dtype), image_grid_thw=image_grid_thw.to(dev),
-             mm_token_type_ids=(ids == cfg.image_token_id).int())
+    # (the patch-embed Conv3d through torch's own convolution, not MIOpen: its first call on a fresh GPU box spends minutes in
+    # kernel search / compilation per dtype)
+    with torch.backends.cudnn.flags(enabled=False):
+        out = hf(input_ids=ids, attention_mask=None if attention_mask is None else attention_mask.to(dev),
+                 pixel_values=pixel_values.to(dev).to(dtype), image_grid_thw=image_grid_thw.to(dev),
+                 mm_token_type_ids=(ids == cfg.image_token_id).int())
     logits = out.logits.float()
     lab = labels.to(dev)
     loss = torch.nn.functional.cross_entropy(logits[:, :-1].reshape(-1, logits.shape[-1]), lab[:, 1:].reshape(-1),

@@ -75,10 +75,11 @@ def test_vision_tower_on_hand_kernels_matches_transformers_fp32(grids):
         flash.attn_forward = real
     assert len(calls) == 2 and all(s == (1, n_patches, 16, 80) for s in calls), calls
     pr = pix.to(torch.bfloat16).float().requires_grad_(True)
-    out_r = ref(pr, grid_thw=thw)
-    out_r = out_r.pooler_output if hasattr(out_r, "pooler_output") else out_r
-    w = torch.randn(out_r.shape, generator=g).to(DEV)
+    with torch.backends.cudnn.flags(enabled=False):          # the oracle's Conv3d without MIOpen's minutes of kernel search
+        out_r = ref(pr, grid_thw=thw)
+        out_r = out_r.pooler_output if hasattr(out_r, "pooler_output") else out_r
+        w = torch.randn(out_r.shape, generator=g).to(DEV)
+        (out_r * w).sum().backward()
     (out_f.float() * w).sum().backward()
-    (out_r * w).sum().backward()
     assert rel_fro(out_f.float().cpu(), out_r.detach().cpu()) < 1.5e-2
     assert rel_fro(pf.grad.float().cpu(), pr.grad.cpu()) < 3e-2

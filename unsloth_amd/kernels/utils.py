@@ -34,7 +34,9 @@ FUSED_NF4_MAX_M = int(os.environ.get("UNSLOTH_AMD_FUSED_NF4_MAX_M", "512"))
 # anti-phase groups) once the launch has enough 256x256 tiles to fill the 256 CUs (GEMM256_MIN_TILES), else the
 # 128x128 register-staged kernel (csrc/gemm.hip); "on"/"off" force it.
 GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
-GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "192"))
+# (160 since round 4: Qwen2-VL's ViT linears with N = 1280 at 4096 patches are 160 half-height tiles -- on the 128 x 128 kernel
+# they ran at 0.18 PFLOP/s, the config-4 step is 2.7 % faster with them on the 256 family: profiles/r04p_config4_min_tiles_ab.txt)
+GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "160"))
 # X @ A^T / dY @ B: streaming LDS-DMA kernel (csrc/lora_side.hip) for total rank <= 64, else the first version
 LORA_XA_V2 = os.environ.get("UNSLOTH_AMD_LORA_XA_V2", "1") == "1"
 

@@ -11,6 +11,7 @@ their forwards are replaced per instance (the way the language tower's attention
     head_dim 80 and 16 : 16 heads go through the zero-padding of kernels/attention._pad_qkv) -- in round 3 this was torch SDPA:
     aotriton's flash kernels at 14 % (forward) and 6 % (backward) of the MFMA peak, 20 % of the config-4 step
     (profiles/r04m_config4_kernel_stats.csv: bwd_kernel_dk_dv 1.07 ms, bwd_kernel_dq 0.38 ms, attn_fwd 0.24 ms per block);
+  * patch embedding: the Conv3d with kernel == stride as ONE GEMM over the flattened patches (no MIOpen convolution);
   * MLP: fc1 / fc2 are the module's own linears (LoRA_W on the MFMA GEMM once adapters are attached), QuickGELU is one streaming
     HIP kernel each way (kernels/quick_gelu.py) instead of three torch elementwise kernels forward and more backward.
 CPU tensors / fp32 activations fall through to transformers' forward (the CPU tests of tests/test_vision.py)."""
@@ -60,9 +61,27 @@ def vision_mlp_fast_forward(self, x):
     return self.fc2(fast_quick_gelu(self.fc1(x)))
 
 
+def patch_embed_fast_forward(self, hidden_states):
+    """PatchEmbed.forward: a Conv3d whose kernel equals its stride IS a linear map of the flattened patch -- [n, C * t * p * p] @
+    W.view(embed_dim, -1)^T on the MFMA GEMM (kernels/fast_dense.Dense_W) instead of a MIOpen convolution (whose first call on a
+    fresh box spends minutes in kernel search / compilation)."""
+    W = self.proj.weight
+    if (not hidden_states.is_cuda) or W.dtype not in (torch.bfloat16, torch.float16) or self.proj.bias is not None \
+            or (W[0].numel() % 8):
+        return self._uamd_hf_forward(hidden_states)
+    from ..kernels.fast_dense import Dense_W
+    x = hidden_states.reshape(-1, W[0].numel()).to(W.dtype)
+    return Dense_W.apply(x, W.view(W.shape[0], -1), None).view(-1, self.embed_dim)
+
+
 def patch_vision_tower(visual):
     """Install the fast forwards on every block of a Qwen2VisionTransformerPretrainedModel. Returns the number of blocks patched."""
     n = 0
+    pe = getattr(visual, "patch_embed", None)
+    if pe is not None and isinstance(getattr(pe, "proj", None), torch.nn.Conv3d) and not hasattr(pe, "_uamd_hf_forward") \
+            and tuple(pe.proj.kernel_size) == tuple(pe.proj.stride) and tuple(pe.proj.padding) == (0, 0, 0):
+        pe._uamd_hf_forward = pe.forward
+        pe.forward = MethodType(patch_embed_fast_forward, pe)
     for blk in getattr(visual, "blocks", []):
         attn, mlp = getattr(blk, "attn", None), getattr(blk, "mlp", None)
         if attn is not None and hasattr(attn, "qkv") and hasattr(attn, "proj") and not hasattr(attn, "_uamd_hf_forward"):
