@@ -81,5 +81,6 @@ def test_forward_and_dq_kernels_do_not_spill(tmp_path):
         if m.group(2) == "attn_fwd_ps_kernel" or not band:
             assert scratch == 0, (m.group(1), scratch)
         else:
-            assert scratch <= 24, (m.group(1), scratch)
+            # (band dQ: 4-5 dwords spilled ACROSS the middle tile loop, stored before it and reloaded after it -- not per tile)
+            assert scratch <= 12, (m.group(1), scratch)
     assert seen == 12                 # 3 kernels x {bf16, fp16} x {plain, band}

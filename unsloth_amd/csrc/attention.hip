@@ -882,37 +882,31 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int lim_blk = full ? p.hi[(int64_t)b * T_ + min(qtile * QT + QT - 1, T_ - 1)] : qtile * QT + QT - 1;
 
     const int nkv_blk = min(lim_blk / KT + 1, (T_ + KT - 1) / KT);
-    int drow[2], dsw[2];
-    unsigned koff[2], voff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 4 + (lane >> 4);
-        drow[i] = row;
-        dsw[i] = ((lane & 15) ^ swz_c(row)) * 16;
-        koff[i] = (unsigned)((int64_t)row * p.k_st * 2 + dsw[i]);
-        voff[i] = (unsigned)((int64_t)row * p.v_st * 2 + dsw[i]);
-    }
     const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
     const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
     const unsigned dst_w = lds_base + wave * 2048;
+    // the four per-lane DMA source offsets are RECOMPUTED at every issue from an opaque copy of the lane id (see
+    // attn_fwd_ps_kernel): kept in registers across the tile loop the band build spilled them, and every tile's reload -- a
+    // scratch (VMEM) load with a compiler-inserted vmcnt(0) behind it -- drained the LDS-DMA ring (13 spilled dwords, reloaded in
+    // all three tile loops, before round 4)
     auto issue = [&](int t, int stage) {
         const int k0 = t * KT;
         const unsigned d = dst_w + stage * STAGE_B;
-        if (k0 + KT <= T_) {
-            dma16x2(kbase + (int64_t)k0 * p.k_st, koff[0], koff[1], d, d + 1024);
-            dma16x2(vbase + (int64_t)k0 * p.v_st, voff[0], voff[1], d + TILE_B, d + TILE_B + 1024);
-        } else {
-            unsigned ko[2], vo[2];
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int rmax = T_ - 1 - k0;                                  // ragged last tile: rows past the end re-read the last key
+        unsigned ko[2], vo[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = min(drow[i], T_ - 1 - k0);
-                ko[i] = (unsigned)((int64_t)r * p.k_st * 2 + dsw[i]);
-                vo[i] = (unsigned)((int64_t)r * p.v_st * 2 + dsw[i]);
-            }
-            dma16x2(kbase + (int64_t)k0 * p.k_st, ko[0], ko[1], d, d + 1024);
-            dma16x2(vbase + (int64_t)k0 * p.v_st, vo[0], vo[1], d + TILE_B, d + TILE_B + 1024);
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 4 + (ln >> 4);
+            const int r = min(row, rmax);
+            const int sw = ((ln & 15) ^ swz_c(row)) * 16;
+            ko[i] = (unsigned)(r * (int)p.k_st * 2 + sw);
+            vo[i] = (unsigned)(r * (int)p.v_st * 2 + sw);
         }
+        dma16x2(kbase + (int64_t)k0 * p.k_st, ko[0], ko[1], d, d + 1024);
+        dma16x2(vbase + (int64_t)k0 * p.v_st, vo[0], vo[1], d + TILE_B, d + TILE_B + 1024);
     };
 
     // row reads (K for S^T, V for dP^T): lane -> row l31 (+32 kt), 16 B at logical slot 2 ks + lh
@@ -1006,7 +1000,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         }
     }
     {
-        T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)q_ld * p.dq_st + (int64_t)head * p.dq_sh;
+        int qr = q_ld;                       // (the row address formed HERE: hoisted, the pointer pair is spilled around the loop)
+        asm volatile("" : "+v"(qr));
+        T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)qr * p.dq_st + (int64_t)head * p.dq_sh;
         store_rows_x4<T>(op, dq_acc, 1.0f, lh, q_pos < T_);
     }
 }
