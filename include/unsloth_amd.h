@@ -375,17 +375,30 @@ typedef struct {
 } uamd_gemv_group;
 int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize, int dtype,
               void* stream);
-/* uamd_gemv_fused: the same launch with the token PRODUCED inside it and the LoRA `t = A x` computed by every block, so that
- * one decoder layer of a decode step is 7 launches instead of 14 (LlamaModel_fast_forward_inference, llama.py:1249-1364:
- * residual adds, fast_rms_layernorm_inference, fast_swiglu_inference and the `mv` of fast_linear_forward are separate
- * torch / kernel launches there).
+/* uamd_gemv_fused: the same launch with the token PRODUCED inside it and the LoRA `t = A x` computed INSIDE it, once, so that
+ * one decoder layer of a decode step is 5 launches (q|k|v, attention, o, gate|up -> h, down) instead of 14
+ * (LlamaModel_fast_forward_inference, llama.py:1249-1364: residual adds, fast_rms_layernorm_inference, fast_swiglu_inference
+ * and the `mv` of fast_linear_forward are separate torch / kernel launches there).
  *   mode 0: x as given.   mode 1: x = (x * sigmoid(x)).to(T) * x2 (SwiGLU; x = gate, x2 = up).
  *   mode 2: h = T(x + res) (x may be NULL: h = res), x' = rmsnorm(h; eps) * norm_w (norm_w in T, or fp32 when w_f32);
  *           h is also written to h_out when non-NULL (by one block; h_out must not alias res or x).
  *   a_rows: [Rt, K] stacked LoRA A rows in T (row stride ld_a), Rt <= 256; group g's t starts at row t_off[g]; a group
- *           takes part when its lora_b / R / lora_scale are set (its lora_t is ignored). NULL: lora_t as in uamd_gemv. */
+ *           takes part when its lora_b / R / lora_scale are set (its lora_t is ignored). NULL: lora_t as in uamd_gemv.
+ *           The first workgroups of the launch compute t (a row, or a 4096-column part of one, per wave) and publish each
+ *           value as an 8-byte {value, tag} granule in `sync`; the weight-row workgroups pick the granules up after their
+ *           own dot products (producers never wait, so the hand-off cannot deadlock whatever the residency; polls are bounded).
+ *   sync:   DEVICE workspace of UAMD_GEMV_SYNC_BYTES, zeroed ONCE by the caller, required with a_rows; launches that share it
+ *           must be ordered (one stream / one graph).
+ *   tag, tag_dev: the launch's tag = tag + UAMD_TAG_STRIDE * *tag_dev (tag_dev NULL: tag alone), never 0 and never a value an
+ *           earlier launch on the same workspace used: a host-side counter for eager launches; for launches replayed from a
+ *           hipGraph a per-launch-site constant < UAMD_TAG_STRIDE plus a device counter the caller advances once per replay.
+ *   glu:    2 groups (gate, up) of the same N: a wave computes row n of both and stores ONE value
+ *           h[n] = (e * sigmoid(e)).to(T) * g at groups[0].y (e, g rounded to T first: the values the separate launches
+ *           would have stored; fast_swiglu_inference, llama.py:572-606). K <= 8192. */
+#define UAMD_GEMV_SYNC_BYTES (8 * 256)
+#define UAMD_TAG_STRIDE 1024u
 typedef struct {
-    int mode, Rt, w_f32, _pad;
+    int mode, Rt, w_f32, glu;
     const void* x2;
     const void* res;
     const void* norm_w;
@@ -394,7 +407,9 @@ typedef struct {
     int64_t ld_a;
     float eps;
     int t_off[4];
-    int _pad2;
+    unsigned tag;
+    void* sync;
+    const int* tag_dev;
 } uamd_gemv_prologue;
 int uamd_gemv_fused(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize, int dtype,
                     void* stream, const uamd_gemv_prologue* pro);
@@ -415,6 +430,20 @@ int uamd_attn_decode(const void* q, int64_t q_sb, const void* k_cache, const voi
                      int64_t cache_sh, const int* kv_len, int len_add, float* partials, void* out, int64_t out_sb,
                      int B, int Hq, int Hk, int D, int nsplit, int split_keys, int window, float scale, int dtype,
                      void* stream);
+/* The three launches above (RoPE + append, split attention, combine) as ONE: every workgroup (split, kv head, batch) rotates
+ * the G query heads it needs from the raw q|k|v row (qkv is NOT modified); the workgroup whose split owns position kv_len[b]
+ * rotates the new k, appends k and v to the cache and uses them from LDS. Keys [max(0, len - window), len), len = kv_len[b] + 1.
+ * The combine happens inside the launch, in split order (bit-identical to uamd_attn_decode's):
+ *   nsplit * Hk * B <= 256 workgroups (all resident at once) and a launch tag given (tag / tag_dev as in uamd_gemv_prologue):
+ *   partials travel as 8-byte {value, tag} granules and every workgroup combines its 1 / nsplit of the outputs; otherwise
+ *   the last workgroup of a (batch, kv head) to arrive combines (a release / acquire fence pair and an arrival counter).
+ * partials: workspace of B * Hq * nsplit * (D + 2) * 8 bytes, zeroed ONCE by the caller. counters: int32 [B * Hk], zeroed ONCE
+ * by the caller (reset by the kernel). One stream of launches per workspace. */
+int uamd_attn_decode_fused(const void* qkv, int64_t ld_qkv, const void* cos_t, const void* sin_t, int64_t ld_cs,
+                           const int* kv_len, const int* rope_pos, void* k_cache, void* v_cache, int64_t cache_sb,
+                           int64_t cache_sh, float* partials, int* counters, void* out, int64_t out_sb, int B, int Hq,
+                           int Hk, int D, int s_max, int nsplit, int split_keys, int window, float scale, unsigned tag,
+                           const int* tag_dev, int dtype, void* stream);
 
 /* uamd_lora_xa2: same contract as uamd_lora_xa for R <= 64, streaming version (csrc/lora_side.hip): 32 rows per
  * block, K split over 4 waves, X and W through a per-wave LDS-DMA ring, fixed-order reduction. */

@@ -160,6 +160,131 @@ def test_attn_decode_matches_fp32_softmax(dtype, Hq, Hk, lens, window):
             assert (got - want).abs().max().item() < (1.2e-2 if dtype == torch.bfloat16 else 2e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Hq,Hk", [(4, 4), (8, 2), (32, 8), (7, 1), (28, 4)])
+@pytest.mark.parametrize("lens,window,S", [((0,), 0, 512), ((1, 127, 128), 0, 512), ((255, 300, 511), 0, 512), ((129, 400), 96, 512),
+                                           ((20,), 96, 512), ((1500, 100, 2046), 0, 2048)])
+def test_attn_decode_fused_is_the_three_launches_bit_for_bit(dtype, Hq, Hk, lens, window, S):
+    """uamd_attn_decode_fused (RoPE + append + split attention + last-arriver combine in ONE launch) against
+    uamd_rope_kv_append -> uamd_attn_decode: same output, same cache, bit for bit, over three consecutive tokens (the arrival
+    counters reset themselves), with the raw q|k|v row left untouched. lens = tokens already in the cache (0: the first one;
+    127 / 128 / 255: the new key is the last of a split / the first of the next / the cache's last slot). Launches of up to 256
+    workgroups combine through {value, tag} granules, larger ones (the S = 2048 case with 8 KV heads: 16 x 8 x 3 = 384) through the
+    arrival counter: both paths are in the grid."""
+    from unsloth_amd.kernels import decode as Dk
+    D, B = 128, len(lens)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(S).float()[:, None] * inv[None, :]
+    cos = torch.cat([ang.cos(), ang.cos()], dim=1).to(dtype).to(DEV)
+    sin = torch.cat([ang.sin(), ang.sin()], dim=1).to(dtype).to(DEV)
+    kc1 = torch.randn(B, Hk, S, D, generator=g(9)).to(dtype).to(DEV)
+    vc1 = torch.randn(B, Hk, S, D, generator=g(10)).to(dtype).to(DEV)
+    kc2, vc2 = kc1.clone(), vc1.clone()
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    part1 = torch.empty(B, Hq, S // 128, D + 2, dtype=torch.float32, device=DEV)
+    part2, cnt = Dk.fused_attn_workspace(B, Hq, Hk, S, D, 128, DEV)
+    scale = 1.0 / math.sqrt(D)
+    for step in range(3):
+        raw = torch.randn(B, (Hq + 2 * Hk) * D, generator=g(20 + step)).to(dtype).to(DEV)
+        q1 = raw.clone()
+        out1 = torch.empty(B, Hq * D, dtype=dtype, device=DEV)
+        Dk.rope_kv_append(q1, cos, sin, kv_len, kc1, vc1, Hq, Hk, D)
+        Dk.attn_decode(q1[:, :Hq * D], kc1, vc1, kv_len, out1, part1, 128, scale, len_add=1, window=window)
+        keep = raw.clone()
+        out2 = torch.full((B, Hq * D), float("nan"), dtype=dtype, device=DEV)
+        Dk.attn_decode_fused(raw, cos, sin, kv_len, kc2, vc2, out2, part2, cnt, 128, scale, Hq, window=window)
+        assert torch.equal(raw, keep)
+        assert torch.equal(out2, out1), (step, (out2.float() - out1.float()).abs().max())
+        assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+        assert int(cnt.abs().sum()) == 0                      # arrival counters (large launches) back at zero
+        kv_len += 1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nf4", [True, False])
+def test_gemv_fused_glu_epilogue_and_the_in_launch_lora_hand_off(dtype, nf4):
+    """uamd_gemv_fused with glu: gate | up in, h = SwiGLU out -- bit-identical to the gate|up launch + uamd_swiglu_fg when there
+    is no adapter (same dot products, same rounding points), within the summation-order noise of t = A x with one. And the
+    hand-off workspace: 40 launches over alternating tokens and shapes sharing it reproduce their first results bit for bit (a
+    stale or torn {value, tag} granule, or a tag that is used twice, shows up as a different or NaN output)."""
+    from unsloth_amd.kernels import decode as D
+    from unsloth_amd.kernels.swiglu import swiglu_fg_kernel
+    K, N, r = 1024, 1408, 8
+    gen = g(91)
+
+    def weight(n, seed):
+        if nf4:
+            W, qs, _ = _nf4(n, K, seed, dtype)
+            return W, qs
+        return (torch.randn(n, K, generator=g(seed)) * 0.05).to(dtype).to(DEV), None
+    bare, lora = [], []
+    for i in range(2):
+        W, qs = weight(N, 300 + i)
+        bias = (torch.randn(N, generator=gen) * 0.1).to(dtype).to(DEV) if i == 0 else None
+        bare.append((W, qs, None, None, None, bias))
+        lora.append((W, qs, (torch.randn(r, K, generator=gen) * 0.05).to(DEV), (torch.randn(N, r, generator=gen) * 0.05).to(DEV),
+                     2.0, bias))
+    xs = [torch.randn(K, generator=gen).to(dtype).to(DEV) for _ in range(2)]
+    for x in xs:
+        e, gg = D.linear_group(x, bare)
+        want = swiglu_fg_kernel(e.view(1, 1, N), gg.view(1, 1, N)).view(-1)
+        (h,) = D.linear_group(x, bare, fused=dict(mode=0, glu=True))
+        assert h.shape == (N,) and torch.equal(h, want)
+        e, gg = D.linear_group(x, lora)
+        want = swiglu_fg_kernel(e.view(1, 1, N), gg.view(1, 1, N)).view(-1)
+        (h,) = D.linear_group(x, lora, fused=dict(mode=0, glu=True))
+        assert (h.float() - want.float()).abs().max() <= 3e-2 * want.float().abs().max()
+    W3, qs3 = weight(384, 310)
+    other = [(W3, qs3, (torch.randn(16, K, generator=gen) * 0.05).to(DEV), (torch.randn(384, 16, generator=gen) * 0.05).to(DEV), 0.5, None)]
+    first = {}
+    for it in range(40):
+        x = xs[it & 1]
+        which = (it // 2) % 3
+        if which == 0:
+            (y,) = D.linear_group(x, lora, fused=dict(mode=0, glu=True))
+        elif which == 1:
+            y = torch.cat(D.linear_group(x, lora, fused=dict(mode=0)))
+        else:
+            (y,) = D.linear_group(x, other, fused=dict(mode=0))
+        assert bool(torch.isfinite(y.float()).all())
+        key = (it & 1, which)
+        if key in first:
+            assert torch.equal(y, first[key]), (it, key)
+        else:
+            first[key] = y.clone()
+    assert D.sync_workspace(x.device)._host >= 40          # one host tag per launch with adapters
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("nf4", [True, False])
+@pytest.mark.parametrize("K,Ns,r", [(14336, (512,), 16), (6144, (96, 40), 8), (4096, (1024, 256, 256), 16), (2080, (40,), 64)])
+def test_gemv_fused_lora_hand_off_at_long_rows(dtype, nf4, K, Ns, r):
+    """uamd_gemv_fused, t = A x inside the launch, where a row of A is split over 1 / 2 / 4 waves of a t workgroup (K <= 4096 /
+    8192 / 16384) and where a launch makes several trips per wave: against the exact fp64 product, and equal (to the fp32
+    summation order of t) to the two-launch path."""
+    from unsloth_amd.kernels import decode as D
+    gen = g(5)
+    x = torch.randn(K, generator=gen).to(dtype)
+    projs, wants = [], []
+    for i, N in enumerate(Ns):
+        if nf4:
+            W, qs, W32 = _nf4(N, K, 400 + i, dtype)
+        else:
+            Wd = (torch.randn(N, K, generator=g(400 + i)) * 0.05).to(dtype)
+            W, qs, W32 = Wd.to(DEV), None, Wd.float()
+        A = (torch.randn(r, K, generator=gen) * 0.05)
+        B = (torch.randn(N, r, generator=gen) * 0.05)
+        projs.append((W, qs, torch.nn.Parameter(A.to(DEV)), torch.nn.Parameter(B.to(DEV)), 2.0, None))
+        wants.append(W32.double().cpu() @ x.double() + 2.0 * (B.double() @ (A.to(dtype).double() @ x.double())))
+    got = D.linear_group(x.to(DEV), projs, fused=dict(mode=0))
+    two = D.linear_group(x.to(DEV), projs)
+    for y, y2, want, N in zip(got, two, wants, Ns):
+        assert y.shape == (N,)
+        scale = want.abs().max().item() + 1e-6
+        assert (y.double().cpu() - want).abs().max().item() / scale < (6e-3 if dtype == torch.bfloat16 else 1.5e-3)
+        assert (y.float() - y2.float()).abs().max().item() <= 1e-2 * scale
+
+
 def _tiny(load_in_4bit=True, r=8):
     from transformers import LlamaConfig
     from unsloth_amd import FastLanguageModel
@@ -322,7 +447,7 @@ def test_fast_generate_kwargs_follow_hf_semantics():
 @pytest.mark.parametrize("wdtype", ["same", "fp32"])
 def test_gemv_fused_prologues_match_the_separate_launches(dtype, wdtype):
     """uamd_gemv_fused: the token produced inside the launch (SwiGLU / residual add + RMSNorm, bit-identical x to the
-    separate kernels) and the LoRA t = A x computed by the launch's own blocks."""
+    separate kernels) and the LoRA t = A x computed by the launch's own first workgroups."""
     from unsloth_amd.kernels import decode as D
     from unsloth_amd.kernels.rms_layernorm import add_rms_fwd, rms_fwd
     from unsloth_amd.kernels.swiglu import swiglu_fg_kernel
@@ -368,8 +493,8 @@ def test_gemv_fused_prologues_match_the_separate_launches(dtype, wdtype):
 
 @pytest.mark.parametrize("load_in_4bit", [True, False])
 def test_fused_decode_step_matches_the_separate_launches(load_in_4bit):
-    """DecodeEngine with 7 launches per layer (uamd_gemv_fused) against the 14-launch step: same tokens, logits within the
-    fp32 summation-order noise of t = A x."""
+    """DecodeEngine with 5 launches per layer (uamd_gemv_fused, uamd_attn_decode_fused) against the 14-launch step: same tokens,
+    logits within the fp32 summation-order noise of t = A x."""
     from unsloth_amd.models import decode as MD
     model = _tiny(load_in_4bit)
     model.eval()

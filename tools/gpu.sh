@@ -11,6 +11,7 @@
 #   trace:POINT        the same with the HIP/RCCL stream timeline kept: TAG_POINT_overlap.csv (kernel start/end per stream)
 #   pmc:POINT          three PMC passes (FETCH_SIZE | WRITE_SIZE | MFMA-busy + clock) -> TAG_POINT_pmc_tables.md
 #   py:SCRIPT[:ARGS]   python SCRIPT ARGS > py_TAG_<basename>.log
+#   pyprof:SCRIPT[:ARGS]  the same under rocprofv3 --kernel-trace -> TAG_<basename>_kernel_stats.csv
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 TAG=$1; shift
@@ -102,6 +103,19 @@ for step in "$@"; do
       S=${arg%%:*}; A=""; [ "$S" != "$arg" ] && A=$(unplus "${arg#*:}")
       timeout 1200 python $S $A > $OUT/py_${TAG}_$(basename $S .py).log 2>&1
       echo "[$step] rc=$? ($SECONDS s)"; tail -25 $OUT/py_${TAG}_$(basename $S .py).log | cut -c1-200 ;;
+    pyprof)      # rocprofv3 --kernel-trace over a python script -> TAG_<basename>_kernel_stats.csv
+      S=${arg%%:*}; A=""; [ "$S" != "$arg" ] && A=$(unplus "${arg#*:}")
+      n=$(basename $S .py)
+      cd /tmp
+      timeout 900 rocprofv3 --kernel-trace -d $OUT/prof_${TAG}_$n -o prof -- python $R/$S $A > $OUT/pyprof_${TAG}_$n.log 2>&1
+      echo "[$step] rc=$? ($SECONDS s)"
+      cd $R
+      DB=$(find $OUT/prof_${TAG}_$n -name '*.db' | head -1)
+      if [ -n "$DB" ]; then
+        python tools/rocpd_stats.py $DB > $OUT/${TAG}_${n}_kernel_stats.csv 2> $OUT/${TAG}_${n}_stats.err
+        head -16 $OUT/${TAG}_${n}_kernel_stats.csv | cut -c1-150
+      else tail -5 $OUT/pyprof_${TAG}_$n.log; fi
+      rm -rf $OUT/prof_${TAG}_$n ;;
     *) echo "unknown step $step" ;;
   esac
 done

@@ -50,9 +50,13 @@ class GemvGroup(ctypes.Structure):
 class GemvPrologue(ctypes.Structure):
     """uamd_gemv_prologue (include/unsloth_amd.h)."""
 
-    _fields_ = [("mode", c_int), ("Rt", c_int), ("w_f32", c_int), ("_pad", c_int), ("x2", c_void_p), ("res", c_void_p),
+    _fields_ = [("mode", c_int), ("Rt", c_int), ("w_f32", c_int), ("glu", c_int), ("x2", c_void_p), ("res", c_void_p),
                 ("norm_w", c_void_p), ("h_out", c_void_p), ("a_rows", c_void_p), ("ld_a", c_int64), ("eps", c_float),
-                ("t_off", c_int * 4), ("_pad2", c_int)]
+                ("t_off", c_int * 4), ("tag", ctypes.c_uint), ("sync", c_void_p), ("tag_dev", c_void_p)]
+
+
+GEMV_SYNC_BYTES = 8 * 256               # UAMD_GEMV_SYNC_BYTES
+TAG_STRIDE = 1024                       # UAMD_TAG_STRIDE
 
 
 class LoraTnProblem(ctypes.Structure):
@@ -150,6 +154,9 @@ SIGNATURES = {
     "uamd_attn_decode": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p,
                                  c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
                                  c_void_p]),
+    "uamd_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_float, ctypes.c_uint, c_void_p, c_int, c_void_p]),
     "uamd_debug_mfma_probe": (c_int, [c_void_p, c_void_p]),
 }
 

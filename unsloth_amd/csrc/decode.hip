@@ -80,10 +80,54 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {             // wave-uni
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
 }
 
+// -DUAMD_DECODE_TRACE: s_memtime stamps at the phase boundaries of gemv_kernel and attn_decode_fused_kernel, 16 per wave
+// (tools/decode_trace.py); never in the shipped library.
+#ifdef UAMD_DECODE_TRACE
+__device__ unsigned long long* g_dec_trace = nullptr;
+#define DSTAMP(I)                                                                                  \
+    do {                                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+        dts[(I)] = __builtin_amdgcn_s_memtime();                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } while (0)
+#define DTRACE_DECL unsigned long long dts[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, __builtin_amdgcn_s_memrealtime(), 0, 0}
+#define DTRACE_FLUSH(NBLK_LINEAR, WAVES)                                                           \
+    do {                                                                                           \
+        if (g_dec_trace && (threadIdx.x & 63) == 0) {                                              \
+            unsigned long long* d = g_dec_trace + ((size_t)(NBLK_LINEAR) * (WAVES) + (threadIdx.x >> 6)) * 16; \
+            dts[14] = __builtin_amdgcn_s_memrealtime();      /* 100 MHz: calibrates the s_memtime ticks of dts[0..12] */ \
+            dts[15] = 1ull + (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 0xf);    /* HW_REG_XCC_ID[3:0] */ \
+            for (int i_ = 0; i_ < 16; ++i_) d[i_] = dts[i_];                                       \
+        }                                                                                          \
+    } while (0)
+#else
+#define DSTAMP(I) do { } while (0)
+#define DTRACE_DECL do { } while (0)
+#define DTRACE_FLUSH(A, B) do { } while (0)
+#endif
+
 #define UAMD_GEMV_MAX_GROUPS 4
 struct GemvArgs {
     const void* x;
     int K, n_groups, bs_shift, total_rows;         // blocksize = 1 << bs_shift
+    int n_tb;                                      // leading workgroups that compute t = A x (pro.a_rows) instead of weight rows
+    // what the load phase needs of each group, apart from g[] so that the kernel fetches it as ONE batch of scalar loads:
+    // hA = absmax_f32 (meta bit 8 set) or absmax_u8; meta = log2(blocksize2) | direct << 8 | lora_b_f32 << 9 | R << 16 (R = 0
+    // without an adapter)
+    const void* hW[UAMD_GEMV_MAX_GROUPS];
+    const void* hA[UAMD_GEMV_MAX_GROUPS];
+    const void* hA2[UAMD_GEMV_MAX_GROUPS];
+    const void* hB[UAMD_GEMV_MAX_GROUPS];
+    int64_t hldw[UAMD_GEMV_MAX_GROUPS];
+    int hldb[UAMD_GEMV_MAX_GROUPS];
+    int hmeta[UAMD_GEMV_MAX_GROUPS];
+    int hN[UAMD_GEMV_MAX_GROUPS];
+    // a wave's trip = RB adjacent rows of ONE group (a group's last trip may be short), so the group is chosen once per trip:
+    // group g owns trips [trip_start[g], trip_start[g + 1]). glu: a trip is RB / 2 rows n of gate and up each.
+    int trip_start[UAMD_GEMV_MAX_GROUPS + 1];
+    int total_trips;
+    int t_ks, t_kp;                                // t = A x: K parts per row (power of 2 <= 8), columns per part (multiple of 512)
     int row_start[UAMD_GEMV_MAX_GROUPS + 1];
     uamd_gemv_group g[UAMD_GEMV_MAX_GROUPS];
     uamd_gemv_prologue pro;                        // mode 0 / a_rows NULL = the plain kernel
@@ -92,9 +136,33 @@ struct GemvArgs {
 // One block = 8 waves sharing the decode table and the token x in LDS; a wave takes RB ADJACENT rows per trip and
 // issues every global load of the trip (weights, absmax codes) before anything else -- on the first trip even before
 // the table is built -- so 4-8 KB per wave are in flight while the fixed costs are paid. NIT = iterations over K.
+//
+// t = A x of the LoRA factors inside the launch (pro.a_rows): the first n_tb workgroups take no weight rows; their waves
+// compute the rows of t and publish each as ONE 8-byte store {fp32 value, tag} (device scope, so it is never torn and needs
+// no fence). The tag is the CALLER's: a value no earlier launch on this workspace has used (pro.tag, a host counter, plus
+// UAMD_TAG_STRIDE x *pro.tag_dev for launches replayed from a hipGraph -- the decode engine's step counter), so granules of
+// earlier launches never match and nothing is cleared or counted between launches. (The first version took the tag from an
+// epoch word that the launch's LAST workgroup advanced: an arrival counter on one word, 512 returning atomics = 6-10 us at
+// the end of every gate|up / down launch, profiles/r04x_decode_phase_trace.txt.) A weight-row wave polls the granules once,
+// after the dot products of its first rows (bounded spin; the producers wait for nobody, so they always get there).
 constexpr int GEMV_THREADS = 512;
+// Group fields: `p.g[gi].F` per ROW with a run-time gi made every access a scalar load whose ADDRESS waited for the previous one
+// -- ~20 dependent round trips (2.5 us) stood between the kernel's entry and its first weight load
+// (profiles/r04u_decode_phase_trace.txt). Now a trip belongs to ONE group: its fields are fetched once per trip from the h* arrays
+// (independent scalar loads at a run-time index, one wait), and kept as integers so that the loads built on them are typed
+// global (gptr) rather than flat.
+// a 64-bit value as a GLOBAL pointer (an integer cast to a plain pointer is a flat address: flat_load, which also counts on
+// lgkmcnt and drags a wait behind every row)
+template <typename V> __device__ __forceinline__ const __attribute__((address_space(1))) V* gptr(uint64_t a) {
+    return (const __attribute__((address_space(1))) V*)a;
+}
+template <typename T> __device__ __forceinline__ float bits16_to_f32(uint32_t b) {
+    union { uint16_t u; T h; } v;
+    v.u = (uint16_t)b;
+    return to_f32(v.h);
+}
 template <typename T, bool NF4, int NIT, int RB>
-__global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
+__global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(GemvArgs p) {     // <= 16: 2 blocks per CU
     constexpr int PAIRS = NF4 ? 16 : 4;              // 16-bit pairs of x per 16-byte weight load
     constexpr int ELEMS = 2 * PAIRS;                 // columns per lane per iteration
     extern __shared__ __attribute__((aligned(16))) unsigned char gemv_smem[];
@@ -105,6 +173,17 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = p.K;
+    DTRACE_DECL;
+    DSTAMP(0);
+    {   // every 64-byte line of the ~0.9 KB kernarg segment in ONE batch of scalar loads: left to the compiler they are fetched
+        // as they are needed, ~8 dependent scalar-cache misses in a row before the first weight load goes out
+        const __attribute__((address_space(4))) int* ka =
+            (const __attribute__((address_space(4))) int*)__builtin_amdgcn_kernarg_segment_ptr();
+        int touch = 0;
+#pragma unroll
+        for (int o = 0; o < (int)sizeof(GemvArgs); o += 64) touch |= ka[o / 4];
+        asm volatile("" ::"s"(touch));
+    }
     // columns past K: x is zero there, so the lane may read any valid address instead (no branches in the row loop)
     int koff[NIT];
 #pragma unroll
@@ -112,51 +191,102 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
         const int k0 = (i * 64 + lane) * ELEMS;
         koff[i] = k0 < K ? k0 : 0;
     }
-    const int nwaves = gridDim.x * (GEMV_THREADS / 64);
+    const int n_tb = p.n_tb;
+    const bool t_block = (int)blockIdx.x < n_tb;
+    const int nwaves = ((int)gridDim.x - n_tb) * (GEMV_THREADS / 64);
+    // the launch's tag (see above): a host constant plus, under a hipGraph, a device counter the caller advances per replay
+    unsigned tag = p.pro.tag;
+    if (p.pro.tag_dev) tag += (unsigned)*p.pro.tag_dev * UAMD_TAG_STRIDE;
     int gis[RB], ns[RB];
     float direct[RB];                                // 1: single-level fp32 absmax, 0: nested
     uint4 w[RB][NIT];
     uint32_t a8[RB][NIT];
     float a2[RB][NIT];
-    auto load_rows = [&](int row0) {
+    uint32_t braw[RB];                               // lane j: B[n][j] of the row's adapter (raw bits), loaded with the weights
+    const int n_groups = p.n_groups, glu = p.pro.glu, total_trips = p.total_trips, bs_shift = p.bs_shift;
+    int t_gi = 0;                                    // the current trip's group (glu: row r belongs to group r & 1)
+    bool valid[RB];
+    auto load_rows = [&](int trip, int r_lo, int r_hi) {      // rows [r_lo, r_hi) of the trip (compile-time bounds after inlining)
+        int gi = 0;
+#pragma unroll
+        for (int i = 1; i < UAMD_GEMV_MAX_GROUPS; ++i)
+            if (i < n_groups && trip >= p.trip_start[i]) gi = i;
+        t_gi = gi;
+        // the trip's group, fetched ONCE: independent scalar loads at a run-time index, one wait for all of them
+        // (glu: both groups, picked by the compile-time parity of r below)
+        const int n0 = glu ? trip * (RB / 2) : (trip - p.trip_start[gi]) * RB;
+        const uint64_t sW = (uint64_t)p.hW[gi], sB = (uint64_t)p.hB[gi];
+        const int sMeta = p.hmeta[gi], sLdb = p.hldb[gi], sN = p.hN[gi];
+        uint64_t sA = 0, sA2 = 0;
+        int64_t sLdw = 0;
+        if constexpr (NF4) { sA = (uint64_t)p.hA[gi]; sA2 = (uint64_t)p.hA2[gi]; } else { sLdw = p.hldw[gi]; }
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const int row = min(row0 + r, p.total_rows - 1);         // a duplicate of the last row, not stored
-            int gi = 0;
-#pragma unroll
-            for (int i = 1; i < UAMD_GEMV_MAX_GROUPS; ++i)
-                if (i < p.n_groups && row >= p.row_start[i]) gi = i;
-            gis[r] = gi;
-            ns[r] = row - p.row_start[gi];
-            const uamd_gemv_group& g = p.g[gi];
-            direct[r] = g.absmax_f32 ? 1.f : 0.f;
+            if (r < r_lo || r >= r_hi) continue;
+            const int gr = r & 1;
+            const uint64_t gW = glu ? (uint64_t)p.hW[gr] : sW, gB = glu ? (uint64_t)p.hB[gr] : sB;
+            const int meta = glu ? p.hmeta[gr] : sMeta, ldb = glu ? p.hldb[gr] : sLdb, Ng = glu ? p.hN[0] : sN;
+            const int nraw = glu ? n0 + (r >> 1) : n0 + r;
+            valid[r] = nraw < Ng;
+            const int nrow = min(nraw, Ng - 1);                      // past the group's end: a duplicate of its last row, not stored
+            gis[r] = glu ? gr : gi;
+            ns[r] = nrow;
+            const bool dir = (meta >> 8) & 1;
+            direct[r] = dir ? 1.f : 0.f;
+            braw[r] = 0;
+            if (gB && lane < (meta >> 16)) {
+                const int64_t bi = (int64_t)nrow * ldb + lane;
+                if ((meta >> 9) & 1) braw[r] = gptr<uint32_t>(gB)[bi];
+                else braw[r] = gptr<uint16_t>(gB)[bi];
+            }
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 a8[r][i] = 0;
                 a2[r][i] = 0.f;
-                if (NF4) {
-                    const int64_t e0 = (int64_t)ns[r] * K + koff[i];
-                    const uamd_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const uamd_u32x4*>((const uint8_t*)g.W + (e0 >> 1)));
+                if constexpr (NF4) {
+                    const uint64_t gA = glu ? (uint64_t)p.hA[gr] : sA, gA2 = glu ? (uint64_t)p.hA2[gr] : sA2;
+                    const int64_t e0 = (int64_t)nrow * K + koff[i];
+                    const uamd_u32x4 v = __builtin_nontemporal_load(gptr<uamd_u32x4>(gW + (e0 >> 1)));
                     w[r][i] = make_uint4(v[0], v[1], v[2], v[3]);
-                    const int64_t blk = e0 >> p.bs_shift;
-                    if (g.absmax_f32) {
-                        a2[r][i] = g.absmax_f32[blk];
+                    const int64_t blk = e0 >> bs_shift;
+                    if (dir) {
+                        a2[r][i] = gptr<float>(gA)[blk];
                     } else {
-                        a8[r][i] = g.absmax_u8[blk];
-                        a2[r][i] = g.absmax2[blk >> g.blocksize2];       // (the host stores log2(blocksize2) here)
+                        a8[r][i] = gptr<uint8_t>(gA)[blk];
+                        a2[r][i] = gptr<float>(gA2)[blk >> (meta & 0xff)];
                     }
                 } else {
-                    w[r][i] = *reinterpret_cast<const uint4*>((const T*)g.W + (int64_t)ns[r] * g.ldw + koff[i]);
+                    const int64_t ldw = glu ? p.hldw[gr] : sLdw;
+                    const uamd_u32x4 v = *gptr<uamd_u32x4>(gW + ((int64_t)nrow * ldw + koff[i]) * (int64_t)sizeof(T));
+                    w[r][i] = make_uint4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
     };
-    int row0 = (blockIdx.x * (GEMV_THREADS / 64) + wave_u) * RB;
-    if (row0 < p.total_rows) load_rows(row0);
+    int trip = t_block ? total_trips : ((int)blockIdx.x - n_tb) * (GEMV_THREADS / 64) + wave_u;
+    if (trip < total_trips) load_rows(trip, 0, RB);
+    // t workgroups: wave (row r, part q of KS) of t = A x streams its <= 8 vectors of the A row NOW, with everything else of the
+    // launch -- A does not depend on the token -- into the registers a weight-row wave uses for its weights
+    const int KS = p.t_ks, Kp = p.t_kp;                    // parts per row (1, 2, 4, 8: adjacent waves of one block), columns per part
+    const int t_wi = (int)blockIdx.x * (GEMV_THREADS / 64) + wave_u;
+    const int t_r = t_wi / KS, t_q = t_wi - t_r * KS;
+    const bool t_wave = t_block && p.pro.a_rows && t_r < p.pro.Rt;
+    uint4* const wflat = &w[0][0];
+    if (t_wave) {
+        const T* arow = (const T*)p.pro.a_rows + (int64_t)t_r * p.pro.ld_a;
+        const int k_end = min(K, (t_q + 1) * Kp);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k0 = t_q * Kp + (j * 64 + lane) * 8;
+            wflat[j] = make_uint4(0, 0, 0, 0);
+            if (k0 < k_end) wflat[j] = *reinterpret_cast<const uint4*>(arow + k0);
+        }
+    }
+    DSTAMP(1);
     // ---- block setup while those loads fly: x (zero-padded; optionally PRODUCED here: SwiGLU of two vectors, or
     //      residual add + RMSNorm), t = A x of the LoRA factors, the nested-absmax maps, the byte -> value-pair table
     float* tl = reinterpret_cast<float*>(gemv_smem + NIT * 64 * ELEMS * sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 +
-                                          (NF4 ? 256 * 32 * 4 : 0));          // [64 ranks x 4 groups] + 8 reduction slots
+                                          (NF4 ? 256 * 32 * 4 : 0));          // [64 ranks x 4 groups] + 8 + 8 reduction slots
     {
         const T* xp = (const T*)p.x;
         const int nvec = NIT * 64 * ELEMS / 8;
@@ -189,53 +319,126 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
         } else {
             // x = rmsnorm(h) * w, h = T(a + res) (a = p.x may be NULL: h = res): fast_rms_layernorm_inference after the
             // residual add of the decoder layer (llama.py:352-606), rounding points of csrc/rms_layernorm.hip. Every block
-            // normalises the whole row for itself; block 0 also writes h (the next residual) to pro.h_out.
-            const T* rp = (const T*)p.pro.res;
-            T* hp = (T*)p.pro.h_out;
-            float ss = 0.f;
-            for (int v = tid; v < nvec; v += GEMV_THREADS) {
-                union { uint4 r; T e[8]; } a, b;
-                b.r = make_uint4(0, 0, 0, 0);
-                if (v * 8 < K) {
-                    b.r = *reinterpret_cast<const uint4*>(rp + v * 8);
-                    if (xp) {
-                        a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) b.e[j] = from_f32<T>(to_f32(a.e[j]) + to_f32(b.e[j]));
-                    }
-                    if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = b.r;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = to_f32(b.e[j]); ss += f * f; }
-                }
-                reinterpret_cast<uint4*>(xs)[v] = b.r;                              // h for now
-            }
-            ss = wave_sum_dpp(ss);
-            if (lane == 0) tl[256 + wave_u] = ss;
-            __syncthreads();
-            float tot = 0.f;
-#pragma unroll
-            for (int w = 0; w < GEMV_THREADS / 64; ++w) tot += tl[256 + w];
-            const float inv = rsqrtf(tot / (float)K + p.pro.eps);
-            for (int v = tid; v < nvec; v += GEMV_THREADS) {
-                if (v * 8 >= K) continue;
-                union { uint4 r; T e[8]; } h;
-                h.r = reinterpret_cast<uint4*>(xs)[v];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float normed = to_f32(h.e[j]) * inv;
-                    if (p.pro.w_f32) {
-                        h.e[j] = from_f32<T>(normed * ((const float*)p.pro.norm_w)[v * 8 + j]);
-                    } else {                                        // (x * r).to(W.dtype) * W, product in W's dtype
-                        h.e[j] = from_f32<T>(round_to<T>(round_to<T>(normed) * to_f32(((const T*)p.pro.norm_w)[v * 8 + j])));
+            // normalises the whole row for itself; block 0 also writes h (the next residual) to pro.h_out. A thread keeps its
+            // (at most 4) vectors of h AND of the norm weight in registers across the one barrier of the reduction: all global
+            // loads of the prologue are issued together, up front.
+            constexpr int VPT = (NIT * 64 * ELEMS / 8 + GEMV_THREADS - 1) / GEMV_THREADS;
+            if constexpr (VPT == 1) {            // K <= 4096 (NF4: the hidden size of every 7-8 B model): registers
+                const T* rp = (const T*)p.pro.res;
+                T* hp = (T*)p.pro.h_out;
+                union V8 { uint4 r; T e[8]; };
+                V8 av[VPT], hv[VPT], wv[VPT];
+                uint4 wf[VPT][2];
+    #pragma unroll
+                for (int k = 0; k < VPT; ++k) {
+                    const int v = tid + k * GEMV_THREADS;
+                    av[k].r = make_uint4(0, 0, 0, 0);
+                    hv[k].r = make_uint4(0, 0, 0, 0);
+                    wv[k].r = make_uint4(0, 0, 0, 0);
+                    wf[k][0] = wf[k][1] = make_uint4(0, 0, 0, 0);
+                    if (v * 8 < K) {
+                        hv[k].r = *reinterpret_cast<const uint4*>(rp + v * 8);
+                        if (xp) av[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);
+                        if (p.pro.w_f32) {
+                            wf[k][0] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8);
+                            wf[k][1] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8 + 4);
+                        } else {
+                            wv[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.norm_w + v * 8);
+                        }
                     }
                 }
-                reinterpret_cast<uint4*>(xs)[v] = h.r;
+                float ss = 0.f;
+    #pragma unroll
+                for (int k = 0; k < VPT; ++k) {
+                    const int v = tid + k * GEMV_THREADS;
+                    if (v * 8 < K) {
+                        if (xp) {
+    #pragma unroll
+                            for (int j = 0; j < 8; ++j) hv[k].e[j] = from_f32<T>(to_f32(av[k].e[j]) + to_f32(hv[k].e[j]));
+                        }
+                        if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = hv[k].r;
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float f = to_f32(hv[k].e[j]); ss += f * f; }
+                    }
+                }
+                ss = wave_sum_dpp(ss);
+                if (lane == 0) tl[256 + wave_u] = ss;
+                __syncthreads();
+                float tot = 0.f;
+    #pragma unroll
+                for (int w = 0; w < GEMV_THREADS / 64; ++w) tot += tl[256 + w];
+                const float inv = rsqrtf(tot / (float)K + p.pro.eps);
+    #pragma unroll
+                for (int k = 0; k < VPT; ++k) {
+                    const int v = tid + k * GEMV_THREADS;
+                    if (v >= NIT * 64 * ELEMS / 8) continue;
+                    V8 o;
+                    o.r = make_uint4(0, 0, 0, 0);
+                    if (v * 8 < K) {
+                        const float wfl[8] = {__uint_as_float(wf[k][0].x), __uint_as_float(wf[k][0].y), __uint_as_float(wf[k][0].z),
+                                              __uint_as_float(wf[k][0].w), __uint_as_float(wf[k][1].x), __uint_as_float(wf[k][1].y),
+                                              __uint_as_float(wf[k][1].z), __uint_as_float(wf[k][1].w)};
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float normed = to_f32(hv[k].e[j]) * inv;
+                            if (p.pro.w_f32) {
+                                o.e[j] = from_f32<T>(normed * wfl[j]);
+                            } else {                                    // (x * r).to(W.dtype) * W, product in W's dtype
+                                o.e[j] = from_f32<T>(round_to<T>(round_to<T>(normed) * to_f32(wv[k].e[j])));
+                            }
+                        }
+                    }
+                    reinterpret_cast<uint4*>(xs)[v] = o.r;
+                }
+            } else {                             // longer rows: two passes over LDS (the register version costs an occupancy step)
+                const T* rp = (const T*)p.pro.res;
+                T* hp = (T*)p.pro.h_out;
+                float ss = 0.f;
+                for (int v = tid; v < nvec; v += GEMV_THREADS) {
+                    union { uint4 r; T e[8]; } a, b;
+                    b.r = make_uint4(0, 0, 0, 0);
+                    if (v * 8 < K) {
+                        b.r = *reinterpret_cast<const uint4*>(rp + v * 8);
+                        if (xp) {
+                            a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
+    #pragma unroll
+                            for (int j = 0; j < 8; ++j) b.e[j] = from_f32<T>(to_f32(a.e[j]) + to_f32(b.e[j]));
+                        }
+                        if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = b.r;
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float f = to_f32(b.e[j]); ss += f * f; }
+                    }
+                    reinterpret_cast<uint4*>(xs)[v] = b.r;                              // h for now
+                }
+                ss = wave_sum_dpp(ss);
+                if (lane == 0) tl[256 + wave_u] = ss;
+                __syncthreads();
+                float tot = 0.f;
+    #pragma unroll
+                for (int w = 0; w < GEMV_THREADS / 64; ++w) tot += tl[256 + w];
+                const float inv = rsqrtf(tot / (float)K + p.pro.eps);
+                for (int v = tid; v < nvec; v += GEMV_THREADS) {
+                    if (v * 8 >= K) continue;
+                    union { uint4 r; T e[8]; } h;
+                    h.r = reinterpret_cast<uint4*>(xs)[v];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float normed = to_f32(h.e[j]) * inv;
+                        if (p.pro.w_f32) {
+                            h.e[j] = from_f32<T>(normed * ((const float*)p.pro.norm_w)[v * 8 + j]);
+                        } else {                                        // (x * r).to(W.dtype) * W, product in W's dtype
+                            h.e[j] = from_f32<T>(round_to<T>(round_to<T>(normed) * to_f32(((const T*)p.pro.norm_w)[v * 8 + j])));
+                        }
+                    }
+                    reinterpret_cast<uint4*>(xs)[v] = h.r;
+                }
             }
         }
         if (NF4) {
             for (int i = tid; i < UAMD_GEMV_MAX_GROUPS * 256; i += GEMV_THREADS) {
                 const int gi = i >> 8;
-                code2[i] = (gi < p.n_groups && p.g[gi].code2) ? p.g[gi].code2[i & 255] : 0.f;
+                const float* c2 = p.g[gi].code2;
+                code2[i] = (gi < p.n_groups && c2) ? c2[i & 255] : 0.f;
             }
             if (tid < 256) {       // thread e builds entry e (high nibble = even element): 32 copies = 8 x 16 bytes
                 const uint32_t v = pack2<T>(kNF4d[tid >> 4], kNF4d[tid & 15]);
@@ -245,34 +448,79 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
             }
         }
     }
+    DSTAMP(2);
     __syncthreads();
-    // ---- t = A x for the stacked LoRA A rows of the launch's projections ([Rt, K], activation dtype): every block
-    //      computes all of it (Rt <= 256 rows x K: L2-resident, 1-2 us) instead of a launch of its own in front of this one
-    if (p.pro.a_rows) {
-        const T* Ar = (const T*)p.pro.a_rows;
-        const int Rt = p.pro.Rt;
-        for (int r = wave_u; r < Rt; r += GEMV_THREADS / 64) {
-            float acc = 0.f;
-            for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
-                union { uint4 r; uint32_t w[4]; } a, xv;
-                a.r = *reinterpret_cast<const uint4*>(Ar + (int64_t)r * p.pro.ld_a + k0);
-                xv.r = *reinterpret_cast<const uint4*>(xs + k0);
+    DSTAMP(3);
+    // ---- t = A x for the stacked LoRA A rows of the launch's projections ([Rt, K], activation dtype), by the first n_tb
+    //      workgroups: (row, K part) per wave from the vectors loaded at entry, published as {value, tag}
+    unsigned long long* gran = reinterpret_cast<unsigned long long*>(p.pro.sync);
+    if (t_block && p.pro.a_rows) {
+        float acc = 0.f;
+        if (t_wave) {
+            const int k_end = min(K, (t_q + 1) * Kp);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = Dot2<T>::run(a.w[j], xv.w[j], acc);
+            for (int j = 0; j < 8; ++j) {
+                const int k0 = t_q * Kp + (j * 64 + lane) * 8;
+                if (k0 < k_end) {
+                    union { uint4 r; uint32_t w[4]; } av, xv;
+                    av.r = wflat[j];
+                    xv.r = *reinterpret_cast<const uint4*>(xs + k0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = Dot2<T>::run(av.w[q], xv.w[q], acc);
+                }
             }
             acc = wave_sum_dpp(acc);
-            if (lane == 0) tl[r] = acc;
         }
-        __syncthreads();
+        if (KS > 1) {                                   // parts of a row -> its part-0 wave, through LDS, summed in part order
+            if (lane == 0) tl[256 + 8 + wave_u] = acc;
+            __syncthreads();
+            if (t_wave && t_q == 0) {
+                acc = 0.f;
+                for (int q = 0; q < KS; ++q) acc += tl[256 + 8 + wave_u + q];
+            }
+        }
+        DSTAMP(4);
+        if (t_wave && t_q == 0 && lane == 0)
+            __hip_atomic_store(gran + t_r, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(acc),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    bool have_t = false;
+    auto fetch_t = [&]() {                            // the launch's t into LDS (every wave for itself; identical values)
+        for (int i = lane; i < p.pro.Rt; i += 64) {
+            unsigned long long v = 0;
+            bool ok = false;
+            for (int spin = 0; spin < (1 << 18); ++spin) {
+                v = __hip_atomic_load(gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = (unsigned)(v >> 32) == tag;
+                if (ok) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+            tl[i] = ok ? __uint_as_float((unsigned)v) : __builtin_nanf("");
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     const uint32_t* lut_lane = lut2 + (lane & 31);
     const uint4* x_lane = reinterpret_cast<const uint4*>(xs) + lane * (PAIRS / 4);
 
-    for (; row0 < p.total_rows; row0 += nwaves * RB) {
+    for (bool first = true; trip < total_trips; trip += nwaves, first = false) {
+        // per-trip (glu: per-parity) fields of the compute phase: scalar selects, once
+        const int cgi = t_gi;
+        const float sOff = p.g[cgi].offset, sScale = p.g[cgi].lora_scale;
+        const int sMeta = p.hmeta[cgi];
+        const int sToff = p.pro.t_off[cgi];
+        const float* sLt = p.g[cgi].lora_t;
         float acc[RB];
+        int n_s[RB];
+        bool v_s[RB];
+        const bool more = trip + nwaves < total_trips;
+        // the rows in two halves: the next trip's loads go out as soon as the registers of a half are free, i.e. half of them
+        // have the other half's dot products to hide behind (they used to be issued after the whole trip)
+        constexpr int HB = RB >= 2 ? RB / 2 : RB;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const uamd_gemv_group& g = p.g[gis[r]];
+            const int gr = r & 1;
+            const float g_offset = glu ? p.g[gr].offset : sOff;
             acc[r] = 0.f;
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
@@ -285,7 +533,7 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
                 }
                 if (NF4) {
                     // branch-free (a branch here splits the row into basic blocks and the dot products sink past all of them)
-                    const float a_nested = code2[gis[r] * 256 + a8[r][i]] * a2[r][i] + g.offset;
+                    const float a_nested = code2[(glu ? gr : cgi) * 256 + a8[r][i]] * a2[r][i] + g_offset;
                     const float a = direct[r] * a2[r][i] + (1.f - direct[r]) * a_nested;       // direct is exactly 0 or 1
                     uint32_t dec[16];                        // all 16 table reads of the load first: one LDS latency, not 16
 #pragma unroll
@@ -308,40 +556,64 @@ __global__ void __launch_bounds__(GEMV_THREADS) gemv_kernel(GemvArgs p) {
                 if (NIT > 2) __builtin_amdgcn_sched_barrier(0);    // keep the table / x reads of later iterations from piling up in registers
             }
             // LoRA: lane j adds s * B[n][j] * t[j]  (t = A x, fp32, from the preceding GEMV launch over the A rows)
-            if (g.lora_b && g.R > 0 && lane < g.R) {
-                const float bv = g.lora_b_f32 ? ((const float*)g.lora_b)[(int64_t)ns[r] * g.ld_lb + lane]
-                                              : to_f32(((const T*)g.lora_b)[(int64_t)ns[r] * g.ld_lb + lane]);
-                // t from the preceding launch (g.lora_t) or computed by this block (pro.a_rows: rows t_off[g] ..)
-                const float tv = p.pro.a_rows ? tl[p.pro.t_off[gis[r]] + lane] : g.lora_t[lane];
-                acc[r] += g.lora_scale * bv * tv;
+            const int g_meta = glu ? p.hmeta[gr] : sMeta;
+            const int g_R = g_meta >> 16;
+            if (g_R > 0) {
+                // t from the preceding launch (lora_t) or from this launch's t workgroups (pro.a_rows: rows t_off[g] ..)
+                if (p.pro.a_rows && !have_t) { DSTAMP(5); fetch_t(); have_t = true; DSTAMP(6); }
+                if (lane < g_R) {
+                    const int toff = glu ? p.pro.t_off[gr] : sToff;
+                    const float tv = p.pro.a_rows ? tl[toff + lane] : (glu ? p.g[gr].lora_t : sLt)[lane];
+                    const float bv = ((g_meta >> 9) & 1) ? __uint_as_float(braw[r]) : bits16_to_f32<T>(braw[r]);
+                    acc[r] += (glu ? p.g[gr].lora_scale : sScale) * bv * tv;
+                }
             }
+            n_s[r] = ns[r];
+            v_s[r] = valid[r];
+            if (more && (r + 1) % HB == 0) load_rows(trip + nwaves, r + 1 - HB, r + 1);
         }
         float tot[RB];
 #pragma unroll
         for (int r = 0; r < RB; ++r) tot[r] = wave_sum_dpp(acc[r]);
-        const int cur = row0;
-        int gi_s[RB], n_s[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) { gi_s[r] = gis[r]; n_s[r] = ns[r]; }
-        if (row0 + nwaves * RB < p.total_rows) load_rows(row0 + nwaves * RB);        // next trip's loads before the stores
+        if (first) DSTAMP(7);
         if (lane == 0) {
+            if (RB >= 2 && p.pro.glu) {
+                // h[n] = (e * sigmoid(e)).to(T) * g with e, g rounded to T first: what uamd_swiglu_fg makes of the two stored rows
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                if (cur + r >= p.total_rows) break;
-                const uamd_gemv_group& g = p.g[gi_s[r]];
-                float v = tot[r];
-                if (g.bias) v += to_f32(((const T*)g.bias)[n_s[r]]);
-                if (g.y_f32) ((float*)g.y)[n_s[r]] = v;
-                else ((T*)g.y)[n_s[r]] = from_f32<T>(v);
+                for (int r = 0; r + 1 < RB; r += 2) {
+                    if (!v_s[r]) break;
+                    float e = tot[r], gg = tot[r + 1];
+                    if (p.g[0].bias) e += to_f32(((const T*)p.g[0].bias)[n_s[r]]);
+                    if (p.g[1].bias) gg += to_f32(((const T*)p.g[1].bias)[n_s[r]]);
+                    e = round_to<T>(e);
+                    gg = round_to<T>(gg);
+                    const float f = e * (1.0f / (1.0f + __expf(-e)));
+                    ((T*)p.g[0].y)[n_s[r]] = from_f32<T>(round_to<T>(f) * gg);
+                }
+            } else {
+                const void* gb = p.g[cgi].bias;
+                void* gy = p.g[cgi].y;
+                const int yf = p.g[cgi].y_f32;
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    if (!v_s[r]) break;
+                    float v = tot[r];
+                    if (gb) v += to_f32(((const T*)gb)[n_s[r]]);
+                    if (yf) ((float*)gy)[n_s[r]] = v;
+                    else ((T*)gy)[n_s[r]] = from_f32<T>(v);
+                }
             }
         }
     }
+    DSTAMP(8);
+    DSTAMP(9);
+    DTRACE_FLUSH(blockIdx.x, GEMV_THREADS / 64);
 }
 
 template <typename T, bool NF4, int NIT, int RB>
-int launch_gemv_n(const GemvArgs& a, hipStream_t st) {
+int launch_gemv_n(const GemvArgs& a0, hipStream_t st) {
     constexpr int ELEMS = NF4 ? 32 : 8;
-    const int lds = NIT * 64 * ELEMS * (int)sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 + (NF4 ? 256 * 32 * 4 : 0) + (256 + 8) * 4;
+    const int lds = NIT * 64 * ELEMS * (int)sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 + (NF4 ? 256 * 32 * 4 : 0) + (256 + 16) * 4;
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -351,11 +623,20 @@ int launch_gemv_n(const GemvArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    const int per_block = (GEMV_THREADS / 64) * RB;
-    int blocks = (a.total_rows + per_block - 1) / per_block;     // one trip per wave until the chip is full
-    if (blocks > 512) blocks = 512;                               // 2 blocks (16 waves) per CU
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((gemv_kernel<T, NF4, NIT, RB>), dim3(blocks), dim3(GEMV_THREADS), lds, st, a);
+    if (a0.pro.glu && RB < 2) return UAMD_ERR_ARG;                // a wave needs the gate row and the up row in one trip
+    GemvArgs a = a0;
+    int trips = 0;
+    for (int i = 0; i < UAMD_GEMV_MAX_GROUPS; ++i) {
+        a.trip_start[i] = trips;
+        if (i < a.n_groups && !a.pro.glu) trips += (a.hN[i] + RB - 1) / RB;
+    }
+    if (a.pro.glu) trips = (a.hN[0] + RB / 2 - 1) / (RB / 2 > 0 ? RB / 2 : 1);
+    a.trip_start[UAMD_GEMV_MAX_GROUPS] = trips;
+    a.total_trips = trips;
+    int blocks = (trips + GEMV_THREADS / 64 - 1) / (GEMV_THREADS / 64);     // one trip per wave until the chip is full
+    if (blocks > 512 - a.n_tb) blocks = 512 - a.n_tb;             // 2 blocks (16 waves) per CU, the t workgroups included: a 513th
+    if (blocks < 1) blocks = 1;                                   // block starts when another one ends, i.e. costs a whole round
+    hipLaunchKernelGGL((gemv_kernel<T, NF4, NIT, RB>), dim3(blocks + a.n_tb), dim3(GEMV_THREADS), lds, st, a);
     return uamd_launch_status();
 }
 
@@ -535,7 +816,307 @@ __global__ void __launch_bounds__(128) attn_decode_combine_kernel(const float* _
     out[(int64_t)b * o_sb + (int64_t)h * DD + d] = from_f32<T>(ll > 0.f ? oo / ll : 0.f);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// RoPE + cache append + split-KV attention + combine as ONE launch (uamd_attn_decode_fused). Same per-key arithmetic, key
+// order and combine order as rope_append_kernel -> attn_decode_kernel -> attn_decode_combine_kernel, so the result is
+// bit-identical to the three launches. What changes:
+//   * every block rotates the G query heads of its KV head itself from the raw q|k|v row (G x 64 pairs; qkv is not written);
+//   * the block whose split owns position len0 = kv_len[b] rotates the new k, appends k and v to the cache and takes both
+//     from LDS when its loop reaches that key (a store followed by a load of the same line in one kernel would depend on the
+//     vector cache's write policy);
+//   * all K / V loads of a split (8 wave-loads of each for 128 keys) are issued before the first one is used: the old loop
+//     paid one HBM round trip per 16 keys, eight in a row;
+//   * the combine. Launches of up to 256 blocks (context 4096 at 8 KV heads): partials travel as 8-byte {value, tag}
+//     granules (one device-scope store each, never torn, no fence; the caller's launch tag as in gemv_kernel) and every block
+//     combines ITS 1 / nsplit of the G x 128 outputs, polling the granules of all splits in split order. Larger launches
+//     (not certainly resident at once): plain partials, release fence, arrival counter; the last block of a (batch, KV head)
+//     combines everything after an acquire fence -- measured at 21 us for this tail (buffer_wbl2 4.5 us, the atomic's round
+//     trip 5.5 us, the cold re-read of the partials 9.5 us; profiles/r04u_decode_phase_trace.txt), the price of the two
+//     launches it replaces.
+struct AttnDecFusedArgs {
+    const void* qkv; int64_t ld_qkv;
+    const void* cos_t; const void* sin_t; int64_t ld_cs;
+    const int* kv_len; const int* rope_pos;
+    void* kc; void* vc; int64_t c_sb, c_sh;
+    float* part; int* counters;
+    void* out; int64_t o_sb;
+    int Hq, Hk, s_max, nsplit, split_keys, window;
+    float scale_log2;
+    int gran;            // 1: partials travel as {value, tag} granules and every block combines its share (whole launch resident)
+    unsigned tag;
+    const int* tag_dev;
+};
+template <typename T, int G>
+__global__ void __launch_bounds__(256) attn_decode_fused_kernel(AttnDecFusedArgs a) {
+    constexpr int NI = 8;                                 // wave-loads of K (and of V) in flight: 128 keys per block trip
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = lane >> 4, l16 = lane & 15;
+    const int len0 = a.kv_len[b];                         // keys already in the cache = index of the new one
+    const int pos = a.rope_pos ? a.rope_pos[b] : len0;
+    const int len = len0 + 1;
+    const int first = (a.window > 0 && len > a.window) ? len - a.window : 0;
+    const int s0 = split * a.split_keys, s1 = min(s0 + a.split_keys, len);
+    const bool own = len0 >= s0 && len0 < s0 + a.split_keys;
+    unsigned tag = a.tag;                                   // the caller's launch tag (see gemv_kernel)
+    if (a.tag_dev) tag += (unsigned)*a.tag_dev * UAMD_TAG_STRIDE;
+    DTRACE_DECL;
+    DSTAMP(0);
+    __shared__ float q_s[G][DD];
+    __shared__ __attribute__((aligned(16))) T kn[DD];
+    __shared__ __attribute__((aligned(16))) T vn[DD];
+    __shared__ float red[4][G][2];
+    __shared__ float red_o[4][G][DD];
+    __shared__ int last_s;
+    const T* row = (const T*)a.qkv + (int64_t)b * a.ld_qkv;
+    const T* cs = (const T*)a.cos_t + (int64_t)pos * a.ld_cs;
+    const T* sn = (const T*)a.sin_t + (int64_t)pos * a.ld_cs;
+    constexpr int HALF = DD / 2;
+    // rounding points of rope_append_kernel (= the training kernel for 16-bit tables): every product and the sum rounded to T
+    for (int i = tid; i < G * HALF; i += 256) {
+        const int g = i / HALF, j = i - g * HALF;
+        const T* v = row + (int64_t)(kvh * G + g) * DD;
+        const float c = to_f32(cs[j]), s = to_f32(sn[j]);
+        const float x1 = to_f32(v[j]), x2 = to_f32(v[j + HALF]);
+        q_s[g][j] = round_to<T>(round_to<T>(x1 * c) - round_to<T>(x2 * s)) * a.scale_log2;
+        q_s[g][j + HALF] = round_to<T>(round_to<T>(x2 * c) + round_to<T>(x1 * s)) * a.scale_log2;
+    }
+    if (own) {
+        if (tid < HALF) {
+            const int j = tid;
+            const T* v = row + (int64_t)(a.Hq + kvh) * DD;
+            const float c = to_f32(cs[j]), s = to_f32(sn[j]);
+            const float x1 = to_f32(v[j]), x2 = to_f32(v[j + HALF]);
+            const T r1 = from_f32<T>(round_to<T>(x1 * c) - round_to<T>(x2 * s));
+            const T r2 = from_f32<T>(round_to<T>(x2 * c) + round_to<T>(x1 * s));
+            kn[j] = r1;
+            kn[j + HALF] = r2;
+            if (len0 < a.s_max) {
+                T* kd = (T*)a.kc + (int64_t)b * a.c_sb + (int64_t)kvh * a.c_sh + (int64_t)len0 * DD;
+                kd[j] = r1;
+                kd[j + HALF] = r2;
+            }
+        } else if (tid >= 64 && tid < 64 + DD) {
+            const int d = tid - 64;
+            const T val = row[(int64_t)(a.Hq + a.Hk + kvh) * DD + d];
+            vn[d] = val;
+            if (len0 < a.s_max) ((T*)a.vc)[(int64_t)b * a.c_sb + (int64_t)kvh * a.c_sh + (int64_t)len0 * DD + d] = val;
+        }
+    }
+    DSTAMP(1);
+    __syncthreads();
+    DSTAMP(2);
+    float m[G], l[G], o[G][8];
+    float qv[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = -INFINITY; l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { qv[g][j] = q_s[g][l16 * 8 + j]; o[g][j] = 0.f; }
+    }
+    const T* kb = (const T*)a.kc + (int64_t)b * a.c_sb + (int64_t)kvh * a.c_sh;
+    const T* vb = (const T*)a.vc + (int64_t)b * a.c_sb + (int64_t)kvh * a.c_sh;
+    const int safe = len0 > 0 ? len0 - 1 : 0;
+    for (int base = max(s0, first & ~15) + wave * 4; base < s1; base += 16 * NI) {
+        Vec16<T> kk[NI], vv[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int key = base + 16 * i + grp;
+            const bool cached = key < s1 && key >= first && key != len0;
+            const int kl = cached ? key : safe;
+            kk[i] = ld16(kb + (int64_t)kl * DD + l16 * 8);
+            vv[i] = ld16(vb + (int64_t)kl * DD + l16 * 8);
+        }
+        DSTAMP(3);
+#ifdef UAMD_DECODE_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DSTAMP(4);
+#endif
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int key = base + 16 * i + grp;
+            if (base + 16 * i >= s1) break;                // (wave-uniform: the old loop's exit)
+            const bool valid = key < s1 && key >= first;
+            if (own && key == len0) {
+                kk[i] = *reinterpret_cast<const Vec16<T>*>(kn + l16 * 8);
+                vv[i] = *reinterpret_cast<const Vec16<T>*>(vn + l16 * 8);
+            }
+            float s[G];
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += qv[g][j] * to_f32(kk[i].e[j]);
+                acc = row16_sum(acc);
+                s[g] = valid ? acc : -INFINITY;
+            }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const float mn = fmaxf(m[g], s[g]);
+                const float mr = mn == -INFINITY ? 0.f : mn;
+                const float alpha = __builtin_amdgcn_exp2f(m[g] - mr);
+                const float pe = __builtin_amdgcn_exp2f(s[g] - mr);
+                m[g] = mn;
+                l[g] = l[g] * alpha + pe;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * alpha + pe * to_f32(vv[i].e[j]);
+            }
+        }
+    }
+    DSTAMP(5);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float mo = __shfl_xor(m[g], off, 64), lo = __shfl_xor(l[g], off, 64);
+            const float mn = fmaxf(m[g], mo);
+            const float mr = mn == -INFINITY ? 0.f : mn;
+            const float aa = __builtin_amdgcn_exp2f(m[g] - mr), c = __builtin_amdgcn_exp2f(mo - mr);
+            l[g] = l[g] * aa + lo * c;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * aa + __shfl_xor(o[g][j], off, 64) * c;
+            m[g] = mn;
+        }
+        if (lane < 16) {
+            if (l16 == 0) { red[wave][g][0] = m[g]; red[wave][g][1] = l[g]; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red_o[wave][g][l16 * 8 + j] = o[g][j];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < G * DD; i += 256) {
+        const int g = i / DD, d = i - g * DD;
+        float mm = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) mm = fmaxf(mm, red[s][g][0]);
+        const float mr = mm == -INFINITY ? 0.f : mm;
+        float ll = 0.f, oo = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const float aa = __builtin_amdgcn_exp2f(red[s][g][0] - mr);
+            ll += red[s][g][1] * aa;
+            oo += red_o[s][g][d] * aa;
+        }
+        if (a.gran) {       // {value, tag} granules: one 8-byte device-scope store each, no fence
+            unsigned long long* pg = reinterpret_cast<unsigned long long*>(a.part) +
+                                     (((int64_t)b * a.Hq + kvh * G + g) * a.nsplit + split) * (DD + 2);
+            const unsigned long long hi = (unsigned long long)tag << 32;
+            __hip_atomic_store(pg + d, hi | __float_as_uint(oo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(pg + DD, hi | __float_as_uint(mm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pg + DD + 1, hi | __float_as_uint(ll), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            float* pp = a.part + (((int64_t)b * a.Hq + kvh * G + g) * a.nsplit + split) * (DD + 2);
+            pp[d] = oo;
+            if (d == 0) { pp[DD] = mm; pp[DD + 1] = ll; }
+        }
+    }
+    if (a.gran) {
+        // ---- every block of the (batch, KV head) combines ITS share of the G x 128 outputs from the granules of all splits, in
+        //      split order (the old combine kernel's arithmetic). All blocks of the launch are resident (the host checks), and
+        //      each has published before it polls: nobody waits for a block that has not started. Polls are bounded.
+        DSTAMP(6);
+        const int chunk = (G * DD + a.nsplit - 1) / a.nsplit;
+        const int i_end = min((split + 1) * chunk, G * DD);
+        for (int i = split * chunk + tid; i < i_end; i += 256) {
+            const int g = i / DD, d = i - g * DD;
+            const unsigned long long* pg = reinterpret_cast<const unsigned long long*>(a.part) +
+                                           ((int64_t)b * a.Hq + kvh * G + g) * a.nsplit * (DD + 2);
+            float mm = -INFINITY, ll = 0.f, oo = 0.f;
+            for (int sb = 0; sb < a.nsplit; sb += 8) {
+                unsigned long long gm[8], gl[8], go[8];
+                for (int spin = 0; spin < (1 << 18); ++spin) {
+                    bool ok = true;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int sp = min(sb + j, a.nsplit - 1);
+                        gm[j] = __hip_atomic_load(pg + sp * (DD + 2) + DD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        gl[j] = __hip_atomic_load(pg + sp * (DD + 2) + DD + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        go[j] = __hip_atomic_load(pg + sp * (DD + 2) + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        ok = ok && (unsigned)(gm[j] >> 32) == tag && (unsigned)(gl[j] >> 32) == tag && (unsigned)(go[j] >> 32) == tag;
+                    if (ok) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (sb + j >= a.nsplit) break;
+                    const float msj = (unsigned)(gm[j] >> 32) == tag ? __uint_as_float((unsigned)gm[j]) : __builtin_nanf("");
+                    const float lsj = __uint_as_float((unsigned)gl[j]), osj = __uint_as_float((unsigned)go[j]);
+                    const float mn = fmaxf(mm, msj);
+                    const float mr = mn == -INFINITY ? 0.f : mn;
+                    const float aa = __builtin_amdgcn_exp2f(mm - mr), c = __builtin_amdgcn_exp2f(msj - mr);
+                    ll = ll * aa + lsj * c;
+                    oo = oo * aa + osj * c;
+                    mm = mn;
+                }
+            }
+            ((T*)a.out)[(int64_t)b * a.o_sb + (int64_t)(kvh * G + g) * DD + d] = from_f32<T>(ll > 0.f ? oo / ll : 0.f);
+        }
+        DSTAMP(9);
+        DSTAMP(10);
+        DTRACE_FLUSH((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 4);
+        return;
+    }
+    // ---- arrival; the last block of this (batch, KV head) combines
+    DSTAMP(6);
+    __threadfence();
+    DSTAMP(7);
+    __syncthreads();
+    int* cnt = a.counters + (int64_t)b * a.Hk + kvh;
+    if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == a.nsplit - 1;
+    }
+    __syncthreads();
+    DSTAMP(8);
+    if (!last_s) {
+        DTRACE_FLUSH((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 4);
+        return;
+    }
+    __threadfence();
+    DSTAMP(9);
+    for (int i = tid; i < G * DD; i += 256) {
+        const int g = i / DD, d = i - g * DD;
+        const float* pp = a.part + ((int64_t)b * a.Hq + kvh * G + g) * a.nsplit * (DD + 2);
+        float mm = -INFINITY, ll = 0.f, oo = 0.f;
+        for (int sb = 0; sb < a.nsplit; sb += 4) {
+            float ms[4], ls[4], os[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = min(sb + j, a.nsplit - 1);
+                ms[j] = sb + j < a.nsplit ? pp[s * (DD + 2) + DD] : -INFINITY;
+                ls[j] = pp[s * (DD + 2) + DD + 1];
+                os[j] = pp[s * (DD + 2) + d];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float mn = fmaxf(mm, ms[j]);
+                const float mr = mn == -INFINITY ? 0.f : mn;
+                const float aa = __builtin_amdgcn_exp2f(mm - mr), c = __builtin_amdgcn_exp2f(ms[j] - mr);
+                ll = ll * aa + ls[j] * c;
+                oo = oo * aa + os[j] * c;
+                mm = mn;
+            }
+        }
+        ((T*)a.out)[(int64_t)b * a.o_sb + (int64_t)(kvh * G + g) * DD + d] = from_f32<T>(ll > 0.f ? oo / ll : 0.f);
+    }
+    if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    DSTAMP(10);
+    DTRACE_FLUSH((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, 4);
+}
+
 }  // namespace
+
+#ifdef UAMD_DECODE_TRACE
+extern "C" int uamd_debug_decode_trace(unsigned long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dec_trace), &buf, sizeof(buf));
+}
+#endif
 
 // y_g[n] = W_g[n, :] . x  (+ s_g * B_g[n, :] . t_g + bias_g[n]) for up to 4 row groups sharing x (one token).
 // nf4 != 0: W_g is bitsandbytes-format NF4 (packed [N, K/2], absmax per `blocksize` codes, nested when absmax_u8 is
@@ -550,7 +1131,10 @@ static int gemv_entry(const void* x, int K, const uamd_gemv_group* groups, int n
     if ((K & 7) || (x && !aligned16(x))) return UAMD_ERR_ALIGN;
     if (mode == 1 && (!pro->x2 || !aligned16(pro->x2))) return UAMD_ERR_ARG;
     if (mode == 2 && (!pro->res || !pro->norm_w || !aligned16(pro->res) || (pro->h_out && !aligned16(pro->h_out)))) return UAMD_ERR_ARG;
-    if (pro && pro->a_rows && (pro->Rt <= 0 || pro->Rt > 256 || (pro->ld_a & 7) || !aligned16(pro->a_rows))) return UAMD_ERR_ARG;
+    if (pro && pro->a_rows && (pro->Rt <= 0 || pro->Rt > 256 || (pro->ld_a & 7) || !aligned16(pro->a_rows) || !pro->sync ||
+                               ((uintptr_t)pro->sync & 7) || (pro->tag == 0 && !pro->tag_dev))) return UAMD_ERR_ARG;
+    const int glu = pro ? pro->glu : 0;
+    if (glu && (n_groups != 2 || groups[0].N != groups[1].N || groups[0].y_f32 || K > 8192)) return UAMD_ERR_ARG;
     if (nf4 && (blocksize < 32 || (blocksize & 31) || (K & 31))) return UAMD_ERR_ARG;
     GemvArgs a;
     auto log2_exact = [](int v) { int sft = 0; while ((1 << sft) < v) ++sft; return (1 << sft) == v ? sft : -1; };
@@ -580,13 +1164,37 @@ static int gemv_entry(const void* x, int K, const uamd_gemv_group* groups, int n
         } else {
             a.g[i] = groups[0];
         }
+        const uamd_gemv_group& h = a.g[i];
+        const bool dir = nf4 && h.absmax_f32;
+        a.hW[i] = h.W;
+        a.hA[i] = dir ? (const void*)h.absmax_f32 : (const void*)h.absmax_u8;
+        a.hA2[i] = h.absmax2;
+        a.hB[i] = h.lora_b;                              // (already NULL when the group has no LoRA term)
+        a.hldw[i] = h.ldw;
+        if (h.lora_b && (h.ld_lb < 0 || h.ld_lb > 0x7fffffffLL)) return UAMD_ERR_ARG;
+        a.hldb[i] = (int)h.ld_lb;
+        a.hN[i] = h.N;
+        a.hmeta[i] = (nf4 && !dir ? h.blocksize2 : 0) | (dir ? 1 << 8 : 0) | (h.lora_b_f32 ? 1 << 9 : 0) | ((h.lora_b ? h.R : 0) << 16);
     }
     a.row_start[UAMD_GEMV_MAX_GROUPS] = rows;
-    a.total_rows = rows;
-    if (pro) a.pro = *pro;
-    else {
+    a.total_rows = rows;                              // (glu: 2 N virtual rows, gate and up rows interleaved)
+    a.n_tb = 0;
+    a.t_ks = 1;
+    a.t_kp = 4096;
+    if (pro) {
+        a.pro = *pro;
+        if (pro->a_rows) {                            // a wave of a t workgroup holds <= 8 vectors (4096 columns) of its A row
+            int ks = 1;
+            while (ks < 8 && ks * 4096 < K) ks *= 2;
+            if (ks * 4096 < K) return UAMD_ERR_ARG;      // K <= 32768
+            a.t_ks = ks;
+            a.t_kp = ((K + ks - 1) / ks + 511) / 512 * 512;
+            a.n_tb = (pro->Rt * ks + GEMV_THREADS / 64 - 1) / (GEMV_THREADS / 64);
+        }
+    } else {
         a.pro.mode = 0; a.pro.x2 = nullptr; a.pro.res = nullptr; a.pro.norm_w = nullptr; a.pro.h_out = nullptr;
-        a.pro.a_rows = nullptr; a.pro.ld_a = 0; a.pro.Rt = 0; a.pro.w_f32 = 0; a.pro.eps = 0.f;
+        a.pro.a_rows = nullptr; a.pro.ld_a = 0; a.pro.Rt = 0; a.pro.w_f32 = 0; a.pro.eps = 0.f; a.pro.glu = 0;
+        a.pro.sync = nullptr; a.pro.tag = 0; a.pro.tag_dev = nullptr;
         for (int i = 0; i < UAMD_GEMV_MAX_GROUPS; ++i) a.pro.t_off[i] = 0;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -600,12 +1208,14 @@ extern "C" int uamd_gemv(const void* x, int K, const uamd_gemv_group* groups, in
     return gemv_entry(x, K, groups, n_groups, nf4, blocksize, dtype, stream, nullptr);
 }
 
-// uamd_gemv with the token PRODUCED inside the launch (one decoder-layer step = 7 launches instead of 14):
+// uamd_gemv with the token PRODUCED inside the launch (one decoder-layer step = 5 launches instead of 14):
 //   pro->mode 1: x = SwiGLU(x, x2)                       (fast_swiglu_inference, llama.py:572-606: down_proj's input)
 //   pro->mode 2: h = x + res (x may be NULL), x' = rmsnorm(h) * norm_w; block 0 writes h to h_out   (the residual add +
 //                fast_rms_layernorm_inference in front of q|k|v, gate|up and lm_head, llama.py:1249-1364)
-//   pro->a_rows: t = A x for the stacked LoRA A rows [Rt, K] computed by every block; group g reads t[t_off[g] ..]
+//   pro->a_rows: t = A x for the stacked LoRA A rows [Rt, K], computed ONCE by the launch's first ceil(Rt / 8) workgroups
+//                and handed to the others through pro->sync; group g reads t[t_off[g] ..]
 //                (the `mv` of fast_linear_forward, utils.py:1107-1117, without a launch of its own)
+//   pro->glu:    gate | up in, h = SwiGLU out (the launch of fast_swiglu_inference's elementwise kernel disappears)
 extern "C" int uamd_gemv_fused(const void* x, int K, const uamd_gemv_group* groups, int n_groups, int nf4, int blocksize,
                                int dtype, void* stream, const uamd_gemv_prologue* pro) {
     return gemv_entry(x, K, groups, n_groups, nf4, blocksize, dtype, stream, pro);
@@ -674,5 +1284,49 @@ extern "C" int uamd_attn_decode(const void* q, int64_t q_sb, const void* k_cache
         hipLaunchKernelGGL((attn_decode_combine_kernel<bf16_t>), dim3(Hq, B), dim3(DD), 0, st, partials, (bf16_t*)out, out_sb, Hq, nsplit);
     else
         hipLaunchKernelGGL((attn_decode_combine_kernel<f16_t>), dim3(Hq, B), dim3(DD), 0, st, partials, (f16_t*)out, out_sb, Hq, nsplit);
+    return uamd_launch_status();
+}
+
+extern "C" int uamd_attn_decode_fused(const void* qkv, int64_t ld_qkv, const void* cos_t, const void* sin_t, int64_t ld_cs,
+                                      const int* kv_len, const int* rope_pos, void* k_cache, void* v_cache,
+                                      int64_t cache_sb, int64_t cache_sh, float* partials, int* counters, void* out,
+                                      int64_t out_sb, int B, int Hq, int Hk, int D, int s_max, int nsplit, int split_keys,
+                                      int window, float scale, unsigned tag, const int* tag_dev, int dtype, void* stream) {
+    if (!qkv || !cos_t || !sin_t || !kv_len || !k_cache || !v_cache || !partials || !counters || !out || B <= 0 || Hq <= 0 ||
+        Hk <= 0 || Hq % Hk || s_max <= 0)
+        return UAMD_ERR_ARG;
+    if (D != DD || nsplit <= 0 || split_keys <= 0 || (split_keys & 15)) return UAMD_ERR_ARG;
+    if (!aligned16(k_cache) || !aligned16(v_cache) || (cache_sb & 7) || (cache_sh & 7)) return UAMD_ERR_ALIGN;
+    const int G = Hq / Hk;
+    AttnDecFusedArgs a;
+    a.qkv = qkv; a.ld_qkv = ld_qkv; a.cos_t = cos_t; a.sin_t = sin_t; a.ld_cs = ld_cs; a.kv_len = kv_len; a.rope_pos = rope_pos;
+    a.kc = k_cache; a.vc = v_cache; a.c_sb = cache_sb; a.c_sh = cache_sh; a.part = partials; a.counters = counters;
+    a.out = out; a.o_sb = out_sb; a.Hq = Hq; a.Hk = Hk; a.s_max = s_max; a.nsplit = nsplit; a.split_keys = split_keys;
+    a.window = window; a.scale_log2 = scale * 1.4426950408889634f;
+    // granule combine only when every block of the launch is certainly resident at once (one 256-thread block per CU of the
+    // smallest part this library runs on): a block polls for the partials of its KV head's other splits
+    a.gran = ((int64_t)nsplit * Hk * B <= 256 && (tag != 0 || tag_dev)) ? 1 : 0;     // (no tag: the arrival-counter path)
+    a.tag = tag;
+    a.tag_dev = tag_dev;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)nsplit, (unsigned)Hk, (unsigned)B);
+#define UAMD_DECODE_LAUNCH(TT, GG) hipLaunchKernelGGL((attn_decode_fused_kernel<TT, GG>), grid, dim3(256), 0, st, a)
+#define UAMD_DECODE_G(TT)                                                                             \
+    switch (G) {                                                                                      \
+        case 1: UAMD_DECODE_LAUNCH(TT, 1); break; case 2: UAMD_DECODE_LAUNCH(TT, 2); break;           \
+        case 3: UAMD_DECODE_LAUNCH(TT, 3); break; case 4: UAMD_DECODE_LAUNCH(TT, 4); break;           \
+        case 5: UAMD_DECODE_LAUNCH(TT, 5); break; case 6: UAMD_DECODE_LAUNCH(TT, 6); break;           \
+        case 7: UAMD_DECODE_LAUNCH(TT, 7); break; case 8: UAMD_DECODE_LAUNCH(TT, 8); break;           \
+        default: return UAMD_ERR_ARG;                                                                 \
+    }
+    if (dtype == UAMD_BF16) {
+        UAMD_DECODE_G(bf16_t)
+    } else if (dtype == UAMD_F16) {
+        UAMD_DECODE_G(f16_t)
+    } else {
+        return UAMD_ERR_DTYPE;
+    }
+#undef UAMD_DECODE_G
+#undef UAMD_DECODE_LAUNCH
     return uamd_launch_status();
 }

@@ -13,6 +13,47 @@ from .. import _lib
 from .._lib import GemvGroup, GemvPrologue
 
 MAX_GROUPS = 4
+_SYNC = {}
+
+
+class HandOff:
+    """Device workspace + tag source of the in-launch hand-offs (uamd_gemv_fused's t = A x, uamd_attn_decode_fused's partials).
+    Every launch on a workspace needs a tag no earlier launch on it used:
+      * eager launches: `next_tag()`, a host counter (step_dev None);
+      * launches captured in a hipGraph: a per-launch-SITE constant `site` (1 .. TAG_STRIDE - 1) plus TAG_STRIDE x the value of
+        the device counter `step_dev` (int32 [1]), which the owner advances once per replay (DecodeEngine: with the position).
+    Launches that share a HandOff must be ordered (one stream / one graph)."""
+
+    def __init__(self, dev, nbytes=None, step_dev=None):
+        self.ws = torch.zeros(((nbytes or _lib.GEMV_SYNC_BYTES) + 3) // 4, dtype=torch.int32, device=dev)
+        self.step_dev = step_dev
+        self._host = 0
+
+    def next_tag(self):
+        # below 2^31 so that host tags and step tags (step * TAG_STRIDE + site, step >= 1) of one workspace cannot meet early; on
+        # wrap-around the workspace is cleared
+        self._host += 1
+        if self._host >= (1 << 31):
+            self.ws.zero_()
+            self._host = 1
+        return self._host
+
+    def tags(self, site=None):
+        """(tag, tag_dev pointer or None) for one launch."""
+        if site is None or self.step_dev is None:
+            return self.next_tag(), None
+        assert 0 < site < _lib.TAG_STRIDE
+        return int(site), self.step_dev
+
+
+def sync_workspace(dev):
+    """The default HandOff of a device, for eager launches on the current stream; a caller that decodes on several streams at
+    once, or under a hipGraph, owns its own (`fused["sync"]`, as DecodeEngine does)."""
+    key = (dev.type, dev.index)
+    ws = _SYNC.get(key)
+    if ws is None:
+        ws = _SYNC[key] = HandOff(dev)
+    return ws
 
 
 def _nf4_fields(qs):
@@ -59,9 +100,11 @@ def lora_a_rows(A_list, dtype):
 def gemv(x, groups, nf4, blocksize=64, pro=None):
     """One launch. x: [K] (contiguous, 16-bit). groups: list of dicts with W, N and optionally qs (quant state),
     y, y_f32, lora_t, lora_b, lora_scale, R, bias. Returns the list of outputs.
-    `pro` (uamd_gemv_fused): dict(mode=0|1|2, x2=, res=, norm_w=, eps=, h_out=, a_rows=, t_off=[per group]) -- the token is
-    produced inside the launch (SwiGLU of x and x2 / residual add + RMSNorm; x may be None in mode 2) and the LoRA
-    t = A x is computed by every block from the stacked A rows instead of arriving from a launch of its own."""
+    `pro` (uamd_gemv_fused): dict(mode=0|1|2, x2=, res=, norm_w=, eps=, h_out=, a_rows=, t_off=[per group], sync=HandOff, site=,
+    glu=) -- the
+    token is produced inside the launch (SwiGLU of x and x2 / residual add + RMSNorm; x may be None in mode 2), the LoRA
+    t = A x is computed once by the launch's first workgroups from the stacked A rows (handed over through `sync`) instead
+    of arriving from a launch of its own, and with glu=True the two groups (gate, up) leave ONE output h = SwiGLU(gate, up)."""
     ref = x if x is not None else pro["res"]
     _lib.require_gpu(ref)
     K = ref.numel()
@@ -111,6 +154,7 @@ def gemv(x, groups, nf4, blocksize=64, pro=None):
         return outs
     P = GemvPrologue()
     P.mode = int(pro.get("mode", 0))
+    P.glu = int(bool(pro.get("glu", False)))
     for name in ("x2", "res", "norm_w", "h_out", "a_rows"):
         tns = pro.get(name)
         setattr(P, name, tns.data_ptr() if tns is not None else None)
@@ -128,6 +172,14 @@ def gemv(x, groups, nf4, blocksize=64, pro=None):
         P.Rt, P.ld_a = int(a_rows.shape[0]), int(a_rows.stride(0))
         for i, off in enumerate(pro["t_off"]):
             P.t_off[i] = int(off)
+        ho = pro.get("sync")
+        if ho is None:
+            ho = sync_workspace(dev)
+        assert isinstance(ho, HandOff) and ho.ws.numel() * 4 >= _lib.GEMV_SYNC_BYTES and ho.ws.device == dev
+        tag, tag_dev = ho.tags(pro.get("site"))
+        P.sync, P.tag = ho.ws.data_ptr(), tag
+        P.tag_dev = tag_dev.data_ptr() if tag_dev is not None else None
+        keep += [ho.ws, tag_dev]
     with _lib.device_ctx(ref):
         rc = _lib.lib().uamd_gemv_fused(_lib.ptr(x) if x is not None else None, K, arr, len(groups), int(bool(nf4)),
                                         int(blocksize), _lib.dtype_code(dtype), _lib.stream_of(ref), ctypes.byref(P))
@@ -139,8 +191,9 @@ def linear_group(x, projs, out=None, fused=None):
     """y_i = W_i x + s_i B_i (A_i x) (+ bias_i) for projections sharing the token x [K]: at most two launches (the A rows
     of all members, then the weights). projs: (W, quant_state, A, B, s[, bias]) as get_lora_parameters(_bias) returns
     them. `out`: optional preallocated [sum N_i] row the outputs are written into back to back. Returns the views.
-    `fused` (dict: mode / x2 / res / norm_w / eps / h_out, see gemv): ONE launch -- the token is produced inside it (x may be
-    None in mode 2) and the A x products are computed by the launch's own blocks."""
+    `fused` (dict: mode / x2 / res / norm_w / eps / h_out / sync / site / glu, see gemv): ONE launch -- the token is produced inside it
+    (x may be None in mode 2), the A x products are computed by the launch's own first workgroups, and with glu=True the two
+    projections (gate, up) return ONE vector h = SwiGLU(gate, up) of N entries."""
     if fused is not None:
         return _linear_group_fused(x, projs, out, fused)
     x = x.reshape(-1)
@@ -181,8 +234,11 @@ def _linear_group_fused(x, projs, out, fused):
     assert all((p[1] is not None) == nf4 for p in projs), "a launch is all-NF4 or all-16-bit"
     assert len(projs) <= MAX_GROUPS
     Ns = [int(p[1].shape[0]) if p[1] is not None else int(p[0].shape[0]) for p in projs]
+    glu = bool(fused.get("glu", False))
+    if glu:
+        assert len(projs) == 2 and Ns[0] == Ns[1], "glu: gate and up of one MLP"
     if out is None:
-        out = torch.empty(sum(Ns), dtype=dtype, device=dev)
+        out = torch.empty(Ns[0] if glu else sum(Ns), dtype=dtype, device=dev)
     with_lora = [p for p in projs if p[2] is not None]
     pro = dict(fused)
     pro.setdefault("mode", 0)
@@ -192,7 +248,7 @@ def _linear_group_fused(x, projs, out, fused):
     groups, col, r0 = [], 0, 0
     for i, (p, N) in enumerate(zip(projs, Ns)):
         W, qs, A, B, s = p[:5]
-        g = dict(W=W, N=N, qs=qs, y=out[col:col + N], bias=p[5] if len(p) > 5 else None)
+        g = dict(W=W, N=N, qs=qs, y=out[:N] if glu else out[col:col + N], bias=p[5] if len(p) > 5 else None)
         if A is not None:
             R = A.shape[0]
             g.update(lora_b=B.detach(), lora_scale=s, R=R)
@@ -202,7 +258,8 @@ def _linear_group_fused(x, projs, out, fused):
         col += N
     pro["t_off"] = t_off
     blocksize = int(projs[0][1].blocksize) if nf4 else 64
-    return gemv(x, groups, nf4=nf4, blocksize=blocksize, pro=pro)
+    ys = gemv(x, groups, nf4=nf4, blocksize=blocksize, pro=pro)
+    return ys[:1] if glu else ys
 
 
 def rope_kv_append(qkv, cos, sin, kv_len, k_cache, v_cache, Hq, Hk, D, rope_pos=None):
@@ -231,4 +288,38 @@ def attn_decode(q, k_cache, v_cache, kv_len, out, partials, split_keys, scale, l
             _lib.ptr(kv_len), int(len_add), _lib.ptr(partials), _lib.ptr(out), out.stride(0), B, Hq, Hk, D, nsplit,
             int(split_keys), int(window), float(scale), _lib.dtype_code(q.dtype), _lib.stream_of(q))
     _lib.check(rc, "uamd_attn_decode")
+    return out
+
+
+def fused_attn_workspace(B, Hq, Hk, S_max, D, split_keys, device, step_dev=None):
+    """(HandOff holding the partials as granules, counters) of uamd_attn_decode_fused for a cache of S_max positions, zeroed
+    here, once."""
+    nsplit = (S_max + split_keys - 1) // split_keys
+    ho = HandOff(device, nbytes=B * Hq * nsplit * (D + 2) * 8, step_dev=step_dev)
+    ho.nsplit = nsplit
+    return ho, torch.zeros(B * Hk, dtype=torch.int32, device=device)
+
+
+def attn_decode_fused(qkv, cos, sin, kv_len, k_cache, v_cache, out, partials, counters, split_keys, scale, Hq, window=0,
+                      rope_pos=None, site=None):
+    """RoPE on the new token's q / k, append of k / v at kv_len[b], split-KV attention over kv_len[b] + 1 keys and the
+    combine, ONE launch (uamd_attn_decode_fused). qkv [B, (Hq + 2 Hk) D] is the raw q|k|v row and is left untouched; out
+    [B, Hq * D]; (partials, counters) from `fused_attn_workspace`, owned by ONE stream of launches; `site`: the launch-site
+    constant when the launch is captured in a hipGraph (HandOff)."""
+    B, Hk, S_max, D = k_cache.shape
+    nsplit = partials.nsplit
+    assert nsplit * split_keys >= S_max and qkv.stride(1) == 1 and out.stride(1) == 1
+    assert partials.ws.numel() * 4 >= B * Hq * nsplit * (D + 2) * 8
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and kv_len.dtype == torch.int32
+    assert counters.dtype == torch.int32 and counters.numel() >= B * Hk
+    assert cos.stride(1) == 1 and sin.stride() == cos.stride() and cos.dtype == qkv.dtype
+    tag, tag_dev = partials.tags(site)
+    with _lib.device_ctx(qkv):
+        rc = _lib.lib().uamd_attn_decode_fused(
+            _lib.ptr(qkv), qkv.stride(0), _lib.ptr(cos), _lib.ptr(sin), cos.stride(0), _lib.ptr(kv_len),
+            _lib.ptr(rope_pos) if rope_pos is not None else None, _lib.ptr(k_cache), _lib.ptr(v_cache), k_cache.stride(0),
+            k_cache.stride(1), partials.ws.data_ptr(), _lib.ptr(counters), _lib.ptr(out), out.stride(0), B, Hq, Hk, D, S_max,
+            nsplit, int(split_keys), int(window), float(scale), tag, tag_dev.data_ptr() if tag_dev is not None else None,
+            _lib.dtype_code(qkv.dtype), _lib.stream_of(qkv))
+    _lib.check(rc, "uamd_attn_decode_fused")
     return out

@@ -7,11 +7,12 @@ KV_CACHE_INCREMENT re-allocations and host syncs for the rotary length.
 
 MI355X design: one `DecodeEngine` per (model, max_seq_len, batch):
   * the KV cache is allocated ONCE at [layers][B, Hk, S_max, D] (288 GB of HBM: no growth, no copies);
-  * a token step is 14 launches per layer (fused add+RMSNorm, LoRA-A GEMV, grouped NF4 GEMV q|k|v, RoPE+append,
-    split-KV attention + combine, GEMV o, fused add+RMSNorm, LoRA-A GEMV, grouped GEMV gate|up, SwiGLU, LoRA-A GEMV, GEMV
-    down) that read the position from DEVICE memory, so the whole step -- all layers, final norm, lm_head GEMV, greedy
-    argmax, position increment -- is captured once as a hipGraph and replayed per token: the step is launch-bound
-    otherwise (~450 launches for ~0.6 ms of HBM traffic at Llama-3-8B NF4);
+  * a token step of one sequence is FIVE launches per layer -- q|k|v GEMV (residual add + RMSNorm inside), attention (RoPE,
+    cache append, split-KV attention and its combine inside), o GEMV, gate|up GEMV (residual add + RMSNorm in, SwiGLU out),
+    down GEMV; every LoRA `A x` is computed once inside the GEMV launch that needs it (uamd_gemv_fused) -- that read the
+    position from DEVICE memory, so the whole step -- all layers, final norm, lm_head GEMV, greedy argmax, position
+    increment -- is captured once as a hipGraph and replayed per token. (Rounds 2-3: 14 launches per layer, ~450 kernels
+    of ~9 us for ~0.6 ms of HBM traffic; still the batch > 1 path and `UNSLOTH_AMD_DECODE_FUSED=0`.);
   * prefill runs the training-path kernels (flash attention over the prompt) and writes K (post-RoPE) / V into the cache.
 Batch > 1 decodes through the fused NF4 GEMM instead of the GEMV (as the reference does, utils.py:1095-1097).
 """
@@ -34,12 +35,12 @@ def _base(model):
     return m
 
 
-# UNSLOTH_AMD_DECODE_FUSED=1: one token of one sequence as 7 launches per layer (uamd_gemv_fused: residual add + RMSNorm /
-# SwiGLU / the LoRA A x inside the GEMV launches) instead of 14. Measured SLOWER under the hipGraph (4.97 vs 4.13 ms per
-# token, profiles/r03r_decode_fused_ab.jsonl; eager 4.96 vs 6.79): every one of a launch's 200-500 blocks recomputes the
-# norm and t = A x (up to 48 rows x K from L2) on its own critical path, which costs more than the launches it removes --
-# a decode GEMV is bound by its fixed latencies (staging, one HBM round trip, reduction), not by launch gaps. Default off.
-FUSED_STEP = os.environ.get("UNSLOTH_AMD_DECODE_FUSED", "0") == "1"
+# UNSLOTH_AMD_DECODE_FUSED=0: one token of one sequence as the 14 separate launches per layer of rounds 2-3 instead of 5.
+# (Round 3's first fused step -- 7 launches, every workgroup recomputing the norm AND t = A x, up to 48 rows x K from L2 --
+# measured slower than the 14, 4.97 vs 4.13 ms per token, profiles/r03r_decode_fused_ab.jsonl; t is now computed once per
+# launch and handed over through a device workspace, RoPE / append / combine ride in the attention launch and SwiGLU in the
+# gate|up epilogue.)
+FUSED_STEP = os.environ.get("UNSLOTH_AMD_DECODE_FUSED", "1") == "1"
 
 
 class DecodeEngine:
@@ -69,14 +70,25 @@ class DecodeEngine:
         kw = dict(dtype=self.dtype, device=self.dev)
         self.k_cache = [torch.zeros(batch, self.Hk, self.S, self.D, **kw) for _ in range(L)]
         self.v_cache = [torch.zeros(batch, self.Hk, self.S, self.D, **kw) for _ in range(L)]
-        self.kv_len = torch.zeros(batch, dtype=torch.int32, device=self.dev)
+        # [kv_len per sequence ..., step counter]: ONE add_(1) per token advances both. The step counter (never reset) is the
+        # device half of the hand-off tags of the fused kernels (kernels/decode.HandOff): unlike the position it cannot repeat
+        # when a new prompt is prefilled or a caller rewinds kv_len
+        self._pos = torch.zeros(batch + 1, dtype=torch.int32, device=self.dev)
+        self._pos[batch] = 1
+        self.kv_len = self._pos[:batch]
+        self.step_ctr = self._pos[batch:]
+        self._steps = 1                               # host mirror of step_ctr (no sync): wrap-around guard
         self.partials = torch.empty(batch, self.Hq, self.S // SPLIT_KEYS, self.D + 2, dtype=torch.float32, device=self.dev)
+        self.fpartials, self.counters = _dk.fused_attn_workspace(batch, self.Hq, self.Hk, self.S, self.D, SPLIT_KEYS, self.dev,
+                                                                  step_dev=self.step_ctr)
+        self.sync = _dk.HandOff(self.dev, step_dev=self.step_ctr)                             # uamd_gemv_fused hand-off
         self.tok = torch.zeros(batch, 1, dtype=torch.long, device=self.dev)
         self.next_tok = torch.zeros(batch, dtype=torch.long, device=self.dev)
         self.logits = None
         tables = _ll._rope_tables(self.core)
         self.cos, self.sin = tables.get(self.S, self.dev, self.dtype)
         self._graph = None
+        assert 5 * L + 1 < 1024, "hand-off tag sites: 5 per layer below UAMD_TAG_STRIDE"
         self._params = [self._layer_params(l) for l in self.core.layers]
         self._head = self.lm.lm_head.weight
         self._sample = None
@@ -175,33 +187,41 @@ class DecodeEngine:
 
     @torch.no_grad()
     def _step_body_fused(self):
-        """One token of one sequence, 7 launches per decoder layer: the residual adds, both RMSNorms, SwiGLU and every
-        LoRA `A x` ride inside the GEMV launches (uamd_gemv_fused); RoPE + cache append, attention and its combine are
-        the other three."""
+        """One token of one sequence, 5 launches per decoder layer: q|k|v (residual add + RMSNorm inside), attention (RoPE,
+        cache append and the split combine inside), o, gate|up (add + RMSNorm in, SwiGLU out), down; every LoRA `A x` inside
+        the GEMV launch that consumes it."""
         H = self.cfg.hidden_size
         core = self.core
         resid = core.embed_tokens(self.tok).to(self.dtype).view(H)
         delta = None
         I = self.cfg.intermediate_size
+        kw = dict(dtype=self.dtype, device=self.dev)
+        nf4 = self._params[0]["gu"][0][1] is not None
+        glu_ok = H <= (8192 if nf4 else 4096)            # a wave needs the gate row and the up row of an n in one trip
         for li in range(len(core.layers)):
             P = self._params[li]
-            qkv = torch.empty(1, (self.Hq + 2 * self.Hk) * self.D, dtype=self.dtype, device=self.dev)
+            qkv = torch.empty(1, (self.Hq + 2 * self.Hk) * self.D, **kw)
             h = torch.empty_like(resid) if delta is not None else None
-            _dk.linear_group(delta, P["qkv"], out=qkv.view(-1),
-                             fused=dict(mode=2, res=resid, norm_w=P["ln1"][0], eps=P["ln1"][1], h_out=h))
+            site = 5 * li + 1                       # launch-site constants of the hand-off tags: 5 per layer
+            _dk.linear_group(delta, P["qkv"], out=qkv.view(-1), fused=dict(mode=2, res=resid, norm_w=P["ln1"][0], eps=P["ln1"][1],
+                                                                           h_out=h, sync=self.sync, site=site))
             if h is not None:
                 resid = h
-            _dk.rope_kv_append(qkv, self.cos, self.sin, self.kv_len, self.k_cache[li], self.v_cache[li],
-                               self.Hq, self.Hk, self.D)
-            a_out = torch.empty(1, self.Hq * self.D, dtype=self.dtype, device=self.dev)
-            _dk.attn_decode(qkv[:, :self.Hq * self.D], self.k_cache[li], self.v_cache[li], self.kv_len, a_out,
-                            self.partials, SPLIT_KEYS, self.scale, len_add=1, window=self.window)
-            (o,) = _dk.linear_group(a_out.view(-1), P["o"], fused=dict(mode=0))
-            gu = torch.empty(2 * I, dtype=self.dtype, device=self.dev)
+            a_out = torch.empty(1, self.Hq * self.D, **kw)
+            _dk.attn_decode_fused(qkv, self.cos, self.sin, self.kv_len, self.k_cache[li], self.v_cache[li], a_out,
+                                  self.fpartials, self.counters, SPLIT_KEYS, self.scale, self.Hq, window=self.window,
+                                  site=site + 1)
+            (o,) = _dk.linear_group(a_out.view(-1), P["o"], fused=dict(mode=0, sync=self.sync, site=site + 2))
             h = torch.empty_like(resid)
-            _dk.linear_group(o, P["gu"], out=gu, fused=dict(mode=2, res=resid, norm_w=P["ln2"][0], eps=P["ln2"][1], h_out=h))
+            pre = dict(mode=2, res=resid, norm_w=P["ln2"][0], eps=P["ln2"][1], h_out=h, sync=self.sync, site=site + 3)
+            if glu_ok:
+                (hmid,) = _dk.linear_group(o, P["gu"], fused=dict(pre, glu=True))
+                (delta,) = _dk.linear_group(hmid, P["down"], fused=dict(mode=0, sync=self.sync, site=site + 4))
+            else:
+                gu = torch.empty(2 * I, **kw)
+                _dk.linear_group(o, P["gu"], out=gu, fused=pre)
+                (delta,) = _dk.linear_group(gu[:I], P["down"], fused=dict(mode=1, x2=gu[I:], sync=self.sync, site=site + 4))
             resid = h
-            (delta,) = _dk.linear_group(gu[:I], P["down"], fused=dict(mode=1, x2=gu[I:]))
         W = self._head
         if W.dtype == self.dtype and W.shape[1] <= 16384:
             (y,) = _dk.gemv(delta, [dict(W=W, N=W.shape[0], y_f32=True)], nf4=False,
@@ -210,7 +230,7 @@ class DecodeEngine:
         else:
             _, xn, _ = add_rms_fwd(delta.view(1, H), resid.view(1, H), core.norm.weight, _eps(core.norm))
             self.logits = self._lm_head(xn)
-        self.kv_len.add_(1)
+        self._pos.add_(1)                                   # positions and the step counter
         if self._sample is None:
             self.next_tok.copy_(torch.argmax(self.logits, dim=-1))
         return self.logits
@@ -244,7 +264,7 @@ class DecodeEngine:
             (delta,) = self._linear(hmid, P["down"])
         _, xn, _ = add_rms_fwd(delta, resid, core.norm.weight, _eps(core.norm))
         self.logits = self._lm_head(xn)
-        self.kv_len.add_(1)
+        self._pos.add_(1)                                   # positions and the step counter
         if self._sample is None:
             self.next_tok.copy_(torch.argmax(self.logits, dim=-1))
         return self.logits
@@ -252,6 +272,12 @@ class DecodeEngine:
     def step(self, token_ids):
         """Feed one token per sequence ([B] or [B, 1]); returns fp32 logits [B, V] for the next position."""
         self.tok.copy_(token_ids.view(self.B, 1))
+        self._steps += 1
+        if self._steps >= (1 << 22) - 8:                     # step * TAG_STRIDE would wrap: start the tags over on clean workspaces
+            self.sync.ws.zero_()
+            self.fpartials.ws.zero_()
+            self.step_ctr.fill_(1)
+            self._steps = 1
         if not self.use_graph:
             return self._step_body()
         if self._graph is None:
