@@ -636,8 +636,10 @@ def main():
                                  + cfgm.hidden_size * cfgm.num_attention_heads * eng.D
                                  + 3 * cfgm.hidden_size * cfgm.intermediate_size)
             hbm_bytes = nparam * 0.516 + V * cfgm.hidden_size * 2 + a.layers * 2 * T * cfgm.num_key_value_heads * eng.D * 2
+            from unsloth_amd.models import decode as _md
             alt["decode_batch_1_context_%d (hipGraph per token)" % T] = {
                 "tokens_per_s": round(1.0 / dtok, 1), "ms_per_token": round(dtok * 1e3, 3),
+                "launches_per_layer": 5 if _md.FUSED_STEP else 14,
                 "hbm_bytes_per_token": int(hbm_bytes), "frac_of_hbm_peak": round(hbm_bytes / dtok / 8.0e12, 3)}
             del eng
             torch.cuda.empty_cache()

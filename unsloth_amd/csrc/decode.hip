@@ -263,6 +263,51 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
             }
         }
     };
+    // ---- the prologue's own operands FIRST (the token / residual / norm weight vectors, the nested-absmax map): vmcnt retires
+    //      loads in issue order, so behind 24 weight loads these few L2 hits waited for the whole HBM round trip and the block's
+    //      set-up (staging, table, barrier) started when it should have been over (profiles/r04y_decode_phase_trace.txt)
+    constexpr int VPT = (NIT * 64 * ELEMS / 8 + GEMV_THREADS - 1) / GEMV_THREADS;      // 16-byte vectors of x per thread
+    const int mode = p.pro.mode;
+    const T* const xp = (const T*)p.x;
+    union V8 { uint4 r; T e[8]; };
+    V8 pa[VPT], pb[VPT], pw[VPT];
+    uint4 pwf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    float c2v[2] = {0.f, 0.f};
+    const bool pre = mode == 0 || VPT == 1;              // operands in registers (mode 1 / 2 of longer rows: the LDS version below)
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {
+        const int v = tid + k * GEMV_THREADS;
+        pa[k].r = pb[k].r = pw[k].r = make_uint4(0, 0, 0, 0);
+        if (pre && v * 8 < K) {
+            if (mode == 0) {
+                pa[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);                       // K % 8 == 0 (host)
+            } else if (mode == 1) {
+                pa[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);
+                pb[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.x2 + v * 8);
+            } else {
+                pb[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.res + v * 8);
+                if (xp) pa[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);
+                if (p.pro.w_f32) {
+                    if (VPT == 1) {
+                        pwf[0] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8);
+                        pwf[1] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8 + 4);
+                    }
+                } else {
+                    pw[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.norm_w + v * 8);
+                }
+            }
+        }
+    }
+    if (NF4) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = tid + q * GEMV_THREADS;             // 4 groups x 256 entries
+            const int gi = i >> 8;
+            const float* c2 = gi == 0 ? p.g[0].code2 : gi == 1 ? p.g[1].code2 : gi == 2 ? p.g[2].code2 : p.g[3].code2;
+            if (gi < p.n_groups && c2) c2v[q] = c2[i & 255];
+        }
+    }
+    const float nf_hi = kNF4d[(tid >> 4) & 15], nf_lo = kNF4d[tid & 15];      // (constant MEMORY: two more loads that belong up here)
     int trip = t_block ? total_trips : ((int)blockIdx.x - n_tb) * (GEMV_THREADS / 64) + wave_u;
     if (trip < total_trips) load_rows(trip, 0, RB);
     // t workgroups: wave (row r, part q of KS) of t = A x streams its <= 8 vectors of the A row NOW, with everything else of the
@@ -288,25 +333,28 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
     float* tl = reinterpret_cast<float*>(gemv_smem + NIT * 64 * ELEMS * sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 +
                                           (NF4 ? 256 * 32 * 4 : 0));          // [64 ranks x 4 groups] + 8 + 8 reduction slots
     {
-        const T* xp = (const T*)p.x;
         const int nvec = NIT * 64 * ELEMS / 8;
-        const int mode = p.pro.mode;
         if (mode == 0) {
-            for (int v = tid; v < nvec; v += GEMV_THREADS) {
-                uint4 val = make_uint4(0, 0, 0, 0);
-                if (v * 8 < K) val = *reinterpret_cast<const uint4*>(xp + v * 8);        // K % 8 == 0 (host)
-                reinterpret_cast<uint4*>(xs)[v] = val;
+#pragma unroll
+            for (int k = 0; k < VPT; ++k) {
+                const int v = tid + k * GEMV_THREADS;
+                if (v < nvec) reinterpret_cast<uint4*>(xs)[v] = pa[k].r;
             }
         } else if (mode == 1) {
             // x = (e * sigmoid(e)).to(T) * g: the SwiGLU of fast_swiglu_inference (llama.py:572-606), rounding points of
             // the training kernel (csrc/glu.hip); p.x = e (gate), pro.x2 = g (up)
             const T* gp = (const T*)p.pro.x2;
             for (int v = tid; v < nvec; v += GEMV_THREADS) {
-                union { uint4 r; T e[8]; } a, b, o;
+                V8 a, b, o;
                 o.r = make_uint4(0, 0, 0, 0);
                 if (v * 8 < K) {
-                    a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
-                    b.r = *reinterpret_cast<const uint4*>(gp + v * 8);
+                    if (VPT == 1) {
+                        a = pa[0];
+                        b = pb[0];
+                    } else {
+                        a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
+                        b.r = *reinterpret_cast<const uint4*>(gp + v * 8);
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float e = to_f32(a.e[j]);
@@ -319,93 +367,62 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
         } else {
             // x = rmsnorm(h) * w, h = T(a + res) (a = p.x may be NULL: h = res): fast_rms_layernorm_inference after the
             // residual add of the decoder layer (llama.py:352-606), rounding points of csrc/rms_layernorm.hip. Every block
-            // normalises the whole row for itself; block 0 also writes h (the next residual) to pro.h_out. A thread keeps its
-            // (at most 4) vectors of h AND of the norm weight in registers across the one barrier of the reduction: all global
-            // loads of the prologue are issued together, up front.
-            constexpr int VPT = (NIT * 64 * ELEMS / 8 + GEMV_THREADS - 1) / GEMV_THREADS;
-            if constexpr (VPT == 1) {            // K <= 4096 (NF4: the hidden size of every 7-8 B model): registers
-                const T* rp = (const T*)p.pro.res;
-                T* hp = (T*)p.pro.h_out;
-                union V8 { uint4 r; T e[8]; };
-                V8 av[VPT], hv[VPT], wv[VPT];
-                uint4 wf[VPT][2];
-    #pragma unroll
-                for (int k = 0; k < VPT; ++k) {
-                    const int v = tid + k * GEMV_THREADS;
-                    av[k].r = make_uint4(0, 0, 0, 0);
-                    hv[k].r = make_uint4(0, 0, 0, 0);
-                    wv[k].r = make_uint4(0, 0, 0, 0);
-                    wf[k][0] = wf[k][1] = make_uint4(0, 0, 0, 0);
-                    if (v * 8 < K) {
-                        hv[k].r = *reinterpret_cast<const uint4*>(rp + v * 8);
-                        if (xp) av[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);
-                        if (p.pro.w_f32) {
-                            wf[k][0] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8);
-                            wf[k][1] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8 + 4);
-                        } else {
-                            wv[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.norm_w + v * 8);
-                        }
-                    }
-                }
+            // normalises the whole row for itself; block 0 also writes h (the next residual) to pro.h_out.
+            const T* rp = (const T*)p.pro.res;
+            T* hp = (T*)p.pro.h_out;
+            if constexpr (VPT == 1) {            // K <= 4096 (NF4: the hidden size of every 7-8 B model): h and w stay in registers
+                const int v = tid;
+                V8 hv = pb[0];
                 float ss = 0.f;
-    #pragma unroll
-                for (int k = 0; k < VPT; ++k) {
-                    const int v = tid + k * GEMV_THREADS;
-                    if (v * 8 < K) {
-                        if (xp) {
-    #pragma unroll
-                            for (int j = 0; j < 8; ++j) hv[k].e[j] = from_f32<T>(to_f32(av[k].e[j]) + to_f32(hv[k].e[j]));
-                        }
-                        if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = hv[k].r;
-    #pragma unroll
-                        for (int j = 0; j < 8; ++j) { const float f = to_f32(hv[k].e[j]); ss += f * f; }
+                if (v * 8 < K) {
+                    if (xp) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) hv.e[j] = from_f32<T>(to_f32(pa[0].e[j]) + to_f32(hv.e[j]));
                     }
+                    if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = hv.r;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = to_f32(hv.e[j]); ss += f * f; }
                 }
                 ss = wave_sum_dpp(ss);
                 if (lane == 0) tl[256 + wave_u] = ss;
                 __syncthreads();
                 float tot = 0.f;
-    #pragma unroll
+#pragma unroll
                 for (int w = 0; w < GEMV_THREADS / 64; ++w) tot += tl[256 + w];
                 const float inv = rsqrtf(tot / (float)K + p.pro.eps);
-    #pragma unroll
-                for (int k = 0; k < VPT; ++k) {
-                    const int v = tid + k * GEMV_THREADS;
-                    if (v >= NIT * 64 * ELEMS / 8) continue;
+                if (v < nvec) {
                     V8 o;
                     o.r = make_uint4(0, 0, 0, 0);
                     if (v * 8 < K) {
-                        const float wfl[8] = {__uint_as_float(wf[k][0].x), __uint_as_float(wf[k][0].y), __uint_as_float(wf[k][0].z),
-                                              __uint_as_float(wf[k][0].w), __uint_as_float(wf[k][1].x), __uint_as_float(wf[k][1].y),
-                                              __uint_as_float(wf[k][1].z), __uint_as_float(wf[k][1].w)};
-    #pragma unroll
+                        const float wfl[8] = {__uint_as_float(pwf[0].x), __uint_as_float(pwf[0].y), __uint_as_float(pwf[0].z),
+                                              __uint_as_float(pwf[0].w), __uint_as_float(pwf[1].x), __uint_as_float(pwf[1].y),
+                                              __uint_as_float(pwf[1].z), __uint_as_float(pwf[1].w)};
+#pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const float normed = to_f32(hv[k].e[j]) * inv;
+                            const float normed = to_f32(hv.e[j]) * inv;
                             if (p.pro.w_f32) {
                                 o.e[j] = from_f32<T>(normed * wfl[j]);
                             } else {                                    // (x * r).to(W.dtype) * W, product in W's dtype
-                                o.e[j] = from_f32<T>(round_to<T>(round_to<T>(normed) * to_f32(wv[k].e[j])));
+                                o.e[j] = from_f32<T>(round_to<T>(round_to<T>(normed) * to_f32(pw[0].e[j])));
                             }
                         }
                     }
                     reinterpret_cast<uint4*>(xs)[v] = o.r;
                 }
             } else {                             // longer rows: two passes over LDS (the register version costs an occupancy step)
-                const T* rp = (const T*)p.pro.res;
-                T* hp = (T*)p.pro.h_out;
                 float ss = 0.f;
                 for (int v = tid; v < nvec; v += GEMV_THREADS) {
-                    union { uint4 r; T e[8]; } a, b;
+                    V8 a, b;
                     b.r = make_uint4(0, 0, 0, 0);
                     if (v * 8 < K) {
                         b.r = *reinterpret_cast<const uint4*>(rp + v * 8);
                         if (xp) {
                             a.r = *reinterpret_cast<const uint4*>(xp + v * 8);
-    #pragma unroll
+#pragma unroll
                             for (int j = 0; j < 8; ++j) b.e[j] = from_f32<T>(to_f32(a.e[j]) + to_f32(b.e[j]));
                         }
                         if (hp && blockIdx.x == 0) *reinterpret_cast<uint4*>(hp + v * 8) = b.r;
-    #pragma unroll
+#pragma unroll
                         for (int j = 0; j < 8; ++j) { const float f = to_f32(b.e[j]); ss += f * f; }
                     }
                     reinterpret_cast<uint4*>(xs)[v] = b.r;                              // h for now
@@ -414,14 +431,14 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
                 if (lane == 0) tl[256 + wave_u] = ss;
                 __syncthreads();
                 float tot = 0.f;
-    #pragma unroll
+#pragma unroll
                 for (int w = 0; w < GEMV_THREADS / 64; ++w) tot += tl[256 + w];
                 const float inv = rsqrtf(tot / (float)K + p.pro.eps);
                 for (int v = tid; v < nvec; v += GEMV_THREADS) {
                     if (v * 8 >= K) continue;
-                    union { uint4 r; T e[8]; } h;
+                    V8 h;
                     h.r = reinterpret_cast<uint4*>(xs)[v];
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float normed = to_f32(h.e[j]) * inv;
                         if (p.pro.w_f32) {
@@ -435,13 +452,10 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
             }
         }
         if (NF4) {
-            for (int i = tid; i < UAMD_GEMV_MAX_GROUPS * 256; i += GEMV_THREADS) {
-                const int gi = i >> 8;
-                const float* c2 = p.g[gi].code2;
-                code2[i] = (gi < p.n_groups && c2) ? c2[i & 255] : 0.f;
-            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) code2[tid + q * GEMV_THREADS] = c2v[q];
             if (tid < 256) {       // thread e builds entry e (high nibble = even element): 32 copies = 8 x 16 bytes
-                const uint32_t v = pack2<T>(kNF4d[tid >> 4], kNF4d[tid & 15]);
+                const uint32_t v = pack2<T>(nf_hi, nf_lo);
                 uint4* dst = reinterpret_cast<uint4*>(lut2 + tid * 32);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) dst[c] = make_uint4(v, v, v, v);
