@@ -114,6 +114,7 @@ for step in "$@"; do
       if [ -n "$DB" ]; then
         python tools/rocpd_stats.py $DB > $OUT/${TAG}_${n}_kernel_stats.csv 2> $OUT/${TAG}_${n}_stats.err
         head -16 $OUT/${TAG}_${n}_kernel_stats.csv | cut -c1-150
+        python tools/rocpd_tail.py $DB 70 40 > $OUT/${TAG}_${n}_tail.csv 2>> $OUT/${TAG}_${n}_stats.err
       else tail -5 $OUT/pyprof_${TAG}_$n.log; fi
       rm -rf $OUT/prof_${TAG}_$n ;;
     *) echo "unknown step $step" ;;
