@@ -156,6 +156,10 @@ constexpr int GEMV_THREADS = 512;
 template <typename V> __device__ __forceinline__ const __attribute__((address_space(1))) V* gptr(uint64_t a) {
     return (const __attribute__((address_space(1))) V*)a;
 }
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {          // a wave-uniform 64-bit value, pinned to scalar registers
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 template <typename T> __device__ __forceinline__ float bits16_to_f32(uint32_t b) {
     union { uint16_t u; T h; } v;
     v.u = (uint16_t)b;
@@ -195,8 +199,12 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
     const bool t_block = (int)blockIdx.x < n_tb;
     const int nwaves = ((int)gridDim.x - n_tb) * (GEMV_THREADS / 64);
     // the launch's tag (see above): a host constant plus, under a hipGraph, a device counter the caller advances per replay
-    unsigned tag = p.pro.tag;
-    if (p.pro.tag_dev) tag += (unsigned)*p.pro.tag_dev * UAMD_TAG_STRIDE;
+    // (the device half is loaded unconditionally from a valid address and only combined where the tag is first needed -- behind
+    //  the first rows' dot products / the t row: a load in an `if` is waited for where the `if` ends, i.e. right here)
+    const int* const tag_src = p.pro.tag_dev ? p.pro.tag_dev : reinterpret_cast<const int*>(p.hW[0]);
+    const unsigned tag_raw = (unsigned)__builtin_nontemporal_load(tag_src);
+    const unsigned tag_mul = p.pro.tag_dev ? UAMD_TAG_STRIDE : 0u;
+#define UAMD_GEMV_TAG (p.pro.tag + tag_raw * tag_mul)
     int gis[RB], ns[RB];
     float direct[RB];                                // 1: single-level fp32 absmax, 0: nested
     uint4 w[RB][NIT];
@@ -228,38 +236,56 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
             const int meta = glu ? p.hmeta[gr] : sMeta, ldb = glu ? p.hldb[gr] : sLdb, Ng = glu ? p.hN[0] : sN;
             const int nraw = glu ? n0 + (r >> 1) : n0 + r;
             valid[r] = nraw < Ng;
-            const int nrow = min(nraw, Ng - 1);                      // past the group's end: a duplicate of its last row, not stored
+            // (readfirstlane: the row is wave-uniform by construction; said explicitly, its 64-bit products stay on the scalar unit
+            //  even where the control flow around the lane-dependent B load would otherwise pull them into vector registers)
+            const int nrow = __builtin_amdgcn_readfirstlane(min(nraw, Ng - 1));   // past the group's end: its last row again, not stored
             gis[r] = glu ? gr : gi;
             ns[r] = nrow;
             const bool dir = (meta >> 8) & 1;
             direct[r] = dir ? 1.f : 0.f;
             braw[r] = 0;
-            if (gB && lane < (meta >> 16)) {
-                const int64_t bi = (int64_t)nrow * ldb + lane;
-                if ((meta >> 9) & 1) braw[r] = gptr<uint32_t>(gB)[bi];
-                else braw[r] = gptr<uint16_t>(gB)[bi];
-            }
+            // addresses: everything that depends on the ROW is wave-uniform (scalar unit, 64 bits); a lane adds a 32-bit byte
+            // offset, so every load is `global_load ..., v_off, s[base]` (14 vector instructions per load before, 64-bit)
+            if constexpr (NF4) {
+                const uint64_t gA = glu ? (uint64_t)p.hA[gr] : sA, gA2 = glu ? (uint64_t)p.hA2[gr] : sA2;
+                const uint64_t rowbase = uniform64((uint64_t)nrow * (uint64_t)K);   // first code of the row (K % 32 == 0)
+                const uint64_t wrow = uniform64(gW + (rowbase >> 1));
+                const uint64_t blk_row = rowbase >> bs_shift;                        // first absmax block the row touches
+                const uint32_t rem = (uint32_t)(rowbase - (blk_row << bs_shift));    // codes of that block before the row
+                const uint64_t arow = uniform64(gA + blk_row * (dir ? 4u : 1u));
+                const uint32_t bs2 = meta & 0xff;
 #pragma unroll
-            for (int i = 0; i < NIT; ++i) {
-                a8[r][i] = 0;
-                a2[r][i] = 0.f;
-                if constexpr (NF4) {
-                    const uint64_t gA = glu ? (uint64_t)p.hA[gr] : sA, gA2 = glu ? (uint64_t)p.hA2[gr] : sA2;
-                    const int64_t e0 = (int64_t)nrow * K + koff[i];
-                    const uamd_u32x4 v = __builtin_nontemporal_load(gptr<uamd_u32x4>(gW + (e0 >> 1)));
+                for (int i = 0; i < NIT; ++i) {
+                    a8[r][i] = 0;
+                    const uamd_u32x4 v = __builtin_nontemporal_load(gptr<uamd_u32x4>(wrow + (uint32_t)(koff[i] >> 1)));
                     w[r][i] = make_uint4(v[0], v[1], v[2], v[3]);
-                    const int64_t blk = e0 >> bs_shift;
+                    const uint32_t dblk = (rem + (uint32_t)koff[i]) >> bs_shift;    // absmax block relative to blk_row
                     if (dir) {
-                        a2[r][i] = gptr<float>(gA)[blk];
+                        a2[r][i] = *gptr<float>(arow + dblk * 4u);
                     } else {
-                        a8[r][i] = gptr<uint8_t>(gA)[blk];
-                        a2[r][i] = gptr<float>(gA2)[blk >> (meta & 0xff)];
+                        a8[r][i] = *gptr<uint8_t>(arow + dblk);
+                        // nested: the fp32 absmax-of-absmax of block (blk_row + dblk) >> bs2; the uniform part again on the base
+                        const uint64_t b2row = blk_row >> bs2;
+                        const uint32_t rem2 = (uint32_t)(blk_row - (b2row << bs2));
+                        a2[r][i] = *gptr<float>(uniform64(gA2 + b2row * 4u) + (((rem2 + dblk) >> bs2) << 2));
                     }
-                } else {
-                    const int64_t ldw = glu ? p.hldw[gr] : sLdw;
-                    const uamd_u32x4 v = *gptr<uamd_u32x4>(gW + ((int64_t)nrow * ldw + koff[i]) * (int64_t)sizeof(T));
+                }
+            } else {
+                const int64_t ldw = glu ? p.hldw[gr] : sLdw;
+                const uint64_t wrow = uniform64(gW + (uint64_t)((int64_t)nrow * ldw) * sizeof(T));
+#pragma unroll
+                for (int i = 0; i < NIT; ++i) {
+                    a8[r][i] = 0;
+                    a2[r][i] = 0.f;
+                    const uamd_u32x4 v = *gptr<uamd_u32x4>(wrow + (uint32_t)(koff[i] * (int)sizeof(T)));
                     w[r][i] = make_uint4(v[0], v[1], v[2], v[3]);
                 }
+            }
+            if (gB && lane < (meta >> 16)) {
+                const bool f32 = (meta >> 9) & 1;
+                const uint64_t brow = gB + (uint64_t)((int64_t)nrow * ldb) * (f32 ? 4u : 2u);
+                if (f32) braw[r] = *gptr<uint32_t>(brow + (uint32_t)(lane * 4));
+                else braw[r] = *gptr<uint16_t>(brow + (uint32_t)(lane * 2));
             }
         }
     };
@@ -274,27 +300,27 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
     uint4 pwf[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     float c2v[2] = {0.f, 0.f};
     const bool pre = mode == 0 || VPT == 1;              // operands in registers (mode 1 / 2 of longer rows: the LDS version below)
+    const bool use_a = pre && xp != nullptr, use_b = pre && mode != 0, use_w = pre && mode == 2 && !p.pro.w_f32;
+    {
+        // BRANCH-FREE: a load inside `if (mode == ..)` has to be complete where the branches join, i.e. every arm ended in an
+        // s_waitcnt and the weight loads below started a memory round trip late. Every vector is loaded from a valid address
+        // (the real one, or element 0 of the weights when the mode has no such operand) and zeroed afterwards if unused.
+        const T* const dummy = (const T*)p.hW[0];
+        const bool use_wf = VPT == 1 && mode == 2 && p.pro.w_f32;
+        const T* const src_a = use_a ? xp : dummy;
+        const T* const src_b = use_b ? (mode == 1 ? (const T*)p.pro.x2 : (const T*)p.pro.res) : dummy;
+        const T* const src_w = use_w ? (const T*)p.pro.norm_w : dummy;
+        const float* const src_wf = use_wf ? (const float*)p.pro.norm_w : (const float*)dummy;
 #pragma unroll
-    for (int k = 0; k < VPT; ++k) {
-        const int v = tid + k * GEMV_THREADS;
-        pa[k].r = pb[k].r = pw[k].r = make_uint4(0, 0, 0, 0);
-        if (pre && v * 8 < K) {
-            if (mode == 0) {
-                pa[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);                       // K % 8 == 0 (host)
-            } else if (mode == 1) {
-                pa[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);
-                pb[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.x2 + v * 8);
-            } else {
-                pb[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.res + v * 8);
-                if (xp) pa[k].r = *reinterpret_cast<const uint4*>(xp + v * 8);
-                if (p.pro.w_f32) {
-                    if (VPT == 1) {
-                        pwf[0] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8);
-                        pwf[1] = *reinterpret_cast<const uint4*>((const float*)p.pro.norm_w + v * 8 + 4);
-                    }
-                } else {
-                    pw[k].r = *reinterpret_cast<const uint4*>((const T*)p.pro.norm_w + v * 8);
-                }
+        for (int k = 0; k < VPT; ++k) {
+            const int v = tid + k * GEMV_THREADS;
+            const bool in = v * 8 < K;                                                       // K % 8 == 0 (host)
+            pa[k].r = *reinterpret_cast<const uint4*>(src_a + (use_a && in ? v * 8 : 0));
+            pb[k].r = *reinterpret_cast<const uint4*>(src_b + (use_b && in ? v * 8 : 0));
+            pw[k].r = *reinterpret_cast<const uint4*>(src_w + (use_w && in ? v * 8 : 0));
+            if (VPT == 1) {
+                pwf[0] = *reinterpret_cast<const uint4*>(src_wf + (use_wf && in ? v * 8 : 0));
+                pwf[1] = *reinterpret_cast<const uint4*>(src_wf + (use_wf && in ? v * 8 + 4 : 0));
             }
         }
     }
@@ -332,6 +358,14 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
     //      residual add + RMSNorm), t = A x of the LoRA factors, the nested-absmax maps, the byte -> value-pair table
     float* tl = reinterpret_cast<float*>(gemv_smem + NIT * 64 * ELEMS * sizeof(T) + UAMD_GEMV_MAX_GROUPS * 256 * 4 +
                                           (NF4 ? 256 * 32 * 4 : 0));          // [64 ranks x 4 groups] + 8 + 8 reduction slots
+#pragma unroll
+    for (int k = 0; k < VPT; ++k) {                        // operands a mode does not have, and vectors past K: zero (the loads above
+        const int v = tid + k * GEMV_THREADS;              // were unconditional; their first USE is down here, behind the weights)
+        const bool in = v * 8 < K;
+        if (!(use_a && in)) pa[k].r = make_uint4(0, 0, 0, 0);
+        if (!(use_b && in)) pb[k].r = make_uint4(0, 0, 0, 0);
+        if (!(use_w && in)) pw[k].r = make_uint4(0, 0, 0, 0);
+    }
     {
         const int nvec = NIT * 64 * ELEMS / 8;
         if (mode == 0) {
@@ -495,11 +529,12 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
         }
         DSTAMP(4);
         if (t_wave && t_q == 0 && lane == 0)
-            __hip_atomic_store(gran + t_r, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(acc),
+            __hip_atomic_store(gran + t_r, ((unsigned long long)UAMD_GEMV_TAG << 32) | (unsigned long long)__float_as_uint(acc),
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     bool have_t = false;
     auto fetch_t = [&]() {                            // the launch's t into LDS (every wave for itself; identical values)
+        const unsigned tag = UAMD_GEMV_TAG;
         for (int i = lane; i < p.pro.Rt; i += 64) {
             unsigned long long v = 0;
             bool ok = false;
