@@ -164,10 +164,11 @@ def test_attn_decode_matches_fp32_softmax(dtype, Hq, Hk, lens, window):
 @pytest.mark.parametrize("Hq,Hk", [(4, 4), (8, 2), (32, 8), (7, 1), (28, 4)])
 @pytest.mark.parametrize("lens,window,S", [((0,), 0, 512), ((1, 127, 128), 0, 512), ((255, 300, 511), 0, 512), ((129, 400), 96, 512),
                                            ((20,), 96, 512), ((1500, 100, 2046), 0, 2048)])
-def test_attn_decode_fused_is_the_three_launches_bit_for_bit(dtype, Hq, Hk, lens, window, S):
-    """uamd_attn_decode_fused (RoPE + append + split attention + last-arriver combine in ONE launch) against
-    uamd_rope_kv_append -> uamd_attn_decode: same output, same cache, bit for bit, over three consecutive tokens (the arrival
-    counters reset themselves), with the raw q|k|v row left untouched. lens = tokens already in the cache (0: the first one;
+def test_attn_decode_fused_is_the_three_launches(dtype, Hq, Hk, lens, window, S):
+    """uamd_attn_decode_fused (RoPE + append + split attention + combine in ONE launch) against uamd_rope_kv_append ->
+    uamd_attn_decode: the same cache bit for bit (same RoPE arithmetic), the same output to the rounding of the output dtype (the
+    keys of a split are accumulated chunk-wise instead of one by one), over three consecutive tokens (tags / arrival counters
+    take care of themselves), with the raw q|k|v row left untouched. lens = tokens already in the cache (0: the first one;
     127 / 128 / 255: the new key is the last of a split / the first of the next / the cache's last slot). Launches of up to 256
     workgroups combine through {value, tag} granules, larger ones (the S = 2048 case with 8 KV heads: 16 x 8 x 3 = 384) through the
     arrival counter: both paths are in the grid."""
@@ -194,7 +195,8 @@ def test_attn_decode_fused_is_the_three_launches_bit_for_bit(dtype, Hq, Hk, lens
         out2 = torch.full((B, Hq * D), float("nan"), dtype=dtype, device=DEV)
         Dk.attn_decode_fused(raw, cos, sin, kv_len, kc2, vc2, out2, part2, cnt, 128, scale, Hq, window=window)
         assert torch.equal(raw, keep)
-        assert torch.equal(out2, out1), (step, (out2.float() - out1.float()).abs().max())
+        err = (out2.float() - out1.float()).abs().max().item()
+        assert err <= (1.6e-2 if dtype == torch.bfloat16 else 2e-3) * max(out1.float().abs().max().item(), 1e-3), (step, err)
         assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
         assert int(cnt.abs().sum()) == 0                      # arrival counters (large launches) back at zero
         kv_len += 1

@@ -867,9 +867,10 @@ __global__ void __launch_bounds__(128) attn_decode_combine_kernel(const float* _
 
 
 // ---------------------------------------------------------------------------------------------------------------
-// RoPE + cache append + split-KV attention + combine as ONE launch (uamd_attn_decode_fused). Same per-key arithmetic, key
-// order and combine order as rope_append_kernel -> attn_decode_kernel -> attn_decode_combine_kernel, so the result is
-// bit-identical to the three launches. What changes:
+// RoPE + cache append + split-KV attention + combine as ONE launch (uamd_attn_decode_fused). Same RoPE arithmetic, key
+// partition and combine order as rope_append_kernel -> attn_decode_kernel -> attn_decode_combine_kernel; the keys of a
+// split are accumulated chunk-wise (one running-max rescale per 8 keys of a lane group instead of one per key), so the
+// result equals the three launches' to fp32 rounding, not bit for bit. What changes:
 //   * every block rotates the G query heads of its KV head itself from the raw q|k|v row (G x 64 pairs; qkv is not written);
 //   * the block whose split owns position len0 = kv_len[b] rotates the new k, appends k and v to the cache and takes both
 //     from LDS when its loop reaches that key (a store followed by a load of the same line in one kernel would depend on the
@@ -982,35 +983,48 @@ __global__ void __launch_bounds__(256) attn_decode_fused_kernel(AttnDecFusedArgs
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         DSTAMP(4);
 #endif
+        // pass 1: the scores of the chunk's keys, all (key, head) pairs independent of each other (the one-key-at-a-time online
+        // softmax this replaces was a single dependent chain per head: 3.9 us for 8 keys with one wave per SIMD to hide nothing
+        // behind, profiles/r04z_decode_phase_trace.txt)
+        float sc[NI][G];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int key = base + 16 * i + grp;
-            if (base + 16 * i >= s1) break;                // (wave-uniform: the old loop's exit)
             const bool valid = key < s1 && key >= first;
             if (own && key == len0) {
                 kk[i] = *reinterpret_cast<const Vec16<T>*>(kn + l16 * 8);
                 vv[i] = *reinterpret_cast<const Vec16<T>*>(vn + l16 * 8);
             }
-            float s[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 float acc = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc += qv[g][j] * to_f32(kk[i].e[j]);
                 acc = row16_sum(acc);
-                s[g] = valid ? acc : -INFINITY;
+                sc[i][g] = valid ? acc : -INFINITY;
             }
+        }
+        // pass 2: one rescale per head and chunk, then the chunk's keys accumulate independently
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                const float mn = fmaxf(m[g], s[g]);
-                const float mr = mn == -INFINITY ? 0.f : mn;
-                const float alpha = __builtin_amdgcn_exp2f(m[g] - mr);
-                const float pe = __builtin_amdgcn_exp2f(s[g] - mr);
-                m[g] = mn;
-                l[g] = l[g] * alpha + pe;
+        for (int g = 0; g < G; ++g) {
+            float mc = sc[0][g];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[g][j] = o[g][j] * alpha + pe * to_f32(vv[i].e[j]);
+            for (int i = 1; i < NI; ++i) mc = fmaxf(mc, sc[i][g]);
+            const float mn = fmaxf(m[g], mc);
+            const float mr = mn == -INFINITY ? 0.f : mn;
+            const float alpha = __builtin_amdgcn_exp2f(m[g] - mr);
+            m[g] = mn;
+            float ls = l[g] * alpha;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[g][j] *= alpha;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float pe = __builtin_amdgcn_exp2f(sc[i][g] - mr);
+                ls += pe;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[g][j] += pe * to_f32(vv[i].e[j]);
             }
+            l[g] = ls;
         }
     }
     DSTAMP(5);
