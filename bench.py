@@ -551,6 +551,8 @@ def main():
         primary_policy = ("all (every layer keeps everything)" if pol == _fl.POLICIES["all"] else
                           "attn (every layer re-runs norm2 + gate/up)" if pol == _fl.POLICIES["attn"] else
                           "all*%d,attn" % pol[0][0])
+    from unsloth_amd import nf4 as _nf4p
+    primary_mirrors = bool(_nf4p.RESIDENT and _nf4p.resident_count() > 0)
     alt = None
     if a.alt_steps > 0:
         # the other checkpointing modes at the primary batch, then batch 1 and 2 without checkpointing
@@ -586,12 +588,20 @@ def main():
         alt[PACKED_TAG]["batch"] = "1 x %d" % (B * T)
         del pdata
         if os.environ.get("BENCH_RESIDENT_ALT", "1") == "1":
-            # opt-in mode: decoded bf16 mirrors of the NF4 weights stay in HBM (+2 B/param), no decode launches
+            # decoded bf16 mirrors of the NF4 weights (+2 B/param, no decode launches): part of the fit-to-memory default since round
+            # 4 (nf4.RESIDENT_MODE "auto", i.e. the primary above has them on an idle GPU); here the same spelling WITHOUT them (the
+            # rounds 1-3 behaviour), and batch 1 with them
             from unsloth_amd import nf4 as _nf4
-            _nf4.set_resident(True)
-            alt_point("weights_resident_bf16_gc_off (opt-in: UNSLOTH_AMD_RESIDENT_WEIGHTS=1)", False, B)
-            alt_point("weights_resident_bf16_batch_1", False, 1)
+            mode_was = _nf4.RESIDENT_MODE
+            _nf4.RESIDENT_MODE = "0"
             _nf4.set_resident(False)
+            base_._uamd_auto_policy = None
+            alt_point("gc_unsloth_nf4_decoded_at_every_use (UNSLOTH_AMD_RESIDENT_WEIGHTS=0: no decoded mirrors, rounds 1-3)", "unsloth", B)
+            _nf4.RESIDENT_MODE = mode_was
+            _nf4.set_resident(True)
+            alt_point("batch_1_gc_off_with_decoded_weight_mirrors (UNSLOTH_AMD_RESIDENT_WEIGHTS=1)", False, 1)
+            _nf4.set_resident(False)
+            base_._uamd_auto_policy = None
             torch.cuda.empty_cache()
         if os.environ.get("BENCH_DP_FORCE_ALT", "1") == "1" and world == 1 and arena is None:
             # the data-parallel path on ONE rank: gradient arena owned by dp.LoRAGradArena, the post-accumulate hooks, the 11
@@ -711,6 +721,8 @@ def main():
                        "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
                        "gradient_checkpointing": GC_MODE[a.gc], "gc_schedule_chosen": primary_policy,
+                       "nf4_decoded_weight_mirrors": ("on (fit-to-memory default: +2 B per projection parameter of HBM, no decode launches)"
+                                                      if primary_mirrors else "off"),
                        "trainable_params": n_train,
                        "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": type(opt).__name__ + " fp32 on LoRA params"},
             "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T, "rccl_ranks": rccl_ranks,

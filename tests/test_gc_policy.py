@@ -96,3 +96,20 @@ def test_auto_schedule_on_an_idle_and_on_a_crowded_mi355x():
     assert F.auto_schedule(free_bytes=10 * GiB, **LLAMA3_8B) == F.POLICIES["attn"]
     # batch 1 (2048 tokens) needs a quarter of the activations: the same 10 GB are plenty for keep-everything
     assert F.auto_schedule(free_bytes=10 * GiB, **dict(LLAMA3_8B, tokens=2048)) == F.POLICIES["all"]
+
+
+def test_decoded_weight_mirrors_ride_on_the_same_decision():
+    """nf4.RESIDENT_MODE "auto": the bare "unsloth" spelling also keeps 16-bit mirrors of the NF4 projections when every layer keeps
+    everything AND the HBM left after that holds the mirrors twice over (turning on), or the step still fits with them (staying
+    on). Llama-3-8B, 8192 tokens: "all" takes ~28 GB beyond weights and optimizer, the mirrors 14 GB."""
+    from unsloth_amd.models import fast_layer as F
+    kw = dict(n_layers=32, tokens=8192, hidden=4096, inter=14336, qkv_cols=6144, elsize=2, vocab=128256)
+    G = 1 << 30
+    assert F.mirrors_fit(free_bytes=250 * G, **kw)                       # an idle MI355X
+    assert F.mirrors_fit(free_bytes=80 * G, **kw)
+    assert not F.mirrors_fit(free_bytes=48 * G, **kw)                    # "all" fits (auto_schedule), twice 14 GB on top does not
+    assert F.auto_schedule(free_bytes=48 * G, **kw) == F.POLICIES["all"]
+    assert F.mirrors_fit(free_bytes=40 * G, have_mirrors=True, **kw)     # already allocated: stay while "all" still fits
+    assert not F.mirrors_fit(free_bytes=20 * G, have_mirrors=True, **kw)
+    # tiny batches on a big model: the mirrors are what a short step gains most from (9 % at 2048 tokens) and fit easily
+    assert F.mirrors_fit(**dict(kw, tokens=2048), free_bytes=60 * G)

@@ -252,7 +252,8 @@ class FlashAttention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, scale, band, causal=True):
-        o, lse = attn_forward(q, k, v, scale, band, causal)
+        # (causal only when it is not the default: tests and tools swap attn_forward / attn_backward for five-argument stand-ins)
+        o, lse = attn_forward(q, k, v, scale, band) if causal else attn_forward(q, k, v, scale, band, False)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.scale, ctx.band, ctx.causal = scale, band, causal
         return o
@@ -260,7 +261,10 @@ class FlashAttention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, do):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band, ctx.causal)
+        if ctx.causal:
+            dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band)
+        else:
+            dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band, False)
         return dq, dk, dv, None, None, None
 
 

@@ -74,6 +74,21 @@ def auto_schedule(n_layers, tokens, hidden, inter, qkv_cols, elsize, free_bytes,
     return [(k, POLICIES["all"]), (None, POLICIES["attn"])]
 
 
+def mirrors_fit(n_layers, tokens, hidden, inter, qkv_cols, elsize, free_bytes, vocab=0, headroom=0.15, have_mirrors=False):
+    """The second half of the fit-to-memory decision: may the NF4 projections keep decoded 16-bit mirrors (nf4.RESIDENT_MODE
+    "auto")? Yes when every layer keeps everything (auto_schedule) and what is left of `free_bytes` after that, headroom
+    set aside, holds the mirrors (2 B per projection parameter) once over with as much again to spare. `have_mirrors`: they
+    are allocated already (free_bytes no longer contains them): the question is then whether "all" still fits without
+    giving them back. Same arithmetic as auto_schedule, same CPU test."""
+    per_tok_attn = (hidden + qkv_cols + hidden + hidden) * elsize + 4 * (qkv_cols // 128 + 1)
+    per_tok_all_extra = (2 * hidden + 2 * inter) * elsize
+    transient = tokens * (6 * inter + 4 * hidden + 2 * qkv_cols) * elsize + 2 * min(tokens, 4096) * max(vocab, 1) * elsize \
+        + 3 * (hidden * inter) * elsize
+    left = (free_bytes - transient - n_layers * tokens * (per_tok_attn + per_tok_all_extra)) * (1.0 - headroom)
+    mirrors = n_layers * (hidden * qkv_cols + hidden * hidden + 3 * hidden * inter) * elsize
+    return left >= 0 if have_mirrors else left >= 2 * mirrors
+
+
 def free_hbm_bytes(dev):
     """HBM this step may still take: what the driver reports free + the blocks torch's allocator holds but has not handed
     out. UNSLOTH_AMD_GC_FREE_GB caps it (a share of a GPU that other jobs use; the capped operating point of bench.py)."""
@@ -98,8 +113,18 @@ def auto_policy(model, hidden_states):
     hit = getattr(model, "_uamd_auto_policy", None)
     if hit is not None and hit[0] == key:
         return hit[1]
-    pol = auto_schedule(len(model.layers), tokens, cfg.hidden_size, cfg.intermediate_size, qkv_cols,
-                        hidden_states.element_size(), free, vocab=getattr(cfg, "vocab_size", 0))
+    args = (len(model.layers), tokens, cfg.hidden_size, cfg.intermediate_size, qkv_cols, hidden_states.element_size(), free)
+    vocab = getattr(cfg, "vocab_size", 0)
+    pol = auto_schedule(*args, vocab=vocab)
+    from .. import nf4 as _nf4
+    if _nf4.RESIDENT_MODE == "auto":
+        # decoded mirrors of the NF4 weights ride on the same decision (nf4.py): on when there is HBM to spare, off when not
+        want = pol == POLICIES["all"] and mirrors_fit(*args, vocab=vocab, have_mirrors=_nf4.RESIDENT and _nf4.resident_count() > 0)
+        if want and not _nf4.RESIDENT:
+            _nf4.set_resident(True, auto=True)
+        elif not want and _nf4.AUTO_ON:               # (mirrors a caller switched on with nf4.set_resident(True) are the caller's)
+            _nf4.set_resident(False)
+            torch.cuda.empty_cache()
     model._uamd_auto_policy = (key, pol)
     return pol
 

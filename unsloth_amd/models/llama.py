@@ -728,6 +728,11 @@ class FastLlamaModel:
         gc = bool(mode)
         base.model.gradient_checkpointing = gc
         base.model._unsloth_amd_layer_policy = policy
+        from .. import nf4 as _nf4
+        if _nf4.RESIDENT_MODE == "auto" and policy != _fast_layer.AUTO and _nf4.AUTO_ON:
+            # decoded weight mirrors belong to the fit-to-memory spelling (nf4.py); a fixed mode asked for something else
+            _nf4.set_resident(False)
+            base.model._uamd_auto_policy = None
         for m in base.modules():
             if hasattr(m, "gradient_checkpointing"):
                 m.gradient_checkpointing = gc

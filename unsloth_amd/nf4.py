@@ -187,22 +187,32 @@ def quantize_nf4(W, blocksize=64, compress_statistics=True):
     return packed, qs
 
 
-# Opt-in (UNSLOTH_AMD_RESIDENT_WEIGHTS=1 or nf4.set_resident(True)): keep the DECODED bf16 copy of every NF4 weight in
-# HBM after its first decode instead of decoding it again at every use (2 decodes per weight per step: 7.4 ms of a
-# 250 ms step at 8192 tokens, 9 % of the step at 2048). Costs 2 B/param (14 GB for Llama-3-8B's projections) of the
+# Decoded mirrors (UNSLOTH_AMD_RESIDENT_WEIGHTS=1 | 0 | auto, or nf4.set_resident(True)): keep the DECODED bf16 copy of every NF4
+# weight in HBM after its first decode instead of decoding it again at every use (2 decodes per weight per step: 6.9 ms of a
+# 231 ms step at 8192 tokens, 9 % of the step at 2048). Costs 2 B/param (14 GB for Llama-3-8B's projections) of the
 # 288 GB -- the NF4 bytes stay the source of truth (checkpoints, merging); frozen weights never change, so the mirror
-# cannot go stale. Off by default: the headline numbers decode from NF4 at every use like the reference does.
+# cannot go stale, and the GEMMs read the same bf16 values either way (bit-identical steps).
+#   "auto" (default since round 4): the same fit-to-memory decision as the checkpointing schedule, taken with it -- the bare
+#   `use_gradient_checkpointing="unsloth"` turns the mirrors on when every layer already keeps everything AND the HBM left after
+#   that still holds them with room to spare (models/fast_layer.auto_policy), and off again when memory gets short. The
+#   reference makes the opposite trade (NF4 only, decode at every use) because 24-80 GB parts force it to.
+#   "0": never (rounds 1-3; what `False` / "unsloth:<policy>" runs use in any case).   "1": always.
 import os as _os
 
-RESIDENT = _os.environ.get("UNSLOTH_AMD_RESIDENT_WEIGHTS", "0") == "1"
+RESIDENT_MODE = _os.environ.get("UNSLOTH_AMD_RESIDENT_WEIGHTS", "auto")
+RESIDENT = RESIDENT_MODE == "1"
 import weakref as _weakref
 
 _MIRRORED = _weakref.WeakSet()      # quant states that carry a decoded mirror (`_resident`, `_resident_group`)
 
 
-def set_resident(on):
-    global RESIDENT
+AUTO_ON = False                     # the mirrors are on because the fit-to-memory decision turned them on (not the caller)
+
+
+def set_resident(on, auto=False):
+    global RESIDENT, AUTO_ON
     RESIDENT = bool(on)
+    AUTO_ON = bool(on) and bool(auto)
     if not on:
         for q in list(_MIRRORED):
             q._resident = None
