@@ -138,11 +138,11 @@ class LoRAGradArena:
         # twice per step, the first time over partial sums that the second reduction then summed over the ranks AGAIN
         # (found in round 4 on the rocprofv3 trace: 16 collectives for 8 buckets; invisible at one rank, and the CPU tests
         # have no sinks). tests/_dp_worker.py now checks, at one rank too, that a bucket is launched once and complete.
-        if id(p) in self._arrived:
-            return
+        self.writes += 1                  # (dirtiness of the arena for optim.FlatAdamW.zero_grad: EVERY report counts -- a second
+        if id(p) in self._arrived:        #  micro-batch writes too; round 4's first dedup skipped it and an accumulation that
+            return                        #  followed a thrown-away backward started from the old sums)
         self._arrived.add(id(p))
         b = self._bucket_of[id(p)]
-        self.writes += 1
         self._pending[b] += 1
         if self._pending[b] == self.buckets[b][2]:
             self._pending[b] = 0
@@ -185,10 +185,14 @@ class LoRAGradArena:
             self._pending = [0] * len(self.buckets)
             self._arrived.clear()
 
-    def zero_grad(self):
-        """Keeps the views: the arena is zeroed in one memset instead of N small ones."""
+    def reset_arrivals(self):
+        """A new accumulation starts (the gradients so far were thrown away or stepped on): nobody has arrived yet."""
         self._arrived.clear()
         self._pending = [0] * len(self.buckets)
+
+    def zero_grad(self):
+        """Keeps the views: the arena is zeroed in one memset instead of N small ones."""
+        self.reset_arrivals()
         self.arena.zero_()
         for p in self.params:
             v = self._views[id(p)]

@@ -125,6 +125,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if self.arena.writes != self._writes_seen:
             self.arena.arena.zero_()
             self._writes_seen = self.arena.writes
+        self.arena.reset_arrivals()                  # (arrival bookkeeping of the exchange: a new accumulation starts)
         for p, _, _, gv in self._views:
             p.grad = gv
 
