@@ -445,6 +445,11 @@ int uamd_attn_decode_fused(const void* qkv, int64_t ld_qkv, const void* cos_t, c
                            int Hk, int D, int s_max, int nsplit, int split_keys, int window, float scale, unsigned tag,
                            const int* tag_dev, int dtype, void* stream);
 
+/* Greedy next token of a decode step: out[r] = argmax_i x[r, i] over `rows` contiguous fp32 rows of n logits (smallest index on
+ * ties, like `logits.argmax(-1)` in HF's generate, llama.py:2167-2259 -> transformers). Two launches, 8 us for 128,256 logits
+ * against 46 us for torch's reduction. Workspaces: ws_val rows * 64 floats, ws_idx rows * 64 int64. */
+int uamd_argmax_f32(const float* x, int rows, int64_t n, float* ws_val, int64_t* ws_idx, int64_t* out, void* stream);
+
 /* uamd_lora_xa2: same contract as uamd_lora_xa for R <= 64, streaming version (csrc/lora_side.hip): 32 rows per
  * block, K split over 4 waves, X and W through a per-wave LDS-DMA ring, fixed-order reduction. */
 int uamd_lora_xa2(const void* X, int64_t ldx, const void* A, int64_t lda, float* out,

@@ -289,6 +289,21 @@ def test_gemv_fused_lora_hand_off_at_long_rows(dtype, nf4, K, Ns, r):
         assert (y.float() - y2.float()).abs().max().item() <= 1e-2 * scale
 
 
+@pytest.mark.parametrize("rows,n", [(1, 128256), (3, 1000), (2, 64), (1, 1), (4, 32000)])
+def test_argmax_kernel_is_torch_argmax_with_first_index_ties(rows, n):
+    from unsloth_amd.kernels import decode as D
+    x = torch.randn(rows, n, generator=g(3)).to(DEV)
+    assert torch.equal(D.argmax_f32(x), torch.argmax(x, dim=-1))
+    x[:, n // 3:] = x[:, n // 3:].clamp(max=0.5)
+    x[:, n // 3] = 7.0
+    if n > 5:
+        x[:, n - 2] = 7.0                          # a tie: the first maximal element wins
+    assert torch.equal(D.argmax_f32(x), torch.full((rows,), n // 3, dtype=torch.long, device=DEV))
+    out = torch.empty(rows, dtype=torch.long, device=DEV)
+    ws = (torch.empty(rows * 64, device=DEV), torch.empty(rows * 64, dtype=torch.long, device=DEV))
+    assert D.argmax_f32(x, out=out, ws=ws) is out and int(out[0]) == n // 3
+
+
 def _tiny(load_in_4bit=True, r=8):
     from transformers import LlamaConfig
     from unsloth_amd import FastLanguageModel

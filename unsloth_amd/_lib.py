@@ -157,6 +157,7 @@ SIGNATURES = {
     "uamd_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_int, c_float, ctypes.c_uint, c_void_p, c_int, c_void_p]),
+    "uamd_argmax_f32": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "uamd_debug_mfma_probe": (c_int, [c_void_p, c_void_p]),
 }
 

@@ -1393,3 +1393,59 @@ extern "C" int uamd_attn_decode_fused(const void* qkv, int64_t ld_qkv, const voi
 #undef UAMD_DECODE_LAUNCH
     return uamd_launch_status();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Greedy next token of the decode step: argmax over the fp32 logits row (the reference: `logits.argmax(-1)` in HF's generate).
+// torch's reduce kernel takes 46 us for the 128,256 logits of one token (profiles/r04z_decode_kernel_stats.csv) -- 1.6 % of the
+// step for half a megabyte. Two launches: 64 blocks find (max, first index) of their slices; one block finishes. Ties go to the
+// SMALLEST index (torch returns the first maximal element on this path too).
+namespace {
+struct MaxIdx { float v; long long i; };
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ MaxIdx wave_best(MaxIdx m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        MaxIdx t;
+        t.v = __shfl_xor(m.v, o, 64);
+        t.i = __shfl_xor(m.i, o, 64);
+        m = better(m, t);
+    }
+    return m;
+}
+__global__ void __launch_bounds__(256) argmax_part_kernel(const float* __restrict__ x, long long n, float* __restrict__ pv,
+                                                          long long* __restrict__ pi) {
+    __shared__ float sv[4];
+    __shared__ long long si[4];
+    const float* row = x + (long long)blockIdx.y * n;
+    MaxIdx m = {-INFINITY, n};
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float v = row[i];
+        if (v > m.v || (v == m.v && i < m.i) || m.i == n) { m.v = v; m.i = i; }       // (NaN never wins; all-NaN rows: index of the scan's start)
+    }
+    m = wave_best(m);
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = m.v; si[threadIdx.x >> 6] = m.i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { MaxIdx t = {sv[w], si[w]}; m = better(m, t); }
+        pv[blockIdx.y * gridDim.x + blockIdx.x] = m.v;
+        pi[blockIdx.y * gridDim.x + blockIdx.x] = m.i;
+    }
+}
+__global__ void __launch_bounds__(64) argmax_final_kernel(const float* __restrict__ pv, const long long* __restrict__ pi, int parts,
+                                                          long long n, long long* __restrict__ out) {
+    MaxIdx m = {-INFINITY, n};
+    for (int i = threadIdx.x; i < parts; i += 64) { MaxIdx t = {pv[blockIdx.x * parts + i], pi[blockIdx.x * parts + i]}; m = better(m, t); }
+    m = wave_best(m);
+    if (threadIdx.x == 0) out[blockIdx.x] = m.i < n ? m.i : 0;
+}
+}  // namespace
+
+// out[r] = argmax_i x[r, i] over `rows` contiguous fp32 rows of n entries; workspace: rows * 64 floats + rows * 64 int64.
+extern "C" int uamd_argmax_f32(const float* x, int rows, int64_t n, float* ws_val, int64_t* ws_idx, int64_t* out, void* stream) {
+    if (!x || !ws_val || !ws_idx || !out || rows <= 0 || n <= 0) return UAMD_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(argmax_part_kernel, dim3(64, (unsigned)rows), dim3(256), 0, st, x, (long long)n, ws_val, (long long*)ws_idx);
+    hipLaunchKernelGGL(argmax_final_kernel, dim3((unsigned)rows), dim3(64), 0, st, ws_val, (const long long*)ws_idx, 64, (long long)n,
+                       (long long*)out);
+    return uamd_launch_status();
+}

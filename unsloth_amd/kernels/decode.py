@@ -323,3 +323,20 @@ def attn_decode_fused(qkv, cos, sin, kv_len, k_cache, v_cache, out, partials, co
             _lib.dtype_code(qkv.dtype), _lib.stream_of(qkv))
     _lib.check(rc, "uamd_attn_decode_fused")
     return out
+
+
+def argmax_f32(logits, out=None, ws=None):
+    """Greedy next token: argmax over the last dimension of contiguous fp32 logits [rows, n] -> int64 [rows] (uamd_argmax_f32).
+    `ws` = (float32 [rows * 64], int64 [rows * 64]) workspaces to reuse under a hipGraph."""
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.is_contiguous()
+    rows, n = logits.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.long, device=logits.device)
+    if ws is None:
+        ws = (torch.empty(rows * 64, dtype=torch.float32, device=logits.device),
+              torch.empty(rows * 64, dtype=torch.long, device=logits.device))
+    with _lib.device_ctx(logits):
+        rc = _lib.lib().uamd_argmax_f32(_lib.ptr(logits), rows, n, _lib.ptr(ws[0]), _lib.ptr(ws[1]), _lib.ptr(out),
+                                        _lib.stream_of(logits))
+    _lib.check(rc, "uamd_argmax_f32")
+    return out

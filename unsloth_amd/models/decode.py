@@ -159,6 +159,17 @@ class DecodeEngine:
         self.logits = self._lm_head(xn.view(B, -1))
         return self.logits
 
+    def _greedy(self):
+        """next_tok = argmax of the step's logits, inside the captured step."""
+        lg = self.logits
+        if lg.dtype == torch.float32 and lg.is_contiguous():
+            if getattr(self, "_amax_ws", None) is None:
+                self._amax_ws = (torch.empty(self.B * 64, dtype=torch.float32, device=self.dev),
+                                 torch.empty(self.B * 64, dtype=torch.long, device=self.dev))
+            _dk.argmax_f32(lg, out=self.next_tok, ws=self._amax_ws)
+        else:
+            self.next_tok.copy_(torch.argmax(lg, dim=-1))
+
     def _lm_head(self, x):                       # x [B, H] -> fp32 logits [B, V]
         W = self._head
         if self.B == 1 and W.dtype == x.dtype and W.shape[1] <= 16384:
@@ -232,7 +243,7 @@ class DecodeEngine:
             self.logits = self._lm_head(xn)
         self._pos.add_(1)                                   # positions and the step counter
         if self._sample is None:
-            self.next_tok.copy_(torch.argmax(self.logits, dim=-1))
+            self._greedy()
         return self.logits
 
     @torch.no_grad()
@@ -266,7 +277,7 @@ class DecodeEngine:
         self.logits = self._lm_head(xn)
         self._pos.add_(1)                                   # positions and the step counter
         if self._sample is None:
-            self.next_tok.copy_(torch.argmax(self.logits, dim=-1))
+            self._greedy()
         return self.logits
 
     def step(self, token_ids):
