@@ -102,7 +102,8 @@ def main():
                     print(f"    {i:2d} {nm:44s} {int(np.median(col)):7d} [{col.min():6d} .. {col.max():6d}]  ({len(col)} waves)")
 
     gemv_names = ["entry", "weight loads of trip 1 issued", "x staged, tables built", "after the barrier", "t row reduced (t workgroups)",
-                  "trip 1 dot products done, poll starts", "t picked up", "trip 1 reduced", "all rows stored", "end"]
+                  "trip 1 dot products done, poll starts", "t picked up", "trip 1 reduced", "all rows stored", "end",
+                  "  (kernarg lines touched)", "  (prologue operand loads issued)", "  (absmax map / NF4 level loads issued)"]
     resid = torch.randn(H, device=dev, dtype=bf)
     delta = torch.randn(H, device=dev, dtype=bf)
     wn = torch.ones(H, device=dev, dtype=bf)

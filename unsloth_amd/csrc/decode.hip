@@ -151,6 +151,7 @@ constexpr int GEMV_THREADS = 512;
 // (profiles/r04u_decode_phase_trace.txt). Now a trip belongs to ONE group: its fields are fetched once per trip from the h* arrays
 // (independent scalar loads at a run-time index, one wait), and kept as integers so that the loads built on them are typed
 // global (gptr) rather than flat.
+#define OPQ(V) asm volatile("" : "+s"(V))          /* pin a wave-uniform value in scalar registers at this point */
 // a 64-bit value as a GLOBAL pointer (an integer cast to a plain pointer is a flat address: flat_load, which also counts on
 // lgkmcnt and drags a wait behind every row)
 template <typename V> __device__ __forceinline__ const __attribute__((address_space(1))) V* gptr(uint64_t a) {
@@ -176,7 +177,8 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
     uint32_t* lut2 = reinterpret_cast<uint32_t*>(code2 + UAMD_GEMV_MAX_GROUPS * 256);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = p.K;
+    int K = p.K;
+    OPQ(K);
     DTRACE_DECL;
     DSTAMP(0);
     {   // every 64-byte line of the ~0.9 KB kernarg segment in ONE batch of scalar loads: left to the compiler they are fetched
@@ -188,6 +190,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
         for (int o = 0; o < (int)sizeof(GemvArgs); o += 64) touch |= ka[o / 4];
         asm volatile("" ::"s"(touch));
     }
+    DSTAMP(10);
     // columns past K: x is zero there, so the lane may read any valid address instead (no branches in the row loop)
     int koff[NIT];
 #pragma unroll
@@ -211,14 +214,25 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
     uint32_t a8[RB][NIT];
     float a2[RB][NIT];
     uint32_t braw[RB];                               // lane j: B[n][j] of the row's adapter (raw bits), loaded with the weights
-    const int n_groups = p.n_groups, glu = p.pro.glu, total_trips = p.total_trips, bs_shift = p.bs_shift;
+    int n_groups = p.n_groups, glu = p.pro.glu, total_trips = p.total_trips, bs_shift = p.bs_shift;
+    // every kernarg scalar the load phase uses, fetched HERE and pinned: left alone, the compiler re-loads them from the kernarg
+    // segment where each row needs them -- ten scalar-cache round trips in a row inside load_rows (1.6 us of the 2.9 us between
+    // a wave's entry and its last load going out, profiles/r04am_decode_phase_trace.txt)
+    int ts1 = p.trip_start[1], ts2 = p.trip_start[2], ts3 = p.trip_start[3];
+    uint64_t gW0 = (uint64_t)p.hW[0], gW1 = (uint64_t)p.hW[1], gB0 = (uint64_t)p.hB[0], gB1 = (uint64_t)p.hB[1];
+    uint64_t gA0 = (uint64_t)p.hA[0], gA1 = (uint64_t)p.hA[1], gA20 = (uint64_t)p.hA2[0], gA21 = (uint64_t)p.hA2[1];
+    int gM0 = p.hmeta[0], gM1 = p.hmeta[1], gL0 = p.hldb[0], gL1 = p.hldb[1], gN0 = p.hN[0];
+    int64_t gD0 = p.hldw[0], gD1 = p.hldw[1];
+    OPQ(n_groups); OPQ(glu); OPQ(total_trips); OPQ(bs_shift); OPQ(ts1); OPQ(ts2); OPQ(ts3);
+    OPQ(gW0); OPQ(gW1); OPQ(gB0); OPQ(gB1); OPQ(gM0); OPQ(gM1); OPQ(gL0); OPQ(gL1); OPQ(gN0);
+    if (NF4) { OPQ(gA0); OPQ(gA1); OPQ(gA20); OPQ(gA21); } else { OPQ(gD0); OPQ(gD1); }
     int t_gi = 0;                                    // the current trip's group (glu: row r belongs to group r & 1)
     bool valid[RB];
     auto load_rows = [&](int trip, int r_lo, int r_hi) {      // rows [r_lo, r_hi) of the trip (compile-time bounds after inlining)
         int gi = 0;
-#pragma unroll
-        for (int i = 1; i < UAMD_GEMV_MAX_GROUPS; ++i)
-            if (i < n_groups && trip >= p.trip_start[i]) gi = i;
+        if (1 < n_groups && trip >= ts1) gi = 1;
+        if (2 < n_groups && trip >= ts2) gi = 2;
+        if (3 < n_groups && trip >= ts3) gi = 3;
         t_gi = gi;
         // the trip's group, fetched ONCE: independent scalar loads at a run-time index, one wait for all of them
         // (glu: both groups, picked by the compile-time parity of r below)
@@ -232,8 +246,8 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
         for (int r = 0; r < RB; ++r) {
             if (r < r_lo || r >= r_hi) continue;
             const int gr = r & 1;
-            const uint64_t gW = glu ? (uint64_t)p.hW[gr] : sW, gB = glu ? (uint64_t)p.hB[gr] : sB;
-            const int meta = glu ? p.hmeta[gr] : sMeta, ldb = glu ? p.hldb[gr] : sLdb, Ng = glu ? p.hN[0] : sN;
+            const uint64_t gW = glu ? (gr ? gW1 : gW0) : sW, gB = glu ? (gr ? gB1 : gB0) : sB;
+            const int meta = glu ? (gr ? gM1 : gM0) : sMeta, ldb = glu ? (gr ? gL1 : gL0) : sLdb, Ng = glu ? gN0 : sN;
             const int nraw = glu ? n0 + (r >> 1) : n0 + r;
             valid[r] = nraw < Ng;
             // (readfirstlane: the row is wave-uniform by construction; said explicitly, its 64-bit products stay on the scalar unit
@@ -247,7 +261,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
             // addresses: everything that depends on the ROW is wave-uniform (scalar unit, 64 bits); a lane adds a 32-bit byte
             // offset, so every load is `global_load ..., v_off, s[base]` (14 vector instructions per load before, 64-bit)
             if constexpr (NF4) {
-                const uint64_t gA = glu ? (uint64_t)p.hA[gr] : sA, gA2 = glu ? (uint64_t)p.hA2[gr] : sA2;
+                const uint64_t gA = glu ? (gr ? gA1 : gA0) : sA, gA2 = glu ? (gr ? gA21 : gA20) : sA2;
                 const uint64_t rowbase = uniform64((uint64_t)nrow * (uint64_t)K);   // first code of the row (K % 32 == 0)
                 const uint64_t wrow = uniform64(gW + (rowbase >> 1));
                 const uint64_t blk_row = rowbase >> bs_shift;                        // first absmax block the row touches
@@ -271,7 +285,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
                     }
                 }
             } else {
-                const int64_t ldw = glu ? p.hldw[gr] : sLdw;
+                const int64_t ldw = glu ? (gr ? gD1 : gD0) : sLdw;
                 const uint64_t wrow = uniform64(gW + (uint64_t)((int64_t)nrow * ldw) * sizeof(T));
 #pragma unroll
                 for (int i = 0; i < NIT; ++i) {
@@ -324,6 +338,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
             }
         }
     }
+    DSTAMP(11);
     if (NF4) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -334,6 +349,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
         }
     }
     const float nf_hi = kNF4d[(tid >> 4) & 15], nf_lo = kNF4d[tid & 15];      // (constant MEMORY: two more loads that belong up here)
+    DSTAMP(12);
     int trip = t_block ? total_trips : ((int)blockIdx.x - n_tb) * (GEMV_THREADS / 64) + wave_u;
     if (trip < total_trips) load_rows(trip, 0, RB);
     // t workgroups: wave (row r, part q of KS) of t = A x streams its <= 8 vectors of the A row NOW, with everything else of the
