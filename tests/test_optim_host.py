@@ -82,3 +82,34 @@ def test_exclude_rope_inv_freq_from_ddp_lists_the_rotary_buffers():
     assert "something.else" in m._ddp_params_and_buffers_to_ignore
     exclude_rope_inv_freq_from_ddp(m)
     assert m._ddp_params_and_buffers_to_ignore.count("model.rotary_emb.inv_freq") == 1
+
+
+def test_arena_dirtiness_counts_every_report_and_arrivals_once():
+    """dp.LoRAGradArena on the CPU, one process: `writes` (what optim.FlatAdamW.zero_grad reads to decide whether the arena has to be
+    cleared) grows with EVERY gradient report -- also the second one of a parameter (a sink's ready() followed by torch's
+    post-accumulate hook, or a second micro-batch) --, while a bucket's arrival count takes each parameter once per accumulation.
+    Round 4's first de-duplication skipped `writes` on the repeat: after a thrown-away backward, zero_grad() found the arena
+    "clean" and the next accumulation started from the old sums (caught on the GPU by test_gradient_accumulation_over_micro_batches)."""
+    import torch
+    from unsloth_amd.dp import LoRAGradArena
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = torch.nn.Parameter(torch.zeros(4, 3))
+            self.b = torch.nn.Parameter(torch.zeros(5))
+    m = M()
+    arena = LoRAGradArena(m, process_group=None, direct=False)
+    assert arena.writes == 0 and len(arena.buckets) == 1
+    for rep in range(2):                              # two backward passes without a reset in between (accumulation)
+        for p in arena.params:
+            arena.ready(p)                            # the sink's report
+            arena.ready(p)                            # ... and torch's hook for the same gradient
+    assert arena.writes == 8                          # every report counted
+    assert len(arena._arrived) == 2 and arena._pending == [0]          # each parameter arrived once; the bucket completed once
+    w = arena.writes
+    arena.reset_arrivals()
+    for p in arena.params:
+        arena.ready(p)
+    assert arena.writes == w + 2 and len(arena._arrived) == 2
+    arena.close()
