@@ -79,7 +79,12 @@ class DecodeEngine:
         self.step_ctr = self._pos[batch:]
         self._steps = 1                               # host mirror of step_ctr (no sync): wrap-around guard
         self.partials = torch.empty(batch, self.Hq, self.S // SPLIT_KEYS, self.D + 2, dtype=torch.float32, device=self.dev)
-        self.fpartials, self.counters = _dk.fused_attn_workspace(batch, self.Hq, self.Hk, self.S, self.D, SPLIT_KEYS, self.dev,
+        # the fused attention's splits: 128 keys each (64 keys = 256 workgroups at context 2048 measured 3.5 % slower per token,
+        # tools/experiments/decode_split_ab.sh), longer ones where 128 would mean more than 256 workgroups -- up to 256 of them
+        # combine through granules, a larger launch pays the 21 us fence + arrival-counter tail: 256 keys at context 8192 with 8 KV
+        # heads, 1024 at 32768
+        self.fsplit = max(SPLIT_KEYS, int(math.ceil(self.S * self.Hk * batch / 256 / 16) * 16))
+        self.fpartials, self.counters = _dk.fused_attn_workspace(batch, self.Hq, self.Hk, self.S, self.D, self.fsplit, self.dev,
                                                                   step_dev=self.step_ctr)
         self.sync = _dk.HandOff(self.dev, step_dev=self.step_ctr)                             # uamd_gemv_fused hand-off
         self.tok = torch.zeros(batch, 1, dtype=torch.long, device=self.dev)
@@ -220,7 +225,7 @@ class DecodeEngine:
                 resid = h
             a_out = torch.empty(1, self.Hq * self.D, **kw)
             _dk.attn_decode_fused(qkv, self.cos, self.sin, self.kv_len, self.k_cache[li], self.v_cache[li], a_out,
-                                  self.fpartials, self.counters, SPLIT_KEYS, self.scale, self.Hq, window=self.window,
+                                  self.fpartials, self.counters, self.fsplit, self.scale, self.Hq, window=self.window,
                                   site=site + 1)
             (o,) = _dk.linear_group(a_out.view(-1), P["o"], fused=dict(mode=0, sync=self.sync, site=site + 2))
             h = torch.empty_like(resid)
