@@ -204,6 +204,31 @@ def test_attn_decode_fused_is_the_three_launches(dtype, Hq, Hk, lens, window, S)
         kv_len += 1
 
 
+@pytest.mark.parametrize("split_keys,lens", [(256, (700, 255, 256)), (512, (1000,)), (64, (130, 64))])
+def test_attn_decode_fused_with_other_split_sizes(split_keys, lens):
+    """The engine gives long contexts longer splits (<= 256 workgroups per launch): several 128-key chunks per workgroup, and the
+    64-key case where a chunk is half empty."""
+    from unsloth_amd.kernels import decode as Dk
+    dtype, D, S, Hq, Hk, B = torch.bfloat16, 128, 1024, 8, 2, len(lens)
+    cos = torch.randn(S, D, generator=g(1)).clamp(-1, 1).to(dtype).to(DEV)
+    sin = torch.randn(S, D, generator=g(2)).clamp(-1, 1).to(dtype).to(DEV)
+    kc1 = torch.randn(B, Hk, S, D, generator=g(9)).to(dtype).to(DEV)
+    vc1 = torch.randn(B, Hk, S, D, generator=g(10)).to(dtype).to(DEV)
+    kc2, vc2 = kc1.clone(), vc1.clone()
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    part1 = torch.empty(B, Hq, S // split_keys, D + 2, dtype=torch.float32, device=DEV)
+    part2, cnt = Dk.fused_attn_workspace(B, Hq, Hk, S, D, split_keys, DEV)
+    raw = torch.randn(B, (Hq + 2 * Hk) * D, generator=g(3)).to(dtype).to(DEV)
+    q1 = raw.clone()
+    out1 = torch.empty(B, Hq * D, dtype=dtype, device=DEV)
+    out2 = torch.full_like(out1, float("nan"))
+    Dk.rope_kv_append(q1, cos, sin, kv_len, kc1, vc1, Hq, Hk, D)
+    Dk.attn_decode(q1[:, :Hq * D], kc1, vc1, kv_len, out1, part1, split_keys, 1.0 / math.sqrt(D), len_add=1)
+    Dk.attn_decode_fused(raw, cos, sin, kv_len, kc2, vc2, out2, part2, cnt, split_keys, 1.0 / math.sqrt(D), Hq)
+    assert torch.equal(kc2, kc1) and torch.equal(vc2, vc1)
+    assert (out2.float() - out1.float()).abs().max().item() <= 1.6e-2 * out1.float().abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("nf4", [True, False])
 def test_gemv_fused_glu_epilogue_and_the_in_launch_lora_hand_off(dtype, nf4):
