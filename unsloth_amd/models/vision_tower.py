@@ -8,8 +8,7 @@ their forwards are replaced per instance (the way the language tower's attention
   * attention: q | k | v stay where the qkv GEMM wrote them ([S, 3, H, D] -> three strided [1, S, H, D] views), the rotary
     embedding (fp32 tables of the 2-D patch positions, row = patch) rotates q and k IN PLACE through csrc/rope_embedding.hip,
     and csrc/attention.hip runs the bidirectional attention inside the `cu_seqlens` windows (kernels/attention.document_band;
-    head_dim 80: ONE padded copy of q | k | v with the two rotary halves at columns 0 and 64 of 128-wide heads, the layout the
-    kernels take natively -- attn_forward's generic zero-padding cost 23 copy / fill launches per block) -- in round 3 this was torch SDPA:
+    head_dim 80 and 16 : 16 heads go through the zero-padding of kernels/attention._pad_qkv) -- in round 3 this was torch SDPA:
     aotriton's flash kernels at 14 % (forward) and 6 % (backward) of the MFMA peak, 20 % of the config-4 step
     (profiles/r04m_config4_kernel_stats.csv: bwd_kernel_dk_dv 1.07 ms, bwd_kernel_dq 0.38 ms, attn_fwd 0.24 ms per block);
   * patch embedding: the Conv3d with kernel == stride as ONE GEMM over the flattened patches (no MIOpen convolution);
@@ -48,44 +47,12 @@ def vision_attention_fast_forward(self, hidden_states, cu_seqlens, position_embe
     S = hidden_states.shape[0]
     H, D = self.num_heads, self.head_dim
     qkv = self.qkv(hidden_states).view(1, S, 3, H, D)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                         # [1, S, H, D] views of the GEMM output
     cos, sin = position_embeddings                                             # [S, D] fp32: row = patch, first D/2 columns used
-    band = _band_of(cu_seqlens, S, qkv.device)
-    if D == 128:
-        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]                     # [1, S, H, D] views of the GEMM output
-        qr, kr = fast_rope_embedding(q.transpose(1, 2), k.transpose(1, 2), cos.float(), sin.float(), None)
-        o = _flash.flash_attention(qr.transpose(1, 2), kr.transpose(1, 2), v, float(self.scaling), band, False)
-        return self.proj(o.reshape(S, H * D))
-    # head_dim 80 (Qwen2-VL): ONE padded copy of q | k | v in the layout the 128-wide kernels take natively -- the two rotary
-    # halves at columns 0 and 64, zeros behind each: RoPE's pairs (j, j + 64) are the real pairs (j, j + D/2), Q K^T and P V see
-    # only zero columns more. Going through attn_forward's generic padding instead cost 23 copy / fill launches per block and
-    # step (three pads forward, five pads and three un-pads backward, q | k | v re-padded there) in a tower that is host-bound.
-    h = D // 2
-    pad = qkv.new_zeros(1, S, 3, H, 128)
-    pad[..., :h] = qkv[..., :h]
-    pad[..., 64:64 + h] = qkv[..., h:]
-    q, k, v = pad[:, :, 0], pad[:, :, 1], pad[:, :, 2]
-    cos_p, sin_p = _padded_tables(cos, sin, h)
-    qr, kr = fast_rope_embedding(q.transpose(1, 2), k.transpose(1, 2), cos_p, sin_p, None)
-    o = _flash.flash_attention(qr.transpose(1, 2), kr.transpose(1, 2), v, float(self.scaling), band, False)      # [1, S, H, 128]
-    return self.proj(torch.cat([o[..., :h], o[..., 64:64 + h]], dim=-1).reshape(S, H * D))
-
-
-_TABLE_CACHE = {}
-
-
-def _padded_tables(cos, sin, h):
-    """[S, 64] fp32 rotary tables for the padded head layout: columns 0 .. h - 1 of the tower's tables, then cos = 1 / sin = 0
-    (those columns multiply zeros). Built once per forward: every block passes the same `position_embeddings`."""
-    hit = _TABLE_CACHE.get("last")
-    if hit is not None and hit[0] is cos and hit[1] is sin:
-        return hit[2], hit[3]
-    S = cos.shape[0]
-    cos_p = torch.ones(S, 64, dtype=torch.float32, device=cos.device)
-    sin_p = torch.zeros(S, 64, dtype=torch.float32, device=cos.device)
-    cos_p[:, :h] = cos[:, :h].float()
-    sin_p[:, :h] = sin[:, :h].float()
-    _TABLE_CACHE["last"] = (cos, sin, cos_p, sin_p)
-    return cos_p, sin_p
+    qr, kr = fast_rope_embedding(q.transpose(1, 2), k.transpose(1, 2), cos.float(), sin.float(), None)
+    o = _flash.flash_attention(qr.transpose(1, 2), kr.transpose(1, 2), v, float(self.scaling), _band_of(cu_seqlens, S, qkv.device),
+                               False)
+    return self.proj(o.reshape(S, H * D))
 
 
 def vision_mlp_fast_forward(self, x):
