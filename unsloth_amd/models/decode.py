@@ -80,7 +80,7 @@ class DecodeEngine:
         self._steps = 1                               # host mirror of step_ctr (no sync): wrap-around guard
         self.partials = torch.empty(batch, self.Hq, self.S // SPLIT_KEYS, self.D + 2, dtype=torch.float32, device=self.dev)
         # the fused attention's splits: 128 keys each (64 keys = 256 workgroups at context 2048 measured 3.5 % slower per token,
-        # tools/experiments/decode_split_ab.sh), longer ones where 128 would mean more than 256 workgroups -- up to 256 of them
+        # profiles/r04_decode_split_keys_ab.txt), longer ones where 128 would mean more than 256 workgroups -- up to 256 of them
         # combine through granules, a larger launch pays the 21 us fence + arrival-counter tail: 256 keys at context 8192 with 8 KV
         # heads, 1024 at 32768
         self.fsplit = max(SPLIT_KEYS, int(math.ceil(self.S * self.Hk * batch / 256 / 16) * 16))
