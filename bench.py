@@ -184,13 +184,53 @@ def fractions(gs, ms_per_step):
     return out
 
 
-def main():
-    # stdout must carry exactly ONE line, the JSON record. Libraries print to the C-level stdout behind Python's back
-    # (RCCL's version banner at the first collective, flushed at exit, i.e. AFTER the record): keep the real stdout
-    # aside for the record and send everything else written to fd 1 to stderr.
-    real_stdout = os.dup(1)
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: become the launcher. One process per GPU under
+    torch.distributed.run on 127.0.0.1 (the driver's own command shape); the ranks find RANK / LOCAL_RANK / WORLD_SIZE in
+    their environment and rank 0 prints the one JSON line on the stdout this process was given. Fewer than N visible
+    devices is an error (exit 2), never a quiet 1-GPU run. BENCH_DRY_LAUNCH=1 (CPU test of this path): no device check,
+    the ranks rendezvous over gloo and report who took part."""
+    import socket
+    dry = os.environ.get("BENCH_DRY_LAUNCH", "0") == "1"
+    if not dry:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write(f"[bench] --gpus {n} but {have} GPU(s) visible: refusing to report a {n}-GPU number\n")
+            raise SystemExit(2)
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stderr.write(f"[bench] --gpus {n} without WORLD_SIZE: launching {n} ranks ({' '.join(cmd[1:8])} ...)\n")
     sys.stdout.flush()
-    os.dup2(2, 1)
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def dry_launch(a, real_stdout):
+    """BENCH_DRY_LAUNCH=1: the launcher / rendezvous / one-line-from-rank-0 path without a GPU (tests/test_bench_launcher.py)."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    took_part = 1
+    if world > 1:
+        dist.init_process_group("gloo")
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        took_part = int(one.item())
+    if rank == 0:
+        rec = {"metric": "bench.py launcher dry run (no GPU work)", "value": 0.0, "unit": "tokens/s", "n_gpus": world,
+               "steps": a.steps, "warmup": a.warmup, "rccl_ranks": took_part, "dry_launch": True}
+        os.write(real_stdout, (json.dumps(rec) + "\n").encode())
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
@@ -218,7 +258,21 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a.gpus, sys.argv[1:])               # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        # a scaling run that quietly measures another world size is worse than no run
+        sys.stderr.write(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: pass the same N to torchrun and to --gpus\n")
+        raise SystemExit(2)
+    # stdout must carry exactly ONE line, the JSON record. Libraries print to the C-level stdout behind Python's back
+    # (RCCL's version banner at the first collective, flushed at exit, i.e. AFTER the record): keep the real stdout
+    # aside for the record and send everything else written to fd 1 to stderr.
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    if os.environ.get("BENCH_DRY_LAUNCH", "0") == "1":
+        return dry_launch(a, real_stdout)
     if world > 1 and os.environ.get("BENCH_ALT_MULTI", "0") != "1":
         a.alt_steps = 0            # the other operating points are a 1-GPU report; a scaling run times the primary only
     if a.only != "primary":
@@ -248,8 +302,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)          # "nccl" IS RCCL on ROCm
     if world > 1 or force_dp:
         init_rccl()
-    if a.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {a.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
 
     from unsloth_amd import FastLanguageModel
     from unsloth_amd.dp import LoRAGradArena
