@@ -220,7 +220,7 @@ def global_num_items(labels, group=None):
     return n
 
 
-_ROTARY_INV_FREQ_BUFFER_NAMES = ("inv_freq", "short_inv_freq", "long_inv_freq")
+_ROTARY_INV_FREQ_BUFFER_NAMES = ("inv_freq", "short_inv_freq", "long_inv_freq", "original_inv_freq")   # the last: transformers 5.x
 
 
 def exclude_rope_inv_freq_from_ddp(model):

@@ -359,16 +359,46 @@ def _rope_tables(model):
     return t
 
 
+_LOGITS_MESSAGE = ("Unsloth: logits are not materialised on the fused cross-entropy path. "
+                   "Set UNSLOTH_RETURN_LOGITS=1 to get them.")
+
+
+def _no_logits(*args, **kwargs):
+    raise NotImplementedError(_LOGITS_MESSAGE)
+
+
 class _EmptyLogits:
-    """Stand-in for `logits` on the fused-CE path (models/_utils.py:3612-3652): any use raises."""
+    """Stand-in for `logits` on the fused-CE path (models/_utils.py:3612-3652). USING it raises; merely LOOKING at it must
+    not: accelerate's bf16 wrapper probes `hasattr(x, "dtype") and x.dtype in (fp16, bf16)` on every field of the model
+    output (accelerate/utils/operations.py convert_to_fp32), and a distributed Trainer pickles / compares it. So an
+    attribute is a callable that raises when called, `.to(...)` gives None, indexing raises, and the object pickles to
+    the singleton."""
 
     def __getattr__(self, name):
-        raise NotImplementedError(
-            "Unsloth: logits are not materialised on the fused cross-entropy path. "
-            "Set UNSLOTH_RETURN_LOGITS=1 to get them.")
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)                 # protocol probes (copy, pickle, numpy) get the truthful answer
+        return (lambda *a, **k: None) if name == "to" else _no_logits
+
+    def __getitem__(self, item):
+        raise NotImplementedError(_LOGITS_MESSAGE)
+
+    def __iter__(self):
+        raise NotImplementedError(_LOGITS_MESSAGE)
+
+    def __reduce__(self):
+        return (_empty_logits, ())
+
+    def __eq__(self, other):
+        return type(other).__name__ == "_EmptyLogits"
+
+    __hash__ = object.__hash__
 
     def __repr__(self):
         return "EMPTY_LOGITS"
+
+
+def _empty_logits():
+    return EMPTY_LOGITS
 
 
 EMPTY_LOGITS = _EmptyLogits()
@@ -594,7 +624,10 @@ class FastLlamaModel:
             m.max_seq_length = max_seq_length
             m = m.model
         m.max_seq_length = max_seq_length
-        model._unsloth_disable_data_parallel = True           # _utils.py:244-249
+        # llama.py:2988-3000 + loader.py:1114: the stock-Trainer glue -- num_items_in_batch reaches the model and is counted
+        # over the shifted labels, no nn.DataParallel around a replica, rotary inv_freq buffers out of DDP's broadcasts
+        from ._utils import prepare_for_trainer
+        prepare_for_trainer(model)
         return model
 
     @staticmethod
@@ -612,7 +645,8 @@ class FastLlamaModel:
             same = (cfg.r == r and cfg.lora_alpha == lora_alpha and cfg.lora_dropout == lora_dropout
                     and sorted(cfg.target_modules) == sorted(target_modules))
             if same:
-                return model
+                from ._utils import exclude_rope_inv_freq_from_ddp
+                return exclude_rope_inv_freq_from_ddp(model)                                # :3228
             raise TypeError("Unsloth: Your model already has LoRA adapters. Your new parameters are different.")
         if not isinstance(r, int) or r <= 0:
             raise TypeError(f"Unsloth: Rank of {str(r)} must be an integer larger than 0.")   # :3140-3143
@@ -671,7 +705,10 @@ class FastLlamaModel:
                   f"{n_o} O layers and {n_mlp} MLP layers.")                        # :3774-3777
         model.for_training = MethodType(FastLlamaModel.for_training, model)          # :3811-3817
         model.for_inference = MethodType(FastLlamaModel.for_inference, model)
-        return model
+        # :3575 + :3595 -- again, on the wrapper: the marker must sit on the object Trainer sees, and the buffers' fully
+        # qualified names changed under the PEFT wrapper ("base_model.model. ...")
+        from ._utils import prepare_for_trainer
+        return prepare_for_trainer(model)
 
     @staticmethod
     def patch_full_finetune(model):

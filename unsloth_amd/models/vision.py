@@ -206,6 +206,8 @@ class FastVisionModel:
         patch_vision_tower(visual)                  # ViT attention (2-D RoPE + non-causal flash) and QuickGELU on the HIP kernels
         model = Qwen2VLFastModel(config, visual, language)
         model.max_seq_length = max_seq_length
+        from ._utils import prepare_for_trainer
+        prepare_for_trainer(model)                  # vision.py:1797-1823, :2162 -- the marker and the DDP ignore list on the wrapper Trainer sees
         return model, tok
 
     @staticmethod
@@ -249,4 +251,5 @@ class FastVisionModel:
                 setattr(parent, leaf, _lora.LoraLayer(module, "default", r, lora_alpha, lora_dropout, use_rslora,
                                                       init_lora_weights))
         model.train()
-        return model
+        from ._utils import prepare_for_trainer
+        return prepare_for_trainer(model)           # vision.py:2257: the buffers' names changed under the PEFT wrapper
