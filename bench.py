@@ -12,7 +12,10 @@ bitsandbytes-format NF4 by our own quantiser; token ids ~ U[0, V), labels = ids,
 (int32, exercising the indexed RoPE path). Nothing is skipped inside the timed region.
 
 The primary number runs under the API default `use_gradient_checkpointing="unsloth"` (the least-recompute schedule that
-fits the free HBM: on an idle 288 GB part every layer keeps everything). `alt` holds the other operating points of the
+fits the free HBM: on an idle 288 GB part every layer keeps everything) with every NF4 weight decoded at every use INSIDE the
+timed step (no decoded mirrors: they are opt-in, reported beside it as `value_with_resident_mirrors`). `vram_batch1_unsloth_min`
+is the low-VRAM operating point (1 x 2048 tokens, layer inputs only); `gpu_baseline` is stock HuggingFace bf16 + torch LoRA +
+SDPA timed on the same GPU on the same batch after everything else (`vs_gpu_baseline` = the ratios). `alt` holds the other operating points of the
 reference: the checkpointing modes, batch 1 / 2, the PADDING-FREE PACKED step its SFT trainer runs by default
 (trainer.py:903-912, utils/packing.py:241-284), BASELINE config 3 (full fine-tuning), config 4 (Qwen2-VL-7B, one image in
 4096 tokens) and config 5 (Mistral-7B seq 4096: CE leg and the chunked GRPO log-prob leg), the DP path forced onto one
@@ -184,6 +187,90 @@ def fractions(gs, ms_per_step):
     return out
 
 
+class TorchLoRALinear(torch.nn.Module):
+    """What PEFT's lora.Linear computes on a frozen nn.Linear (peft is not installed here): base(x) + B(A(x)) * alpha / r, the
+    factors fp32 parameters used in the activation dtype under autocast."""
+
+    def __init__(self, base, r, alpha, gen):
+        super().__init__()
+        self.base, self.scale = base, alpha / r
+        dev = base.weight.device
+        self.lora_A = torch.nn.Parameter((torch.rand(r, base.in_features, generator=gen) * 2 - 1).mul_(base.in_features ** -0.5).to(dev))
+        self.lora_B = torch.nn.Parameter((torch.randn(base.out_features, r, generator=gen) * 0.02).to(dev))
+
+    def forward(self, x):
+        F_ = torch.nn.functional
+        return self.base(x) + F_.linear(F_.linear(x, self.lora_A.to(x.dtype)), self.lora_B.to(x.dtype)) * self.scale
+
+
+def hf_gpu_baseline(cfg, dev, B, T, r, steps=3, warmup=2, seed=0):
+    """Stock HuggingFace `LlamaForCausalLM` (its own RMSNorm / RoPE / SwiGLU / loss modules, attn_implementation="sdpa") in
+    bf16 with torch LoRA r on the same 7 projections, bf16 autocast, torch's fused AdamW on the factors, no gradient
+    checkpointing -- the same B x T synthetic batch, forward + backward + optimizer step, on this GPU. Base weights are
+    bf16, not NF4: bitsandbytes is not installed here, so HF cannot run a 4-bit model at all; that spares the baseline the
+    dequantisation work and costs it ~10 GB of weights. Every class-level patch of unsloth_amd is undone first."""
+    from transformers import AutoModelForCausalLM
+    from unsloth_amd.kernels import unpatch_rms_layernorm
+    from unsloth_amd.kernels.cross_entropy_loss import unpatch_loss_functions
+    from unsloth_amd.models import llama as _L
+    _L.unpatch_all()
+    unpatch_rms_layernorm()
+    unpatch_loss_functions()
+    torch.manual_seed(3407)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        with torch.device(dev):
+            hf = AutoModelForCausalLM.from_config(cfg, attn_implementation="sdpa")
+    finally:
+        torch.set_default_dtype(old)
+    hf.to(torch.bfloat16)
+    for p in hf.parameters():
+        p.requires_grad_(False)
+    g_ = torch.Generator(device="cpu").manual_seed(3407)
+    for layer in hf.model.layers:
+        for parent, names in ((layer.self_attn, ("q_proj", "k_proj", "v_proj", "o_proj")), (layer.mlp, ("gate_proj", "up_proj", "down_proj"))):
+            for n in names:
+                setattr(parent, n, TorchLoRALinear(getattr(parent, n), r, r, g_))
+    params = [p for p in hf.parameters() if p.requires_grad]
+    o = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
+    hf.train()
+    hf.config.use_cache = False
+    gi = torch.Generator(device="cpu").manual_seed(seed)
+    bt = [torch.randint(0, cfg.vocab_size, (B, T), generator=gi).to(dev) for _ in range(2)]
+
+    def step(i):
+        ids = bt[i % 2]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = hf(input_ids=ids, labels=ids, use_cache=False).loss
+        loss.backward()
+        o.step()
+        o.zero_grad(set_to_none=True)
+        return loss.detach()
+
+    try:
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        times, losses = [], []
+        for i in range(steps):
+            t0 = time.perf_counter()
+            losses.append(step(i))
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+        med = sorted(times)[len(times) // 2]
+        return {"value": round(B * T / med, 1), "unit": "tokens/s", "ms_per_step": round(med * 1e3, 2),
+                "peak_vram_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "steps": steps, "timing": "median step",
+                "what": "stock HF LlamaForCausalLM bf16 (sdpa) + torch LoRA r=%d on 7 projections + fused torch AdamW, bf16 autocast, "
+                        "no gradient checkpointing, %d x %d tokens, same GPU, after the runs above" % (r, B, T),
+                "base_weights": "bf16 (HF cannot run NF4 here: no bitsandbytes)", "trainable_params": sum(p.numel() for p in params),
+                "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)]}
+    finally:
+        del hf, o, params
+        torch.cuda.empty_cache()
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: become the launcher. One process per GPU under
     torch.distributed.run on 127.0.0.1 (the driver's own command shape); the ranks find RANK / LOCAL_RANK / WORLD_SIZE in
@@ -250,6 +337,8 @@ def main():
                     help="time ONE operating point with --steps / --warmup as the whole run (per-point rocprofv3 profiles); "
                          "the JSON line then describes that point. 'primary' (default) = the BASELINE metric + every alt point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gpu-baseline", action="store_true", default=os.environ.get("BENCH_GPU_BASELINE", "1") == "0",
+                    help="skip the stock-HuggingFace bf16 + torch-LoRA + SDPA step timed on the same GPU after everything else")
     ap.add_argument("--roofline-every", type=int, default=int(os.environ.get("BENCH_ROOFLINE_EVERY", 4)),
                     help="HIP-event pairs around the GEMM launches on every Nth timed step (the first one always). An event "
                          "pair drains the queue around its kernel: ~12 us per GEMM, 292 GEMMs per step = 1.4 %% of the step "
@@ -277,7 +366,7 @@ def main():
         a.alt_steps = 0            # the other operating points are a 1-GPU report; a scaling run times the primary only
     if a.only != "primary":
         a.alt_steps = 0
-        a.no_cpu_baseline = True
+        a.no_cpu_baseline = a.no_gpu_baseline = True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -604,7 +693,9 @@ def main():
                           "attn (every layer re-runs norm2 + gate/up)" if pol == _fl.POLICIES["attn"] else
                           "all*%d,attn" % pol[0][0])
     from unsloth_amd import nf4 as _nf4p
-    primary_mirrors = bool(_nf4p.RESIDENT and _nf4p.resident_count() > 0)
+    primary_mirrors = bool(_nf4p.mirrors_on(base_) and _nf4p.resident_count(base_) > 0)
+    primary_mirror_gb = round(_nf4p.resident_bytes(base_) / 2**30, 2)
+    with_mirrors = batch1_min = gpu_base = None
     alt = None
     if a.alt_steps > 0:
         # the other checkpointing modes at the primary batch, then batch 1 and 2 without checkpointing
@@ -633,6 +724,13 @@ def main():
         for bs in (1, 2):
             if bs != B:
                 alt_point(f"batch_{bs}_gc_off", False, bs)
+        # the VRAM half of the metric at the reference's own operating point: ONE 2048-token row, only the layer inputs kept
+        # (SURVEY 9.11 budgets 7-8 GB for it). Everything that lives in HBM counts: NF4 base, bf16 embeddings + lm_head, LoRA
+        # factors / gradients / AdamW moments, decode scratch, activations.
+        B1MIN_TAG = "batch_1_gc_unsloth_min (1 x 2048 tokens, layer inputs only: the low-VRAM operating point)"
+        alt_point(B1MIN_TAG, "unsloth:min", 1)
+        batch1_min = {k: alt[B1MIN_TAG][k] for k in ("value", "ms_per_step", "peak_vram_gb")}
+        batch1_min.update(batch=1, seq_len=T, gradient_checkpointing="unsloth:min", survey_budget_gb="7-8 (SURVEY 9.11)")
         # the reference's DEFAULT SFT step: padding-free packed row (band attention + indexed RoPE with restarting positions)
         pdata, pni, ndocs = make_packed_batches(B * T, V)
         alt_point(PACKED_TAG, GC_MODE[a.gc], 1, (pdata, pni), documents_per_batch=ndocs, tokens_per_row=B * T)
@@ -640,19 +738,17 @@ def main():
         alt[PACKED_TAG]["batch"] = "1 x %d" % (B * T)
         del pdata
         if os.environ.get("BENCH_RESIDENT_ALT", "1") == "1":
-            # decoded bf16 mirrors of the NF4 weights (+2 B/param, no decode launches): part of the fit-to-memory default since round
-            # 4 (nf4.RESIDENT_MODE "auto", i.e. the primary above has them on an idle GPU); here the same spelling WITHOUT them (the
-            # rounds 1-3 behaviour), and batch 1 with them
+            # decoded bf16 mirrors of the NF4 weights (+2 B per projection parameter, no decode launches, bit-identical steps):
+            # OPT-IN since round 5 (UNSLOTH_AMD_RESIDENT_WEIGHTS=auto | 1, nf4.set_resident) -- the headline above decodes NF4
+            # inside every step, as the reference does. Here: this model's projections with mirrors, at the primary batch and at 1.
             from unsloth_amd import nf4 as _nf4
-            mode_was = _nf4.RESIDENT_MODE
-            _nf4.RESIDENT_MODE = "0"
-            _nf4.set_resident(False)
-            base_._uamd_auto_policy = None
-            alt_point("gc_unsloth_nf4_decoded_at_every_use (UNSLOTH_AMD_RESIDENT_WEIGHTS=0: no decoded mirrors, rounds 1-3)", "unsloth", B)
-            _nf4.RESIDENT_MODE = mode_was
-            _nf4.set_resident(True)
+            _nf4.set_resident(True, model=base_)
+            MIRROR_TAG = "gc_unsloth_with_decoded_weight_mirrors (opt-in UNSLOTH_AMD_RESIDENT_WEIGHTS=auto | 1: no NF4 decode in the step)"
+            alt_point(MIRROR_TAG, "unsloth", B)
+            with_mirrors = {k: alt[MIRROR_TAG][k] for k in ("value", "ms_per_step", "peak_vram_gb", "steps", "timing")}
+            with_mirrors["mirror_gb"] = round(_nf4.resident_bytes(base_) / 2**30, 2)
             alt_point("batch_1_gc_off_with_decoded_weight_mirrors (UNSLOTH_AMD_RESIDENT_WEIGHTS=1)", False, 1)
-            _nf4.set_resident(False)
+            _nf4.set_resident(False, model=base_)
             base_._uamd_auto_policy = None
             torch.cuda.empty_cache()
         if os.environ.get("BENCH_DP_FORCE_ALT", "1") == "1" and world == 1 and arena is None:
@@ -714,6 +810,24 @@ def main():
         if os.environ.get("BENCH_FULLFT_ALT", "1") == "1" and world == 1:
             guarded(alt, "config3_full_finetune_bf16_1gpu (every parameter trains, fp32-master AdamW)",
                     lambda: run_fullft(a.alt_steps, 2))
+    opt_name = type(opt).__name__
+    if world == 1 and not a.no_gpu_baseline:
+        # stock HuggingFace on the SAME box, the SAME batch: what the reference's "x faster than HF" is measured against
+        # (/root/reference README.md:87). Our model, optimizer and caches go first: the baseline gets the GPU alone.
+        if hasattr(opt, "close"):
+            opt.close()
+        if arena is not None:
+            arena.close()
+        del opt, arena, base_
+        model = None
+        import gc as _gc
+        _gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            gpu_base = hf_gpu_baseline(cfg, dev, B, T, a.rank, steps=max(2, a.alt_steps), warmup=2, seed=rank)
+        except Exception as ex:
+            gpu_base = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+            torch.cuda.empty_cache()
     rccl_ranks = None
     if dist.is_initialized():
         one = torch.ones(1, device=dev)
@@ -773,12 +887,18 @@ def main():
                        "model": "Llama-3-8B (synthetic weights)", "global_batch": B * world, "seq_len": T,
                        "parallelism": f"dp{world}", "layers": a.layers, "lora_rank": a.rank,
                        "gradient_checkpointing": GC_MODE[a.gc], "gc_schedule_chosen": primary_policy,
-                       "nf4_decoded_weight_mirrors": ("on (fit-to-memory default: +2 B per projection parameter of HBM, no decode launches)"
-                                                      if primary_mirrors else "off"),
+                       "nf4_decoded_weight_mirrors": ("on (%s GB of bf16 mirrors: no NF4 decode in the step)" % primary_mirror_gb
+                                                      if primary_mirrors else
+                                                      "off (every NF4 weight is decoded at every use INSIDE the timed step)"),
                        "trainable_params": n_train,
-                       "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": type(opt).__name__ + " fp32 on LoRA params"},
+                       "attention": "csrc/attention.hip (causal GQA flash, fwd+bwd)", "optimizer": opt_name + " fp32 on LoRA params"},
             "peak_vram_gb": round(peak / 2**30, 2), "tokens_per_step_per_gpu": B * T, "rccl_ranks": rccl_ranks,
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
+            "value_with_resident_mirrors": with_mirrors, "vram_batch1_unsloth_min": batch1_min,
+            "gpu_baseline": gpu_base,
+            "vs_gpu_baseline": ({"tokens_per_s_ratio": round(tokens / dt / gpu_base["value"], 2),
+                                 "peak_vram_ratio": round(peak / 2**30 / gpu_base["peak_vram_gb"], 2)}
+                                if gpu_base and gpu_base.get("value") else None),
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())

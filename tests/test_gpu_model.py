@@ -185,6 +185,30 @@ def test_layer_called_with_hf_signature_runs_the_fused_path():
         assert rel_fro(got, ref) < 1e-2, rel_fro(got, ref)
 
 
+def test_decoded_weight_mirrors_are_a_per_model_decision():
+    """one model's fit-to-memory decision must not switch mirrors on for every NF4 model of the process (a frozen
+    reference / policy model loaded later, an inference engine). The switch sits on the model's own quant states."""
+    from unsloth_amd import nf4
+    from unsloth_amd.kernels import utils as U
+    ids, labels, pos = _batch(seed=9)
+    batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    fused, U.FUSED_NF4 = U.FUSED_NF4, False
+    try:
+        a, b = _tiny(gc=False, head_dim=128, seed=1), _tiny(gc=False, head_dim=128, seed=2)
+        ia, ib = a.get_base_model().model, b.get_base_model().model
+        nf4.set_resident(True, auto=True, model=ia)
+        assert nf4.mirrors_on(ia) and not nf4.mirrors_on(ib) and not nf4.RESIDENT
+        for m in (a, b):
+            m(**batch).loss.backward()
+        assert nf4.resident_count(ia) == 14 and nf4.resident_count(ib) == 0
+        assert nf4.resident_bytes(ia) == 2 * 2 * (256 * (512 + 2 * 256) + 512 * 256 + 3 * 256 * 704)
+        a.for_training(use_gradient_checkpointing="unsloth:attn")        # a fixed policy asked for something else: they go
+        assert nf4.resident_count(ia) == 0 and not nf4.mirrors_on(ia)
+    finally:
+        U.FUSED_NF4 = fused
+        nf4.set_resident(False)
+
+
 def test_resident_decoded_weights_are_bitwise_neutral():
     """opt-in UNSLOTH_AMD_RESIDENT_WEIGHTS: the decoded bf16 mirrors kept in HBM change nothing but the launch count."""
     from unsloth_amd import nf4

@@ -551,7 +551,7 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False, pre_xa=None):
         xa, offs, xk = _xa_and_rank_block(X2d, [p[2] for p in with_lora], use256)
     results, dense_groups, nf4_groups, keep = [], [], [], []
     resident = None
-    if _nf4.RESIDENT and len(projs) > 1 and all(q is not None for (_, q, _, _, _) in projs) and not any(fused_nf4):
+    if len(projs) > 1 and all(q is not None and _nf4.mirror_wanted(q) for (_, q, _, _, _) in projs) and not any(fused_nf4):
         _, resident = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
     li = 0
     for gi, (W, W_quant, A, B, s) in enumerate(projs):
@@ -716,7 +716,7 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
     if NN_DX and have_xk and _use_gemm256(M, Ntot, [Kin]) and Kin % 8 == 0:
         # NN form: [W_q; W_k; W_v] stacked by ROWS is just the three row-major decodes one after the other -- the
         # layout the forward uses -- and the GEMM contracts over those rows (no transposed copy of any weight)
-        if _nf4.RESIDENT:
+        if all(_nf4.mirror_wanted(p_[1]) for p_ in projs):
             Wcat, _ = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
         else:
             Wcat = _nf4.scratch(dYcat.device, Ntot * Kin, dtype, slot=2).view(Ntot, Kin)

@@ -119,11 +119,14 @@ def auto_policy(model, hidden_states):
     from .. import nf4 as _nf4
     if _nf4.RESIDENT_MODE == "auto":
         # decoded mirrors of the NF4 weights ride on the same decision (nf4.py): on when there is HBM to spare, off when not
-        want = pol == POLICIES["all"] and mirrors_fit(*args, vocab=vocab, have_mirrors=_nf4.RESIDENT and _nf4.resident_count() > 0)
-        if want and not _nf4.RESIDENT:
-            _nf4.set_resident(True, auto=True)
-        elif not want and _nf4.AUTO_ON:               # (mirrors a caller switched on with nf4.set_resident(True) are the caller's)
-            _nf4.set_resident(False)
+        # -- of THIS model's projections only (the switch sits on its quant states): another NF4 model in the process (a
+        # reference / policy model, an engine) decides for itself, from the memory that is free when ITS first step runs
+        auto_on = getattr(model, "_uamd_mirrors_auto", False)
+        want = pol == POLICIES["all"] and mirrors_fit(*args, vocab=vocab, have_mirrors=auto_on and _nf4.resident_count(model) > 0)
+        if want and not auto_on and not _nf4.RESIDENT:
+            _nf4.set_resident(True, auto=True, model=model)
+        elif not want and auto_on:                    # (mirrors a caller switched on with nf4.set_resident(True) are the caller's)
+            _nf4.set_resident(False, model=model)
             torch.cuda.empty_cache()
     model._uamd_auto_policy = (key, pol)
     return pol

@@ -766,9 +766,9 @@ class FastLlamaModel:
         base.model.gradient_checkpointing = gc
         base.model._unsloth_amd_layer_policy = policy
         from .. import nf4 as _nf4
-        if _nf4.RESIDENT_MODE == "auto" and policy != _fast_layer.AUTO and _nf4.AUTO_ON:
+        if policy != _fast_layer.AUTO and getattr(base.model, "_uamd_mirrors_auto", False):
             # decoded weight mirrors belong to the fit-to-memory spelling (nf4.py); a fixed mode asked for something else
-            _nf4.set_resident(False)
+            _nf4.set_resident(False, model=base.model)
             base.model._uamd_auto_policy = None
         for m in base.modules():
             if hasattr(m, "gradient_checkpointing"):

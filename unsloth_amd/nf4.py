@@ -187,41 +187,76 @@ def quantize_nf4(W, blocksize=64, compress_statistics=True):
     return packed, qs
 
 
-# Decoded mirrors (UNSLOTH_AMD_RESIDENT_WEIGHTS=1 | 0 | auto, or nf4.set_resident(True)): keep the DECODED bf16 copy of every NF4
-# weight in HBM after its first decode instead of decoding it again at every use (2 decodes per weight per step: 6.9 ms of a
-# 231 ms step at 8192 tokens, 9 % of the step at 2048). Costs 2 B/param (14 GB for Llama-3-8B's projections) of the
-# 288 GB -- the NF4 bytes stay the source of truth (checkpoints, merging); frozen weights never change, so the mirror
+# Decoded mirrors (UNSLOTH_AMD_RESIDENT_WEIGHTS=0 | auto | 1, or nf4.set_resident(True[, model=...])): keep the DECODED bf16
+# copy of an NF4 weight in HBM after its first decode instead of decoding it again at every use (2 decodes per weight per step:
+# 6.9 ms of a 231 ms step at 8192 tokens, 9 % of the step at 2048). Costs 2 B/param (14 GB for Llama-3-8B's projections) of
+# the 288 GB -- the NF4 bytes stay the source of truth (checkpoints, merging); frozen weights never change, so the mirror
 # cannot go stale, and the GEMMs read the same bf16 values either way (bit-identical steps).
-#   "auto" (default since round 4): the same fit-to-memory decision as the checkpointing schedule, taken with it -- the bare
-#   `use_gradient_checkpointing="unsloth"` turns the mirrors on when every layer already keeps everything AND the HBM left after
-#   that still holds them with room to spare (models/fast_layer.auto_policy), and off again when memory gets short. The
-#   reference makes the opposite trade (NF4 only, decode at every use) because 24-80 GB parts force it to.
-#   "0": never (rounds 1-3; what `False` / "unsloth:<policy>" runs use in any case).   "1": always.
+#   "0" (default; rounds 1-3 and again since round 5): never, unless a caller asks. This is what "QLoRA NF4" means in the
+#        reference -- the weights are decoded inside every step -- and what bench.py's headline number pays.
+#   "auto": the same fit-to-memory decision as the checkpointing schedule, taken with it and PER MODEL: the bare
+#        `use_gradient_checkpointing="unsloth"` turns the mirrors of THAT model's projections on when every layer already keeps
+#        everything AND the HBM left after that still holds them with room to spare (models/fast_layer.auto_policy), and off
+#        again when memory gets short. A second NF4 model in the process (a reference / policy model) takes its own decision.
+#   "1": every NF4 weight of the process, always (the process-wide switch: nf4.set_resident(True)).
+# The switch lives on the quant states (`_mirror_on`), set for one model's projections by set_resident(on, model=m); the
+# module-level RESIDENT is only the process-wide "1".
 import os as _os
 
-RESIDENT_MODE = _os.environ.get("UNSLOTH_AMD_RESIDENT_WEIGHTS", "auto")
+RESIDENT_MODE = _os.environ.get("UNSLOTH_AMD_RESIDENT_WEIGHTS", "0")
 RESIDENT = RESIDENT_MODE == "1"
 import weakref as _weakref
 
 _MIRRORED = _weakref.WeakSet()      # quant states that carry a decoded mirror (`_resident`, `_resident_group`)
 
 
-AUTO_ON = False                     # the mirrors are on because the fit-to-memory decision turned them on (not the caller)
+def _model_quant_states(model):
+    return [m.weight.quant_state for m in model.modules()
+            if isinstance(m, Linear4bit) and getattr(m.weight, "quant_state", None) is not None]
 
 
-def set_resident(on, auto=False):
-    global RESIDENT, AUTO_ON
-    RESIDENT = bool(on)
-    AUTO_ON = bool(on) and bool(auto)
-    if not on:
-        for q in list(_MIRRORED):
-            q._resident = None
-            q._resident_group = None
-        _MIRRORED.clear()
+def mirror_wanted(qs):
+    """May this weight keep a decoded mirror? The process-wide switch, or its own model's decision."""
+    return RESIDENT or getattr(qs, "_mirror_on", False)
 
 
-def resident_count():
-    return sum(1 for q in _MIRRORED if getattr(q, "_resident", None) is not None)
+def _drop(q):
+    q._resident = None
+    q._resident_group = None
+    _MIRRORED.discard(q)
+
+
+def set_resident(on, auto=False, model=None):
+    """model=None: the process-wide switch (every NF4 weight; off also clears every per-model decision). model=m: the
+    projections of m only; `auto` records on m that the fit-to-memory decision (not the caller) turned them on."""
+    global RESIDENT
+    if model is None:
+        RESIDENT = bool(on)
+        if not on:
+            for q in list(_MIRRORED):
+                q._mirror_on = False
+                _drop(q)
+        return
+    for q in _model_quant_states(model):
+        q._mirror_on = bool(on)
+        if not on and not RESIDENT:
+            _drop(q)
+    model._uamd_mirrors_auto = bool(on) and bool(auto)
+
+
+def mirrors_on(model):
+    """Does any projection of `model` want a mirror (by its own decision or the process-wide switch)?"""
+    return any(mirror_wanted(q) for q in _model_quant_states(model))
+
+
+def resident_count(model=None):
+    qs = _MIRRORED if model is None else _model_quant_states(model)
+    return sum(1 for q in qs if getattr(q, "_resident", None) is not None)
+
+
+def resident_bytes(model=None):
+    qs = _MIRRORED if model is None else _model_quant_states(model)
+    return sum(q._resident.numel() * q._resident.element_size() for q in qs if getattr(q, "_resident", None) is not None)
 
 
 def resident_group(packed_list, qs_list):
@@ -276,7 +311,7 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
     dtype = qs.dtype
     shape = (cols, rows) if transpose else (rows, cols)
     mirror_here = False
-    if RESIDENT and out is None and use_global_buffer and not transpose:
+    if out is None and use_global_buffer and not transpose and mirror_wanted(qs):
         hit = getattr(qs, "_resident", None)
         if hit is not None and hit.dtype == dtype and hit.device == packed.device:
             return hit
