@@ -116,31 +116,36 @@ class GemmTimer:
 
         pair_cache = {}
 
-        def pairs(q, band):
-            """(query, key) pairs inside the mask, summed over the batch: T (T + 1) / 2 per row for plain causal attention,
-            sum_q (q - lo[q] + 1) under a packed / windowed band. A 0-d tensor (no host sync here) or a float."""
+        def pairs(q, band, causal):
+            """(query, key) pairs inside the mask, summed over the batch. Causal: T (T + 1) / 2 per row, sum_q (q - lo[q] + 1)
+            under a packed / windowed band. Non-causal (the ViT): T * T per row, sum_q (hi[q] - lo[q] + 1) under a document
+            band. A 0-d tensor (no host sync here) or a float."""
             B, T = q.shape[0], q.shape[1]
             if band is None:
-                return B * T * (T + 1) / 2.0
-            lo = band[0]
-            key = (lo.data_ptr(), B, T)
+                return B * T * (T + 1) / 2.0 if causal else float(B) * T * T
+            lo, hi = band[0], band[1]
+            key = (lo.data_ptr(), hi.data_ptr(), B, T, causal)
             if key not in pair_cache:
-                pair_cache[key] = (torch.arange(T, device=lo.device, dtype=torch.int64).unsqueeze(0) - lo.to(torch.int64) + 1).sum()
+                last = torch.arange(T, device=lo.device, dtype=torch.int64).unsqueeze(0) if causal else hi.to(torch.int64)
+                pair_cache[key] = (last - lo.to(torch.int64) + 1).sum()
             return pair_cache[key]
 
         def attn_timed(which, mult, fn):
+            names = ("q", "k", "v", "scale", "band", "causal") if which == "fwd" else \
+                    ("do", "q", "k", "v", "o", "lse", "scale", "band", "causal")
+
             def run(*args, **kw):
                 if not self.enabled:
                     return fn(*args, **kw)
-                q = args[0] if which == "fwd" else args[1]
-                band = kw.get("band", args[-1] if len(args) == (5 if which == "fwd" else 8) else None)
+                bound = dict(zip(names, args), **kw)            # by position AND by keyword (ADVICE r4: causal=False calls)
+                q, band, causal = bound["q"], bound.get("band"), bound.get("causal", True)
                 Hq, D = q.shape[2], q.shape[3]
                 unit = mult * 4.0 * D * Hq            # forward: S = Q K^T and O = P V; backward 2.5x (S again + 4 products)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 out = fn(*args, **kw)
                 e.record()
-                recs.setdefault("attention_" + which, []).append((s, e, (unit, pairs(q, band)), 0.0))
+                recs.setdefault("attention_" + which, []).append((s, e, (unit, pairs(q, band, causal)), 0.0))
                 return out
             return run
 

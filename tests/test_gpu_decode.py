@@ -460,8 +460,9 @@ def test_generate_train_generate_uses_the_trained_factors():
 
 def test_fast_generate_kwargs_follow_hf_semantics():
     """eos / pad default from generation_config, finished rows emit the pad id, max_length is
-    honoured, and arguments the engine does not implement (top_p, a padded attention_mask, ...) go to HF's generate
-    instead of being dropped."""
+    honoured, and arguments the engine does not implement (repetition_penalty, a padded attention_mask, ...) go to HF's
+    generate instead of being dropped. Nucleus sampling (top_p, also when only the checkpoint's generation_config asks for
+    it, as Llama-3-Instruct's does) stays on the engine since round 5."""
     from unsloth_amd import FastLanguageModel
     model = _tiny(True)
     FastLanguageModel.for_inference(model)
@@ -477,14 +478,22 @@ def test_fast_generate_kwargs_follow_hf_semantics():
     assert model.generate(input_ids=ids, max_length=12).shape[1] <= 12
     calls = []
     model._old_generate = lambda *a, **k: (calls.append(k), free)[1]
-    model.generate(input_ids=ids, max_new_tokens=3, top_p=0.9)
-    assert calls and calls[-1].get("top_p") == 0.9
+    model.generate(input_ids=ids, max_new_tokens=3, repetition_penalty=1.3)
+    assert calls and calls[-1].get("repetition_penalty") == 1.3
     mask = torch.ones_like(ids)
     mask[1, :3] = 0
     model.generate(input_ids=ids, max_new_tokens=3, attention_mask=mask)
     assert len(calls) == 2 and calls[-1].get("attention_mask") is mask
     model.generate(input_ids=ids, max_new_tokens=3, attention_mask=torch.ones_like(ids), top_p=1.0)
     assert len(calls) == 2                                   # neutral values stay on the engine
+    # nucleus sampling on the engine: a tiny top_p keeps only the most likely token -> the greedy continuation
+    base.generation_config.eos_token_id = None
+    greedy = model.generate(input_ids=ids, max_new_tokens=4)
+    sampled = model.generate(input_ids=ids, max_new_tokens=4, do_sample=True, top_p=1e-4, generator=torch.Generator(device=DEV).manual_seed(3))
+    assert len(calls) == 2 and torch.equal(greedy, sampled)
+    base.generation_config.do_sample, base.generation_config.top_p, base.generation_config.temperature = True, 0.9, 0.6
+    out = model.generate(input_ids=ids, max_new_tokens=4)   # the checkpoint's own sampling settings: still the engine
+    assert len(calls) == 2 and out.shape == greedy.shape
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

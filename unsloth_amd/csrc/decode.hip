@@ -1366,6 +1366,29 @@ extern "C" int uamd_attn_decode(const void* q, int64_t q_sb, const void* k_cache
     return uamd_launch_status();
 }
 
+namespace {
+// How many blocks of attn_decode_fused_kernel<T, G> are CERTAINLY resident at once on the current device: one per compute
+// unit THIS device has (a CPX / SPX partition reports its own CU count), and none when a block does not fit a CU at all.
+// The granule combine below polls for the other splits' partials, so a launch larger than this must not take it (a block
+// that starts only after another exits would be waited for in vain: 2^18 polls, then NaN). Cached per device.
+template <typename T, int G>
+int attn_fused_resident_blocks() {
+    static int cap[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cap[dev] == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_decode_fused_kernel<T, G>, 256, 0) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        cap[dev] = per_cu >= 1 && cus >= 1 ? cus : -1;
+    }
+    return cap[dev] > 0 ? cap[dev] : 0;
+}
+}  // namespace
+
 extern "C" int uamd_attn_decode_fused(const void* qkv, int64_t ld_qkv, const void* cos_t, const void* sin_t, int64_t ld_cs,
                                       const int* kv_len, const int* rope_pos, void* k_cache, void* v_cache,
                                       int64_t cache_sb, int64_t cache_sh, float* partials, int* counters, void* out,
@@ -1383,13 +1406,19 @@ extern "C" int uamd_attn_decode_fused(const void* qkv, int64_t ld_qkv, const voi
     a.out = out; a.o_sb = out_sb; a.Hq = Hq; a.Hk = Hk; a.s_max = s_max; a.nsplit = nsplit; a.split_keys = split_keys;
     a.window = window; a.scale_log2 = scale * 1.4426950408889634f;
     // granule combine only when every block of the launch is certainly resident at once (one 256-thread block per CU of the
-    // smallest part this library runs on): a block polls for the partials of its KV head's other splits
-    a.gran = ((int64_t)nsplit * Hk * B <= 256 && (tag != 0 || tag_dev)) ? 1 : 0;     // (no tag: the arrival-counter path)
+    // device this call runs on, attn_fused_resident_blocks): a block polls for the partials of its KV head's other splits
+    const int64_t blocks = (int64_t)nsplit * Hk * B;
+    const bool want_gran = tag != 0 || tag_dev;                                       // (no tag: the arrival-counter path)
+    a.gran = 0;
     a.tag = tag;
     a.tag_dev = tag_dev;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)nsplit, (unsigned)Hk, (unsigned)B);
-#define UAMD_DECODE_LAUNCH(TT, GG) hipLaunchKernelGGL((attn_decode_fused_kernel<TT, GG>), grid, dim3(256), 0, st, a)
+#define UAMD_DECODE_LAUNCH(TT, GG)                                                                     \
+    do {                                                                                               \
+        a.gran = (want_gran && blocks <= attn_fused_resident_blocks<TT, GG>()) ? 1 : 0;                \
+        hipLaunchKernelGGL((attn_decode_fused_kernel<TT, GG>), grid, dim3(256), 0, st, a);             \
+    } while (0)
 #define UAMD_DECODE_G(TT)                                                                             \
     switch (G) {                                                                                      \
         case 1: UAMD_DECODE_LAUNCH(TT, 1); break; case 2: UAMD_DECODE_LAUNCH(TT, 2); break;           \

@@ -178,6 +178,9 @@ def _dhidden(chunk, dlogits, weight, weight_t, out):
         _u._launch_gemm(chunk, [_u._group(weight_t, out, H, weight_t.stride(0))], nf4=False)
 
 
+_DW_SCALE_ROWS = 8192        # rows of the lm_head gradient scaled in fp32 at a time (64-128 MB instead of 2 GB)
+
+
 class _FusedLinearCE(torch.autograd.Function):
     """loss = sum_rows CE(hidden @ W^T) / n_items without ever holding [T, V] logits.
 
@@ -235,17 +238,25 @@ class _FusedLinearCE(torch.autograd.Function):
             P = ctx.weight_param
             V = P.shape[0]
             sink = _u.grad_sink(P)
+            # the upstream scale in fp32, ONE rounding (like d(hidden) below): the scalar rounded to bf16 first would bias the
+            # lm_head gradient by up to 2^-9 against every other parameter's. In ROW CHUNKS: a whole [V, H] fp32 temporary is
+            # 2.1 GB for a 128k x 4096 head, at the loss peak of a full fine-tuning step
             if sink is not None:
                 view = sink.grad_view(P)
-                # the upstream scale in fp32, ONE rounding (like d(hidden) below and like the non-sink branch): the scalar rounded
-                # to bf16 first would bias the lm_head gradient by up to 2^-9 against every other parameter's
-                if sink.first_write(P):
-                    view.copy_(dW[:V].to(torch.float32) * scale)
+                first = sink.first_write(P)
+            else:
+                view, first = torch.empty((V, dW.shape[1]), dtype=P.dtype, device=dW.device), True
+            for r0 in range(0, V, _DW_SCALE_ROWS):
+                r1 = min(V, r0 + _DW_SCALE_ROWS)
+                part = dW[r0:r1].to(torch.float32) * scale
+                if first:
+                    view[r0:r1].copy_(part)
                 else:
-                    view.add_((dW[:V].to(torch.float32) * scale).to(view.dtype))
+                    view[r0:r1].add_(part.to(view.dtype))
+            if sink is not None:
                 sink.ready(P)
             else:
-                d_weight = (dW[:V].to(torch.float32) * scale).to(P.dtype)
+                d_weight = view
         if dh is not None and ctx.needs_input_grad[0]:
             # the upstream scale (1/accumulation steps, a GradScaler factor, ...) is applied in fp32 and the
             # product rounded once: casting the scalar to bf16 first would put 2^-9 of relative error on every

@@ -313,9 +313,9 @@ class DecodeEngine:
 
     @torch.no_grad()
     def generate(self, input_ids, max_new_tokens=32, eos_token_id=None, do_sample=False, temperature=1.0, top_k=0,
-                 generator=None, pad_token_id=None):
-        """Greedy (default) or temperature / top-k sampling. Returns [B, T + new] token ids. Rows that have produced an
-        end-of-sequence token keep emitting `pad_token_id` (default: the first eos id), like HF's generate."""
+                 generator=None, pad_token_id=None, top_p=1.0):
+        """Greedy (default) or temperature / top-k / nucleus sampling. Returns [B, T + new] token ids. Rows that have produced
+        an end-of-sequence token keep emitting `pad_token_id` (default: the first eos id), like HF's generate."""
         input_ids = input_ids.to(self.dev)
         logits = self.prefill(input_ids)
         out = [input_ids]
@@ -326,10 +326,7 @@ class DecodeEngine:
         room = self.S - input_ids.shape[1]
         for i in range(min(max_new_tokens, room)):
             if do_sample:
-                lg = logits / max(temperature, 1e-6)
-                if top_k:
-                    kth = torch.topk(lg, top_k, dim=-1).values[:, -1:]
-                    lg = lg.masked_fill(lg < kth, float("-inf"))
+                lg = filter_logits(logits / max(temperature, 1e-6), top_k, top_p)
                 nxt = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).view(-1)
             else:
                 nxt = torch.argmax(logits, dim=-1)
@@ -345,6 +342,22 @@ class DecodeEngine:
         return torch.cat(out, dim=1)
 
 
+def filter_logits(logits, top_k=0, top_p=1.0):
+    """HF's warper order and rules (generation/logits_process.py TopKLogitsWarper, TopPLogitsWarper) on [B, V] logits: keep the
+    top_k largest (ties with the k-th stay), then the smallest set of most probable tokens whose mass reaches top_p -- a
+    token goes when the cumulative probability of it and everything LESS likely is <= 1 - top_p; the most likely token
+    always stays. Everything else becomes -inf."""
+    if top_k and top_k < logits.shape[-1]:
+        kth = torch.topk(logits, int(top_k), dim=-1).values[..., -1:]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        ascending, order = torch.sort(logits, descending=False, dim=-1)
+        drop = ascending.softmax(dim=-1).cumsum(dim=-1) <= (1.0 - float(top_p))
+        drop[..., -1:] = False
+        logits = logits.masked_fill(drop.scatter(-1, order, drop), float("-inf"))
+    return logits
+
+
 def _eps(norm):
     return float(getattr(norm, "variance_epsilon", getattr(norm, "eps", 1e-6)))
 
@@ -352,20 +365,20 @@ def _eps(norm):
 # generate() arguments the decode engine implements itself; anything else a caller passes changes what HF's generate would
 # return, so such calls go to the original `generate` (kept as `model._old_generate` by for_inference) instead of being
 # silently ignored
-_ENGINE_KWARGS = {"max_new_tokens", "max_length", "eos_token_id", "pad_token_id", "do_sample", "temperature", "top_k",
+_ENGINE_KWARGS = {"max_new_tokens", "max_length", "eos_token_id", "pad_token_id", "do_sample", "temperature", "top_k", "top_p",
                   "attention_mask", "use_cache", "generator", "max_seq_len", "return_dict_in_generate", "output_scores",
                   "generation_config", "tokenizer"}
 
 
 def unsloth_fast_generate(model, input_ids=None, max_new_tokens=None, max_seq_len=None, **kwargs):
     """llama.py:2167-2259 counterpart: `model.generate(...)` after `FastLanguageModel.for_inference(model)`.
-    The reference forwards every keyword to HF's generate; the engine covers greedy / temperature / top-k decoding of
-    unpadded batches. Calls outside that (top_p, repetition_penalty, beams, streamers, logits processors, a padded
+    The reference forwards every keyword to HF's generate; the engine covers greedy / temperature / top-k / top-p decoding of
+    unpadded batches. Calls outside that (repetition_penalty, beams, streamers, logits processors, a padded
     attention_mask, ...) are handed to HF's own generate (`model._old_generate`) -- or raise when it is unavailable."""
     input_ids = kwargs.pop("inputs", input_ids)
     attention_mask = kwargs.get("attention_mask", None)
     padded = attention_mask is not None and not bool(torch.all(attention_mask != 0))
-    neutral = {"top_p": (None, 1.0), "repetition_penalty": (None, 1.0), "num_beams": (None, 1), "streamer": (None,),
+    neutral = {"repetition_penalty": (None, 1.0), "num_beams": (None, 1), "streamer": (None,),
                "num_return_sequences": (None, 1), "min_new_tokens": (None, 0), "return_dict_in_generate": (None, False),
                "output_scores": (None, False), "generation_config": (None,)}
     unsupported = [k for k, v in kwargs.items()
@@ -392,8 +405,8 @@ def unsloth_fast_generate(model, input_ids=None, max_new_tokens=None, max_seq_le
     if pad is None and gen_cfg is not None:
         pad = getattr(gen_cfg, "pad_token_id", None)
     # Sampling defaults come from the model's generation_config like in HF's generate (a checkpoint that ships
-    # do_sample=True / temperature / top_k / top_p samples without the caller saying so); explicit keywords win. A
-    # generation_config top_p below 1 (the engine has no nucleus filter) goes to HF's own generate.
+    # do_sample=True / temperature / top_k / top_p -- Llama-3-Instruct's does -- samples without the caller saying so);
+    # explicit keywords win.
     def gen_default(name, fallback):
         if name in kwargs and kwargs[name] is not None:
             return kwargs[name]
@@ -402,19 +415,14 @@ def unsloth_fast_generate(model, input_ids=None, max_new_tokens=None, max_seq_le
     do_sample = bool(gen_default("do_sample", False))
     temperature = float(gen_default("temperature", 1.0))
     top_k = int(gen_default("top_k", 0) or 0) if do_sample else 0
-    top_p = float(gen_default("top_p", 1.0))
-    if do_sample and top_p < 1.0:
-        old = getattr(model, "_old_generate", None)
-        if old is None:
-            raise NotImplementedError("unsloth_fast_generate: nucleus sampling (top_p < 1) needs HF's generate")
-        return old(input_ids, max_new_tokens=max_new_tokens, **kwargs)
+    top_p = float(gen_default("top_p", 1.0)) if do_sample else 1.0
     need = input_ids.shape[1] + max_new_tokens
     eng = getattr(model, "_uamd_decode_engine", None)
     if eng is None or eng.B != input_ids.shape[0] or eng.S < need:
         eng = DecodeEngine(model, max_seq_len=max(need, max_seq_len or 0), batch=input_ids.shape[0])
         model._uamd_decode_engine = eng
     return eng.generate(input_ids, max_new_tokens=max_new_tokens, eos_token_id=eos,
-                        do_sample=do_sample, temperature=temperature, top_k=top_k,
+                        do_sample=do_sample, temperature=temperature, top_k=top_k, top_p=top_p,
                         generator=kwargs.get("generator", None), pad_token_id=pad)
 
 
