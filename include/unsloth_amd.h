@@ -155,6 +155,23 @@ int uamd_glu_bwd_xa(int act, void* DW, void* e, void* g, int M, int K, int64_t l
                     void* out_k_u, int64_t ld_k_u, int k_cols_u,
                     const void* Wg, int64_t ldwg, int Rg, float* out_g, int64_t ld_out_g, int out_cols_g,
                     void* out_k_g, int64_t ld_k_g, int k_cols_g, int dtype, void* stream);
+/* The same two calls with the columns of every 16-row group SPLIT over adjacent workgroups of 1024 columns (round 5: workgroups
+ * that each walk along their own rows sweep the matrix column slab by column slab, 4.4-4.8 TB/s on the access pattern alone;
+ * split over 14 adjacent workgroups 5.8; tools/probes/tile_shape_probe.hip). The rank products of a part go to `ws` as fp32
+ * partials and the workgroup that finishes a row group last adds them in part order (deterministic). ws: >=
+ * uamd_glu_xa_workspace(M, K, n_products, max rank) floats; counters: (M + 15) / 16 ints, ZERO on entry, left zero. One workspace
+ * per device and stream. UAMD_TUNE_GLU_XA < 3 or a GeGLU activation run the unsplit kernels of the calls above (ws unused).
+ * Same results: the element-wise outputs bit for bit, the rank products up to fp32 summation order. */
+int64_t uamd_glu_xa_workspace(int M, int K, int n_products, int max_rank);
+int uamd_glu_fwd_xa_ws(int act, const void* e, const void* g, void* h, int M, int K, int64_t ld, const void* W, int64_t ldw,
+                       int R, float* out, int64_t ld_out, int out_cols, void* out_k, int64_t ld_k, int k_cols,
+                       float* ws, int64_t ws_floats, int* counters, int dtype, void* stream);
+int uamd_glu_bwd_xa_ws(int act, void* DW, void* e, void* g, int M, int K, int64_t ld,
+                       const void* Wu, int64_t ldwu, int Ru, float* out_u, int64_t ld_out_u, int out_cols_u,
+                       void* out_k_u, int64_t ld_k_u, int k_cols_u,
+                       const void* Wg, int64_t ldwg, int Rg, float* out_g, int64_t ld_out_g, int out_cols_g,
+                       void* out_k_g, int64_t ld_k_g, int k_cols_g, float* ws, int64_t ws_floats, int* counters,
+                       int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Cross entropy.  Replaces cross_entropy_loss.py:35-111 / :114-199 (+ host logsumexp :366-370) and
@@ -291,7 +308,12 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * trip, loads issued ahead, shift instead of the 64-bit division (default), 0 = one group per lane */
 #define UAMD_TUNE_GEMM_PLAIN 9  /* (UAMD_GEMM_PLAIN) persistent 256x256 GEMM without accumulate / bias: 1 = the kernel instance whose
                                  * epilogue has no global loads (default: no vmcnt(0) in the K loop), 0 = the run-time-dispatch instance */
-#define UAMD_TUNE_COUNT 10
+#define UAMD_TUNE_GLU_XA 10     /* (UAMD_GLU_XA) the gated activation fused with the LoRA rank products: 0 = 4 waves per 16-row block, two
+                                 * 16-byte vectors per thread per tensor, tiles requested one step ahead (rounds 3-4); 1 = 8 waves, one
+                                 * vector per thread; 2 = 8 waves and every tile requested two steps ahead; 3 (default) = 2 with the
+                                 * columns of a row group split over adjacent workgroups (uamd_glu_{fwd,bwd}_xa_ws; without a
+                                 * workspace: 2), part size by shape; 7 / 4 / 5 / 6 = parts of 4 / 8 / 14 / 28 tiles always */
+#define UAMD_TUNE_COUNT 11
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);

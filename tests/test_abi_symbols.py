@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     src = open(os.path.join(ROOT, "include", "unsloth_amd.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:int|void)\s+(\w+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:int|void|int64_t)\s+(\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 

@@ -102,3 +102,71 @@ def test_lora_mlp_block_with_and_without_the_fusion():
             U.GLU_FUSED = keep
     for a, b in zip(res["all"], res[False]):
         assert rel_fro(a, b) < 3e-3
+
+
+@pytest.mark.parametrize("M,K,r", [(2048, 14336, 16), (300, 1024, 8), (17, 264, 32), (33, 5632, 64), (5, 8, 4), (64, 520, 16)])
+def test_fused_activation_schedules_agree(M, K, r):
+    """UAMD_TUNE_GLU_XA (knob 10): 0 = 4 waves per 16-row block (rounds 3-4), 1 = 8 waves, 2 = 8 waves + tiles requested two steps
+    ahead, 3 = the flat grid (one tile per workgroup, partial rank products summed in tile order by the last workgroup of a row
+    group: default). The element-wise outputs are the same arithmetic on the same operands: BIT-IDENTICAL; the rank products sum
+    the same tile products over 4 resp. 8 partial accumulators: equal up to fp32 summation order. K = 264 / 520 / 8: one, three
+    and a fraction of a 256-column tile (every remainder branch of the depth-2 loop: 1, 2, 3, 4 and 56 = 3 * 17 + 5 tiles)."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels import utils as U
+    L = _lib.lib()
+    dtype = torch.bfloat16
+    g_ = torch.Generator().manual_seed(M * 7 + K)
+    e = torch.randn(M, K, generator=g_).to(dtype).to(DEV)
+    g = torch.randn(M, K, generator=g_).to(dtype).to(DEV)
+    DW = (torch.randn(M, K, generator=g_) * 0.1).to(dtype).to(DEV)
+    H = 512
+    down, up, gate = _proj(H, K, r, g_, dtype), _proj(K, H, r, g_, dtype), _proj(K, H, r, g_, dtype)
+    keep = U.GLU_FUSED
+    U.GLU_FUSED = "all"
+    res = {}
+    try:
+        for v in (0, 1, 2, 3, 4, 7):
+            assert L.uamd_set_tuning(10, v) == 0
+            out = U.glu_fwd_xa("swiglu", e, g, down)
+            if out is None:
+                pytest.skip("shape not fusable")
+            h, (xa, _, xk) = out
+            h2, df, de, (pu, pg) = U.glu_bwd_terms("swiglu", DW.clone(), e.clone(), g.clone(), up, gate)
+            res[v] = (h, h2, df, de, xa, pu, pg)
+    finally:
+        L.uamd_set_tuning(10, 3)
+        U.GLU_FUSED = keep
+    for v in (1, 2, 3, 4, 7):
+        for a, b in zip(res[0][:4], res[v][:4]):
+            assert torch.equal(a, b), v
+        for a, b in zip(res[0][4:], res[v][4:]):
+            assert rel_fro(a, b) < 1e-5, v
+    for a, b in zip(res[1][4:], res[2][4:]):                  # the same 8 partial sums, the same order: bitwise
+        assert torch.equal(a, b)
+
+
+def test_flat_grid_is_run_to_run_deterministic_and_leaves_its_counters_zero():
+    """The workgroup that finishes a row group LAST differs from run to run; the sum it forms does not (tile order). And the
+    arrival counters are zero again after every launch -- the next launch depends on it."""
+    from unsloth_amd.kernels import utils as U
+    dtype = torch.bfloat16
+    g_ = torch.Generator().manual_seed(5)
+    M, K, r = 1000, 14336, 16
+    e = torch.randn(M, K, generator=g_).to(dtype).to(DEV)
+    g = torch.randn(M, K, generator=g_).to(dtype).to(DEV)
+    DW = (torch.randn(M, K, generator=g_) * 0.1).to(dtype).to(DEV)
+    down, up, gate = _proj(512, K, r, g_, dtype), _proj(K, 512, r, g_, dtype), _proj(K, 512, r, g_, dtype)
+    keep = U.GLU_FUSED
+    U.GLU_FUSED = "all"
+    try:
+        runs = []
+        for _ in range(4):
+            h, (xa, _, xk) = U.glu_fwd_xa("swiglu", e, g, down)
+            _, _, _, (pu, pg) = U.glu_bwd_terms("swiglu", DW.clone(), e.clone(), g.clone(), up, gate)
+            runs.append((xa.clone(), pu.clone(), pg.clone()))
+        torch.cuda.synchronize()
+        for other in runs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(runs[0], other))
+        assert U._GLU_WS and all(int(c.abs().sum()) == 0 for _, c in U._GLU_WS.values())
+    finally:
+        U.GLU_FUSED = keep

@@ -4,7 +4,8 @@ The knobs pick between schedules of one computation (grid shape, raster order, c
 bit-identical to the default's -- except `UAMD_TUNE_RMS_VAR`, whose two kernels reduce a row in a different order (wave shuffle
 tree vs. block LDS tree): fp32 sums within rounding, 16-bit outputs within 1 ulp. Knobs 3, 4, 6, 7, 8 and 9 (transposing dequant,
 attention forward kernel, GEMM tile height / persistence / plain epilogue, x4 dequant) have their own parametrised tests in
-tests/test_gpu_nf4_gemm.py and tests/test_gpu_attention.py; this file covers 0, 1, 2 and 5.
+tests/test_gpu_nf4_gemm.py and tests/test_gpu_attention.py, knob 10 (fused activation schedules) in tests/test_gpu_glu_fused.py; this
+file covers 0, 1, 2 and 5.
 (The reference has no such knobs: its Triton launches are fixed, kernels/swiglu.py:41-60, rms_layernorm.py:23-60.)"""
 import pytest
 import torch
@@ -99,4 +100,4 @@ def test_gemm256_raster_group_height_is_bitwise_neutral(lib, group_m):
 
 
 def test_set_tuning_refuses_what_it_does_not_know(lib):
-    assert lib.uamd_set_tuning(-1, 0) != 0 and lib.uamd_set_tuning(10, 0) != 0 and lib.uamd_set_tuning(0, -1) != 0
+    assert lib.uamd_set_tuning(-1, 0) != 0 and lib.uamd_set_tuning(11, 0) != 0 and lib.uamd_set_tuning(0, -1) != 0

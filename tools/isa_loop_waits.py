@@ -30,32 +30,62 @@ sys.path.insert(0, ROOT)
 
 
 def loops_of(asm_path):
+    """{kernel: [(header label, instructions, loads, stores, [vmcnt waits], [body offsets of full vmcnt(0)]), ...]} for every
+    innermost loop that touches global memory. A loop = the header block (`; =>This Inner Loop Header`) plus every block
+    LLVM annotates with `in Loop: Header=<that block>` -- wherever the layout put them (a rotated loop keeps its latch
+    BEFORE the header and falls through into it: a "label ... branch back to the label" scan misses those)."""
     lines = open(asm_path).read().split("\n")
-    kern, lastlab, out = None, None, {}
-    for i, l in enumerate(lines):
-        m = re.match(r"^(_Z\w+):", l)
-        if m:
-            kern = m.group(1)
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
-        if m:
-            lastlab = m.group(1)
-        if "Loop Header" in l and kern and lastlab:
-            lab, end = lastlab, None
-            for j in range(i + 1, min(len(lines), i + 10000)):
-                if re.match(r"^_Z\w+:", lines[j]) or ".Lfunc_end" in lines[j]:
-                    break
-                if re.search(r"s_c?branch\w*\s+" + re.escape(lab) + r"\s*$", lines[j].split(";")[0].rstrip()):
-                    end = j
-            if end is None:
-                continue
-            body = [b for b in lines[i + 1:end + 1] if b.strip() and not b.strip().startswith(";")]
+    out, kern = {}, None
+    blocks = []                                      # (label, header it belongs to or None, is_header, [lines]) of the current kernel
+
+    def flush():
+        if kern is None:
+            return
+        headers = [b[0] for b in blocks if b[2]]
+        for h in headers:
+            short = h.lstrip(".L")                   # annotations say BB2_3 for .LBB2_3
+            body = []
+            for lab, owner, is_h, ls in blocks:
+                if lab == h or owner == short:
+                    body += ls
+            body = [b for b in body if b.strip() and not b.strip().startswith(";")]
             nld = sum(("global_load" in b or "buffer_load" in b) for b in body)
             nst = sum(("global_store" in b or "buffer_store" in b) for b in body)
             if not (nld or nst):
                 continue
             waits = [re.search(r"vmcnt\((\d+)\)", b).group(1) for b in body if "vmcnt(" in b]
             drains = [k for k, b in enumerate(body) if re.search(r"s_waitcnt\s+vmcnt\(0\)", b)]
-            out.setdefault(kern, []).append((lab, len(body), nld, nst, waits, drains))
+            out.setdefault(kern, []).append((h, len(body), nld, nst, waits, drains))
+
+    for l in lines:
+        m = re.match(r"^(_Z\w+):", l)
+        if m:
+            flush()
+            kern, blocks = m.group(1), []
+            continue
+        if ".Lfunc_end" in l:
+            flush()
+            kern, blocks = None, []
+            continue
+        if kern is None:
+            continue
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)$", l)
+        if m:
+            blocks.append([m.group(1), None, False, []])
+            note = m.group(2)
+        elif blocks and re.match(r"^\s+;\s+(=>|Parent Loop|Child Loop|in Loop)", l):
+            note = l                                  # the annotation of a nested loop's block continues on comment lines
+        else:
+            note = None
+            if blocks:
+                blocks[-1][3].append(l)
+        if note is not None and blocks:
+            owner = re.search(r"in Loop: Header=(BB\d+_\d+)", note)
+            if owner:
+                blocks[-1][1] = owner.group(1)
+            if "Inner Loop Header" in note:            # innermost loops only: the hand-pipelined ones
+                blocks[-1][2] = True
+    flush()
     return out
 
 

@@ -137,6 +137,12 @@ SIGNATURES = {
     "uamd_glu_bwd_xa": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]
                         + [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int] * 2
                         + [c_int, c_void_p]),
+    "uamd_glu_xa_workspace": (c_int64, [c_int, c_int, c_int, c_int]),
+    "uamd_glu_fwd_xa_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_int,
+                                   c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
+    "uamd_glu_bwd_xa_ws": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]
+                           + [c_void_p, c_int64, c_int, c_void_p, c_int64, c_int, c_void_p, c_int64, c_int] * 2
+                           + [c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "uamd_adamw_shard": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64] + [ctypes.c_double] * 8
                          + [c_int, c_void_p]),
     "uamd_lora_tn": (c_int, [ctypes.POINTER(LoraTnProblem), c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),

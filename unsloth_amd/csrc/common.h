@@ -63,6 +63,13 @@ template <typename T> __device__ __forceinline__ T from_f32(float x) { return (T
 // round a float through T (the "rounding point" of the reference kernels)
 template <typename T> __device__ __forceinline__ float round_to(float x) { return (float)((T)x); }
 
+// sigmoid(x) = 1 / (1 + exp(-x)) with the IEEE division (11 of the ~26 instructions the SwiGLU forward spends per element).
+// Round 5 measured the cheaper v_rcp_f32 + one Newton step (two fmas, <= 1 fp32 ulp off) in its place: the fused activation
+// kernels were NOT faster forward and 7 % slower backward (profiles/r05_glu_xa_ab.jsonl, "default" = Newton against
+// "libunsloth_amd_ieee.so") -- they are bound by bytes in flight, not by VALU issue -- so the exact quotient stays.
+// One definition for glu.hip and the decode GEMV's SwiGLU prologue (bit-identical to each other, tests/test_gpu_decode.py).
+__device__ __forceinline__ float uamd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -408,7 +408,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float e = to_f32(a.e[j]);
-                        const float f = e * (1.0f / (1.0f + __expf(-e)));
+                        const float f = e * uamd_sigmoid(e);
                         o.e[j] = from_f32<T>(round_to<T>(f) * to_f32(b.e[j]));
                     }
                 }
@@ -652,7 +652,7 @@ __global__ void __launch_bounds__(GEMV_THREADS, NIT <= 16 ? 4 : 2) gemv_kernel(G
                     if (p.g[1].bias) gg += to_f32(((const T*)p.g[1].bias)[n_s[r]]);
                     e = round_to<T>(e);
                     gg = round_to<T>(gg);
-                    const float f = e * (1.0f / (1.0f + __expf(-e)));
+                    const float f = e * uamd_sigmoid(e);
                     ((T*)p.g[0].y)[n_s[r]] = from_f32<T>(round_to<T>(f) * gg);
                 }
             } else {

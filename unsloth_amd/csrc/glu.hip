@@ -25,8 +25,11 @@
 namespace {
 
 enum { ACT_SWIGLU = 0, ACT_GEGLU_EXACT = 1, ACT_GEGLU_APPROX = 2 };
+#ifndef UAMD_GLU_KNOCK
+#define UAMD_GLU_KNOCK 0      /* != 0: timing-only builds of glu_xa_kernel with one ingredient compiled out (results are wrong) */
+#endif
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return uamd_sigmoid(x); }      // common.h
 
 // forward activation f(e) in fp32, plus (for backward) df/de
 template <int ACT>
@@ -310,18 +313,28 @@ constexpr int GX_TK = 256;                       // columns per tile
 constexpr int GX_LD = GX_TK * 2 + 16;            // LDS row stride in bytes
 constexpr int GX_TILE = 16 * GX_LD;              // 8,448 B per operand tile
 
-template <typename T, int ACT, int NS, int NT>
-__global__ void __launch_bounds__(256)
+// KS = 1: the block above (4 waves, two vectors per thread per tensor, two k-steps per wave). KS = 2 (round 5): the SAME
+// 16-row x 256-column tile worked by 8 waves -- one vector per thread per tensor, one k-step per wave: half the streamed
+// registers and fragments per thread (the backward instance went from 176 to <= 128 VGPRs), so two 8-wave blocks fit a CU
+// and every SIMD has 4 waves to hide the activation arithmetic behind (the kernel is VALU-heavy: ~26 instructions per
+// element forward, two of them quarter-rate, at 2 waves per SIMD: profiles/r05_glu_xa_ab.jsonl).
+template <typename T, int ACT, int NS, int NT, int KS, int PD>
+__global__ void __launch_bounds__(256 * KS, 2 * KS)
 glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __restrict__ H, int M, int K, int64_t ld,
-              GluXaOut o0, GluXaOut o1) {
+              GluXaOut o0, GluXaOut o1, float* __restrict__ part, int* __restrict__ counters, int nparts, int tpb) {
     typedef typename GluMfma<T>::frag frag_t;
-    constexpr int NV = 2, NQ = 2;                                        // vectors per thread per tensor, k-steps per wave
-    constexpr int RED = 4 * 16 * NS * NT * 16 * 4;                       // bytes of the final reduction buffer
+    constexpr int NWAVE = 4 * KS, NTHR = 256 * KS;
+    constexpr int NV = 2 / KS, NQ = 2 / KS;                              // vectors per thread per tensor, k-steps per wave
+    constexpr int RED = NWAVE * 16 * NS * NT * 16 * 4;                   // bytes of the final reduction buffer
     constexpr int LDS_B = 2 * NS * GX_TILE > RED ? 2 * NS * GX_TILE : RED;
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_B];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const int m0 = blockIdx.x * 16;
+    // nparts > 1 (round 5): the columns of a 16-row group are SPLIT over nparts adjacent workgroups of tpb tiles each
+    // (blockIdx = row group * nparts + part) -- see the note on the grid's memory sweep in front of launch_xa
+    const int rg = nparts > 1 ? (int)(blockIdx.x / (unsigned)nparts) : (int)blockIdx.x;
+    const int cpart = nparts > 1 ? (int)(blockIdx.x - (unsigned)rg * (unsigned)nparts) : 0;
+    const int m0 = rg * 16;
     glu_f32x4_t acc[NS][NT];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -335,17 +348,19 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
         woff0[t] = (int64_t)min(t * 16 + l15, o0.R - 1) * o0.ldw + l4 * 8;
         woff1[t] = NS > 1 ? (int64_t)min(t * 16 + l15, o1.R - 1) * o1.ldw + l4 * 8 : 0;
     }
-    // streaming side: vector v of this thread = row 8 v + 2 wave + (lane >> 5) of the block, columns 8 (lane & 31) ..
+    // streaming side: vector v of this thread = row (16 / NV) v + 2 wave + (lane >> 5) of the block, columns 8 (lane & 31) ..
     const int srow = 2 * wave + (lane >> 5), scol = (lane & 31) * 8;
     int64_t roff[NV];
     bool row_ok[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const int r = m0 + 8 * v + srow;
+        const int r = m0 + (16 / NV) * v + srow;
         row_ok[v] = r < M;
         roff[v] = (int64_t)(row_ok[v] ? r : M - 1) * ld;                 // clamped rows are computed and never stored
     }
-    const int ntiles = (K + GX_TK - 1) / GX_TK;
+    const int ntiles_all = (K + GX_TK - 1) / GX_TK;
+    const int it_begin = nparts > 1 ? cpart * tpb : 0;
+    const int ntiles = nparts > 1 ? min(it_begin + tpb, ntiles_all) : ntiles_all;       // (exclusive END of this block's tiles)
     // two register sets for the streamed operands AND the LoRA factor's fragments, used alternately (the loop is unrolled
     // by two: a `cur = next` copy at the end of a tile would make the compiler wait for the prefetch right there). One set
     // = everything tile `it` consumes, requested one tile ahead in consumption order (vmcnt retires in order: data first,
@@ -354,8 +369,8 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
         Vec16<T> e[NV], g[NV], dw[NV];
         uint4 wf0[NQ][NT], wf1[NS > 1 ? NQ : 1][NT];
     };
-    Regs A, B;
-    auto load_tile = [&](int it, Regs& r) {
+    Regs A, B, C;                                                        // (C: the third set of the depth-2 prefetch, PD == 2)
+    auto load_data = [&](int it, Regs& r) {
         const int c = it * GX_TK + scol;
         const int cc = c + 8 <= K ? c : 0;
 #pragma unroll
@@ -365,22 +380,38 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
             if (NS > 1) r.dw[v] = ld16_nt(DW + roff[v] + cc);
         }
         __builtin_amdgcn_sched_barrier(0);
+    };
+    auto load_frags = [&](int it, Regs& r) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int kc = it * GX_TK + (wave + 4 * q) * 32;
+            const int kc = it * GX_TK + (wave + NWAVE * q) * 32;
             const int kk = kc + l4 * 8 + 8 <= K ? kc : 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
+#if UAMD_GLU_KNOCK & 1     /* knock-out build (tools/glu_xa_ab.py): no factor-fragment loads */
+                r.wf0[q][t] = make_uint4(kk, kk, kk, kk);
+                if (NS > 1) r.wf1[q][t] = make_uint4(kk, kk, kk, kk);
+#else
                 r.wf0[q][t] = *reinterpret_cast<const uint4*>(W0 + woff0[t] + kk);
                 if (NS > 1) r.wf1[q][t] = *reinterpret_cast<const uint4*>(W1 + woff1[t] + kk);
+#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto tile = [&](int it, Regs& r, Regs& rn) {
+    auto load_tile = [&](int it, Regs& r) {
+        load_data(it, r);
+        if constexpr (PD == 1) load_frags(it, r);
+    };
+    auto tile = [&](int it, Regs& r, Regs& rn, int it_next, auto prefetch) {
         unsigned char* buf = smem + (it & 1) * NS * GX_TILE;
-        // unconditional (the last tile is simply fetched once more: behind a branch the compiler drains vmcnt at the join)
-        load_tile(it + 1 < ntiles ? it + 1 : it, rn);
+        // PD == 2: the factor fragments of THIS tile (L2-resident: half a microsecond, hidden by the activation arithmetic
+        // below) go out BEFORE the data of the tile two steps ahead: vmcnt retires in order, so the wait in front of the MFMAs
+        // covers them and everything older, never the younger prefetch. One fragment set instead of three: the registers
+        // that keep the backward instance at 4 waves per SIMD.
+        if constexpr (PD == 2) load_frags(it, r);
+        // compile-time yes / no, never a run-time branch (behind a branch the compiler drains vmcnt at the join)
+        if constexpr (decltype(prefetch)::value) load_tile(it_next, rn);
         const int c = it * GX_TK + scol;
         const bool col_ok = c + 8 <= K;
 #pragma unroll
@@ -409,10 +440,16 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
                 v0.raw = make_uint4(0, 0, 0, 0);
                 v1.raw = make_uint4(0, 0, 0, 0);
             }
-            unsigned char* dst = buf + (8 * v + srow) * GX_LD + scol * 2;
+#if !(UAMD_GLU_KNOCK & 2)
+            unsigned char* dst = buf + ((16 / NV) * v + srow) * GX_LD + scol * 2;
             *reinterpret_cast<uint4*>(dst) = v0.raw;
             if (NS > 1) *reinterpret_cast<uint4*>(dst + GX_TILE) = v1.raw;
+#endif
         }
+#if UAMD_GLU_KNOCK & 2     /* knock-out build: no LDS hand-off, no barrier, no MFMA -- the activation on this tiling alone */
+        (void)buf;
+        return;
+#endif
         // the tile is complete (and buf ^ 1 is free again). NOT __syncthreads(): that drains vmcnt too, i.e. waits for
         // the NEXT tile's loads issued above -- the prefetch would buy nothing (first build: 4.1 / 4.65 TB/s)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -420,11 +457,11 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const unsigned char* src = buf + l15 * GX_LD + ((wave + 4 * q) * 32 + l4 * 8) * 2;
+            const unsigned char* src = buf + l15 * GX_LD + ((wave + NWAVE * q) * 32 + l4 * 8) * 2;
             union { uint4 r; frag_t f; } a0, a1, w;
             a0.r = *reinterpret_cast<const uint4*>(src);
             if (NS > 1) a1.r = *reinterpret_cast<const uint4*>(src + GX_TILE);
-            const bool k_ok = it * GX_TK + (wave + 4 * q) * 32 + l4 * 8 + 8 <= K;
+            const bool k_ok = it * GX_TK + (wave + NWAVE * q) * 32 + l4 * 8 + 8 <= K;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 w.r = k_ok ? r.wf0[q][t] : make_uint4(0, 0, 0, 0);
@@ -436,18 +473,44 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
             }
         }
     };
-    load_tile(0, A);
-    {
+    constexpr std::true_type yes{};
+    constexpr std::false_type no{};
+    load_tile(it_begin, A);
+    if constexpr (PD == 1) {
         // pairs of tiles in a branch-free body; an odd last tile after the loop (a conditional second tile inside the loop
-        // is a join at which hipcc drains vmcnt -- prefetched loads AND the previous tile's stores -- every iteration)
-        int it = 0;
+        // is a join at which hipcc drains vmcnt -- prefetched loads AND the previous tile's stores -- every iteration). The
+        // last tile is simply fetched once more.
+        int it = it_begin;
         for (; it + 1 < ntiles; it += 2) {
-            tile(it, A, B);
-            tile(it + 1, B, A);
+            tile(it, A, B, it + 1 < ntiles ? it + 1 : it, yes);
+            tile(it + 1, B, A, it + 2 < ntiles ? it + 2 : it + 1, yes);
         }
-        if (it < ntiles) tile(it, A, B);
+        if (it < ntiles) tile(it, A, B, it, yes);
+    } else {
+        // PD == 2: every tile is requested TWO tile steps before it is consumed (three register sets in rotation, the loop
+        // unrolled by three): the kernel's rate is bytes in flight / latency, and one tile ahead is 24-49 KB per CU
+        // (profiles/r05_glu_xa_ab.jsonl: neither cheaper arithmetic nor twice the waves moved it).
+        load_tile(it_begin + 1 < ntiles ? it_begin + 1 : it_begin, B);
+        int it = it_begin;
+        for (; it + 4 < ntiles; it += 3) {
+            tile(it, A, C, it + 2, yes);
+            tile(it + 1, B, A, it + 3, yes);
+            tile(it + 2, C, B, it + 4, yes);
+        }
+        // 1 .. 4 tiles left (A holds tile `it`, B tile it + 1); what is still missing is fetched, nothing twice
+        const int rem = ntiles - it;
+        if (rem >= 3) {
+            tile(it, A, C, it + 2, yes);
+            if (rem == 4) tile(it + 1, B, A, it + 3, yes);
+            else tile(it + 1, B, A, 0, no);
+            tile(it + 2, C, B, 0, no);
+            if (rem == 4) tile(it + 3, A, B, 0, no);
+        } else {
+            tile(it, A, B, 0, no);
+            if (rem == 2) tile(it + 1, B, A, 0, no);
+        }
     }
-    // ---- 4 partial tiles -> LDS -> fixed-order sum. acc[s][t][i] = C[row 4 l4 + i][rank t * 16 + l15]
+    // ---- NWAVE partial tiles -> LDS -> fixed-order sum. acc[s][t][i] = C[row 4 l4 + i][rank t * 16 + l15]
     constexpr int RW = NS * NT * 16;                                     // floats per row of the reduction buffer
     __syncthreads();                                                     // every wave is done with the operand tiles
     float* red = reinterpret_cast<float*>(smem);
@@ -458,29 +521,72 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
 #pragma unroll
             for (int i = 0; i < 4; ++i) red[(wave * 16 + 4 * l4 + i) * RW + (s * NT + t) * 16 + l15] = acc[s][t][i];
     __syncthreads();
+    if (nparts > 1) {
+        // ---- this block's [16 x RW] sums are a PARTIAL over its columns: to the workspace; the block that finishes the row group
+        //      LAST (an arrival counter per row group, zero on entry, left zero) adds the parts in PART ORDER -- a fixed order
+        //      whoever arrives last: deterministic -- and writes `out` / `out_k`.
+        //      No __threadfence() / release-acquire atomics: at agent scope they are `buffer_wbl2`, a write-back of the whole L2,
+        //      per workgroup while 0.7-1.4 GB of results stream through it (a one-tile-per-workgroup build of this scheme: 4.7 ms
+        //      instead of 0.27). The partials are agent-scope atomic stores (write-through) and agent-scope atomic loads (never
+        //      served from a non-coherent line): waiting for this thread's stores to be acknowledged (vmcnt(0)) before the
+        //      barrier in front of the counter's increment is all the ordering there is to establish.
+        __shared__ int s_last;
+        float* mine = part + (int64_t)blockIdx.x * (16 * RW);
+        for (int idx = tid; idx < 16 * RW; idx += NTHR) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWAVE; ++w) v += red[w * 16 * RW + idx];
+            __hip_atomic_store(mine + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) s_last = __hip_atomic_fetch_add(counters + rg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nparts - 1;
+        __syncthreads();
+        if (!s_last) return;
+        float* pg = part + (int64_t)rg * nparts * (16 * RW);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const GluXaOut& o = s == 0 ? o0 : o1;
+            const int wide = o.out_cols > o.k_cols ? o.out_cols : o.k_cols;
+            for (int idx = tid; idx < 16 * wide; idx += NTHR) {
+                const int mm = idx / wide, cl = idx - mm * wide;
+                if (m0 + mm >= M) continue;
+                float v = 0.f;
+                if (cl < o.R) {
+                    float* q = pg + mm * RW + s * NT * 16 + cl;
+                    for (int p_ = 0; p_ < nparts; ++p_)
+                        v += __hip_atomic_load(q + (int64_t)p_ * (16 * RW), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (cl < o.out_cols) o.out[(int64_t)(m0 + mm) * o.ld_out + cl] = v;
+                if (o.out_k != nullptr && cl < o.k_cols) ((T*)o.out_k)[(int64_t)(m0 + mm) * o.ld_k + cl] = from_f32<T>(v);
+            }
+        }
+        if (tid == 0) __hip_atomic_store(counters + rg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const GluXaOut& o = s == 0 ? o0 : o1;
-        for (int idx = tid; idx < 16 * o.out_cols; idx += 256) {
+        for (int idx = tid; idx < 16 * o.out_cols; idx += NTHR) {
             const int mm = idx / o.out_cols, c = idx - mm * o.out_cols;
             if (m0 + mm >= M) continue;
             float v = 0.f;
             if (c < o.R) {
                 const float* q = red + mm * RW + s * NT * 16 + c;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += q[w * 16 * RW];
+                for (int w = 0; w < NWAVE; ++w) v += q[w * 16 * RW];
             }
             o.out[(int64_t)(m0 + mm) * o.ld_out + c] = v;
         }
         if (o.out_k != nullptr) {
-            for (int idx = tid; idx < 16 * o.k_cols; idx += 256) {
+            for (int idx = tid; idx < 16 * o.k_cols; idx += NTHR) {
                 const int mm = idx / o.k_cols, c = idx - mm * o.k_cols;
                 if (m0 + mm >= M) continue;
                 float v = 0.f;
                 if (c < o.R) {
                     const float* q = red + mm * RW + s * NT * 16 + c;
-    #pragma unroll
-                for (int w = 0; w < 4; ++w) v += q[w * 16 * RW];
+#pragma unroll
+                    for (int w = 0; w < NWAVE; ++w) v += q[w * 16 * RW];
                 }
                 ((T*)o.out_k)[(int64_t)(m0 + mm) * o.ld_k + c] = from_f32<T>(v);
             }
@@ -488,17 +594,56 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
     }
 }
 
+// The grid's memory sweep (round 5). What held the fused kernels at 4.6-5.0 TB/s was neither their arithmetic (a cheaper
+// sigmoid: nothing), nor occupancy (8 waves per block: +1 %), nor prefetch depth (two tiles ahead: nothing), nor anything the
+// fusion adds (LDS hand-off, barrier, MFMAs and factor loads compiled out: 141 of 150 us remain, profiles/r05_glu_xa_knock.jsonl)
+// -- it is the ORDER in which the grid touches memory. 512 workgroups that each walk along their own 16 rows sweep the matrix
+// column slab by column slab: every DRAM page is visited dozens of times, 512 bytes at a time. tools/probes/tile_shape_probe.hip
+// isolates it on e * g alone (profiles/r05_tile_shape_probe.jsonl): workgroups walking 16 rows 4.4-4.8 TB/s at any prefetch
+// depth; the same walk with the columns of a row group split over 2 / 4 / 14 ADJACENT workgroups 5.1 / 5.3 / 5.8; one tile per
+// workgroup numbered row-group-major 6.4; the flat kernel 6.6. One tile per workgroup was built and measured: 267 us against
+// 148 -- 28,672 workgroups each paying a prologue, three barriers, a store acknowledgement and an atomic round trip for 8 KB
+// per tensor. The split keeps the pipelined walk and gets most of the sweep back: GX_TPB tiles (1024 columns) per workgroup,
+// blockIdx = row group * parts + part, the rank products of a part to a workspace ([row group][part][16][NS * NT * 16] fp32:
+// 1 % of the kernel's traffic), summed in part order by whichever workgroup finishes the row group last.
+constexpr int GX_TPB = 4;
+
 template <typename T, int ACT, int NS>
 int launch_xa(void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, const GluXaOut& o0, const GluXaOut& o1,
-              hipStream_t st) {
+              hipStream_t st, float* ws, int* counters) {
     const int R = NS > 1 ? (o0.R > o1.R ? o0.R : o1.R) : o0.R;
-    const dim3 grid((unsigned)((M + 15) / 16)), block(256);
-    if (R <= 16)
-        hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 1>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
-    else if (R <= 32)
-        hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 2>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
-    else
-        hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, 4>), grid, block, 0, st, (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1);
+    // UAMD_TUNE_GLU_XA: 3 = 2 + the column split (needs the workspace); 2 = 8 waves per 16-row block, tiles requested two steps
+    // ahead; 1 = 8 waves, one step ahead; 0 = 4 waves, one step ahead (rounds 3-4)
+    // (SwiGLU only -- the one activation the callers fuse, kernels/utils.py glu_fwd_xa: the GeGLU instances keep the round-3 form.
+    // The BACKWARD at ranks above 16 too: two products x two rank tiles of fragments do not fit the 128 registers of 4 waves per
+    // SIMD -- hipcc's bf16 build answers with a full vmcnt(0) in the tile loop, tests/test_isa_loop_waits.py -- so it stays at
+    // 4 waves x 176 registers)
+    const int xv = ACT == ACT_SWIGLU ? uamd_tuning_get(UAMD_TUNE_GLU_XA) : 0;
+    const int ntiles = (K + GX_TK - 1) / GX_TK;
+    // tiles per part. Measured at K = 14336 (profiles/r05_glu_xa_ab.jsonl: 4 / 8 / 14 / 28 tiles at 8192, 4096 and 2048 rows):
+    // the forward is fastest with TWO parts at every size (134 vs 149 us, 37 vs 55 us at 2048 rows -- where it also doubles the
+    // workgroups of a grid that had one per two CUs); the backward with parts of 8 tiles at 8192 rows (268 vs 300 us), of 28
+    // below (75 vs 104 us at 2048). Parts of 4 tiles lose to the unsplit walk (fill and drain of the two-deep prefetch per
+    // 4 tiles of work). UAMD_TUNE_GLU_XA: 3 = this rule; 7 / 4 / 5 / 6 = 4 / 8 / 14 / 28 tiles always (the A/B scan).
+    const int tpb = xv == 7 ? GX_TPB : xv == 4 ? 8 : xv == 5 ? 14 : xv == 6 ? 28 : (NS > 1 && M >= 8192 ? 8 : 28);
+    int nparts = (xv >= 3 && ws != nullptr && counters != nullptr) ? (ntiles + tpb - 1) / tpb : 1;
+    if (nparts < 2) nparts = 1;
+    const int64_t blocks = (int64_t)((M + 15) / 16) * nparts;
+    if (blocks > 0x7fffffffLL) return UAMD_ERR_ARG;
+    const dim3 grid((unsigned)blocks);
+#define GLU_XA_ARGS (T*)dw, (T*)e, (T*)g, (T*)h, M, K, ld, o0, o1, ws, counters, nparts, tpb
+#define GLU_XA_LAUNCH(NT_)                                                                                                   \
+    do {                                                                                                                     \
+        if constexpr (ACT != ACT_SWIGLU || (NS > 1 && NT_ > 1)) hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, NT_, 1, 1>), grid, dim3(256), 0, st, GLU_XA_ARGS); \
+        else if (xv >= 2) hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, NT_, 2, 2>), grid, dim3(512), 0, st, GLU_XA_ARGS);   \
+        else if (xv == 1) hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, NT_, 2, 1>), grid, dim3(512), 0, st, GLU_XA_ARGS);   \
+        else hipLaunchKernelGGL((glu_xa_kernel<T, ACT, NS, NT_, 1, 1>), grid, dim3(256), 0, st, GLU_XA_ARGS);                \
+    } while (0)
+    if (R <= 16) GLU_XA_LAUNCH(1);
+    else if (R <= 32) GLU_XA_LAUNCH(2);
+    else GLU_XA_LAUNCH(4);
+#undef GLU_XA_LAUNCH
+#undef GLU_XA_ARGS
     return uamd_launch_status();
 }
 
@@ -510,9 +655,16 @@ int check_xa_out(const GluXaOut& o, int K) {
     return UAMD_OK;
 }
 
+// floats of workspace the column split needs for an [M, K] launch (uamd_glu_xa_workspace)
+int64_t xa_ws_floats(int M, int K, int NS, int R) {
+    const int NT = R <= 16 ? 1 : (R <= 32 ? 2 : 4);
+    const int ntiles = (K + GX_TK - 1) / GX_TK;
+    return (int64_t)((M + 15) / 16) * ((ntiles + GX_TPB - 1) / GX_TPB) * 16 * (NS * NT * 16);
+}
+
 template <int NS>
 int glu_xa_entry(int act, void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, const GluXaOut& o0,
-                 const GluXaOut& o1, int dtype, void* stream) {
+                 const GluXaOut& o1, int dtype, void* stream, float* ws = nullptr, int64_t ws_floats = 0, int* counters = nullptr) {
     if (M < 0 || K <= 0 || !e || !g || (NS == 1 ? !h : !dw)) return UAMD_ERR_ARG;
     if (M == 0) return UAMD_OK;
     if ((K & 7) || (ld & 7) || !aligned16(e) || !aligned16(g) || (NS == 1 ? !aligned16(h) : !aligned16(dw))) return UAMD_ERR_ALIGN;
@@ -520,11 +672,12 @@ int glu_xa_entry(int act, void* dw, void* e, void* g, void* h, int M, int K, int
     if (rc) return rc;
     if (NS > 1 && (rc = check_xa_out(o1, K))) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (ws != nullptr && ws_floats < xa_ws_floats(M, K, NS, NS > 1 ? (o0.R > o1.R ? o0.R : o1.R) : o0.R)) return UAMD_ERR_ARG;
 #define GLU_XA_CASE(TT, DC)                                                                          \
     if (dtype == DC) {                                                                              \
-        if (act == ACT_SWIGLU) return launch_xa<TT, ACT_SWIGLU, NS>(dw, e, g, h, M, K, ld, o0, o1, st);          \
-        if (act == ACT_GEGLU_EXACT) return launch_xa<TT, ACT_GEGLU_EXACT, NS>(dw, e, g, h, M, K, ld, o0, o1, st); \
-        if (act == ACT_GEGLU_APPROX) return launch_xa<TT, ACT_GEGLU_APPROX, NS>(dw, e, g, h, M, K, ld, o0, o1, st); \
+        if (act == ACT_SWIGLU) return launch_xa<TT, ACT_SWIGLU, NS>(dw, e, g, h, M, K, ld, o0, o1, st, ws, counters);          \
+        if (act == ACT_GEGLU_EXACT) return launch_xa<TT, ACT_GEGLU_EXACT, NS>(dw, e, g, h, M, K, ld, o0, o1, st, ws, counters); \
+        if (act == ACT_GEGLU_APPROX) return launch_xa<TT, ACT_GEGLU_APPROX, NS>(dw, e, g, h, M, K, ld, o0, o1, st, ws, counters); \
         return UAMD_ERR_ARG;                                                                        \
     }
     GLU_XA_CASE(bf16_t, UAMD_BF16)
@@ -557,6 +710,31 @@ extern "C" int uamd_glu_bwd_xa(int act, void* DW, void* e, void* g, int M, int K
     return glu_xa_entry<2>(act, DW, e, g, nullptr, M, K, ld, o0, o1, dtype, stream);
 }
 
+// The same two calls with a workspace: `ws` = at least uamd_glu_xa_workspace(M, K, n_products, max rank) floats, `counters` =
+// (M + 15) / 16 ints that are ZERO on entry (the kernel leaves them zero): the column split (the note in front of launch_xa). One
+// workspace per device and stream: two launches in flight on different streams must not share it.
+extern "C" int64_t uamd_glu_xa_workspace(int M, int K, int n_products, int max_rank) {
+    if (M < 0 || K <= 0 || n_products < 1 || n_products > 2 || max_rank < 1 || max_rank > 64) return -1;
+    return xa_ws_floats(M, K, n_products, max_rank);
+}
+extern "C" int uamd_glu_fwd_xa_ws(int act, const void* e, const void* g, void* h, int M, int K, int64_t ld, const void* W,
+                                  int64_t ldw, int R, float* out, int64_t ld_out, int out_cols, void* out_k, int64_t ld_k,
+                                  int k_cols, float* ws, int64_t ws_floats, int* counters, int dtype, void* stream) {
+    GluXaOut o0{out, ld_out, R, out_cols, out_k, ld_k, k_cols, W, ldw};
+    return glu_xa_entry<1>(act, nullptr, const_cast<void*>(e), const_cast<void*>(g), h, M, K, ld, o0, o0, dtype, stream, ws,
+                           ws_floats, counters);
+}
+extern "C" int uamd_glu_bwd_xa_ws(int act, void* DW, void* e, void* g, int M, int K, int64_t ld,
+                                  const void* Wu, int64_t ldwu, int Ru, float* out_u, int64_t ld_out_u, int out_cols_u,
+                                  void* out_k_u, int64_t ld_k_u, int k_cols_u,
+                                  const void* Wg, int64_t ldwg, int Rg, float* out_g, int64_t ld_out_g, int out_cols_g,
+                                  void* out_k_g, int64_t ld_k_g, int k_cols_g, float* ws, int64_t ws_floats, int* counters,
+                                  int dtype, void* stream) {
+    GluXaOut o0{out_u, ld_out_u, Ru, out_cols_u, out_k_u, ld_k_u, k_cols_u, Wu, ldwu};
+    GluXaOut o1{out_g, ld_out_g, Rg, out_cols_g, out_k_g, ld_k_g, k_cols_g, Wg, ldwg};
+    return glu_xa_entry<2>(act, DW, e, g, nullptr, M, K, ld, o0, o1, dtype, stream, ws, ws_floats, counters);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // QuickGELU, y = x * sigmoid(1.702 x): the activation of Qwen2-VL's vision MLP (fc1 -> act -> fc2; BASELINE config 4). The
 // reference leaves it to the zoo compiler's fused graph (unsloth/models/vision.py:881-1990); here one streaming kernel each way,
@@ -573,7 +751,7 @@ __global__ void __launch_bounds__(256) quick_gelu_kernel(const T* __restrict__ X
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float v = to_f32(x.e[j]);
-            const float sg = 1.0f / (1.0f + __expf(-1.702f * v));
+            const float sg = uamd_sigmoid(1.702f * v);
             if (BWD) y.e[j] = from_f32<T>(to_f32(y.e[j]) * (sg + 1.702f * v * sg * (1.0f - sg)));
             else y.e[j] = from_f32<T>(v * sg);
         }
@@ -582,7 +760,7 @@ __global__ void __launch_bounds__(256) quick_gelu_kernel(const T* __restrict__ X
     if (blockIdx.x == 0) {
         for (int64_t k = nvec * VEC + threadIdx.x; k < n; k += 256) {
             const float v = to_f32(X[k]);
-            const float sg = 1.0f / (1.0f + __expf(-1.702f * v));
+            const float sg = uamd_sigmoid(1.702f * v);
             Y[k] = from_f32<T>(BWD ? to_f32(Y[k]) * (sg + 1.702f * v * sg * (1.0f - sg)) : v * sg);
         }
     }

@@ -915,6 +915,24 @@ def _glu_fusable(dtype, tensors, ranks, backward):
             and all(r is not None and r % 8 == 0 and 0 < r <= 64 for r in ranks))
 
 
+_GLU_WS = {}        # (device index, stream) -> (fp32 partials, int32 arrival counters): the flat-grid kernels' workspace
+
+
+def _glu_workspace(t, n_products, max_rank):
+    """Per device and stream (two launches in flight on different streams must not share it), grown on demand. The counters
+    are zero when a launch starts and the kernel leaves them zero (the last workgroup of a row group resets its counter)."""
+    M, K = t.shape
+    need = int(_lib.lib().uamd_glu_xa_workspace(M, K, n_products, max_rank))
+    groups = (M + 15) // 16
+    key = (t.device.index, int(torch.cuda.current_stream(t.device).cuda_stream))
+    ent = _GLU_WS.get(key)
+    if ent is None or ent[0].numel() < need or ent[1].numel() < groups:
+        part = torch.empty(max(need, ent[0].numel() if ent else 0), dtype=torch.float32, device=t.device)
+        counters = torch.zeros(max(groups, ent[1].numel() if ent else 0), dtype=torch.int32, device=t.device)
+        ent = _GLU_WS[key] = (part, counters)
+    return ent
+
+
 def glu_fwd_xa(act, e, g, down, n_out_cols_hint=None):
     """h = act(e) * g AND the down projection's X A^T (fp32 [M, r]) + rank block, in ONE pass over e and g
     (uamd_glu_fwd_xa). `down` = (W, W_quant, A, B, s[, bias]). Returns (h, pre_xa) with pre_xa = (xa, offs, xk) as
@@ -937,11 +955,13 @@ def glu_fwd_xa(act, e, g, down, n_out_cols_hint=None):
     xa = torch.empty((M, r), dtype=torch.float32, device=e.device)
     xk = torch.empty((M, _rank_width(r)), dtype=dtype, device=e.device) if want_k else None
     with _lib.device_ctx(e):
-        rc = _lib.lib().uamd_glu_fwd_xa(_GLU_ACTS[act], _lib.ptr(e), _lib.ptr(g), _lib.ptr(h), M, K, e.stride(0), _lib.ptr(Ac),
-                                        Ac.stride(0), r, _lib.ptr(xa), xa.stride(0), r,
-                                        _lib.ptr(xk) if xk is not None else None, xk.stride(0) if xk is not None else 0,
-                                        xk.shape[1] if xk is not None else 0, _lib.dtype_code(dtype), _lib.stream_of(e))
-    _lib.check(rc, "uamd_glu_fwd_xa")
+        part, counters = _glu_workspace(e, 1, r)
+        rc = _lib.lib().uamd_glu_fwd_xa_ws(_GLU_ACTS[act], _lib.ptr(e), _lib.ptr(g), _lib.ptr(h), M, K, e.stride(0), _lib.ptr(Ac),
+                                           Ac.stride(0), r, _lib.ptr(xa), xa.stride(0), r,
+                                           _lib.ptr(xk) if xk is not None else None, xk.stride(0) if xk is not None else 0,
+                                           xk.shape[1] if xk is not None else 0, _lib.ptr(part), part.numel(), _lib.ptr(counters),
+                                           _lib.dtype_code(dtype), _lib.stream_of(e))
+    _lib.check(rc, "uamd_glu_fwd_xa_ws")
     return h, (xa, [(0, r)], xk)
 
 
@@ -964,14 +984,15 @@ def glu_bwd_terms(act, DW, e, g, up, gate):
     pu, pg = shared[:, :ru], shared[:, ru:]
     null = None
     with _lib.device_ctx(e):
-        rc = _lib.lib().uamd_glu_bwd_xa(
+        part, counters = _glu_workspace(e, 2, max(ru, rg))
+        rc = _lib.lib().uamd_glu_bwd_xa_ws(
             _GLU_ACTS[act], _lib.ptr(DW), _lib.ptr(e), _lib.ptr(g), M, K, e.stride(0),
             _lib.ptr(But), But.stride(0), ru, _lib.ptr(pu), shared.stride(0), ru,
             _lib.ptr(xk) if want_k else null, xk.stride(0) if want_k else 0, ru if want_k else 0,
             _lib.ptr(Bgt), Bgt.stride(0), rg, _lib.ptr(pg), shared.stride(0), rg,
             _lib.ptr(xk[:, ru:]) if want_k else null, xk.stride(0) if want_k else 0, (xk.shape[1] - ru) if want_k else 0,
-            _lib.dtype_code(dtype), _lib.stream_of(e))
-    _lib.check(rc, "uamd_glu_bwd_xa")
+            _lib.ptr(part), part.numel(), _lib.ptr(counters), _lib.dtype_code(dtype), _lib.stream_of(e))
+    _lib.check(rc, "uamd_glu_bwd_xa_ws")
     if want_k:
         pu._uamd_xk = (xk, 0)
         pg._uamd_xk = (xk, ru)
