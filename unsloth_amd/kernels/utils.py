@@ -895,12 +895,15 @@ def lora_tn(problems, targets=None):
 # the gated activation fused with the LoRA skinny products (csrc/glu.hip glu_xa_kernel). Measured at Llama-3-8B MLP widths,
 # 8192 tokens, in the step (profiles/r03ab_bench_kernel_stats.csv, after the tile loop lost its per-iteration vmcnt drain):
 # backward 281 us against 217 + 2 x ~65 us for the separate launches, forward 157 us against 108 + 57 us; whole step +0.3-0.5 %
-# with the forward fused too (profiles/r03ab_bench_ab.txt). At 2048 tokens 128 blocks leave half the chip idle (118 vs 109 us,
-# profiles/r03j_glu_fused_bench.jsonl), so both directions are fused from 4096 tokens on.
+# with the forward fused too (profiles/r03ab_bench_ab.txt). At 2048 tokens 128 blocks left half the chip idle (118 vs 109 us,
+# profiles/r03j_glu_fused_bench.jsonl) and rounds 3-4 fused from 4096 tokens on; with the columns of a row group split over
+# adjacent workgroups (round 5, csrc/glu.hip launch_xa) the fused kernels win there too -- 38 vs 55 us forward, 79 vs 109 us
+# backward at 2048 tokens, 139 vs 153 / 252 vs 325 us at 8192; batch-1 step -1.7 % (profiles/r05_glu_fused_bench.txt) -- so both
+# directions are fused from 2048 tokens on.
 # UNSLOTH_AMD_GLU_FUSED = "both" (default) | "bwd" (backward only, round 3's first default) | "all" (both, any size) | "0".
 GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "both")
 GLU_FUSED = {"1": "all", "0": False, "": "both"}.get(GLU_FUSED, GLU_FUSED)
-GLU_FUSED_MIN_ROWS = 4096
+GLU_FUSED_MIN_ROWS = 2048
 _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 
 
