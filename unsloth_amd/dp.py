@@ -34,9 +34,10 @@ class LoRAGradArena:
     def __init__(self, model, process_group=None, bucket_bytes=None, overlap=True, direct=True):
         if bucket_bytes is None:
             # a bucket closes at the first decoder-layer boundary past this size: Llama-3-8B r=16 factors are 5.24 MB per
-            # layer, so 16 MB means FOUR layers = 20 MB per bucket, 8 buckets; the LAST one (layers 3..0) is the only exchange
-            # nothing can overlap (runnable 0.4 ms before the optimizer kernel) -- still far above the size where an
-            # xGMI ring is latency-bound
+            # layer, so 16 MB means FOUR layers = 21 MB per bucket; the LAST exchange is the only one nothing can overlap
+            # (runnable 0.4 ms before the optimizer kernel), so the first decoder layer is a bucket of its own
+            # (below): 9 buckets = 7 x 21 MB, layers 3..1 (15.7 MB), layer 0 (5.2 MB) -- all far above the size where an xGMI
+            # ring is latency-bound
             bucket_bytes = int(float(os.environ.get("UNSLOTH_AMD_DP_BUCKET_MB", "16")) * (1 << 20))
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
@@ -57,9 +58,13 @@ class LoRAGradArena:
         self._bucket_of = {}
         off, b_start, b_count = 0, 0, 0
         last_layer = None
+        # the gradients that arrive LAST (the first decoder layer's: backward ends there) get a bucket of their own: its
+        # all-reduce is the one exchange nothing can overlap -- it becomes runnable when the backward is over -- so it should be
+        # as small as a bucket gets (one layer: 5.2 MB for Llama-3-8B r=16 instead of the 21 MB of a four-layer bucket)
+        final_layer = _layer_index(named[-1][0])
         for n, p in named:
             layer = _layer_index(n)
-            if b_count and layer != last_layer and (off - b_start) * 4 >= bucket_bytes:
+            if b_count and layer != last_layer and ((off - b_start) * 4 >= bucket_bytes or layer == final_layer):
                 self.buckets.append([b_start, off, b_count])
                 b_start, b_count = off, 0
             if p.dtype != torch.float32:
