@@ -296,7 +296,7 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * attn_fwd_kernel, one block per work item); bit 0 = attn_fwd_kernel always; bit 1 = attn_fwd_ps_kernel
                                  * always. (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
                                  * round-1 dK/dV kernel, a 4-wave dQ kernel -- all measured at parity or slower: removed in round 4,
-                                 * tools/experiments/attention_removed_r04.hip) */
+                                 * git 4501bb3:tools/experiments/attention_removed_r04.hip) */
 #define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
 #define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 // 84 softmax instructions moved from P3 into P4's MFMA shadow lengthened P4 by what they shortened P3; the tile step is 4,500
 // cycles in this kernel, in attn_fwd_kernel and in the 4-wave x 64-row kernel of round 2 alike
 // (profiles/r04_attn_ab_three_forward_kernels.jsonl), 3,750 with the K/V DMA compiled out, 4,800 with every tile read from the
-// same L2-resident addresses. The ping-pong alone (one block per item: tools/experiments/attention_removed_r04.hip) was 4 %
+// same L2-resident addresses. The ping-pong alone (one block per item: git 4501bb3:tools/experiments/attention_removed_r04.hip) was 4 %
 // SLOWER than the lockstep kernel: the same tile step plus two more barriers of pipeline fill per block.
 //
 // Persistence. At 4 x 2048 tokens a block's tile loop is 16.5 tiles, and every block pays ~28,000 cycles that do not depend on
