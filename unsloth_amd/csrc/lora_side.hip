@@ -72,7 +72,18 @@ template <> struct Mfma16<f16_t> {
 constexpr int TN_ZT = 32 * 256;                  // Z tile bytes
 constexpr int TN_PT = 32 * 64;                   // P tile bytes
 constexpr int TN_STAGE = TN_ZT + TN_PT;          // 10 KiB
-constexpr int TN_WAVE_LDS = 2 * TN_STAGE;        // 20 KiB per wave, 80 KiB per block
+// Stages of the per-wave ring: 2 (20 KiB per wave, two 4-wave blocks per CU = 8 waves x ONE stage in flight = 80 KiB per CU).
+// Round 5 built the 4-stage ring (40 KiB per wave, one block per CU, THREE stages = 120 KiB per CU in flight,
+// -DUAMD_TN_STAGES=4) on the hypothesis that the kernel is bound by bytes in flight: 184.9 vs 184.7 us on a layer's six MLP
+// problems (906 MB, 4.9 TB/s), 66.5 vs 60.8 us on one [8192, 14336] problem (profiles/r05_lora_tn_stages_ab.txt) -- it is not;
+// 4.9 TB/s is what workgroups that walk down rows in 256-byte pieces get from this memory system whatever they keep in
+// flight (tools/probes/tile_shape_probe.hip, the note in front of launch_xa in glu.hip).
+#ifndef UAMD_TN_STAGES
+#define UAMD_TN_STAGES 2
+#endif
+constexpr int TN_NST = UAMD_TN_STAGES;
+static_assert(TN_NST >= 2 && TN_NST <= 4, "ring of 2..4 stages (4 x 4 x 10 KiB = the 160 KiB of a CU)");
+constexpr int TN_WAVE_LDS = TN_NST * TN_STAGE;   // 20 KiB per wave, 80 KiB per block
 
 __device__ __forceinline__ void tn_dma(const void* gptr, unsigned lds_dst) {
     unsigned keep;
@@ -159,15 +170,24 @@ __global__ void __launch_bounds__(256) lora_tn_kernel(TnArgs a) {
     const int m_base = sblk * a.rows_per_wave;
     const int m_end = min(m_base + a.rows_per_wave, M);
     const int nch = (m_end - m_base + 31) / 32;
-    if (nch > 0) issue(m_base, 0);
+#pragma unroll
+    for (int i = 0; i < TN_NST - 1; ++i)
+        if (i < nch) issue(m_base + 32 * i, i);
     for (int ch = 0; ch < nch; ++ch) {
         const int m0 = m_base + ch * 32;
-        const int stage = ch & 1;
-        if (ch + 1 < nch) {
-            issue(m0 + 32, stage ^ 1);
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        const int stage = ch % TN_NST;
+        // the stage (ch - 1) % NST was read in the previous step (its ds_reads have returned: the MFMAs consumed them): refill
+        // it with the step NST - 1 ahead, then wait until only the NST - 1 younger stages (10 DMA instructions each) are out
+        if (ch + TN_NST - 1 < nch) {
+            issue(m0 + 32 * (TN_NST - 1), (ch + TN_NST - 1) % TN_NST);
+            if (TN_NST == 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (TN_NST == 3) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int younger = nch - 1 - ch;            // stages still in flight behind this one: 0 .. NST - 2
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const unsigned char* sz = my + stage * TN_STAGE;
         // A operand: P^T[rank][rows], rounded to T; rows past M and ranks past R contribute zero
