@@ -62,7 +62,7 @@ for step in "$@"; do
       cd /tmp
       EXTRA=""; [ $kind = trace ] && EXTRA="--rccl-trace --hip-runtime-trace"
       timeout 900 rocprofv3 --kernel-trace $EXTRA -d $OUT/prof_${TAG}_$P -o bench -- python $R/bench.py --only $P --steps $K --warmup 1 \
-          --no-cpu-baseline --alt-steps 0 > $OUT/prof_${TAG}_$P.log 2>&1
+          --no-cpu-baseline --no-gpu-baseline --alt-steps 0 > $OUT/prof_${TAG}_$P.log 2>&1
       echo "[$step] rc=$? ($SECONDS s)"
       cd $R
       DB=$(find $OUT/prof_${TAG}_$P -name '*.db' | head -1)
@@ -80,7 +80,7 @@ for step in "$@"; do
     pmc)
       P=$arg
       cd /tmp
-      BENCH="python $R/bench.py --only $P --steps 2 --warmup 1 --alt-steps 0 --no-cpu-baseline"
+      BENCH="python $R/bench.py --only $P --steps 2 --warmup 1 --alt-steps 0 --no-cpu-baseline --no-gpu-baseline"
       for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
         set -- $pass; t=$1; shift
         timeout 420 rocprofv3 --kernel-trace --pmc "$@" -d $OUT/pmc_$t -o pmc -- $BENCH > $OUT/pmc_${TAG}_$t.log 2>&1

@@ -43,7 +43,11 @@ def algorithmic_bytes(name, T, H=4096, I=14336, V=128256, Hq=32, Hk=8, D=128):
         return 2 * T * (Hq + Hk) * D * 2 + 2 * T * (D // 2) * 2
     if name.startswith("glu_fwd"):
         return 3 * T * I * 2
-    if name.startswith("glu_bwd") or name.startswith("glu_xa"):
+    if name.startswith("glu_xa"):
+        # glu_xa_kernel<T, ACT, NS, NT, KS, PD> printed as "<bf16,0NS...>": NS = 1 is the forward twin (3 tensor passes), 2 the backward
+        m = re.search(r"<\w+,\d(\d)", name)
+        return (3 if m and m.group(1) == "1" else 6) * T * I * 2
+    if name.startswith("glu_bwd"):
         return 6 * T * I * 2
     if name.startswith("ce_fwd"):
         return None          # row chunks: the chunk height is not in the name
