@@ -107,8 +107,8 @@ def test_lora_mlp_block_with_and_without_the_fusion():
 @pytest.mark.parametrize("M,K,r", [(2048, 14336, 16), (300, 1024, 8), (17, 264, 32), (33, 5632, 64), (5, 8, 4), (64, 520, 16)])
 def test_fused_activation_schedules_agree(M, K, r):
     """UAMD_TUNE_GLU_XA (knob 10): 0 = 4 waves per 16-row block (rounds 3-4), 1 = 8 waves, 2 = 8 waves + tiles requested two steps
-    ahead, 3 = the flat grid (one tile per workgroup, partial rank products summed in tile order by the last workgroup of a row
-    group: default). The element-wise outputs are the same arithmetic on the same operands: BIT-IDENTICAL; the rank products sum
+    ahead, 3 = 2 + the columns of a row group split over adjacent workgroups (partial rank products summed in part order by the
+    last workgroup of the row group: default; 4 / 7 = parts of 8 / 4 tiles always). The element-wise outputs are the same arithmetic on the same operands: BIT-IDENTICAL; the rank products sum
     the same tile products over 4 resp. 8 partial accumulators: equal up to fp32 summation order. K = 264 / 520 / 8: one, three
     and a fraction of a 256-column tile (every remainder branch of the depth-2 loop: 1, 2, 3, 4 and 56 = 3 * 17 + 5 tiles)."""
     from unsloth_amd import _lib
@@ -145,7 +145,7 @@ def test_fused_activation_schedules_agree(M, K, r):
         assert torch.equal(a, b)
 
 
-def test_flat_grid_is_run_to_run_deterministic_and_leaves_its_counters_zero():
+def test_column_split_is_run_to_run_deterministic_and_leaves_its_counters_zero():
     """The workgroup that finishes a row group LAST differs from run to run; the sum it forms does not (tile order). And the
     arrival counters are zero again after every launch -- the next launch depends on it."""
     from unsloth_amd.kernels import utils as U

@@ -1,8 +1,9 @@
-"""A/B of the fused gated-activation kernels (uamd_glu_fwd_xa / uamd_glu_bwd_xa) on one MI355X: UAMD_GLU_XA = 0 (4 waves per
-16-row block, rounds 3-4) against 1 (8 waves) 2 (8 waves, tiles requested two steps ahead) and 3 (the flat grid, one tile per
-workgroup: round 5), interleaved rounds, min over rounds, beside the plain activation
-kernels. Llama-3-8B MLP widths, r = 16. TB/s = ALGORITHMIC bytes (3 resp. 6 x [M, 14336] bf16) / time. JSON lines; run it
-once more under UNSLOTH_AMD_LIB=<a build with -DUAMD_SIGMOID_IEEE=1> for the division A/B (the label says which library)."""
+"""A/B of the fused gated-activation kernels (uamd_glu_fwd_xa_ws / uamd_glu_bwd_xa_ws) on one MI355X over UAMD_GLU_XA: 0 = 4 waves
+per 16-row block (rounds 3-4), 1 = 8 waves, 2 = 8 waves + tiles requested two steps ahead, 3 = 2 + the columns of a row group split
+over adjacent workgroups with the shipped part-size rule, 4 / 5 / 6 = parts of 8 / 14 / 28 tiles always; interleaved rounds, min over
+rounds, beside the plain activation kernels, cold and right after a burst of GEMMs. Llama-3-8B MLP widths, r = 16. TB/s =
+ALGORITHMIC bytes (3 resp. 6 x [M, 14336] bf16) / time. JSON lines (appended to argv[1]); run it under UNSLOTH_AMD_LIB=<another
+build> for library A/Bs (the label says which library)."""
 import json
 import os
 import sys

@@ -918,7 +918,7 @@ def _glu_fusable(dtype, tensors, ranks, backward):
             and all(r is not None and r % 8 == 0 and 0 < r <= 64 for r in ranks))
 
 
-_GLU_WS = {}        # (device index, stream) -> (fp32 partials, int32 arrival counters): the flat-grid kernels' workspace
+_GLU_WS = {}        # (device index, stream) -> (fp32 partials, int32 arrival counters): the column-split kernels' workspace
 
 
 def _glu_workspace(t, n_products, max_rank):
