@@ -312,7 +312,7 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * 16-byte vectors per thread per tensor, tiles requested one step ahead (rounds 3-4); 1 = 8 waves, one
                                  * vector per thread; 2 = 8 waves and every tile requested two steps ahead; 3 (default) = 2 with the
                                  * columns of a row group split over adjacent workgroups (uamd_glu_{fwd,bwd}_xa_ws; without a
-                                 * workspace: 2), part size by shape; 7 / 4 / 5 / 6 = parts of 4 / 8 / 14 / 28 tiles always */
+                                 * workspace: 2) where that measured faster -- rows of whole 4 KB pages, or at most 2048 rows --; 8 = always */
 #define UAMD_TUNE_COUNT 11
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,

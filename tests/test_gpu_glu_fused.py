@@ -108,7 +108,7 @@ def test_lora_mlp_block_with_and_without_the_fusion():
 def test_fused_activation_schedules_agree(M, K, r):
     """UAMD_TUNE_GLU_XA (knob 10): 0 = 4 waves per 16-row block (rounds 3-4), 1 = 8 waves, 2 = 8 waves + tiles requested two steps
     ahead, 3 = 2 + the columns of a row group split over adjacent workgroups (partial rank products summed in part order by the
-    last workgroup of the row group: default; 4 / 7 = parts of 8 / 4 tiles always). The element-wise outputs are the same arithmetic on the same operands: BIT-IDENTICAL; the rank products sum
+    last workgroup of the row group) where the shape rule says so: default; 8 = the split always. The element-wise outputs are the same arithmetic on the same operands: BIT-IDENTICAL; the rank products sum
     the same tile products over 4 resp. 8 partial accumulators: equal up to fp32 summation order. K = 264 / 520 / 8: one, three
     and a fraction of a 256-column tile (every remainder branch of the depth-2 loop: 1, 2, 3, 4 and 56 = 3 * 17 + 5 tiles)."""
     from unsloth_amd import _lib
@@ -125,7 +125,7 @@ def test_fused_activation_schedules_agree(M, K, r):
     U.GLU_FUSED = "all"
     res = {}
     try:
-        for v in (0, 1, 2, 3, 4, 7):
+        for v in (0, 1, 2, 3, 8):
             assert L.uamd_set_tuning(10, v) == 0
             out = U.glu_fwd_xa("swiglu", e, g, down)
             if out is None:
@@ -136,7 +136,7 @@ def test_fused_activation_schedules_agree(M, K, r):
     finally:
         L.uamd_set_tuning(10, 3)
         U.GLU_FUSED = keep
-    for v in (1, 2, 3, 4, 7):
+    for v in (1, 2, 3, 8):
         for a, b in zip(res[0][:4], res[v][:4]):
             assert torch.equal(a, b), v
         for a, b in zip(res[0][4:], res[v][4:]):

@@ -1,6 +1,6 @@
 """A/B of the fused gated-activation kernels (uamd_glu_fwd_xa_ws / uamd_glu_bwd_xa_ws) on one MI355X over UAMD_GLU_XA: 0 = 4 waves
 per 16-row block (rounds 3-4), 1 = 8 waves, 2 = 8 waves + tiles requested two steps ahead, 3 = 2 + the columns of a row group split
-over adjacent workgroups with the shipped part-size rule, 4 / 5 / 6 = parts of 8 / 14 / 28 tiles always; interleaved rounds, min over
+in two over adjacent workgroups where the shipped shape rule says so, 8 = split always; interleaved rounds, min over
 rounds, beside the plain activation kernels, cold and right after a burst of GEMMs. Llama-3-8B MLP widths, r = 16. TB/s =
 ALGORITHMIC bytes (3 resp. 6 x [M, 14336] bf16) / time. JSON lines (appended to argv[1]); run it under UNSLOTH_AMD_LIB=<another
 build> for library A/Bs (the label says which library)."""
@@ -41,8 +41,9 @@ def heat(ms=60):
 
 
 out = open(sys.argv[1], "a") if len(sys.argv) > 1 else None
-for M in (8192, 4096, 2048):
-    K, H, r = 14336, 4096, 16
+SHAPES = [tuple(int(x) for x in sh.split("x")) for sh in os.environ.get("GLU_AB_SHAPES", "8192x14336,4096x14336,2048x14336").split(",")]
+for M, K in SHAPES:
+    H, r = 4096, int(os.environ.get("GLU_AB_RANK", "16"))
     dt = torch.bfloat16
     e = torch.randn(M, K, generator=g_).to(dt).to(dev)
     g = torch.randn(M, K, generator=g_).to(dt).to(dev)
@@ -62,17 +63,13 @@ for M in (8192, 4096, 2048):
         "fwd_xa1": knob(1, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
         "fwd_xa2": knob(2, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
         "fwd_xa3": knob(3, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
-        "fwd_xa4": knob(4, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
-        "fwd_xa5": knob(5, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
-        "fwd_xa6": knob(6, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
+        "fwd_xa8": knob(8, lambda: U.glu_fwd_xa("swiglu", e, g, down)),
         "fwd_plain": lambda: swiglu_fg_kernel(e, g),
         "bwd_xa0": knob(0, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
         "bwd_xa1": knob(1, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
         "bwd_xa2": knob(2, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
         "bwd_xa3": knob(3, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
-        "bwd_xa4": knob(4, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
-        "bwd_xa5": knob(5, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
-        "bwd_xa6": knob(6, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
+        "bwd_xa8": knob(8, lambda: U.glu_bwd_terms("swiglu", DW, e, g, up, gate)),
         "bwd_plain": lambda: swiglu_DWf_DW_dfg_kernel(DW, e, g),
     }
     for f in cands.values():
@@ -85,7 +82,7 @@ for M in (8192, 4096, 2048):
                 if hot:
                     heat()
                 best[k] = min(best[k], run(f, 6 if hot else 10))
-        rec = dict(lib=LIBTAG, tokens=M, after_gemm_burst=hot)
+        rec = dict(lib=LIBTAG, tokens=M, K=K, rank=r, after_gemm_burst=hot)
         for k, v in best.items():
             nbytes = (3 if k.startswith("fwd") else 6) * M * K * 2
             rec[k] = dict(us=round(v, 1), TBps=round(nbytes / v / 1e6, 2))

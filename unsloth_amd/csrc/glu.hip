@@ -603,10 +603,13 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
 // depth; the same walk with the columns of a row group split over 2 / 4 / 14 ADJACENT workgroups 5.1 / 5.3 / 5.8; one tile per
 // workgroup numbered row-group-major 6.4; the flat kernel 6.6. One tile per workgroup was built and measured: 267 us against
 // 148 -- 28,672 workgroups each paying a prologue, three barriers, a store acknowledgement and an atomic round trip for 8 KB
-// per tensor. The split keeps the pipelined walk and gets most of the sweep back: GX_TPB tiles (1024 columns) per workgroup,
-// blockIdx = row group * parts + part, the rank products of a part to a workspace ([row group][part][16][NS * NT * 16] fp32:
-// 1 % of the kernel's traffic), summed in part order by whichever workgroup finishes the row group last.
-constexpr int GX_TPB = 4;
+// per tensor -- and parts of 4 tiles lose to the unsplit walk as well (fill and drain of the prefetch per 4 tiles). What ships keeps
+// the pipelined walk and splits the columns of a row group over TWO adjacent workgroups where that measured faster (the rule in
+// launch_xa): blockIdx = row group * parts + part, the rank products of a part to a workspace ([row group][part][16][NS * NT *
+// 16] fp32: well under 1 % of the kernel's traffic), summed in part order by whichever workgroup finishes the row group last.
+// The probe measured e * g at 28,672-byte rows; at other widths the unsplit walk is not as far from the flat sweep and the split
+// buys nothing (launch_xa), so "the order of the sweep" is the mechanism for Llama-3-8B's MLP width, not a law.
+constexpr int GX_TPB = 4;     // (workspace sizing: parts of at least this many tiles)
 
 template <typename T, int ACT, int NS>
 int launch_xa(void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, const GluXaOut& o0, const GluXaOut& o1,
@@ -620,12 +623,17 @@ int launch_xa(void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, con
     // 4 waves x 176 registers)
     const int xv = ACT == ACT_SWIGLU ? uamd_tuning_get(UAMD_TUNE_GLU_XA) : 0;
     const int ntiles = (K + GX_TK - 1) / GX_TK;
-    // tiles per part. Measured at K = 14336 (profiles/r05_glu_xa_ab.jsonl: 4 / 8 / 14 / 28 tiles at 8192, 4096 and 2048 rows):
-    // the forward is fastest with TWO parts at every size (134 vs 149 us, 37 vs 55 us at 2048 rows -- where it also doubles the
-    // workgroups of a grid that had one per two CUs); the backward with parts of 8 tiles at 8192 rows (268 vs 300 us), of 28
-    // below (75 vs 104 us at 2048). Parts of 4 tiles lose to the unsplit walk (fill and drain of the two-deep prefetch per
-    // 4 tiles of work). UAMD_TUNE_GLU_XA: 3 = this rule; 7 / 4 / 5 / 6 = 4 / 8 / 14 / 28 tiles always (the A/B scan).
-    const int tpb = xv == 7 ? GX_TPB : xv == 4 ? 8 : xv == 5 ? 14 : xv == 6 ? 28 : (NS > 1 && M >= 8192 ? 8 : 28);
+    // When to split, and into how many parts: measured, not derived (profiles/r05_glu_xa_ab.jsonl: parts of 4 / 8 / 14 / 28 tiles
+    // and two / seven EVEN parts at [8192 | 4096 | 2048] x 14336, 4096 x 18944, 8192 x 11008, [8192 | 2048] x 5632, 16384 x
+    // 14336). TWO EVEN PARTS win wherever a row is a whole number of 4 KB pages -- Llama-3-8B / Mistral-7B's 14336 columns: every
+    // workgroup of the unsplit walk then starts its rows at the same offset inside a page -- at every height (forward 149 -> 135,
+    // 78 -> 70, 57 -> 39 us; backward 311 -> 282, 160 -> 146, 104 -> 76 us at 8192 / 4096 / 2048 rows), and for short grids
+    // (<= 2048 rows: 128 workgroups for 256 CUs) at any width (2048 x 5632 backward 43 -> 35 us). Elsewhere the split is neutral
+    // (4096 x 18944: 92 / 191 vs 94 / 192 us) or a few percent slower (8192 x 11008, 8192 x 5632), and uneven or many parts lose
+    // outright (three parts of 28 + 28 + 18 tiles at 18944 columns: +20 %; parts of 4 tiles: the prefetch's fill and drain per 4
+    // tiles of work). UAMD_TUNE_GLU_XA: 3 = this rule, 8 = two even parts always (A/B).
+    const bool two = ntiles >= 8 && (xv == 8 || ((int64_t)K * (int64_t)sizeof(T)) % 4096 == 0 || M <= 2048);
+    const int tpb = two ? (ntiles + 1) / 2 : ntiles;
     int nparts = (xv >= 3 && ws != nullptr && counters != nullptr) ? (ntiles + tpb - 1) / tpb : 1;
     if (nparts < 2) nparts = 1;
     const int64_t blocks = (int64_t)((M + 15) / 16) * nparts;
