@@ -208,7 +208,7 @@ class TorchLoRALinear(torch.nn.Module):
         return self.base(x) + F_.linear(F_.linear(x, self.lora_A.to(x.dtype)), self.lora_B.to(x.dtype)) * self.scale
 
 
-def hf_gpu_baseline(cfg, dev, B, T, r, steps=3, warmup=2, seed=0):
+def hf_gpu_baseline(cfg, dev, B, T, r, steps=3, warmup=2, seed=0, checkpointing=False):
     """Stock HuggingFace `LlamaForCausalLM` (its own RMSNorm / RoPE / SwiGLU / loss modules, attn_implementation="sdpa") in
     bf16 with torch LoRA r on the same 7 projections, bf16 autocast, torch's fused AdamW on the factors, no gradient
     checkpointing -- the same B x T synthetic batch, forward + backward + optimizer step, on this GPU. Base weights are
@@ -241,6 +241,8 @@ def hf_gpu_baseline(cfg, dev, B, T, r, steps=3, warmup=2, seed=0):
     o = torch.optim.AdamW(params, lr=2e-4, weight_decay=0.01, fused=True)
     hf.train()
     hf.config.use_cache = False
+    if checkpointing:           # HF's own per-layer activation checkpointing (non-reentrant: the frozen embeddings give no input gradient)
+        hf.gradient_checkpointing_enable(gradient_checkpointing_kwargs={"use_reentrant": False})
     gi = torch.Generator(device="cpu").manual_seed(seed)
     bt = [torch.randint(0, cfg.vocab_size, (B, T), generator=gi).to(dev) for _ in range(2)]
 
@@ -268,7 +270,8 @@ def hf_gpu_baseline(cfg, dev, B, T, r, steps=3, warmup=2, seed=0):
         return {"value": round(B * T / med, 1), "unit": "tokens/s", "ms_per_step": round(med * 1e3, 2),
                 "peak_vram_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2), "steps": steps, "timing": "median step",
                 "what": "stock HF LlamaForCausalLM bf16 (sdpa) + torch LoRA r=%d on 7 projections + fused torch AdamW, bf16 autocast, "
-                        "no gradient checkpointing, %d x %d tokens, same GPU, after the runs above" % (r, B, T),
+                        "%s, %d x %d tokens, same GPU, after the runs above"
+                        % (r, "HF gradient checkpointing (every layer, non-reentrant)" if checkpointing else "no gradient checkpointing", B, T),
                 "base_weights": "bf16 (HF cannot run NF4 here: no bitsandbytes)", "trainable_params": sum(p.numel() for p in params),
                 "loss_first_last": [round(float(losses[0]), 4), round(float(losses[-1]), 4)]}
     finally:
@@ -833,6 +836,14 @@ def main():
         except Exception as ex:
             gpu_base = {"error": f"{type(ex).__name__}: {ex}"[:300]}
             torch.cuda.empty_cache()
+        if gpu_base.get("value") and a.alt_steps > 0:
+            # ... and with HF's own activation checkpointing: the memory-lean operating point, against `gc_unsloth_min` / `True` above
+            try:
+                gpu_base["with_gradient_checkpointing"] = hf_gpu_baseline(cfg, dev, B, T, a.rank, steps=max(2, a.alt_steps), warmup=2,
+                                                                          seed=rank, checkpointing=True)
+            except Exception as ex:
+                gpu_base["with_gradient_checkpointing"] = {"error": f"{type(ex).__name__}: {ex}"[:300]}
+                torch.cuda.empty_cache()
     rccl_ranks = None
     if dist.is_initialized():
         one = torch.ones(1, device=dev)
@@ -882,6 +893,15 @@ def main():
             if os.environ.get("BENCH_CPU_CONFIG1", "1") == "1":
                 from oracle.cpu_baseline import time_config1
                 cpu["config1_tinyllama_direct"] = time_config1(budget_s=min(15.0, a.cpu_budget))
+        vs_gpu = None
+        if gpu_base and gpu_base.get("value"):
+            vs_gpu = {"tokens_per_s_ratio": round(tokens / dt / gpu_base["value"], 2),
+                      "peak_vram_ratio": round(peak / 2**30 / gpu_base["peak_vram_gb"], 2)}
+            hgc = gpu_base.get("with_gradient_checkpointing") or {}
+            ours = (alt or {}).get("gc_unsloth_min (keep layer inputs only)") or {}
+            if hgc.get("value") and ours.get("value"):       # both sides keeping only what a checkpointed layer keeps
+                vs_gpu["checkpointed"] = {"ours": "gc_unsloth_min", "tokens_per_s_ratio": round(ours["value"] / hgc["value"], 2),
+                                          "peak_vram_ratio": round(ours["peak_vram_gb"] / hgc["peak_vram_gb"], 2)}
         rec = {
             "metric": "train tokens/sec, Llama-3-8B QLoRA (NF4) r=16 seq2048 bf16", "value": round(tokens / dt, 1),
             "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -901,9 +921,7 @@ def main():
             "loss_first_last": [round(loss_vals[0], 4), round(loss_vals[-1], 4)], "setup_s": round(setup_s, 1),
             "value_with_resident_mirrors": with_mirrors, "vram_batch1_unsloth_min": batch1_min,
             "gpu_baseline": gpu_base,
-            "vs_gpu_baseline": ({"tokens_per_s_ratio": round(tokens / dt / gpu_base["value"], 2),
-                                 "peak_vram_ratio": round(peak / 2**30 / gpu_base["peak_vram_gb"], 2)}
-                                if gpu_base and gpu_base.get("value") else None),
+            "vs_gpu_baseline": vs_gpu,
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())
