@@ -33,6 +33,32 @@ def supported(q, k, v):
             and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) <= 8)
 
 
+_ZEROS = {}         # (shape, dtype, device) -> a zero tensor that is only ever READ (the padding operand of the concatenations below)
+
+
+def _zeros(shape, dtype, device):
+    key = (tuple(shape), dtype, device)
+    z = _ZEROS.get(key)
+    if z is None:
+        if len(_ZEROS) > 64:
+            _ZEROS.clear()
+        z = _ZEROS[key] = torch.zeros(shape, dtype=dtype, device=device)
+    return z
+
+
+def _pad_heads(x, G, Gp, D):
+    """[B,T,Hk*G,D] (any strides, d contiguous) -> contiguous [B,T,Hk*Gp,128], zeros in the added head slots / columns. ONE
+    concatenation with a cached zero operand per padded axis (torch.nn.functional.pad is a fill + a copy: two launches and a
+    write of the whole result where one launch writes it once -- 950 of config 4's launches per step were these, round 4)."""
+    B, T, Hq, _ = x.shape
+    Hk = Hq // G
+    if D != 128:
+        x = torch.cat([x, _zeros((B, T, Hq, 128 - D), x.dtype, x.device)], dim=-1)
+    if Gp != G:
+        x = torch.cat([x.reshape(B, T, Hk, G, 128), _zeros((B, T, Hk, Gp - G, 128), x.dtype, x.device)], dim=3)
+    return x.reshape(B, T, Hk * Gp, 128)
+
+
 def _pad_qkv(q, k, v):
     """Zero-padding onto a native shape. Head dim D < 128: extra zero columns change neither Q K^T nor the real columns
     of P V. Group size G not in {1,2,4,8}: every KV group gets Gp - G extra query heads that are all zero -- their
@@ -42,18 +68,15 @@ def _pad_qkv(q, k, v):
     Hk = k.shape[2]
     G = Hq // Hk
     Gp = next(g for g in _GROUPS if g >= G)
-    F = torch.nn.functional
-    qp = F.pad(q.reshape(B, T, Hk, G, D), (0, 128 - D, 0, Gp - G)).view(B, T, Hk * Gp, 128)
-    kp = F.pad(k, (0, 128 - D)) if D != 128 else k
-    vp = F.pad(v, (0, 128 - D)) if D != 128 else v
+    qp = _pad_heads(q, G, Gp, D)
+    kp = _pad_heads(k, 1, 1, D) if D != 128 else k
+    vp = _pad_heads(v, 1, 1, D) if D != 128 else v
     return qp, kp, vp, G, Gp
 
 
 def _pad_like_q(x, G, Gp):
     """[B,T,Hq,D] -> [B,T,Hk*Gp,128] with the same zero padding as the queries (for O and dO)."""
-    B, T, Hq, D = x.shape
-    Hk = Hq // G
-    return torch.nn.functional.pad(x.reshape(B, T, Hk, G, D), (0, 128 - D, 0, Gp - G)).view(B, T, Hk * Gp, 128)
+    return _pad_heads(x, G, Gp, x.shape[-1])
 
 
 def _strides(*ts):
@@ -204,7 +227,8 @@ def attn_backward(do, q, k, v, o, lse, scale=None, band=None, causal=True):
     if not native(q, k, v):
         qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
         lse_full = torch.as_strided(lse, (B, Hq, Tp), (Hq * Tp, Tp, 1))
-        lsep = torch.nn.functional.pad(lse_full.view(B, Hk, G, Tp), (0, 0, 0, Gp - G)).view(B, Hk * Gp, Tp)
+        lsep = lse_full if Gp == G else torch.cat([lse_full.view(B, Hk, G, Tp), _zeros((B, Hk, Gp - G, Tp), lse.dtype, lse.device)],
+                                                  dim=2).view(B, Hk * Gp, Tp)
         extra = () if causal else (False,)
         dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, _pad_like_q(o, G, Gp), lsep[:, :, :T], scale, band,
                                          *extra)
