@@ -329,7 +329,7 @@ def test_padding_free_packed_batch_equals_per_document_oracle(head_dim, monkeypa
     from unsloth_amd.utils.packing import enable_padding_free_metadata
     bands = []
     real = flash.attn_forward
-    monkeypatch.setattr(flash, "attn_forward", lambda q, k, v, s=None, band=None: (bands.append((q.shape[-1], band)), real(q, k, v, s, band))[1])
+    monkeypatch.setattr(flash, "attn_forward", lambda q, k, v, s=None, band=None, *a, **kw: (bands.append((q.shape[-1], band)), real(q, k, v, s, band, *a, **kw))[1])
     model = _tiny(head_dim=head_dim)
     g = torch.Generator().manual_seed(5)
     docs = [torch.randint(0, 1000, (n,), generator=g).tolist() for n in (40, 17, 64)]
@@ -397,7 +397,7 @@ def test_key_padding_mask_rows_equal_the_unpadded_rows(head_dim, monkeypatch):
     from unsloth_amd.kernels import attention as flash
     calls = []
     real = flash.attn_forward
-    monkeypatch.setattr(flash, "attn_forward", lambda q, k, v, s=None, band=None: (calls.append(band is not None), real(q, k, v, s, band))[1])
+    monkeypatch.setattr(flash, "attn_forward", lambda q, k, v, s=None, band=None, *a, **kw: (calls.append(band is not None), real(q, k, v, s, band, *a, **kw))[1])
     sdpa = []
     real_sdpa = torch.nn.functional.scaled_dot_product_attention
     monkeypatch.setattr(torch.nn.functional, "scaled_dot_product_attention",

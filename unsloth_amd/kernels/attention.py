@@ -171,7 +171,7 @@ def _band_ptrs(band, B, T, dev):
     return _lib.ptr(lo), _lib.ptr(hi)
 
 
-def attn_forward(q, k, v, scale=None, band=None, causal=True):
+def attn_forward(q, k, v, scale=None, band=None, causal=True, keep_padded=None):
     """q [B,T,Hq,128], k/v [B,T,Hk,128] (strided views are fine) -> (o [B,T,Hq,128] contiguous, lse [B,Hq,T] fp32).
     `band` = (lo, hi) from attention_band() restricts the causal mask to packed documents / a sliding window.
     causal=False: bidirectional attention inside the documents of `band` = document_band(...) (None: each row one document)."""
@@ -184,6 +184,8 @@ def attn_forward(q, k, v, scale=None, band=None, causal=True):
         assert supported(q, k, v), "head_dim <= 128 and at most 8 query heads per KV head"
         qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
         op, lsep = _forward_native(qp, kp, vp, scale, band) if causal else _forward_native(qp, kp, vp, scale, band, False)
+        if keep_padded is not None:       # the caller saves the padded operands for attn_backward(padded=...) instead of q, k, v, o
+            keep_padded.extend([qp, kp, vp, op, lsep])
         o = op.view(B, T, Hk, Gp, 128)[:, :, :, :G, :D].reshape(B, T, Hq, D)
         Tp = _pad32(T)
         lse = torch.as_strided(lsep, (B, Hk, Gp, Tp), (Hk * Gp * Tp, Gp * Tp, Tp, 1))[:, :, :G].reshape(B, Hq, Tp)
@@ -214,24 +216,32 @@ def _forward_native(q, k, v, scale, band, causal=True):
     return o, lse[:, :, :T]
 
 
-def attn_backward(do, q, k, v, o, lse, scale=None, band=None, causal=True):
+def attn_backward(do, q, k, v, o, lse, scale=None, band=None, causal=True, padded=None):
     """Gradients of attn_forward: (dq [B,T,Hq,D], dk, dv [B,T,Hk,D]) in q's dtype, column blocks of one buffer. `lse` is the view
-    attn_forward returned (its storage is padded to a multiple of 32 positions). Two launches, deterministic."""
-    _lib.require_gpu(do, q, k, v, o)
+    attn_forward returned (its storage is padded to a multiple of 32 positions). Two launches, deterministic.
+    `padded` = what attn_forward(keep_padded=[...]) collected for a shape that runs zero-padded: (qp, kp, vp, op, lsep) are used as
+    they are (q, k, v then only give the shapes; o and lse may be None) and only dO is padded here."""
+    _lib.require_gpu(do, q, k, v)
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
     if scale is None:
         scale = 1.0 / math.sqrt(D)
     Tp = _pad32(T)
-    assert lse.stride(1) == Tp and lse.stride(2) == 1, "pass the LSE returned by attn_forward"
+    assert padded is not None or (lse.stride(1) == Tp and lse.stride(2) == 1), "pass the LSE returned by attn_forward"
     if not native(q, k, v):
-        qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
-        lse_full = torch.as_strided(lse, (B, Hq, Tp), (Hq * Tp, Tp, 1))
-        lsep = lse_full if Gp == G else torch.cat([lse_full.view(B, Hk, G, Tp), _zeros((B, Hk, Gp - G, Tp), lse.dtype, lse.device)],
-                                                  dim=2).view(B, Hk * Gp, Tp)
         extra = () if causal else (False,)
-        dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, _pad_like_q(o, G, Gp), lsep[:, :, :T], scale, band,
-                                         *extra)
+        if padded is not None:
+            qp, kp, vp, op, lsep = padded
+            G = Hq // Hk
+            Gp = qp.shape[2] // Hk
+            dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, op, lsep, scale, band, *extra)
+        else:
+            qp, kp, vp, G, Gp = _pad_qkv(q, k, v)
+            lse_full = torch.as_strided(lse, (B, Hq, Tp), (Hq * Tp, Tp, 1))
+            lsep = lse_full if Gp == G else torch.cat([lse_full.view(B, Hk, G, Tp), _zeros((B, Hk, Gp - G, Tp), lse.dtype, lse.device)],
+                                                      dim=2).view(B, Hk * Gp, Tp)
+            dqp, dkp, dvp = _backward_native(_pad_like_q(do, G, Gp), qp, kp, vp, _pad_like_q(o, G, Gp), lsep[:, :, :T], scale, band,
+                                             *extra)
         # same contract as below: dQ | dK | dV as column blocks of ONE buffer
         dqkv = torch.empty((B, T, (Hq + 2 * Hk) * D), dtype=q.dtype, device=q.device)
         dq = dqkv[..., :Hq * D].view(B, T, Hq, D)
@@ -277,13 +287,28 @@ class FlashAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, scale, band, causal=True):
         # (causal only when it is not the default: tests and tools swap attn_forward / attn_backward for five-argument stand-ins)
+        ctx.scale, ctx.band, ctx.causal = scale, band, causal
+        if q.is_cuda and not native(q, k, v) and supported(q, k, v):
+            # a shape that runs zero-padded (the ViT's head_dim 80, group sizes 3 / 5 / 6 / 7): keep the PADDED operands for the
+            # backward instead of padding q, k, v, o and the LSE a second time there (288 GB: the copies are cheaper kept than redone)
+            kept = []
+            o, _ = attn_forward(q, k, v, scale, band, causal, keep_padded=kept)
+            ctx.save_for_backward(*kept)
+            ctx.shapes = (q.shape, k.shape)
+            return o
         o, lse = attn_forward(q, k, v, scale, band) if causal else attn_forward(q, k, v, scale, band, False)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale, ctx.band, ctx.causal = scale, band, causal
+        ctx.shapes = None
         return o
 
     @staticmethod
     def backward(ctx, do):
+        if ctx.shapes is not None:
+            qs, ks = ctx.shapes
+            q = do.new_empty(1).expand(qs)                         # shapes only (no storage): the padded operands are what is read
+            k = do.new_empty(1).expand(ks)
+            dq, dk, dv = attn_backward(do, q, k, k, None, None, ctx.scale, ctx.band, ctx.causal, padded=tuple(ctx.saved_tensors))
+            return dq, dk, dv, None, None, None
         q, k, v, o, lse = ctx.saved_tensors
         if ctx.causal:
             dq, dk, dv = attn_backward(do, q, k, v, o, lse, ctx.scale, ctx.band)
