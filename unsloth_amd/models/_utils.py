@@ -24,12 +24,20 @@ from ..dp import exclude_rope_inv_freq_from_ddp  # noqa: F401  (re-export: the r
 
 
 def iter_wrapped_models(model):
-    """model, then whatever it wraps (`.model` / `.base_model` / `.module`), each once."""
-    seen = set()
-    while model is not None and id(model) not in seen:
-        seen.add(id(model))
-        yield model
-        model = next((m for m in (getattr(model, a, None) for a in ("model", "base_model", "module")) if m is not None), None)
+    """model, then everything it wraps through `.base_model` / `.model` / `.module`, each object once (a PEFT wrapper forwards
+    unknown attributes to the wrapped model, so one chain alone can skip a level: all three are followed)."""
+    seen, queue = set(), [model]
+    while queue:
+        m = queue.pop(0)
+        if m is None or id(m) in seen or not hasattr(m, "__dict__"):
+            continue
+        seen.add(id(m))
+        yield m
+        for a in ("base_model", "model", "module"):
+            try:
+                queue.append(getattr(m, a, None))
+            except Exception:
+                pass
 
 
 def is_unsloth_model(model):
