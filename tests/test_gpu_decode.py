@@ -458,6 +458,29 @@ def test_generate_train_generate_uses_the_trained_factors():
     assert after.shape == before.shape
 
 
+def test_generate_raises_on_poisoned_logits_instead_of_emitting_tokens():
+    """a timed-out in-launch hand-off writes NaN on purpose; generate() must turn that into an error, not into token
+    ids. The poison is injected where a timeout would put it: the engine's step output."""
+    from unsloth_amd import FastLanguageModel
+    from unsloth_amd.models.decode import DecodeEngine
+    model = _tiny(True)
+    FastLanguageModel.for_inference(model)
+    ids = torch.randint(0, 1000, (1, 7), generator=g(31)).to(DEV)
+    eng = DecodeEngine(model, max_seq_len=64, batch=1, use_graph=False)
+    good = eng.generate(ids, max_new_tokens=4)
+    assert good.shape == (1, 11)
+    real = eng.step
+    calls = []
+
+    def poisoned(tok):
+        lg = real(tok)
+        calls.append(1)
+        return lg * float("nan") if len(calls) == 2 else lg
+    eng.step = poisoned
+    with pytest.raises(RuntimeError, match="non-finite logits"):
+        eng.generate(ids, max_new_tokens=5)
+
+
 def test_fast_generate_kwargs_follow_hf_semantics():
     """eos / pad default from generation_config, finished rows emit the pad id, max_length is
     honoured, and arguments the engine does not implement (repetition_penalty, a padded attention_mask, ...) go to HF's

@@ -324,7 +324,13 @@ class DecodeEngine:
         pad = pad_token_id if pad_token_id is not None else (eos[0] if eos else 0)
         done = torch.zeros(self.B, dtype=torch.bool, device=self.dev)
         room = self.S - input_ids.shape[1]
+        # a hand-off inside the fused decode launches that times out (csrc/decode.hip: a workgroup polled 2^18 times for a granule
+        # that never came) poisons its output with NaN on purpose; NaN logits would otherwise turn into plausible-looking token ids
+        # through argmax / multinomial. One element per row and token is accumulated (NaN * 0 = NaN) and looked at ONCE, after
+        # the loop: no sync per token, and no silently wrong text.
+        poison = torch.zeros(self.B, dtype=torch.float32, device=self.dev)
         for i in range(min(max_new_tokens, room)):
+            poison += logits[:, 0].float() * 0.0
             if do_sample:
                 lg = filter_logits(logits / max(temperature, 1e-6), top_k, top_p)
                 nxt = torch.multinomial(torch.softmax(lg, dim=-1), 1, generator=generator).view(-1)
@@ -339,6 +345,10 @@ class DecodeEngine:
                     break
             if i + 1 < min(max_new_tokens, room):
                 logits = self.step(nxt)
+        if bool(torch.isnan(poison).any()):
+            raise RuntimeError("unsloth_amd decode: non-finite logits -- an in-launch hand-off of the fused decode step timed out "
+                               "(not every workgroup of a launch was resident: a CU-masked / shared GPU?) or the model produced "
+                               "NaN / inf. UNSLOTH_AMD_DECODE_FUSED=0 runs the 14-launch step without hand-offs.")
         return torch.cat(out, dim=1)
 
 
