@@ -14,6 +14,14 @@ LoRA_MLP / LoRA_QKV / LoRA_W Functions on dense bf16 weights -- each at a small 
 (hidden 4096, intermediate 14336, head_dim 128, vocab 128256). Every case stores its inputs, so the parity tests
 (tests/test_gpu_ref_bf16_golden.py) feed the HIP kernels the very same bits.
 It also re-runs the fp16 cases of the interpreter fixture natively and records the differences (harness check).
+
+`--only linear_ce --out gpurun_out/ref_triton_bf16_linear_ce.pt` writes the SEPARATE fixture that pins row a7 (fused
+linear cross entropy): the reference's own materialised-logits branch, unsloth/models/llama.py:1525-1562 --
+`logits = lm_head(hidden)` in bf16, the label shift of :1545-1551, `fast_cross_entropy_loss` (the native Triton kernels of
+unsloth/kernels/cross_entropy_loss.py:421-449) and autograd back to `d hidden` -- which SURVEY 8(c) and the reference's own
+comment at llama.py:1490-1496 declare equivalent to the third-party `unsloth_fused_ce_loss` our kernel replaces. The lm_head
+weight is stored as (seed, scale, shape, crc32) and rebuilt by `linear_ce_weight` (torch's CPU generator is deterministic),
+so the fixture stays small at V = 128256.
 """
 import argparse
 import importlib
@@ -63,9 +71,54 @@ def load_reference(ref):
     return {n: importlib.import_module("unsloth.kernels." + n) for n in names}
 
 
+def linear_ce_weight(seed, V, H, scale):
+    """The lm_head weight of a linear_ce case, rebuilt from its seed (bf16 [V, H]) + the crc32 of its bits."""
+    import zlib
+    W = (torch.randn(V, H, generator=torch.Generator().manual_seed(seed)) * scale).to(torch.bfloat16)
+    return W, zlib.crc32(W.view(torch.int16).numpy().tobytes())
+
+
+LINEAR_CE_CASES = (
+    # tag, V, H, B, T, kwargs of fast_cross_entropy_loss, n_items, fraction of ignored labels
+    ("v32000", 32000, 256, 2, 48, {}, None, 0.1),
+    ("v128256", 128256, 128, 1, 64, {}, None, 0.1),
+    ("v128256_nitems", 128256, 128, 2, 40, {}, 1000, 0.5),
+    ("v32000_softcap", 32000, 256, 2, 48, dict(logit_softcapping=30.0), None, 0.1),
+    ("v70000_scale", 70000, 128, 1, 56, dict(logit_scaling=0.125), 333, 0.2),
+    ("v32001_odd", 32001, 256, 1, 72, {}, None, 0.0),
+)
+
+
+def linear_ce_cases(ce, dev):
+    """llama.py:1525-1562 run as the reference runs it (see the module docstring). Returns {name: case}."""
+    G = {}
+    for i, (tag, V, H, B, T, kw, n_items, ignore) in enumerate(LINEAR_CE_CASES):
+        gen = torch.Generator().manual_seed(9000 + i)
+        hidden = (torch.randn(B, T, H, generator=gen) * 0.7).to(torch.bfloat16)
+        labels = torch.randint(0, V, (B, T), generator=gen)
+        labels[torch.rand(B, T, generator=gen) < ignore] = -100
+        labels[0, 1] = V - 1
+        W, crc = linear_ce_weight(7000 + i, V, H, 0.05)
+        hg = hidden.to(dev).requires_grad_(True)
+        Wd = W.to(dev)
+        logits = torch.nn.functional.linear(hg, Wd)                     # self.lm_head(hidden_states.to(dtype))   :1525
+        lab = labels.to(dev)
+        shift = torch.empty_like(lab)                                   # :1545-1551
+        shift[..., :-1] = lab[..., 1:]
+        shift[..., -1] = -100
+        loss = ce.fast_cross_entropy_loss(logits=logits, labels=shift, n_items=n_items, **kw)      # :1556-1562
+        loss.backward()
+        G["linear_ce_" + tag] = dict(hidden=hidden, labels=labels, W_seed=7000 + i, W_scale=0.05, V=V, H=H, W_crc32=crc,
+                                     n_items=n_items, kw=dict(kw), loss=loss.detach().float().cpu().clone(),
+                                     dhidden=hg.grad.detach().cpu().clone())
+        print("ok   linear_ce_" + tag, float(loss), flush=True)
+    return G
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(HERE, "..", "gpurun_out", "ref_triton_bf16.pt"))
+    ap.add_argument("--only", default="", help="'linear_ce': write only the a7 fixture (see the module docstring)")
     a = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("needs the MI355X (native Triton run)")
@@ -75,6 +128,16 @@ def main():
     rms, rope, ce, sw, ge, fl, ku = (R["rms_layernorm"], R["rope_embedding"], R["cross_entropy_loss"], R["swiglu"],
                                      R["geglu"], R["fast_lora"], R["utils"])
     dev = "cuda"
+    if a.only == "linear_ce":
+        G = linear_ce_cases(ce, dev)
+        G["_meta"] = dict(torch=torch.__version__, triton=triton.__version__, device=torch.cuda.get_device_name(0),
+                          arch=getattr(torch.cuda.get_device_properties(0), "gcnArchName", "?"),
+                          device_type=getattr(ku, "DEVICE_TYPE", None), reference_root=ref,
+                          note="llama.py:1525-1562: lm_head -> label shift -> fast_cross_entropy_loss (native Triton) -> d hidden")
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        torch.save(G, a.out)
+        print("wrote", os.path.abspath(a.out), os.path.getsize(a.out), "bytes;", len(G) - 1, "cases")
+        return
     G, errors = {}, {}
     gen = torch.Generator().manual_seed(3407)
 

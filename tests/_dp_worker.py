@@ -1,7 +1,12 @@
-"""Worker of tests/test_gpu_dp_rccl.py: one process per rank, RCCL ("nccl" backend) over the visible GPUs.
+"""Worker of tests/test_gpu_dp_rccl.py: one process per rank, RCCL ("nccl" backend) over the visible GPUs -- or, with
+DP_TEST_BACKEND=gloo and DP_TEST_ONE_DEVICE=1, TWO ranks sharing device 0 (RCCL refuses two ranks on one device; gloo carries
+the collectives, natively or host-staged by tests/_gloo_cuda_shim.py): the one configuration that ever shipped wrong
+numbers here -- REAL GPU gradient sinks (kernels/utils.GRAD_SINKS: the fused LoRA-gradient kernel adds straight into the
+arena) x world_size > 1 -- on the single GPU a test box has.
 Every rank builds the same tiny QLoRA model, trains one step on ITS batch through dp.LoRAGradArena (bucketed async
 all-reduce launched from the gradient hooks, overlapped with the backward), and checks the reduced gradients
-against a local replay of every rank's batch without any collective. Exit code 0 = pass."""
+against a local replay of every rank's batch without any collective; then gradient accumulation under no_sync(), a step
+after zero_grad(set_to_none=True), and the optimizer step (replicas must end identical). Exit code 0 = pass."""
 import os
 import sys
 
@@ -30,8 +35,8 @@ def build(dev, gc):
     return model
 
 
-def batch_of(rank, dev):
-    g = torch.Generator().manual_seed(100 + rank)
+def batch_of(rank, dev, micro=0):
+    g = torch.Generator().manual_seed(100 + rank + 1000 * micro)
     ids = torch.randint(0, 1000, (2, 64), generator=g)
     labels = ids.clone()
     labels[0, : 3 + rank] = -100
@@ -42,10 +47,18 @@ def batch_of(rank, dev):
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)))
+    backend = os.environ.get("DP_TEST_BACKEND", "nccl")
+    dev = torch.device("cuda", 0 if os.environ.get("DP_TEST_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", rank)))
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+    transport = "rccl"
+    if backend == "gloo":
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests._gloo_cuda_shim import install
+        transport = "gloo " + install(dev)
+    else:
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
     from unsloth_amd.dp import LoRAGradArena, global_num_items
+    from unsloth_amd.kernels.utils import GRAD_SINKS
     gc = os.environ.get("DP_TEST_GC", "off")
     gc = {"off": False, "on": True}.get(gc, gc)
     # ---- reference: every rank's batch replayed locally, loss normalised by the GLOBAL token count, grads summed
@@ -59,6 +72,8 @@ def main():
     # ---- data parallel: this rank's batch only, exchange through the arena
     model = build(dev, gc)
     arena = LoRAGradArena(model, bucket_bytes=int(os.environ.get("DP_TEST_BUCKET", 1 << 16)))
+    # REAL GPU sinks: every trainable factor's gradient is added into the arena by the fused kernel, not by AccumulateGrad
+    assert arena.arena.is_cuda and all(GRAD_SINKS.get(id(p)) is not None and GRAD_SINKS[id(p)]() is arena for p in arena.params)
     mine = batch_of(rank, dev)
     n = global_num_items(mine["labels"])
     assert int(n) == n_global, (int(n), n_global)
@@ -86,6 +101,44 @@ def main():
                 worst = max(worst, err)
         assert worst < 1e-5, f"rank {rank} step {step}: reduced gradient differs from the local replay: {worst}"
         arena.zero_grad()
+
+    def check(tag, want_):
+        w = max(float((p.grad - want_[name]).norm() / (want_[name].norm() + 1e-30))
+                for name, p in model.named_parameters() if p.requires_grad)
+        assert w < 1e-5, f"rank {rank} {tag}: reduced gradient differs from the local replay: {w}"
+        return w
+    # ---- after zero_grad(set_to_none=True) (PyTorch's default): the sinks re-attach the arena views and start from zero,
+    #      although the slices still hold the previous step's REDUCED sums
+    out = model(**mine, num_items_in_batch=n)
+    out.loss.backward()
+    arena.finish()
+    for p in arena.params:
+        p.grad = None
+    arena.reset_arrivals()
+    c0 = arena.collectives
+    out = model(**mine, num_items_in_batch=n)
+    out.loss.backward()
+    arena.finish()
+    assert arena.collectives - c0 == len(arena.buckets)
+    worst = max(worst, check("after set_to_none", want))
+    arena.zero_grad()
+    # ---- gradient accumulation: micro-batch 0 under no_sync() (no exchange), micro-batch 1 exchanges the SUM of both
+    ref = build(dev, gc)
+    n_acc = sum(int((batch_of(r, dev, m)["labels"][:, 1:] != -100).sum()) for r in range(world) for m in range(2))
+    for r in range(world):
+        for m in range(2):
+            ref(**batch_of(r, dev, m), num_items_in_batch=n_acc).loss.backward()
+    want_acc = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.requires_grad}
+    del ref
+    c0 = arena.collectives
+    with arena.no_sync():
+        model(**batch_of(rank, dev, 0), num_items_in_batch=n_acc).loss.backward()
+    assert arena.collectives == c0, "no exchange inside no_sync()"
+    model(**batch_of(rank, dev, 1), num_items_in_batch=n_acc).loss.backward()
+    arena.finish()
+    assert arena.collectives - c0 == len(arena.buckets), "one exchange per bucket for the whole accumulation window"
+    worst = max(worst, check("accumulation under no_sync", want_acc))
+    arena.zero_grad()
     # ---- the whole training step on top of the same arena: optim.FlatAdamW steps on the REDUCED gradients in one
     #      launch and zeroes the arena in the same pass; every rank must end with identical parameters
     from unsloth_amd.optim import FlatAdamW
@@ -106,7 +159,7 @@ def main():
     assert int(one.item()) == world
     dist.barrier()
     dist.destroy_process_group()
-    print(f"rank {rank}/{world} ok: buckets {arena.describe()['buckets']}, worst rel err {worst:.2e}", flush=True)
+    print(f"rank {rank}/{world} ok [{transport}]: buckets {arena.describe()['buckets']}, worst rel err {worst:.2e}", flush=True)
 
 
 if __name__ == "__main__":

@@ -1,7 +1,8 @@
 """-m gpu: the data-parallel exchange on real RCCL. One GPU: a 1-rank "nccl" group (every collective is really
-issued, hooks + side stream + arena ordering exercised; UNSLOTH_AMD_DP_FORCE=1). Two or more visible GPUs: two ranks,
-different batches, reduced LoRA gradients == the local replay of both batches (skipped on a single-GPU box -- the
-driver's 8-GPU SCALE run is where N > 1 is measured; the N > 1 logic itself is covered on CPU by test_dp_gloo.py)."""
+issued, hooks + side stream + arena ordering exercised; UNSLOTH_AMD_DP_FORCE=1), AND two ranks sharing that one GPU with
+the collectives carried by gloo (`*_two_ranks_one_gpu_*`: world_size 2 x real GPU gradient sinks -- runs on every box).
+Two or more visible GPUs: two ranks on RCCL, different batches, reduced LoRA gradients == the local replay of both batches
+(skipped on a single-GPU box -- the driver's 8-GPU SCALE run is where N > 1 on RCCL is measured)."""
 import os
 import socket
 import subprocess
@@ -31,6 +32,7 @@ def _run(world, extra_env, worker="_dp_worker.py"):
         # one node, no fabric: keep RCCL's bootstrap off interface / InfiniBand probing (seen to take 100 s on one box)
         env.setdefault("NCCL_SOCKET_IFNAME", "lo")
         env.setdefault("NCCL_IB_DISABLE", "1")
+        env.setdefault("GLOO_SOCKET_IFNAME", "lo")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", worker)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -65,6 +67,23 @@ def test_full_finetune_forced_one_rank_rccl_group():
     gradient sinks, sharded AdamW, in-place all-gather -- bit-identical to the same steps without any collective."""
     outs = _run(1, {"UNSLOTH_AMD_DP_FORCE": "1"}, worker="_fullft_worker.py")
     assert "rank 0/1 ok" in outs[0]
+
+
+@pytest.mark.parametrize("gc,bucket", [("off", 1 << 16), ("unsloth", 1 << 30)])
+def test_two_ranks_one_gpu_real_sinks_lora_arena(gc, bucket):
+    """world_size 2 x REAL GPU gradient sinks on ONE device (collectives over gloo: RCCL refuses two ranks per device):
+    one exchange per bucket per step, complete when launched, reduced gradients == single-process replay of both batches,
+    also after zero_grad(set_to_none=True) and across a no_sync() accumulation; replicas identical after FlatAdamW."""
+    outs = _run(2, {"DP_TEST_GC": gc, "DP_TEST_BUCKET": str(bucket), "DP_TEST_BACKEND": "gloo", "DP_TEST_ONE_DEVICE": "1"})
+    assert "rank 0/2 ok [gloo" in outs[0] and "rank 1/2 ok [gloo" in outs[1], outs
+
+
+def test_two_ranks_one_gpu_real_sinks_full_finetune():
+    """BASELINE config 3's exchange with two ranks on one device: FullGradBuckets' sinks + sharded AdamW + all-gather;
+    exchanged gradients == replay of both batches, replicas identical after three steps."""
+    outs = _run(2, {"DP_TEST_BACKEND": "gloo", "DP_TEST_ONE_DEVICE": "1"}, worker="_fullft_worker.py")
+    assert "rank 0/2 ok [gloo" in outs[0] and "rank 1/2 ok [gloo" in outs[1], outs
+    assert "exchanged gradients == replay of 2 batches" in outs[0]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs")
