@@ -111,7 +111,7 @@ def linear_ce_cases(ce, dev):
         G["linear_ce_" + tag] = dict(hidden=hidden, labels=labels, W_seed=7000 + i, W_scale=0.05, V=V, H=H, W_crc32=crc,
                                      n_items=n_items, kw=dict(kw), loss=loss.detach().float().cpu().clone(),
                                      dhidden=hg.grad.detach().cpu().clone())
-        print("ok   linear_ce_" + tag, float(loss), flush=True)
+        print("ok   linear_ce_" + tag, float(loss.detach()), flush=True)
     return G
 
 
