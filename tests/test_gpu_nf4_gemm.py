@@ -414,6 +414,7 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
     U.GEMM256_MODE = "on"
     try:
         L.uamd_set_tuning(6, 0)                  # 256-row tiles (the persistent walk exists for those)
+        L.uamd_set_tuning(11, 0)                 # the 8-wave kernels (whole-tile NT launches would take gemm_nt256s_kernel)
         for accumulate in (False, True):
             ref = run(0, accumulate)
             for plain in (1, 0):                 # knob 9: the load-free-epilogue instance (default) / the run-time-dispatch one
@@ -434,6 +435,69 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
         L.uamd_set_tuning(6, 1)
         L.uamd_set_tuning(7, 1)
         L.uamd_set_tuning(9, 1)
+        L.uamd_set_tuning(11, 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,Ns,K,rank", [(4096, (4096, 1024, 1024), 512, True),      # 3 groups, per-group rank blocks
+                                         (512, (256,), 128, False),                    # the minimum: two K tiles, no loop trip
+                                         (512, (512,), 192, True),                     # one loop trip + one rank tile
+                                         (2048, (2560,), 1024, True),
+                                         (1024, (1024,), 4096, False),                 # a long K loop
+                                         (256, (768, 256), 320, True)])                # odd K-tile count
+def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(dtype, M, Ns, K, rank):
+    """gemm_nt256s_kernel (4 waves x 128 x 128, hand-ordered K loop, `buffer_load ... lds` pieces with SGPR offsets; knob 11,
+    default for whole-tile NT launches) against the 8-wave gemm_nt256_kernel: same LDS image, same per-accumulator k order
+    (main tiles in order, then the rank block's), so BIT-IDENTICAL -- multi-group launches with per-group rank blocks,
+    accumulate, bias-free, padded row strides; and run-to-run deterministic."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels.utils import _group, _launch_gemm
+    from unsloth_amd.kernels import utils as U
+    L = _lib.lib()
+    Xs = torch.empty(M, K + 64, dtype=dtype, device=DEV)[:, :K]          # lda != K
+    Xs.copy_(torch.randn(M, K, generator=g(271)).to(dtype))
+    xk = torch.zeros(M, 64, dtype=dtype, device=DEV)
+    xk[:, :16] = torch.randn(M, 16, generator=g(272)).to(dtype).to(DEV)
+    Bs, BKs = [], []
+    for i, N in enumerate(Ns):
+        Bs.append((torch.randn(N, K, generator=g(273 + i)) * 0.05).to(dtype).to(DEV))
+        bk = torch.zeros((N, 64), dtype=dtype, device=DEV)
+        bk[:, :16] = (torch.randn(N, 16, generator=g(283 + i)) * 0.05).to(dtype).to(DEV)
+        BKs.append(bk)
+
+    def run(knob, accumulate):
+        outs = [torch.full((M, N), 0.25, dtype=dtype, device=DEV) for N in Ns]
+        groups = []
+        for i, N in enumerate(Ns):
+            use_rank = rank and i != 1
+            groups.append(_group(Bs[i], outs[i], N, Bs[i].stride(0), xa=xk if use_rank else None, ld_xa=64, R=16, scale=1.0,
+                                 xk=xk if use_rank else None, bk=BKs[i] if use_rank else None))
+        L.uamd_set_tuning(11, knob)
+        _launch_gemm(Xs, groups, nf4=False, accumulate=accumulate, nn=False)
+        return outs
+
+    old = U.GEMM256_MODE
+    U.GEMM256_MODE = "on"
+    try:
+        L.uamd_set_tuning(6, 0)
+        L.uamd_set_tuning(7, 0)
+        for accumulate in (False, True):
+            ref = run(0, accumulate)
+            got = run(1, accumulate)
+            again = run(1, accumulate)
+            for r, o, o2 in zip(ref, got, again):
+                assert torch.equal(o, o2), "run-to-run"
+                assert torch.equal(r, o), float((r.float() - o.float()).abs().max())
+        y = run(1, False)[0]
+        want = Xs.float().cpu() @ Bs[0].float().cpu().t()
+        if rank:
+            want = want + xk.float().cpu() @ BKs[0].float().cpu().t()
+        _check_gemm(y, want, dtype, K, "gemm256s")
+    finally:
+        U.GEMM256_MODE = old
+        L.uamd_set_tuning(6, 1)
+        L.uamd_set_tuning(7, 1)
+        L.uamd_set_tuning(11, 1)
 
 
 def test_gemm256_transpose_detecting_and_k_order(force256):

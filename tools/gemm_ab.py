@@ -1,5 +1,6 @@
 """A/B of the large-M GEMM kernels on one MI355X (one process, interleaved rounds, random N(0,1)*0.02-scale data):
-torch.matmul (hipBLASLt) and gemm256.hip ("pp"), contiguous and row-padded operands. Checks each against torch first."""
+torch.matmul (hipBLASLt), gemm256.hip's 8-wave kernels ("pp") and its one-wave-per-SIMD kernel ("s4"), contiguous and
+row-padded operands. Checks each against torch first."""
 import json
 import os
 import sys
@@ -35,13 +36,15 @@ def main():
         ref = X @ W.t()
         cands = {"torch": lambda: X @ W.t()}
 
-        def mk(gm=8):
+        def mk(gm=8, s=0):
             def f():
                 L.uamd_set_tuning(1, gm)
+                L.uamd_set_tuning(11, s)
                 U.GEMM256_MODE = "on"
                 return U.lora_linear_forward(X, [(W, None, None, None, None)])[0]
             return f
-        cands["pp"] = mk(8)
+        cands["pp"] = mk(8)            # the 8-wave ping-pong kernels (rounds 1-5)
+        cands["s4"] = mk(8, 1)         # gemm_nt256s_kernel: one wave per SIMD, hand-ordered K loop (round 6)
         pad = int(os.environ.get("GEMM_AB_PAD", "64"))
         Xp = torch.empty(M, K + pad, device=DEV, dtype=bf)[:, :K]
         Xp.copy_(X)
@@ -50,9 +53,10 @@ def main():
 
         def pp_pad():
             L.uamd_set_tuning(1, 8)
+            L.uamd_set_tuning(11, 1)
             U.GEMM256_MODE = "on"
             return U.lora_linear_forward(Xp, [(Wp, None, None, None, None)])[0]
-        cands["pp_pad"] = pp_pad
+        cands["s4_pad"] = pp_pad
         cands["torch_pad"] = lambda: Xp @ Wp.t()
         for name, f in cands.items():
             y = f()

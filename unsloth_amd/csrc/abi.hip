@@ -6,9 +6,9 @@
 extern "C" int uamd_version(void) { return (0 << 16) | 2; }
 
 namespace {
-int g_knob[UAMD_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
-const char* const kEnv[UAMD_TUNE_COUNT] = {"UAMD_GLU_VAR", "UAMD_GEMM_GROUP_M", "UAMD_STREAM_NT", "UAMD_DEQUANT_T", "UAMD_ATTN_VAR", "UAMD_RMS_VAR", "UAMD_GEMM_HALF", "UAMD_GEMM_PERSIST", "UAMD_DEQUANT_X4", "UAMD_GEMM_PLAIN", "UAMD_GLU_XA"};
-const int kDefault[UAMD_TUNE_COUNT] = {2, 8, 0, 1, 0, 1, 1, 1, 1, 1, 3};
+int g_knob[UAMD_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+const char* const kEnv[UAMD_TUNE_COUNT] = {"UAMD_GLU_VAR", "UAMD_GEMM_GROUP_M", "UAMD_STREAM_NT", "UAMD_DEQUANT_T", "UAMD_ATTN_VAR", "UAMD_RMS_VAR", "UAMD_GEMM_HALF", "UAMD_GEMM_PERSIST", "UAMD_DEQUANT_X4", "UAMD_GEMM_PLAIN", "UAMD_GLU_XA", "UAMD_GEMM_S"};
+const int kDefault[UAMD_TUNE_COUNT] = {2, 8, 0, 1, 0, 1, 1, 1, 1, 1, 3, 1};
 }  // namespace
 
 // value of a knob: uamd_set_tuning() > environment variable > built-in default (the measured-fastest setting)

@@ -750,6 +750,172 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// One wave per SIMD: 4 waves x (128 x 128) wave tiles, the whole accumulator in the 256 AGPRs, and a K loop whose
+// instruction ORDER is written out (gemm256s_loop.inc, generated by tools/gen/gen_gemm256s.py -- schedule documented
+// there). Why (round 6, profiles/r06_gemm_isa_census.md): per K tile and SIMD the 8-wave ping-pong kernels above issue 349
+// instructions for their 128 MFMAs (two waves x {24 ds_read_b128, 8 DMA pieces x 5 instructions, 18 waits, 8 barriers,
+// setprio / nop padding}) and read 192 KiB of fragments from LDS; the vendor kernel that is 4-10 % ahead on every NT step
+// shape issues 225 and reads 128 KiB -- 128 x 128 wave tiles feed every fragment to eight MFMAs instead of four / eight,
+// `buffer_load ... lds` with SGPR piece offsets is one vector + one scalar instruction per DMA piece, and a wave alone on
+// its SIMD keeps the matrix pipe's full rate as long as no more than ~3 single-issue instructions sit between two
+// MFMAs (profiles/r05_mfma_issue_probe.jsonl) -- which only a hand-ordered stream guarantees. Round 2's 4-wave build
+// (hipcc-ordered, full vmcnt(0) drain + one barrier per tile, 3-instruction global_load_lds pieces) measured 4-20 %
+// slower than the ping-pong kernel; this one differs in exactly those three points.
+// Same LDS tile image, swizzle, XCD raster, rank-block-as-K-tiles and per-accumulator k order as gemm_nt256_kernel, so the
+// results are BIT-IDENTICAL to it (tests/test_gpu_nf4_gemm.py). Host contract (gemm256_entry): M % 256 == 0, every
+// N_g % 256 == 0 (no edge tiles: the piece offsets ride in SGPRs, rows cannot be clamped per lane), K >= 128.
+#include "gemm256s_loop.inc"
+
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+
+template <typename T>
+__global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename Mfma2<T>::frag frag_t;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;       // wave owns rows wm*128.., cols wn*128..
+    const int l15 = lane & 15, l4 = lane >> 4;
+
+    int tile = blockIdx.x;
+    {
+        const int nt = p.total_tiles, q = nt >> 3, r = nt & 7, x = tile & 7, j = tile >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+    }
+    int tm, tn_lin;
+    {
+        const int gm = p.group_m, tiles_n = p.tile_start[UAMD_G256_MAX_GROUPS];
+        const int per_group = gm * tiles_n;
+        const int rg = tile / per_group;
+        const int first_m = rg * gm;
+        const int gsz = min(gm, p.tiles_m - first_m);
+        const int rem = tile - rg * per_group;
+        tn_lin = rem / gsz;
+        tm = first_m + (rem - tn_lin * gsz);
+    }
+    int gi = 0;
+#pragma unroll
+    for (int i = 1; i < UAMD_G256_MAX_GROUPS; ++i)
+        if (i < p.n_groups && tn_lin >= p.tile_start[i]) gi = i;
+    const uamd_gemm_group& g = p.g[gi];
+    const int m0 = __builtin_amdgcn_readfirstlane(tm * TM);
+    const int n0 = __builtin_amdgcn_readfirstlane((tn_lin - p.tile_start[gi]) * TN);
+    const int M = p.M, N = g.N;
+
+    f32x4_t acc[64];                   // acc[x * 8 + y]: n-tile x, m-tile y of the wave's 128 x 128
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    frag_t yf[2][8], xf[2][8];         // [k-half][tile]: A-operand (m) and B-operand (n) fragments
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { yf[h][i] = frag_t{}; xf[h][i] = frag_t{}; }
+
+    // ---- DMA sources. Piece c (0..7) of operand A issued by wave w fills sub-tile c*4 + w = rows (c*4 + w)*8 .. +7 of
+    //      the tile, [8 rows x 64 k] = 8 full lines; lane -> (row = lane >> 3, swizzled 16-byte slot) as everywhere in
+    //      this file. The per-lane part (row inside the first piece, slot) is ONE 32-bit offset per operand; the piece
+    //      (c * 32 rows) and the K tile ride in the eight scalar offsets so[c], advanced by `step` after every use.
+    const int sub_row = lane >> 3;
+    const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
+    auto u32 = [](int64_t v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v); };
+    auto make_srd = [&](const void* base, int64_t byte_off) {
+        const uint64_t a = (uint64_t)(uintptr_t)base + (uint64_t)byte_off;
+        i32x4_t r;
+        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));     // stride 0: raw buffer
+        r[2] = -1;                                                                       // num_records: no clamping used
+        r[3] = 0x00020000;                                                               // 32-bit data format, raw
+        return r;
+    };
+    const int lda = __builtin_amdgcn_readfirstlane((int)p.lda), ldb = __builtin_amdgcn_readfirstlane((int)g.ldb);
+    i32x4_t srdA = make_srd(p.A, (int64_t)m0 * lda * (int64_t)sizeof(T));
+    i32x4_t srdB = make_srd(g.B, (int64_t)n0 * ldb * (int64_t)sizeof(T));
+    unsigned voffA = (unsigned)(((wave * 8 + sub_row) * lda + sub_slot * 8) * (int)sizeof(T));
+    unsigned voffB = (unsigned)(((wave * 8 + sub_row) * ldb + sub_slot * 8) * (int)sizeof(T));
+    unsigned soA[8], soB[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        soA[c] = u32((int64_t)c * 32 * lda * (int64_t)sizeof(T));
+        soB[c] = u32((int64_t)c * 32 * ldb * (int64_t)sizeof(T));
+    }
+    unsigned stepA = TK * sizeof(T), stepB = TK * sizeof(T);
+    const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;      // 0: no static LDS in this kernel (stage bit = 0x10000)
+    unsigned m0A = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024), m0B = m0A + 32 * 1024;
+    const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
+    unsigned rdA[2], rdB[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        rdA[h] = lds_base + (wm * 8) * 2048 + (frag_off0 ^ (h * 64));
+        rdB[h] = lds_base + 32 * 1024 + (wn * 8) * 2048 + (frag_off0 ^ (h * 64));
+    }
+    const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);       // host: >= 2
+    const int nk_rank = __builtin_amdgcn_readfirstlane(g.lora_xk != nullptr ? g.Rk / TK : 0);
+    unsigned cnt = 0;
+
+#define G256S_ASM(BODY)                                                                                        \
+    asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_SO, G256S_OUT_M0, [cnt] "+s"(cnt) \
+                 : G256S_IN_DMA : "memory", "m0", "scc")
+#define G256S_RUN(MACRO)                                                    \
+    do {                                                                    \
+        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(MACRO("bf16")); \
+        else G256S_ASM(MACRO("f16"));                                       \
+    } while (0)
+
+    // ---- prologue: K tiles 0 and 1 in flight, tile 0 landed and published, its k-half-0 fragments in registers
+    G256S_RUN(G256S_ISSUE_TILE);
+    G256S_RUN(G256S_ISSUE_TILE);
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    G256S_RUN(G256S_READ0);
+    // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper
+    cnt = (unsigned)(nk_main - 2);
+    if (cnt) G256S_RUN(G256S_LOOP0);
+    // ---- the rank block's tiles are fetched from XK [M, Rk] / BK [N, Rk] by the same bodies: only the sources change
+    if (nk_rank) {
+        const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
+        srdA = make_srd(g.lora_xk, (int64_t)m0 * ld_xk * (int64_t)sizeof(T));
+        srdB = make_srd(g.lora_bk, (int64_t)n0 * ld_bk * (int64_t)sizeof(T));
+        int ln = lane;
+        asm volatile("" : "+v"(ln));             // rebuilt here, not held across the main loop
+        const int sr = ln >> 3, ss = (ln & 7) ^ (((wave & 1) << 2) | (sr >> 1));
+        voffA = (unsigned)(((wave * 8 + sr) * ld_xk + ss * 8) * (int)sizeof(T));
+        voffB = (unsigned)(((wave * 8 + sr) * ld_bk + ss * 8) * (int)sizeof(T));
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            soA[c] = u32((int64_t)c * 32 * ld_xk * (int64_t)sizeof(T));
+            soB[c] = u32((int64_t)c * 32 * ld_bk * (int64_t)sizeof(T));
+        }
+        cnt = (unsigned)nk_rank;
+        G256S_RUN(G256S_LOOP0);
+    }
+    G256S_RUN(G256S_NODMA);
+    G256S_RUN(G256S_LAST);
+#undef G256S_RUN
+#undef G256S_ASM
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // last MFMA's write -> the epilogue's v_accvgpr_read (asm MFMAs)
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = ..+4*l4 (B-operand is MFMA source A)
+    T* Cg = (T*)g.C;
+    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
+    const T* bias = (const T*)g.bias;
+    auto epi = [&](auto acc_c, auto bias_c) {
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            const int m = m0 + wm * 128 + y * 16 + l15;
+            if (m >= M) continue;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const int n = n0 + wn * 128 + x * 16 + l4 * 4;
+                if (n >= N) continue;
+                const f32x4_t v = acc[x * 8 + y];
+                store_c4<T, decltype(acc_c)::value, decltype(bias_c)::value>(Cg + (int64_t)m * g.ldc + n, v[0], v[1], v[2], v[3],
+                                                                             n, N, vec_ok, bias);
+            }
+        }
+    };
+    UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Half-height variant: 128 x 256 x 64 tiles, same LDS-DMA ping-pong, for launches whose 256 x 256 tiling would leave
 // CUs idle (M = 2048 tokens: o_proj / down_proj / every dX GEMM have 8 x 16 = 128 such tiles for 256 CUs; the
 // 128-row tiling gives 256). Each wave group owns 64 rows (wave tile 64 x 64, 32 MFMAs per K tile), a K tile is
@@ -994,6 +1160,21 @@ int launch256h(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
+template <typename T>
+int launch256s(const G256Args& a, hipStream_t st) {
+    static bool attr_set[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL((gemm_nt256s_kernel<T>), dim3((unsigned)a.total_tiles), dim3(256), LDS_BYTES, st, a);
+    return uamd_launch_status();
+}
+
 template <typename T, bool BNN, bool ATN = false>
 int launch256(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
@@ -1125,6 +1306,16 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
         if (dtype == UAMD_BF16) return bnn ? launch256h<bf16_t, true>(a, st) : launch256h<bf16_t, false>(a, st);
         if (dtype == UAMD_F16) return bnn ? launch256h<f16_t, true>(a, st) : launch256h<f16_t, false>(a, st);
         return UAMD_ERR_DTYPE;
+    }
+    // whole-tile NT launches: the one-wave-per-SIMD kernel (UAMD_TUNE_GEMM_S)
+    if (!bnn && K >= 2 * TK && (M & (TM - 1)) == 0 && uamd_tuning_get(UAMD_TUNE_GEMM_S) != 0) {
+        bool whole = true;
+        for (int i = 0; i < n_groups; ++i) whole = whole && (groups[i].N & (TN - 1)) == 0;
+        if (whole) {
+            if (dtype == UAMD_BF16) return launch256s<bf16_t>(a, st);
+            if (dtype == UAMD_F16) return launch256s<f16_t>(a, st);
+            return UAMD_ERR_DTYPE;
+        }
     }
     // persistent walk (UAMD_TUNE_GEMM_PERSIST: 1 = when every CU gets >= 4 tiles (default), 2 = whenever it gets more than
     // one, 0 = never). Measured (profiles/r02i_gemm_persist_ab.txt): +0.5 % at 7 tiles per CU, -2.5 % .. 0 at 2 tiles per CU
