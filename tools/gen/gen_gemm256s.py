@@ -53,6 +53,22 @@ def adv(op, c):
     return f"s_add_u32 %[so{op}{c}], %[so{op}{c}], %[step{op}]"
 
 
+def knock(instrs, drop):
+    """timing experiments only (results are garbage): drop 'dma' (pieces + their SALU), 'read' (fragment reads), 'sync'
+    (waits + barriers)"""
+    out = []
+    for i in instrs:
+        op = i.split()[0]
+        if "dma" in drop and (op.startswith("buffer_load") or (op.startswith("s_") and ("m0" in i or "%[so" in i))):
+            continue
+        if "read" in drop and op.startswith("ds_read"):
+            continue
+        if "sync" in drop and op in ("s_waitcnt", "s_barrier"):
+            continue
+        out.append(i)
+    return out
+
+
 def body(kind, shift=0):
     """kind: 'dma' | 'nodma' | 'last'. Returns the instruction list of one K tile. `shift` moves the LDS-DMA / ds_read
     positions of the middle section by one MFMA (the vendor loop has two bodies selected by SIMD parity, so that the four
@@ -164,6 +180,19 @@ def main():
     for s in (0, 1):
         emit_macro(f"G256S_LOOP{s}", ["1:"] + body("dma", s),
                    ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b"])
+    tail = ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b"]
+    # both bodies in ONE statement, selected by the SIMD id's low bit (HW_ID[4]) -- a C++ if / else around two asm statements
+    # makes every "+s" operand a PHI, which hipcc then refuses to keep in SGPRs. %[cnt] doubles as the scratch register.
+    tail2 = ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 2b"]
+    par = ["s_getreg_b32 %[tmp], hwreg(HW_REG_HW_ID, 4, 1)", "s_cmp_eq_u32 %[tmp], 0", "s_cbranch_scc0 2f"] + \
+        ["1:"] + body("dma", 0) + tail + ["s_branch 3f", "2:"] + body("dma", 1) + tail2 + ["3:"]
+    emit_macro("G256S_LOOP_PAR", par)
+    for name, drop in (("KND", {"dma"}), ("KNR", {"read"}), ("KMF", {"dma", "read"}), ("KMO", {"dma", "read", "sync"})):
+        emit_macro(f"G256S_LOOP_{name}", ["1:"] + knock(body("dma", 0), drop), tail)
+    # experiments (gemm_s4_knock.py): no soffset advance (garbage results); loop head aligned to 64 bytes; shifted by 4 bytes
+    emit_macro("G256S_LOOP_XSO", ["1:"] + [i for i in body("dma", 0) if not ("%[so" in i and i.startswith("s_add"))], tail)
+    emit_macro("G256S_LOOP_AL64", [".p2align 6", "1:"] + body("dma", 0), tail)
+    emit_macro("G256S_LOOP_SH4", [".p2align 6", "s_nop 0", "1:"] + body("dma", 0), tail)
     emit_macro("G256S_NODMA", body("nodma"))
     emit_macro("G256S_LAST", body("last"))
     # a whole tile's 16 pieces back to back (prologue), soffsets advanced, DMA destination flipped

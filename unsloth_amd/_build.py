@@ -65,7 +65,8 @@ def _stale(out, deps):
 def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "unsloth_amd.h"), os.path.join(CSRC, "attn_acc256.inc")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "unsloth_amd.h"), os.path.join(CSRC, "attn_acc256.inc"),
+               os.path.join(CSRC, "gemm256s_loop.inc")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

@@ -768,7 +768,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
-template <typename T>
+// VAR: 0 = one loop body; 1 = two bodies selected by SIMD parity (the DMA / fragment-read positions of the odd SIMDs moved by
+// one MFMA, as the vendor loop does); 2.. = knock-out timing builds (no DMA / no fragment reads / neither / MFMAs only:
+// results are garbage, tools/gemm_ab.py never uses them for anything but a clock).
+template <typename T, int VAR>
 __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -850,10 +853,10 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     }
     const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);       // host: >= 2
     const int nk_rank = __builtin_amdgcn_readfirstlane(g.lora_xk != nullptr ? g.Rk / TK : 0);
-    unsigned cnt = 0;
+    unsigned cnt = 0, tmp;
 
 #define G256S_ASM(BODY)                                                                                        \
-    asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_SO, G256S_OUT_M0, [cnt] "+s"(cnt) \
+    asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_SO, G256S_OUT_M0, [cnt] "+s"(cnt), [tmp] "=&s"(tmp) \
                  : G256S_IN_DMA : "memory", "m0", "scc")
 #define G256S_RUN(MACRO)                                                    \
     do {                                                                    \
@@ -868,7 +871,27 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     G256S_RUN(G256S_READ0);
     // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper
     cnt = (unsigned)(nk_main - 2);
-    if (cnt) G256S_RUN(G256S_LOOP0);
+    if (cnt) {
+        if constexpr (VAR == 1) {
+            G256S_RUN(G256S_LOOP_PAR);         // HW_ID[4] = low bit of the SIMD id: odd SIMDs take the shifted body
+        } else if constexpr (VAR == 2) {
+            G256S_RUN(G256S_LOOP_KND);
+        } else if constexpr (VAR == 3) {
+            G256S_RUN(G256S_LOOP_KNR);
+        } else if constexpr (VAR == 4) {
+            G256S_RUN(G256S_LOOP_KMF);
+        } else if constexpr (VAR == 5) {
+            G256S_RUN(G256S_LOOP_KMO);
+        } else if constexpr (VAR == 6) {
+            G256S_RUN(G256S_LOOP_XSO);
+        } else if constexpr (VAR == 7) {
+            G256S_RUN(G256S_LOOP_AL64);
+        } else if constexpr (VAR == 8) {
+            G256S_RUN(G256S_LOOP_SH4);
+        } else {
+            G256S_RUN(G256S_LOOP0);
+        }
+    }
     // ---- the rank block's tiles are fetched from XK [M, Rk] / BK [N, Rk] by the same bodies: only the sources change
     if (nk_rank) {
         const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
@@ -1160,19 +1183,36 @@ int launch256h(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
-template <typename T>
-int launch256s(const G256Args& a, hipStream_t st) {
+template <typename T, int VAR>
+int launch256s_(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_nt256s_kernel<T>), dim3((unsigned)a.total_tiles), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt256s_kernel<T, VAR>), dim3((unsigned)a.total_tiles), dim3(256), LDS_BYTES, st, a);
     return uamd_launch_status();
+}
+
+template <typename T>
+int launch256s(const G256Args& a, hipStream_t st) {
+    const int v = uamd_tuning_get(UAMD_TUNE_GEMM_S);
+#ifdef UAMD_G256S_KNOCKOUTS
+    if (std::is_same<T, bf16_t>::value) {
+        if (v == 3) return launch256s_<T, 2>(a, st);
+        if (v == 4) return launch256s_<T, 3>(a, st);
+        if (v == 5) return launch256s_<T, 4>(a, st);
+        if (v == 6) return launch256s_<T, 5>(a, st);
+        if (v == 7) return launch256s_<T, 6>(a, st);
+        if (v == 8) return launch256s_<T, 7>(a, st);
+        if (v == 9) return launch256s_<T, 8>(a, st);
+    }
+#endif
+    return v == 2 ? launch256s_<T, 1>(a, st) : launch256s_<T, 0>(a, st);
 }
 
 template <typename T, bool BNN, bool ATN = false>
