@@ -4,25 +4,39 @@
 
 One wave per SIMD (4 waves x 128 x 128 wave tiles, 256 accumulator AGPRs): nothing else fills the matrix pipe, so the wave
 has to pipeline itself -- instruction ORDER is the design, and it is written here instead of being left to hipcc's
-scheduler. The order follows the steady-state loop of the vendor kernel for these shapes, read from its disassembly
+scheduler. The skeleton follows the steady-state loop of the vendor kernel for these shapes, read from its disassembly
 (`tools/isa_census.py`, profiles/r06_gemm_isa_census.md): per K tile of 64 and per wave 128 MFMAs, 32 ds_read_b128, 16 LDS-DMA
 pieces, 3 barriers, and never more than two single-issue instructions between two consecutive MFMAs.
 
 Tile t is multiplied out of LDS stage s = t & 1 in two k-halves of 32 (fragment register sets 0 / 1: 8 A-operand + 8
 B-operand fragments each). While the 64 MFMAs of k-half 0 run, the fragments of k-half 1 are read (A first, then B); as soon
 as EVERY wave has finished reading an operand's half of the stage (barrier 1: A, barrier 2: B) that half receives tile t + 2
-by LDS-DMA. While the 64 MFMAs of k-half 1 run, the rest of tile t + 2's pieces are issued, `s_waitcnt vmcnt(13)` retires
-tile t + 1 (13 = the pieces of tile t + 2 issued so far: the counter never drains), barrier 3 publishes it, and the
-k-half-0 fragments of tile t + 1 are read from the other stage.
+by LDS-DMA. During the 64 MFMAs of k-half 1, `s_waitcnt vmcnt(16)` retires tile t + 1 (16 = the pieces of tile t + 2, all in
+flight: the counter never drains), barrier 3 publishes it, and the k-half-0 fragments of tile t + 1 are read from the other
+stage.
 
-Three bodies: DMA (steady state; also the loop), NODMA (tile nk - 2: nothing left to fetch, vmcnt(0)), LAST (tile nk - 1:
-nothing to fetch, nothing to read). Operands are named; the operand lists are macros too, so the kernel binds them once.
+What round 6's measurements changed against the vendor's placement (profiles/r06d_gemm_s4_knockouts_alignment.jsonl):
+  * every DMA piece is issued as EARLY as its half of the stage allows (A: MFMAs 21..35, B: 46..60; the vendor spreads B's
+    pieces up to MFMA 124): on K = 14336 the loop is latency-exposed -- a fifth of the pieces miss the XCD's L2 every tile
+    -- and the last piece had 96 MFMAs (0.7 us) to land, now 160;
+  * the K advance is two 64-bit scalar adds on the buffer descriptors' bases (PINNED s[84:87] / s[88:91]: an asm operand
+    cannot name half of a register tuple) instead of sixteen adds on the piece offsets;
+  * the loop head is 64-byte aligned and every 4-byte instruction sits next to another one, so that all 8-byte
+    instructions (MFMA, ds_read, buffer_load, literal SALU) stay 8-byte aligned: +2.5 % measured, and a 4-byte shift of
+    the same stream costs that much again (MI355X_MICROARCH "code-placement sensitivity").
+
+Bodies: LOOP (steady state), NODMA (tile nk - 2: nothing left to fetch, vmcnt(0)), LAST (tile nk - 1: nothing to fetch,
+nothing to read). Operands are named; the operand lists are macros too, so the kernel binds them once.
 B-operand = the matrix whose rows become output COLUMNS (the weight), read as MFMA source A (the lane then holds four
 consecutive n of one m: 8-byte stores); A-operand = the activations, MFMA source B. acc[x * 8 + y] = n-tile x, m-tile y.
 """
-import sys
+import os
 
-NT_LDS = [c * 4096 for c in range(8)]         # piece c of a wave: sub-tile c * 4 + w, 1 KiB each
+SRD = {"A": "s[84:87]", "B": "s[88:91]"}
+SRD_LO = {"A": ("s84", "s85"), "B": ("s88", "s89")}
+OPOFF = {"A": 0, "B": 32 * 1024}
+M0_BIAS = 64          # %[m0b] = LDS address of the wave's first piece in the target stage + 64: every "m0 = base + k" is then
+                      # an 8-byte literal add (k = 0 would be an inline constant = a 4-byte instruction)
 
 
 def mfma(h, x, y):
@@ -39,18 +53,112 @@ def rd_x(h, x):
 
 
 def dma(op, c):
-    """piece c of operand op ('A' / 'B'): the load, then (after the next MFMA) the soffset advance; M0 for the NEXT piece."""
-    return f"buffer_load_dwordx4 %[voff{op}], %[srd{op}], %[so{op}{c}] offen lds"
+    return f"buffer_load_dwordx4 %[voff{op}], {SRD[op]}, %[so{op}{c}] offen lds"
 
 
-def m0_for(op, c, lds=NT_LDS):
-    if c == 0:
-        return f"s_mov_b32 m0, %[m0{op}]"
-    return f"s_add_u32 m0, %[m0{op}], {lds[c]}"
+def m0_for(op, c):
+    return f"s_add_u32 m0, %[m0b], {OPOFF[op] + c * 4096 - M0_BIAS}"
 
 
-def adv(op, c):
-    return f"s_add_u32 %[so{op}{c}], %[so{op}{c}], %[step{op}]"
+def advance():
+    out = []
+    for op in "AB":
+        lo, hi = SRD_LO[op]
+        out += [f"s_add_u32 {lo}, {lo}, %[step{op}]", f"s_addc_u32 {hi}, {hi}, 0"]
+    return out
+
+
+def size(ins):
+    op = ins.split()[0]
+    if op.startswith(("v_mfma", "ds_read", "buffer_load", "v_xor")):
+        return 8
+    toks = ins.replace(",", " ").split()[1:]
+    lits = [t for t in toks if t.lstrip("-").isdigit() or t.startswith("0x")]
+    if op in ("s_add_u32", "s_xor_b32", "s_mov_b32") and lits:
+        v = int(lits[0], 0)
+        return 4 if -16 <= v <= 64 else 8
+    if op.endswith(":") or op.startswith("."):
+        return 0
+    return 4
+
+
+# Where things sit (MFMA index an instruction FOLLOWS). Rules every schedule keeps: A pieces after barrier 1, B pieces after
+# barrier 2, X1 reads between the barriers, everything of tile t + 2 issued before `vm` counts as in flight at the vmcnt.
+SCHEDULES = {
+    # the vendor loop's own placement (profiles/r06_gemm_isa_census.md): pieces never closer than 2-3 MFMAs, B's spread late
+    "vendor": dict(y1=[0, 2, 4, 6, 8, 10, 12, 14], bar1=21, A=[22, 25, 28, 31, 34, 52, 55, 58], x1=[24, 27, 30, 33, 36, 38, 40, 42],
+                   bar2=51, B=[61, 64, 85, 87, 89, 96, 100, 124], xor=83, bar3=92, y0=[93, 94, 95, 97, 98, 102, 103, 104],
+                   x0=[105, 106, 109, 111, 114, 116, 119, 122]),
+    # every piece as early as its half of the stage allows, one per two MFMAs (measured: 13 % SLOWER on K = 14336 -- a piece
+    # issued right behind another one waits for it in the address path)
+    "early": dict(y1=[0, 2, 4, 6, 8, 10, 12, 14], bar1=21, A=[21, 23, 25, 27, 29, 31, 33, 35], x1=[22, 24, 26, 28, 30, 32, 34, 36],
+                  bar2=46, B=[46, 48, 50, 52, 54, 56, 58, 60], xor=82, bar3=92, y0=[92, 93, 94, 95, 96, 97, 98, 99],
+                  x0=[103, 105, 107, 109, 111, 114, 117, 120]),
+    # the vendor's placement with the vmcnt / barrier 3 and the next tile's reads moved 10 MFMAs later
+    "late3": dict(y1=[0, 2, 4, 6, 8, 10, 12, 14], bar1=21, A=[22, 25, 28, 31, 34, 52, 55, 58], x1=[24, 27, 30, 33, 36, 38, 40, 42],
+                  bar2=51, B=[61, 64, 85, 87, 89, 96, 100, 124], xor=83, bar3=102, y0=[102, 103, 104, 105, 106, 107, 108, 109],
+                  x0=[110, 112, 114, 116, 118, 120, 122, 123]),
+    # one piece per three MFMAs from barrier 1 on, A and B alternating once B's half is free: all 16 issued by MFMA 79
+    "even3": dict(y1=[0, 2, 4, 6, 8, 10, 12, 14], bar1=21, A=[22, 28, 34, 40, 46, 52, 58, 64], x1=[24, 26, 30, 32, 36, 38, 42, 44],
+                  bar2=48, B=[49, 55, 61, 67, 70, 73, 76, 79], xor=83, bar3=92, y0=[93, 94, 95, 96, 97, 98, 99, 100],
+                  x0=[103, 105, 107, 109, 111, 114, 117, 120]),
+}
+SCHED = os.environ.get("G256S_SCHED", "vendor")
+
+
+def body(kind, drop=()):
+    """kind: 'dma' | 'nodma' | 'last'. One K tile as an instruction list."""
+    S = SCHEDULES[SCHED]
+    after = {i: [] for i in range(-1, 130)}          # instructions issued AFTER MFMA i
+    before = {i: [] for i in range(128)}             # instructions directly BEFORE MFMA i
+    d = kind == "dma"
+    nxt = kind != "last"
+    # ---- phase 1 (k-half 0, MFMAs 0..63): the k-half-1 fragments, A-operand first
+    for y in range(8):
+        after[S["y1"][y]].append(rd_y(1, y))
+    # barrier 1: every wave has read the A half of this stage (k-half 0 at the end of the previous tile, k-half 1 now)
+    before[S["bar1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    for x in range(8):
+        after[S["x1"][x]].append(rd_x(1, x))
+    # barrier 2: every wave has read the B half of this stage
+    before[S["bar2"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
+    if d:
+        for op in "AB":
+            for c in range(8):
+                p = S[op][c]
+                after[p - 1].insert(0, m0_for(op, c))      # M0 one MFMA ahead of its piece
+                after[p].insert(0, dma(op, c))
+        last = max(S["A"] + S["B"])
+        after[last + 1] += advance()                                       # sources: next K tile
+        after[last + 2].append("s_xor_b32 %[m0b], %[m0b], 0x10000")        # destination: the other stage
+    # ---- phase 2 (k-half 1, MFMAs 64..127)
+    if nxt:
+        after[S["xor"]] += ["v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdB0], 0x10000, %[rdB0]"]
+        after[S["xor"] + 1] += ["v_xor_b32 %[rdA1], 0x10000, %[rdA1]", "v_xor_b32 %[rdB1], 0x10000, %[rdB1]"]
+        # tile t + 1 has landed (only pieces of tile t + 2 are in flight) and every wave knows it
+        inflight = sum(1 for p in S["A"] + S["B"] if p < S["bar3"])
+        before[S["bar3"]] += [f"s_waitcnt vmcnt({inflight})" if d else "s_waitcnt vmcnt(0)", "s_barrier"]
+        for y in range(8):
+            after[S["y0"][y]].append(rd_y(0, y))
+        for x in range(8):
+            after[S["x0"][x]].append(rd_x(0, x))
+    out = []
+    i = 0
+    for h in range(2):
+        for x in range(8):
+            for y in range(8):
+                out += before[i]
+                if i == 127 and kind == "dma":
+                    out += ["s_waitcnt lgkmcnt(0)", "s_sub_u32 %[cnt], %[cnt], 1"]      # SCC = borrow: the trip count is cnt + 1
+                elif i == 127 and nxt:
+                    out += ["s_waitcnt lgkmcnt(0)", "s_nop 0"]
+                out.append(mfma(h, x, y))
+                out += after[i]
+                i += 1
+    out += after[128] + after[129]
+    if drop:
+        out = knock(out, drop)
+    return out
 
 
 def knock(instrs, drop):
@@ -59,151 +167,76 @@ def knock(instrs, drop):
     out = []
     for i in instrs:
         op = i.split()[0]
-        if "dma" in drop and (op.startswith("buffer_load") or (op.startswith("s_") and ("m0" in i or "%[so" in i))):
+        if "dma" in drop and (op.startswith("buffer_load") or (op.startswith("s_") and any(t in i for t in ("m0", "s84", "s85", "s88", "s89")))):
             continue
         if "read" in drop and op.startswith("ds_read"):
             continue
         if "sync" in drop and op in ("s_waitcnt", "s_barrier"):
             continue
+        if "vm" in drop and op == "s_waitcnt" and "vmcnt" in i:
+            out.append("s_nop 0")
+            continue
+        if "bar" in drop and op == "s_barrier":
+            out.append("s_nop 0")
+            continue
         out.append(i)
     return out
 
 
-def body(kind, shift=0):
-    """kind: 'dma' | 'nodma' | 'last'. Returns the instruction list of one K tile. `shift` moves the LDS-DMA / ds_read
-    positions of the middle section by one MFMA (the vendor loop has two bodies selected by SIMD parity, so that the four
-    waves of a workgroup do not present their LDS traffic in the same cycle)."""
-    after = {i: [] for i in range(-1, 128)}          # instructions issued AFTER MFMA i (-1: before the first)
-    before = {i: [] for i in range(128)}             # instructions that must sit directly BEFORE MFMA i
-    d = kind == "dma"
-    nxt = kind != "last"
-    # ---- phase 1: k-half 0 MFMAs 0..63; read A(h=1) behind MFMAs 0,2,..,14
-    for y in range(8):
-        after[2 * y].append(rd_y(1, y))
-    if d:
-        after[15].append(m0_for("A", 0))
-    # barrier 1: every wave has read the A half of this stage (k-half 0 at the end of the previous tile, k-half 1 now)
-    before[21].append("s_waitcnt lgkmcnt(0)")
-    after[21].append("s_barrier")
-    # A pieces 0..4 interleaved with B(h=1) fragment reads 0..4, then reads 5..7
-    s = shift
-    pos = 22
-    for c in range(5):
-        if s == 0:                       # DMA, M0, read
-            pd, pr = pos, pos + 2
-        else:                            # read, DMA, M0 (the other SIMD parity's order)
-            pd, pr = pos + 2, pos + 1
-        if d:
-            after[pd].append(dma("A", c))
-            after[pd + 1].append(m0_for("A", c + 1))
-            after[pd + 1].append(adv("A", c))
-        after[pr].append(rd_x(1, c))
-        pos += 3
-    for c, p in ((5, 38), (6, 40), (7, 42)):
-        after[p].append(rd_x(1, c))
-    # barrier 2: every wave has read the B half of this stage
-    before[51].append("s_waitcnt lgkmcnt(0)")
-    after[51].append("s_barrier")
-    if d:
-        for c, p in ((5, 52), (6, 55), (7, 58)):
-            after[p + s].append(dma("A", c))
-            after[p + 1 + s].append(m0_for("A", c + 1) if c < 7 else m0_for("B", 0))
-            after[p + 1 + s].append(adv("A", c))
-        after[61 + s].append(dma("B", 0))
-        after[62 + s].append(m0_for("B", 1))
-        after[62 + s].append(adv("B", 0))
-        # ---- phase 2: k-half 1 MFMAs 64..127
-        after[64 + s].append(dma("B", 1))
-        after[65 + s].append(m0_for("B", 2))
-        after[65 + s].append(adv("B", 1))
-    if nxt:
-        # the fragment read pointers move to the other stage (tile t + 1); stage bit = 0x10000
-        after[83].append("v_xor_b32 %[rdA0], 0x10000, %[rdA0]")
-        after[83].append("v_xor_b32 %[rdB0], 0x10000, %[rdB0]")
-        after[84 - s].append("v_xor_b32 %[rdA1], 0x10000, %[rdA1]")
-        after[84 - s].append("v_xor_b32 %[rdB1], 0x10000, %[rdB1]")
-    if d:
-        for c, p in ((2, 85), (3, 87), (4, 89)):
-            after[p - s].append(dma("B", c))
-            after[p + 1 - s].append(m0_for("B", c + 1))
-            after[p + 1 - s].append(adv("B", c))
-    if nxt:
-        # tile t + 1 has landed (13 newer pieces in flight) and every wave knows it
-        before[92].append("s_waitcnt vmcnt(13)" if d else "s_waitcnt vmcnt(0)")
-        after[92].append("s_barrier")
-        ypos = [93, 94, 95, 97, 98, 102, 103, 104]
-        for y, p in enumerate(ypos):
-            after[p].append(rd_y(0, y))
-        xpos = [105, 106, 109, 111, 114, 116, 119, 122]
-        for x, p in enumerate(xpos):
-            after[p].append(rd_x(0, x))
-    if d:
-        after[96 - s].append(dma("B", 5))
-        after[97 - s].append(m0_for("B", 6))
-        after[97 - s].append(adv("B", 5))
-        after[100 - s].append(dma("B", 6))
-        after[101 - s].append(m0_for("B", 7))
-        after[101 - s].append(adv("B", 6))
-        after[124 - s].append(dma("B", 7))
-        after[125].append(adv("B", 7))
-        # the DMA destination moves to the other stage for the next tile
-        after[126].append("s_xor_b32 %[m0A], %[m0A], 0x10000")
-        after[126].append("s_xor_b32 %[m0B], %[m0B], 0x10000")
-    if nxt:
-        before[127].append("s_waitcnt lgkmcnt(0)")
-    out = list(after[-1])
-    i = 0
-    for h in range(2):
-        for x in range(8):
-            for y in range(8):
-                out += before[i]
-                out.append(mfma(h, x, y))
-                out += after[i]
-                i += 1
-    return out
+def aligned(instrs):
+    """s_nop 0 in front of every 8-byte instruction that would start at 4 mod 8 (the layout above needs none in the loop;
+    this is the guard that keeps it so when the schedule is edited)"""
+    out, off, pads = [], 0, 0
+    for ins in instrs:
+        n = size(ins)
+        if n == 8 and off % 8 == 4:
+            out.append("s_nop 0")
+            off += 4
+            pads += 1
+        out.append(ins)
+        off += n
+    return out, pads
 
 
 def lit(ins):
     return '    "' + ins + '\\n\\t"'
 
 
-def emit_macro(name, instrs, tail=()):
+def emit_macro(name, instrs):
     print(f"#define {name}(TS) \\")
-    lines = [lit(i) for i in instrs] + [lit(i) for i in tail]
-    print(" \\\n".join(lines))
+    print(" \\\n".join(lit(i) for i in instrs))
     print()
+
+
+def loop(instrs):
+    b, pads = aligned(instrs)
+    return [".p2align 6", "1:"] + b + ["s_cbranch_scc0 1b"], pads
 
 
 def main():
     print("// GENERATED by tools/gen/gen_gemm256s.py -- do not edit (the schedule is documented there).")
     print("// clang-format off")
-    for s in (0, 1):
-        emit_macro(f"G256S_LOOP{s}", ["1:"] + body("dma", s),
-                   ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b"])
-    tail = ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 1b"]
-    # both bodies in ONE statement, selected by the SIMD id's low bit (HW_ID[4]) -- a C++ if / else around two asm statements
-    # makes every "+s" operand a PHI, which hipcc then refuses to keep in SGPRs. %[cnt] doubles as the scratch register.
-    tail2 = ["s_sub_u32 %[cnt], %[cnt], 1", "s_cmp_lg_u32 %[cnt], 0", "s_cbranch_scc1 2b"]
-    par = ["s_getreg_b32 %[tmp], hwreg(HW_REG_HW_ID, 4, 1)", "s_cmp_eq_u32 %[tmp], 0", "s_cbranch_scc0 2f"] + \
-        ["1:"] + body("dma", 0) + tail + ["s_branch 3f", "2:"] + body("dma", 1) + tail2 + ["3:"]
-    emit_macro("G256S_LOOP_PAR", par)
-    for name, drop in (("KND", {"dma"}), ("KNR", {"read"}), ("KMF", {"dma", "read"}), ("KMO", {"dma", "read", "sync"})):
-        emit_macro(f"G256S_LOOP_{name}", ["1:"] + knock(body("dma", 0), drop), tail)
-    # experiments (gemm_s4_knock.py): no soffset advance (garbage results); loop head aligned to 64 bytes; shifted by 4 bytes
-    emit_macro("G256S_LOOP_XSO", ["1:"] + [i for i in body("dma", 0) if not ("%[so" in i and i.startswith("s_add"))], tail)
-    emit_macro("G256S_LOOP_AL64", [".p2align 6", "1:"] + body("dma", 0), tail)
-    emit_macro("G256S_LOOP_SH4", [".p2align 6", "s_nop 0", "1:"] + body("dma", 0), tail)
-    emit_macro("G256S_NODMA", body("nodma"))
-    emit_macro("G256S_LAST", body("last"))
-    # a whole tile's 16 pieces back to back (prologue), soffsets advanced, DMA destination flipped
+    l, pads = loop(body("dma"))
+    print(f"// schedule '{SCHED}'; steady-state loop: {sum(size(i) for i in l)} bytes, {pads} alignment pads")
+    emit_macro("G256S_LOOP", l)
+    for name, drop in (("KND", {"dma"}), ("KNR", {"read"}), ("KMF", {"dma", "read"}), ("KMO", {"dma", "read", "sync"}),
+                       ("KNV", {"vm"}), ("KNB", {"bar"})):
+        emit_macro(f"G256S_LOOP_{name}", loop(body("dma", drop))[0])
+    emit_macro("G256S_NODMA", [".p2align 3"] + aligned(body("nodma"))[0])
+    emit_macro("G256S_LAST", [".p2align 3"] + aligned(body("last"))[0])
+    # the sources of the DMA: buffer descriptors (raw, no range clamp) over the tile origins of both operands
+    src = []
+    for op in "AB":
+        lo, hi = SRD_LO[op]
+        w2, w3 = ("s86", "s87") if op == "A" else ("s90", "s91")
+        src += [f"s_mov_b64 s[{lo[1:]}:{hi[1:]}], %[base{op}]", f"s_mov_b32 {w2}, -1", f"s_mov_b32 {w3}, 0x20000"]
+    emit_macro("G256S_SETSRC", src)
+    # a whole tile's 16 pieces back to back (prologue), sources advanced, DMA destination flipped
     pro = []
     for op in "AB":
         for c in range(8):
-            pro.append(m0_for(op, c))
-            pro.append("s_nop 0")
-            pro.append(dma(op, c))
-            pro.append(adv(op, c))
-    pro += ["s_xor_b32 %[m0A], %[m0A], 0x10000", "s_xor_b32 %[m0B], %[m0B], 0x10000"]
+            pro += [m0_for(op, c), "s_nop 0", dma(op, c)]
+    pro += advance() + ["s_xor_b32 %[m0b], %[m0b], 0x10000"]
     emit_macro("G256S_ISSUE_TILE", pro)
     rd = [rd_y(0, y) for y in range(8)] + [rd_x(0, x) for x in range(8)] + ["s_waitcnt lgkmcnt(0)"]
     emit_macro("G256S_READ0", rd)
@@ -211,14 +244,15 @@ def main():
     acc = ", ".join(f'[acc{q}] "+a"(acc[{q}])' for q in range(64))
     fr = ", ".join(f'[{n}{h}_{i}] "+v"({n}f[{h}][{i}])' for n in "yx" for h in range(2) for i in range(8))
     rdp = ", ".join(f'[rd{o}{h}] "+v"(rd{o}[{h}])' for o in "AB" for h in range(2))
-    so = ", ".join(f'[so{o}{c}] "+s"(so{o}[{c}])' for o in "AB" for c in range(8))
+    so = ", ".join(f'[so{o}{c}] "s"(so{o}[{c}])' for o in "AB" for c in range(8))
     print("#define G256S_OUT_ACC " + acc)
     print("#define G256S_OUT_FRAGS " + fr)
     print("#define G256S_OUT_RD " + rdp)
-    print("#define G256S_OUT_SO " + so)
-    print('#define G256S_OUT_M0 [m0A] "+s"(m0A), [m0B] "+s"(m0B)')
-    print('#define G256S_IN_DMA [voffA] "v"(voffA), [voffB] "v"(voffB), [srdA] "s"(srdA), [srdB] "s"(srdB), '
+    print('#define G256S_OUT_M0 [m0b] "+s"(m0b)')
+    print("#define G256S_IN_SO " + so)
+    print('#define G256S_IN_DMA [voffA] "v"(voffA), [voffB] "v"(voffB), [baseA] "s"(baseA), [baseB] "s"(baseB), '
           '[stepA] "s"(stepA), [stepB] "s"(stepB)')
+    print('#define G256S_CLOBBER "memory", "m0", "scc", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"')
     print("// clang-format on")
 
 

@@ -186,6 +186,23 @@ def our_loops(source="gemm256.hip"):
             body = [i for lab_, own, _, ls_ in blocks if lab_ == h or own == short for i in ls_]
             if sum(classify(i) == "mfma" for i in body) > sum(classify(i) == "mfma" for i in best):
                 best = body
+        # a loop written in inline asm carries no LLVM loop annotation: take the largest ASMSTART..ASMEND block that
+        # branches back to a local label of its own
+        blk, on = [], False
+        for l in ls:
+            if "#ASMSTART" in l:
+                blk, on = [], True
+                continue
+            if "#ASMEND" in l:
+                on = False
+                ins = [re.sub(r"\s*;.*$", "", t.strip()) for t in blk]
+                ins = [t for t in ins if t and not t.startswith((";", ".", "//")) and not re.match(r"^\d+:$", t)]
+                if any(re.match(r"s_cbranch_scc[01]\s+\d+b", t) for t in ins) and \
+                        sum(classify(i) == "mfma" for i in ins) > sum(classify(i) == "mfma" for i in best):
+                    best = ins
+                continue
+            if on:
+                blk.append(l)
         if best:
             out[k] = (best, meta.get(k, {}))
     return out
@@ -209,7 +226,7 @@ def fmt(rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="")
-    ap.add_argument("--kernels", default="gemm_nt256p_kernelIDF16bLb0ELb1E,gemm_nt256_kernelIDF16bLb0ELb0E,gemm_nt256s",
+    ap.add_argument("--kernels", default="gemm_nt256p_kernelIDF16bLb0ELb1E,gemm_nt256s_kernelIDF16bLi0E",
                     help="comma-separated substrings of our (mangled) kernel names")
     a = ap.parse_args()
     rows, detail = [], []

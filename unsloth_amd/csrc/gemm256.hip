@@ -763,14 +763,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
 // slower than the ping-pong kernel; this one differs in exactly those three points.
 // Same LDS tile image, swizzle, XCD raster, rank-block-as-K-tiles and per-accumulator k order as gemm_nt256_kernel, so the
 // results are BIT-IDENTICAL to it (tests/test_gpu_nf4_gemm.py). Host contract (gemm256_entry): M % 256 == 0, every
-// N_g % 256 == 0 (no edge tiles: the piece offsets ride in SGPRs, rows cannot be clamped per lane), K >= 128.
+// N_g % 256 == 0 (no edge tiles: the piece offsets ride in SGPRs, rows cannot be clamped per lane), K >= 192.
 #include "gemm256s_loop.inc"
 
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
-// VAR: 0 = one loop body; 1 = two bodies selected by SIMD parity (the DMA / fragment-read positions of the odd SIMDs moved by
-// one MFMA, as the vendor loop does); 2.. = knock-out timing builds (no DMA / no fragment reads / neither / MFMAs only:
-// results are garbage, tools/gemm_ab.py never uses them for anything but a clock).
+// VAR: 0 = the kernel; 2..5 = knock-out timing builds (-DUAMD_G256S_KNOCKOUTS: no DMA / no fragment reads / neither / MFMAs
+// only -- results are garbage, tools/gemm_s4_knock.py uses them for nothing but a clock).
 template <typename T, int VAR>
 __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -821,18 +820,15 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     const int sub_row = lane >> 3;
     const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
     auto u32 = [](int64_t v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v); };
-    auto make_srd = [&](const void* base, int64_t byte_off) {
-        const uint64_t a = (uint64_t)(uintptr_t)base + (uint64_t)byte_off;
-        i32x4_t r;
-        r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffu));     // stride 0: raw buffer
-        r[2] = -1;                                                                       // num_records: no clamping used
-        r[3] = 0x00020000;                                                               // 32-bit data format, raw
-        return r;
+    auto sgpr64 = [](const void* q, int64_t byte_off) {      // a wave-uniform address as a value the compiler keeps in SGPRs
+        const uint64_t u = (uint64_t)(uintptr_t)q + (uint64_t)byte_off;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return ((uint64_t)hi << 32) | lo;
     };
     const int lda = __builtin_amdgcn_readfirstlane((int)p.lda), ldb = __builtin_amdgcn_readfirstlane((int)g.ldb);
-    i32x4_t srdA = make_srd(p.A, (int64_t)m0 * lda * (int64_t)sizeof(T));
-    i32x4_t srdB = make_srd(g.B, (int64_t)n0 * ldb * (int64_t)sizeof(T));
+    // buffer descriptors (built inside the asm, in the pinned s[84:87] / s[88:91]) start at the TILE's first row
+    uint64_t baseA = sgpr64(p.A, (int64_t)m0 * lda * (int64_t)sizeof(T));
+    uint64_t baseB = sgpr64(g.B, (int64_t)n0 * ldb * (int64_t)sizeof(T));
     unsigned voffA = (unsigned)(((wave * 8 + sub_row) * lda + sub_slot * 8) * (int)sizeof(T));
     unsigned voffB = (unsigned)(((wave * 8 + sub_row) * ldb + sub_slot * 8) * (int)sizeof(T));
     unsigned soA[8], soB[8];
@@ -843,7 +839,7 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     }
     unsigned stepA = TK * sizeof(T), stepB = TK * sizeof(T);
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;      // 0: no static LDS in this kernel (stage bit = 0x10000)
-    unsigned m0A = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024), m0B = m0A + 32 * 1024;
+    unsigned m0b = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024 + 64);     // + 64: gen_gemm256s.py M0_BIAS
     const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
     unsigned rdA[2], rdB[2];
 #pragma unroll
@@ -851,52 +847,48 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
         rdA[h] = lds_base + (wm * 8) * 2048 + (frag_off0 ^ (h * 64));
         rdB[h] = lds_base + 32 * 1024 + (wn * 8) * 2048 + (frag_off0 ^ (h * 64));
     }
-    const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);       // host: >= 2
+    const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);       // host: >= 3
     const int nk_rank = __builtin_amdgcn_readfirstlane(g.lora_xk != nullptr ? g.Rk / TK : 0);
-    unsigned cnt = 0, tmp;
+    unsigned cnt = 0;
 
-#define G256S_ASM(BODY)                                                                                        \
-    asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_SO, G256S_OUT_M0, [cnt] "+s"(cnt), [tmp] "=&s"(tmp) \
-                 : G256S_IN_DMA : "memory", "m0", "scc")
+#define G256S_ASM(BODY)                                                                              \
+    asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt)   \
+                 : G256S_IN_SO, G256S_IN_DMA : G256S_CLOBBER)
 #define G256S_RUN(MACRO)                                                    \
     do {                                                                    \
         if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(MACRO("bf16")); \
         else G256S_ASM(MACRO("f16"));                                       \
     } while (0)
+// bodies without DMA take no DMA operands: the values the rank-block branch below rewrites are then dead at its join
+// (as live-out "s" operands they become PHIs, which hipcc refuses to keep in SGPRs: "illegal VGPR to SGPR copy")
+#define G256S_ASM_C(BODY) asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD : : "memory")
+#define G256S_RUN_C(MACRO)                                                  \
+    do {                                                                    \
+        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM_C(MACRO("bf16")); \
+        else G256S_ASM_C(MACRO("f16"));                                     \
+    } while (0)
 
     // ---- prologue: K tiles 0 and 1 in flight, tile 0 landed and published, its k-half-0 fragments in registers
+    G256S_RUN(G256S_SETSRC);
     G256S_RUN(G256S_ISSUE_TILE);
     G256S_RUN(G256S_ISSUE_TILE);
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    G256S_RUN(G256S_READ0);
-    // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper
-    cnt = (unsigned)(nk_main - 2);
-    if (cnt) {
-        if constexpr (VAR == 1) {
-            G256S_RUN(G256S_LOOP_PAR);         // HW_ID[4] = low bit of the SIMD id: odd SIMDs take the shifted body
-        } else if constexpr (VAR == 2) {
-            G256S_RUN(G256S_LOOP_KND);
-        } else if constexpr (VAR == 3) {
-            G256S_RUN(G256S_LOOP_KNR);
-        } else if constexpr (VAR == 4) {
-            G256S_RUN(G256S_LOOP_KMF);
-        } else if constexpr (VAR == 5) {
-            G256S_RUN(G256S_LOOP_KMO);
-        } else if constexpr (VAR == 6) {
-            G256S_RUN(G256S_LOOP_XSO);
-        } else if constexpr (VAR == 7) {
-            G256S_RUN(G256S_LOOP_AL64);
-        } else if constexpr (VAR == 8) {
-            G256S_RUN(G256S_LOOP_SH4);
-        } else {
-            G256S_RUN(G256S_LOOP0);
-        }
-    }
-    // ---- the rank block's tiles are fetched from XK [M, Rk] / BK [N, Rk] by the same bodies: only the sources change
+    G256S_RUN_C(G256S_READ0);
+    // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper (the loop runs cnt + 1 trips)
+    //      -- unconditional (host: K >= 192): a branch around an asm statement with "+s" operands makes them PHIs
+    cnt = (unsigned)(nk_main - 3);
+    if constexpr (VAR == 2) G256S_RUN(G256S_LOOP_KND);
+    else if constexpr (VAR == 3) G256S_RUN(G256S_LOOP_KNR);
+    else if constexpr (VAR == 4) G256S_RUN(G256S_LOOP_KMF);
+    else if constexpr (VAR == 5) G256S_RUN(G256S_LOOP_KMO);
+    else if constexpr (VAR == 6) G256S_RUN(G256S_LOOP_KNV);
+    else if constexpr (VAR == 7) G256S_RUN(G256S_LOOP_KNB);
+    else G256S_RUN(G256S_LOOP);
+    // ---- the rank block's tiles are fetched from XK [M, Rk] / BK [N, Rk] by the same body: only the sources change
     if (nk_rank) {
         const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
-        srdA = make_srd(g.lora_xk, (int64_t)m0 * ld_xk * (int64_t)sizeof(T));
-        srdB = make_srd(g.lora_bk, (int64_t)n0 * ld_bk * (int64_t)sizeof(T));
+        baseA = sgpr64(g.lora_xk, (int64_t)m0 * ld_xk * (int64_t)sizeof(T));
+        baseB = sgpr64(g.lora_bk, (int64_t)n0 * ld_bk * (int64_t)sizeof(T));
         int ln = lane;
         asm volatile("" : "+v"(ln));             // rebuilt here, not held across the main loop
         const int sr = ln >> 3, ss = (ln & 7) ^ (((wave & 1) << 2) | (sr >> 1));
@@ -907,11 +899,14 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
             soA[c] = u32((int64_t)c * 32 * ld_xk * (int64_t)sizeof(T));
             soB[c] = u32((int64_t)c * 32 * ld_bk * (int64_t)sizeof(T));
         }
-        cnt = (unsigned)nk_rank;
-        G256S_RUN(G256S_LOOP0);
+        G256S_RUN(G256S_SETSRC);
+        cnt = (unsigned)(nk_rank - 1);
+        G256S_RUN(G256S_LOOP);
     }
-    G256S_RUN(G256S_NODMA);
-    G256S_RUN(G256S_LAST);
+    G256S_RUN_C(G256S_NODMA);
+    G256S_RUN_C(G256S_LAST);
+#undef G256S_RUN_C
+#undef G256S_ASM_C
 #undef G256S_RUN
 #undef G256S_ASM
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // last MFMA's write -> the epilogue's v_accvgpr_read (asm MFMAs)
@@ -1209,10 +1204,10 @@ int launch256s(const G256Args& a, hipStream_t st) {
         if (v == 6) return launch256s_<T, 5>(a, st);
         if (v == 7) return launch256s_<T, 6>(a, st);
         if (v == 8) return launch256s_<T, 7>(a, st);
-        if (v == 9) return launch256s_<T, 8>(a, st);
     }
 #endif
-    return v == 2 ? launch256s_<T, 1>(a, st) : launch256s_<T, 0>(a, st);
+    (void)v;
+    return launch256s_<T, 0>(a, st);
 }
 
 template <typename T, bool BNN, bool ATN = false>
@@ -1348,7 +1343,7 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
         return UAMD_ERR_DTYPE;
     }
     // whole-tile NT launches: the one-wave-per-SIMD kernel (UAMD_TUNE_GEMM_S)
-    if (!bnn && K >= 2 * TK && (M & (TM - 1)) == 0 && uamd_tuning_get(UAMD_TUNE_GEMM_S) != 0) {
+    if (!bnn && K >= 3 * TK && (M & (TM - 1)) == 0 && uamd_tuning_get(UAMD_TUNE_GEMM_S) != 0) {
         bool whole = true;
         for (int i = 0; i < n_groups; ++i) whole = whole && (groups[i].N & (TN - 1)) == 0;
         if (whole) {
