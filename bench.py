@@ -422,6 +422,8 @@ def main():
                     p.data.copy_((torch.randn(p.shape, generator=g_) * 0.02).to(p.device))
         return n_train
 
+    last_timing = {}
+
     def timed_steps(step_fn, steps, warmup, per_step=False):
         """W untimed + exactly K timed calls of step_fn(i), barrier + synchronize on both sides, MAX over ranks.
         per_step (the short `alt` points only, never the primary): every step is bracketed on its own and the MEDIAN step
@@ -453,7 +455,13 @@ def main():
             dt = time.perf_counter() - t0
         timer.enabled = False
         peak = torch.cuda.max_memory_allocated()
+        last_timing["per_rank_ms_per_step"] = [round(dt / steps * 1e3, 2)]
         if world > 1:
+            # every rank's own clock over the same K steps (the line's ms_per_step is their MAX): a straggler shows here
+            mine = torch.tensor([dt / steps * 1e3], device=dev, dtype=torch.float64)
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            last_timing["per_rank_ms_per_step"] = [round(float(t), 2) for t in allr]
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax)
@@ -690,7 +698,26 @@ def main():
     # the PRIMARY measurement first, on the freshly initialised model (loss_first_last starts at ~ln V); the other operating
     # points afterwards (their warm-up / timing steps keep training the same adapters, which no longer matters)
     batches, n_items = make_batches(B)
+    if arena is not None:
+        arena.timing = True              # events around the waits of finish(): what the overlap with the backward did not hide
     dt, peak, loss_vals, gs = measure(GC_MODE[a.gc], a.steps, a.warmup)
+    primary_per_rank = list(last_timing.get("per_rank_ms_per_step", []))
+    dp_diag = None
+    if arena is not None:
+        # (warm-up steps' waits are in the sum too: divide by all the steps that ran)
+        exposed = arena.exposed_ms() / max(1, a.steps + a.warmup)
+        arena.timing = False
+        ex = torch.tensor([exposed], device=dev, dtype=torch.float64)
+        exs = [torch.zeros_like(ex) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(exs, ex)
+        else:
+            exs = [ex]
+        dp_diag = dict(dp_exposed_ms=round(max(float(t) for t in exs), 3), dp_exposed_ms_per_rank=[round(float(t), 3) for t in exs],
+                       dp_buckets=len(arena.buckets), dp_bucket_mb=[round((e - s_) * 4 / 2**20, 1) for s_, e, _ in arena.buckets],
+                       dp_collectives_per_step=round(arena.collectives / max(1, a.steps + a.warmup), 2),
+                       note="dp_exposed_ms = HIP events on the compute stream around the waits of LoRAGradArena.finish(), per step, "
+                            "MAX over ranks: the part of the exchange the backward did not hide")
     base_ = model.get_base_model().model
     sched = getattr(base_, "_uamd_auto_policy", None)
     primary_policy = None
@@ -922,6 +949,7 @@ def main():
             "value_with_resident_mirrors": with_mirrors, "vram_batch1_unsloth_min": batch1_min,
             "gpu_baseline": gpu_base,
             "vs_gpu_baseline": vs_gpu,
+            "per_rank_ms_per_step": primary_per_rank, "dp": dp_diag,
             "roofline": roofline, "cpu_baseline": cpu, "alt": alt,
         }
         os.write(real_stdout, (json.dumps(rec) + "\n").encode())

@@ -155,12 +155,15 @@ int uamd_glu_bwd_xa(int act, void* DW, void* e, void* g, int M, int K, int64_t l
                     void* out_k_u, int64_t ld_k_u, int k_cols_u,
                     const void* Wg, int64_t ldwg, int Rg, float* out_g, int64_t ld_out_g, int out_cols_g,
                     void* out_k_g, int64_t ld_k_g, int k_cols_g, int dtype, void* stream);
-/* The same two calls with the columns of every 16-row group SPLIT over adjacent workgroups of 1024 columns (round 5: workgroups
- * that each walk along their own rows sweep the matrix column slab by column slab, 4.4-4.8 TB/s on the access pattern alone;
- * split over 14 adjacent workgroups 5.8; tools/probes/tile_shape_probe.hip). The rank products of a part go to `ws` as fp32
- * partials and the workgroup that finishes a row group last adds them in part order (deterministic). ws: >=
- * uamd_glu_xa_workspace(M, K, n_products, max rank) floats; counters: (M + 15) / 16 ints, ZERO on entry, left zero. One workspace
- * per device and stream. UAMD_TUNE_GLU_XA < 3 or a GeGLU activation run the unsplit kernels of the calls above (ws unused).
+/* The same two calls with the columns of every 16-row group SPLIT into TWO EVEN parts taken by adjacent workgroups -- where that
+ * measured faster (round 5, tools/probes/tile_shape_probe.hip: workgroups that each walk along their own rows sweep the matrix
+ * column slab by column slab, 4.4-4.8 TB/s on the access pattern alone): rows of whole 4 KiB pages (K * itemsize % 4096 == 0) or
+ * at most 2048 rows, and at least 8 column tiles; everywhere else (and for UAMD_TUNE_GLU_XA < 3, a GeGLU activation, or a target
+ * other than gfx942 / gfx950) these calls run the unsplit kernels above and `ws` is unused. The rank products of a part go to `ws`
+ * as fp32 partials and the workgroup that finishes a row group last adds them in part order (deterministic).
+ * ws: >= uamd_glu_xa_workspace(M, K, n_products, max rank) floats -- an UPPER bound sized for parts of at least 4 tiles, not the
+ * shipped two-part rule; counters: (M + 15) / 16 ints, ZERO on entry, left zero by a launch that completes (re-zero them after any
+ * launch that returned an error). One workspace per device and stream.
  * Same results: the element-wise outputs bit for bit, the rank products up to fp32 summation order. */
 int64_t uamd_glu_xa_workspace(int M, int K, int n_products, int max_rank);
 int uamd_glu_fwd_xa_ws(int act, const void* e, const void* g, void* h, int M, int K, int64_t ld, const void* W, int64_t ldw,

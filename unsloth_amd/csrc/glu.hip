@@ -609,6 +609,24 @@ glu_xa_kernel(T* __restrict__ DW, T* __restrict__ E, T* __restrict__ G, T* __res
 // 16] fp32: well under 1 % of the kernel's traffic), summed in part order by whichever workgroup finishes the row group last.
 // The probe measured e * g at 28,672-byte rows; at other widths the unsplit walk is not as far from the flat sweep and the split
 // buys nothing (launch_xa), so "the order of the sweep" is the mechanism for Llama-3-8B's MLP width, not a law.
+// is the current device one whose ISA the fence-free split hand-off was written for (see launch_xa)?
+inline bool split_handoff_ok() {
+    static int ok[64] = {0};            // 0 = unknown, 1 = yes, 2 = no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (ok[dev] == 0) {
+        hipDeviceProp_t pr;
+        bool y = false;
+        if (hipGetDeviceProperties(&pr, dev) == hipSuccess) {
+            const char* a = pr.gcnArchName;
+            auto starts = [&](const char* q) { for (int i = 0; q[i]; ++i) if (a[i] != q[i]) return false; return true; };
+            y = starts("gfx942") || starts("gfx950");
+        }
+        ok[dev] = y ? 1 : 2;
+    }
+    return ok[dev] == 1;
+}
+
 constexpr int GX_TPB = 4;     // (workspace sizing: parts of at least this many tiles)
 
 template <typename T, int ACT, int NS>
@@ -632,7 +650,12 @@ int launch_xa(void* dw, void* e, void* g, void* h, int M, int K, int64_t ld, con
     // (4096 x 18944: 92 / 191 vs 94 / 192 us) or a few percent slower (8192 x 11008, 8192 x 5632), and uneven or many parts lose
     // outright (three parts of 28 + 28 + 18 tiles at 18944 columns: +20 %; parts of 4 tiles: the prefetch's fill and drain per 4
     // tiles of work). UAMD_TUNE_GLU_XA: 3 = this rule, 8 = two even parts always (A/B).
-    const bool two = ntiles >= 8 && (xv == 8 || ((int64_t)K * (int64_t)sizeof(T)) % 4096 == 0 || M <= 2048);
+    // The split's hand-off (relaxed agent-scope stores + s_waitcnt vmcnt(0) + barrier + relaxed counter increment, no fence) is
+    // outside the C++ memory model: it is correct because gfx942 / gfx950 write such stores through and count them in vmcnt. Any
+    // other target gets the unsplit kernel. `counters` must be all zero on entry: a launch that died mid-flight leaves them
+    // dirty -- the host wrapper (kernels/utils.py) re-zeroes its counters whenever a launch of this family returned an error.
+    const bool kSplitOk = split_handoff_ok();
+    const bool two = kSplitOk && ntiles >= 8 && (xv == 8 || ((int64_t)K * (int64_t)sizeof(T)) % 4096 == 0 || M <= 2048);
     const int tpb = two ? (ntiles + 1) / 2 : ntiles;
     int nparts = (xv >= 3 && ws != nullptr && counters != nullptr) ? (ntiles + tpb - 1) / tpb : 1;
     if (nparts < 2) nparts = 1;

@@ -82,6 +82,10 @@ class LoRAGradArena:
         self.writes = 0                                    # gradients accumulated so far (optim.FlatAdamW: "is the arena dirty?")
         self._handles = []
         self._sync = True
+        # timing = True: finish() brackets its waits with events on the compute stream -- the time the step is BLOCKED on
+        # the exchange (what the overlap did not hide); read with exposed_ms() after a synchronize (bench.py `dp_exposed_ms`)
+        self.timing = False
+        self._wait_events = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         self._views = {id(p): p.grad for p in self.params}
         import weakref as _weakref
@@ -170,12 +174,27 @@ class LoRAGradArena:
             for b in range(len(self.buckets)):
                 if not self._launched[b]:
                     self._launch(b)
+            timed = self.timing and self.arena.is_cuda
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             for h in self._handles:
                 h.wait()
+            if timed:
+                e1.record()
+                self._wait_events.append((e0, e1))
         self._handles = []
         self._pending = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._arrived.clear()
+
+    def exposed_ms(self, reset=True):
+        """Sum over the finish() calls since the last reset of the time the compute stream spent waiting for collectives
+        (timing = True; call after torch.cuda.synchronize())."""
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        if reset:
+            self._wait_events = []
+        return ms
 
     @contextmanager
     def no_sync(self):

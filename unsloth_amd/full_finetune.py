@@ -107,6 +107,8 @@ class FullGradBuckets:
         self._written = set()                  # ids whose gradient view holds THIS step's gradient
         self._arrived = set()                  # ids counted towards their bucket in THIS backward
         self._sync = True
+        self.timing = False                    # wait() brackets itself with events: exposed_ms() (see dp.LoRAGradArena)
+        self._wait_events = []
         self.collectives = 0                   # reduce-scatters issued so far (telemetry: tests, bench)
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         # direct sinks (kernels/utils.GRAD_SINKS): the weight-gradient GEMM / the norm dW kernel / the chunked lm_head
@@ -212,9 +214,23 @@ class FullGradBuckets:
     def wait(self, bi):
         b = self.buckets[bi]
         if b["handle"] is not None:
+            timed = self.timing and self.device.type == "cuda"
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             b["handle"].wait()
+            if timed:
+                e1.record()
+                self._wait_events.append((e0, e1))
             b["handle"] = None
         b["launched"] = False
+
+    def exposed_ms(self, reset=True):
+        """Time the compute stream spent blocked on reduce-scatters since the last reset (timing = True; after a synchronize)."""
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        if reset:
+            self._wait_events = []
+        return ms
 
     def gather_params(self, bi, async_op=True):
         """All-gather the updated parameter slices of bucket `bi` back into its flat parameter buffer (in place)."""

@@ -33,17 +33,22 @@ def supported(q, k, v):
             and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) <= 8)
 
 
-_ZEROS = {}         # (shape, dtype, device) -> a zero tensor that is only ever READ (the padding operand of the concatenations below)
+_ZEROS = {}         # (dtype, device) -> ONE flat zero buffer that is only ever READ (the padding operand of the concatenations below)
 
 
 def _zeros(shape, dtype, device):
-    key = (tuple(shape), dtype, device)
+    """A zero tensor of `shape` as a view of a per-(dtype, device) flat buffer that only ever GROWS (a buffer is never freed
+    while a concatenation on some stream may still read it, and variable shapes -- ViT grids, packed rows -- share it instead of
+    pinning one tensor per shape)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    key = (dtype, torch.device(device))
     z = _ZEROS.get(key)
-    if z is None:
-        if len(_ZEROS) > 64:
-            _ZEROS.clear()
-        z = _ZEROS[key] = torch.zeros(shape, dtype=dtype, device=device)
-    return z
+    if z is None or z.numel() < n:
+        grown = torch.zeros(max(n, 2 * z.numel() if z is not None else 0), dtype=dtype, device=device)
+        z = _ZEROS[key] = grown          # the old buffer stays alive as long as a view of it does
+    return z[:n].view(tuple(int(d) for d in shape))
 
 
 def _pad_heads(x, G, Gp, D):

@@ -964,6 +964,8 @@ def glu_fwd_xa(act, e, g, down, n_out_cols_hint=None):
                                            _lib.ptr(xk) if xk is not None else None, xk.stride(0) if xk is not None else 0,
                                            xk.shape[1] if xk is not None else 0, _lib.ptr(part), part.numel(), _lib.ptr(counters),
                                            _lib.dtype_code(dtype), _lib.stream_of(e))
+    if rc != 0:
+        counters.zero_()                 # a launch that did not complete may leave arrival counts behind (include/unsloth_amd.h)
     _lib.check(rc, "uamd_glu_fwd_xa_ws")
     return h, (xa, [(0, r)], xk)
 
@@ -995,6 +997,8 @@ def glu_bwd_terms(act, DW, e, g, up, gate):
             _lib.ptr(Bgt), Bgt.stride(0), rg, _lib.ptr(pg), shared.stride(0), rg,
             _lib.ptr(xk[:, ru:]) if want_k else null, xk.stride(0) if want_k else 0, (xk.shape[1] - ru) if want_k else 0,
             _lib.ptr(part), part.numel(), _lib.ptr(counters), _lib.dtype_code(dtype), _lib.stream_of(e))
+    if rc != 0:
+        counters.zero_()
     _lib.check(rc, "uamd_glu_bwd_xa_ws")
     if want_k:
         pu._uamd_xk = (xk, 0)

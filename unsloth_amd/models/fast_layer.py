@@ -122,8 +122,9 @@ def auto_policy(model, hidden_states):
         # -- of THIS model's projections only (the switch sits on its quant states): another NF4 model in the process (a
         # reference / policy model, an engine) decides for itself, from the memory that is free when ITS first step runs
         auto_on = getattr(model, "_uamd_mirrors_auto", False)
+        callers = _nf4.mirrors_on(model) and not auto_on        # switched on by the caller (model=m or process-wide): not ours
         want = pol == POLICIES["all"] and mirrors_fit(*args, vocab=vocab, have_mirrors=auto_on and _nf4.resident_count(model) > 0)
-        if want and not auto_on and not _nf4.RESIDENT:
+        if want and not auto_on and not callers:
             _nf4.set_resident(True, auto=True, model=model)
         elif not want and auto_on:                    # (mirrors a caller switched on with nf4.set_resident(True) are the caller's)
             _nf4.set_resident(False, model=model)

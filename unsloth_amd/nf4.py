@@ -208,6 +208,8 @@ RESIDENT = RESIDENT_MODE == "1"
 import weakref as _weakref
 
 _MIRRORED = _weakref.WeakSet()      # quant states that carry a decoded mirror (`_resident`, `_resident_group`)
+_MARKED = _weakref.WeakSet()        # quant states whose `_mirror_on` a per-model set_resident(True, model=m) raised
+_MARKED_MODELS = _weakref.WeakSet() # ... and those models (their `_uamd_mirrors_auto` record)
 
 
 def _model_quant_states(model):
@@ -233,15 +235,29 @@ def set_resident(on, auto=False, model=None):
     if model is None:
         RESIDENT = bool(on)
         if not on:
-            for q in list(_MIRRORED):
+            # every per-model decision too: the states that already hold a mirror AND the ones only marked so far (a model
+            # switched on with model=m whose weights have not been decoded yet), and the owners' "auto" records
+            for q in list(_MIRRORED) + list(_MARKED):
                 q._mirror_on = False
                 _drop(q)
+            _MARKED.clear()
+            for m in list(_MARKED_MODELS):
+                m._uamd_mirrors_auto = False
+            _MARKED_MODELS.clear()
         return
     for q in _model_quant_states(model):
         q._mirror_on = bool(on)
-        if not on and not RESIDENT:
-            _drop(q)
+        if on:
+            _MARKED.add(q)
+        else:
+            _MARKED.discard(q)
+            if not RESIDENT:
+                _drop(q)
     model._uamd_mirrors_auto = bool(on) and bool(auto)
+    if on:
+        _MARKED_MODELS.add(model)
+    else:
+        _MARKED_MODELS.discard(model)
 
 
 def mirrors_on(model):
