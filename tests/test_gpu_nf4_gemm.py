@@ -438,18 +438,20 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
         L.uamd_set_tuning(11, 1)
 
 
+@pytest.mark.parametrize("nn", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,Ns,K,rank", [(4096, (4096, 1024, 1024), 512, True),      # 3 groups, per-group rank blocks
-                                         (512, (256,), 128, False),                    # the minimum: two K tiles, no loop trip
+                                         (512, (256,), 128, False),                    # below the kernel's K >= 192: the 8-wave path
                                          (512, (512,), 192, True),                     # one loop trip + one rank tile
                                          (2048, (2560,), 1024, True),
                                          (1024, (1024,), 4096, False),                 # a long K loop
                                          (256, (768, 256), 320, True)])                # odd K-tile count
-def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(dtype, M, Ns, K, rank):
+def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(nn, dtype, M, Ns, K, rank):
     """gemm_nt256s_kernel (4 waves x 128 x 128, hand-ordered K loop, `buffer_load ... lds` pieces with SGPR offsets; knob 11,
-    default for whole-tile NT launches) against the 8-wave gemm_nt256_kernel: same LDS image, same per-accumulator k order
-    (main tiles in order, then the rank block's), so BIT-IDENTICAL -- multi-group launches with per-group rank blocks,
-    accumulate, bias-free, padded row strides; and run-to-run deterministic."""
+    default for whole-tile NT and NN launches) against the 8-wave gemm_nt256_kernel: same LDS image, same per-accumulator k
+    order (main tiles in order, then the rank block's), so BIT-IDENTICAL -- multi-group launches with per-group rank blocks,
+    accumulate, bias-free, padded row strides, both operand forms (NN: B and BK as [K, N], transposing fragment reads into
+    pinned registers); and run-to-run deterministic."""
     from unsloth_amd import _lib
     from unsloth_amd.kernels.utils import _group, _launch_gemm
     from unsloth_amd.kernels import utils as U
@@ -460,9 +462,18 @@ def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(dtype, M, Ns, K, ran
     xk[:, :16] = torch.randn(M, 16, generator=g(272)).to(dtype).to(DEV)
     Bs, BKs = [], []
     for i, N in enumerate(Ns):
-        Bs.append((torch.randn(N, K, generator=g(273 + i)) * 0.05).to(dtype).to(DEV))
-        bk = torch.zeros((N, 64), dtype=dtype, device=DEV)
-        bk[:, :16] = (torch.randn(N, 16, generator=g(283 + i)) * 0.05).to(dtype).to(DEV)
+        W = (torch.randn(N, K, generator=g(273 + i)) * 0.05).to(dtype)
+        blk = (torch.randn(N, 16, generator=g(283 + i)) * 0.05).to(dtype)
+        if nn:                                                    # [K, N] with a padded row stride
+            Bn = torch.empty(K, N + 8, dtype=dtype, device=DEV)[:, :N]
+            Bn.copy_(W.t())
+            Bs.append(Bn)
+            bk = torch.zeros((64, N), dtype=dtype, device=DEV)
+            bk[:16] = blk.t().to(DEV)
+        else:
+            Bs.append(W.to(DEV))
+            bk = torch.zeros((N, 64), dtype=dtype, device=DEV)
+            bk[:, :16] = blk.to(DEV)
         BKs.append(bk)
 
     def run(knob, accumulate):
@@ -473,7 +484,7 @@ def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(dtype, M, Ns, K, ran
             groups.append(_group(Bs[i], outs[i], N, Bs[i].stride(0), xa=xk if use_rank else None, ld_xa=64, R=16, scale=1.0,
                                  xk=xk if use_rank else None, bk=BKs[i] if use_rank else None))
         L.uamd_set_tuning(11, knob)
-        _launch_gemm(Xs, groups, nf4=False, accumulate=accumulate, nn=False)
+        _launch_gemm(Xs, groups, nf4=False, accumulate=accumulate, nn=nn)
         return outs
 
     old = U.GEMM256_MODE
@@ -489,9 +500,9 @@ def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(dtype, M, Ns, K, ran
                 assert torch.equal(o, o2), "run-to-run"
                 assert torch.equal(r, o), float((r.float() - o.float()).abs().max())
         y = run(1, False)[0]
-        want = Xs.float().cpu() @ Bs[0].float().cpu().t()
+        want = Xs.float().cpu() @ (Bs[0].float().cpu() if nn else Bs[0].float().cpu().t())
         if rank:
-            want = want + xk.float().cpu() @ BKs[0].float().cpu().t()
+            want = want + xk.float().cpu() @ (BKs[0].float().cpu() if nn else BKs[0].float().cpu().t())
         _check_gemm(y, want, dtype, K, "gemm256s")
     finally:
         U.GEMM256_MODE = old

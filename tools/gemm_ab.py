@@ -26,6 +26,7 @@ def run(fn, iters):
 
 def main():
     out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
+    outfile = out
     bf = torch.bfloat16
     L = _lib.lib()
     shapes = [(8192, 4096, 4096, "o"), (8192, 14336, 4096, "gate"), (8192, 4096, 14336, "down"),
@@ -76,6 +77,42 @@ def main():
         if out:
             out.write(json.dumps(rec) + "\n")
             out.flush()
+        del X, W, ref
+    # the dX products (NN: B given as [K, N], the weight's own row-major layout): dY [M, out] @ W [out, in]
+    from unsloth_amd.kernels.utils import _group, _launch_gemm
+    for M, N, K, tag in [(8192, 14336, 4096, "down-dX"), (8192, 4096, 14336, "gate-dX"), (8192, 4096, 4096, "o-dX"),
+                         (2048, 14336, 4096, "down-dX@2k")]:
+        X = torch.randn(M, K, device=DEV, dtype=bf)
+        W = (torch.randn(K, N, device=DEV) * 0.02).to(bf)
+        ref = X @ W
+        out = torch.empty(M, N, device=DEV, dtype=bf)
+
+        def mkn(sv):
+            def f():
+                L.uamd_set_tuning(1, 8)
+                L.uamd_set_tuning(11, sv)
+                _launch_gemm(X, [_group(W, out, N, W.stride(0))], nf4=False, accumulate=False, nn=True)
+                return out
+            return f
+        cands = {"torch": lambda: X @ W, "pp": mkn(0), "s4": mkn(1)}
+        for name, f in cands.items():
+            y = f()
+            rel = float((y.float() - ref.float()).norm() / ref.float().norm())
+            if rel > 2e-2 or rel != rel:
+                print(json.dumps(dict(shape=tag, kernel=name, ERROR="mismatch", rel=rel)), flush=True)
+        for f in cands.values():
+            run(f, 3)
+        best = {k: 1e9 for k in cands}
+        for _ in range(5):
+            for name, f in cands.items():
+                best[name] = min(best[name], run(f, 10))
+        fl = 2.0 * M * N * K
+        rec = dict(shape=tag, form="NN", M=M, N=N, K=K, **{k: round(fl / v / 1e12, 1) for k, v in best.items()})
+        print(json.dumps(rec), flush=True)
+        if outfile:
+            outfile.write(json.dumps(rec) + "\n")
+            outfile.flush()
+        L.uamd_set_tuning(11, 1)
         del X, W, ref
 
 

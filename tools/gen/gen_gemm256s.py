@@ -32,16 +32,31 @@ consecutive n of one m: 8-byte stores); A-operand = the activations, MFMA source
 """
 import os
 
+NN = False             # set by main(): B-operand given as [K, N] (the dX products): transposing fragment reads, 2-k-row pieces
 SRD = {"A": "s[84:87]", "B": "s[88:91]"}
 SRD_LO = {"A": ("s84", "s85"), "B": ("s88", "s89")}
-OPOFF = {"A": 0, "B": 32 * 1024}
-M0_BIAS = 64          # %[m0b] = LDS address of the wave's first piece in the target stage + 64: every "m0 = base + k" is then
-                      # an 8-byte literal add (k = 0 would be an inline constant = a 4-byte instruction)
+M0_BIAS = 64          # %[m0bA] / %[m0bB] = LDS address of the wave's first piece of that operand in the target stage + 64: every
+                      # "m0 = base + k" is then an 8-byte literal add (k = 0 would be an inline constant = a 4-byte instruction)
+# LDS offset of a wave's piece c relative to its first piece. Row-major operand tiles ([256 rows][64 k], NT): sub-tile c * 4 + w.
+# [64 k][256 n] tiles (NN): a piece is two k-rows; sub-tile u = (w & 1) | (c & 1) << 1 | (w >> 1) << 2 | (c >> 1) << 3, so that the
+# bank swizzle f(k-row) = (krow & 3) | ((krow >> 3) & 1) << 2 does not depend on c and ONE per-lane offset serves all pieces.
+PIECE_LDS_ROWS = [c * 4096 for c in range(8)]
+PIECE_LDS_NN = [(c & 1) * 2048 + (c >> 1) * 8192 for c in range(8)]
+XREG0 = 192           # NN: the B-operand fragments live in PINNED v[192:255] (a 64-bit transposing read fills HALF a fragment, and an
+                      # asm operand cannot name half of a register tuple): fragment (h, x) = v[192 + 32 h + 4 x : +3]
+
+
+def xreg(h, x, half=None):
+    r = XREG0 + 32 * h + 4 * x
+    if half is None:
+        return f"v[{r}:{r + 3}]"
+    return f"v[{r + 2 * half}:{r + 2 * half + 1}]"
 
 
 def mfma(h, x, y):
     q = x * 8 + y
-    return f"v_mfma_f32_16x16x32_\" TS \" %[acc{q}], %[x{h}_{x}], %[y{h}_{y}], %[acc{q}]"
+    xs = xreg(h, x) if NN else f"%[x{h}_{x}]"
+    return f"v_mfma_f32_16x16x32_\" TS \" %[acc{q}], {xs}, %[y{h}_{y}], %[acc{q}]"
 
 
 def rd_y(h, y):
@@ -49,7 +64,12 @@ def rd_y(h, y):
 
 
 def rd_x(h, x):
-    return f"ds_read_b128 %[x{h}_{x}], %[rdB{h}] offset:{x * 2048}"
+    """B-operand fragment x of k-half h: one instruction (row-major tile) or two transposing reads (k-rows 0-3 | 4-7 of the
+    lane's 8, 4 x 512 bytes apart; the k-half is 32 k-rows = 16 KiB further)"""
+    if NN:
+        return [f"ds_read_b64_tr_b16 {xreg(h, x, 0)}, %[rdBn{x}] offset:{h * 16384}",
+                f"ds_read_b64_tr_b16 {xreg(h, x, 1)}, %[rdBn{x}] offset:{h * 16384 + 2048}"]
+    return [f"ds_read_b128 %[x{h}_{x}], %[rdB{h}] offset:{x * 2048}"]
 
 
 def dma(op, c):
@@ -57,7 +77,8 @@ def dma(op, c):
 
 
 def m0_for(op, c):
-    return f"s_add_u32 m0, %[m0b], {OPOFF[op] + c * 4096 - M0_BIAS}"
+    off = (PIECE_LDS_NN if (NN and op == "B") else PIECE_LDS_ROWS)[c]
+    return f"s_add_u32 m0, %[m0b{op}], {off - M0_BIAS}"
 
 
 def advance():
@@ -70,7 +91,7 @@ def advance():
 
 def size(ins):
     op = ins.split()[0]
-    if op.startswith(("v_mfma", "ds_read", "buffer_load", "v_xor")):
+    if op.startswith(("v_mfma", "ds_read", "buffer_load", "v_xor")):     # (v_xor: VOP2 + 32-bit literal)
         return 8
     toks = ins.replace(",", " ").split()[1:]
     lits = [t for t in toks if t.lstrip("-").isdigit() or t.startswith("0x")]
@@ -119,7 +140,7 @@ def body(kind, drop=()):
     # barrier 1: every wave has read the A half of this stage (k-half 0 at the end of the previous tile, k-half 1 now)
     before[S["bar1"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     for x in range(8):
-        after[S["x1"][x]].append(rd_x(1, x))
+        after[S["x1"][x]] += rd_x(1, x)
     # barrier 2: every wave has read the B half of this stage
     before[S["bar2"]] += ["s_waitcnt lgkmcnt(0)", "s_barrier"]
     if d:
@@ -130,18 +151,24 @@ def body(kind, drop=()):
                 after[p].insert(0, dma(op, c))
         last = max(S["A"] + S["B"])
         after[last + 1] += advance()                                       # sources: next K tile
-        after[last + 2].append("s_xor_b32 %[m0b], %[m0b], 0x10000")        # destination: the other stage
+        after[last + 2] += ["s_xor_b32 %[m0bA], %[m0bA], 0x10000", "s_xor_b32 %[m0bB], %[m0bB], 0x10000"]   # destination: the other stage
     # ---- phase 2 (k-half 1, MFMAs 64..127)
     if nxt:
-        after[S["xor"]] += ["v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdB0], 0x10000, %[rdB0]"]
-        after[S["xor"] + 1] += ["v_xor_b32 %[rdA1], 0x10000, %[rdA1]", "v_xor_b32 %[rdB1], 0x10000, %[rdB1]"]
+        if NN:
+            xs = [f"v_xor_b32 %[rdBn{x}], 0x10000, %[rdBn{x}]" for x in range(8)]
+            for k in range(4):           # ten pointer flips over five MFMA gaps
+                after[S["xor"] - 3 + k] += xs[2 * k:2 * k + 2]
+            after[S["xor"] + 1] += ["v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdA1], 0x10000, %[rdA1]"]
+        else:
+            after[S["xor"]] += ["v_xor_b32 %[rdA0], 0x10000, %[rdA0]", "v_xor_b32 %[rdB0], 0x10000, %[rdB0]"]
+            after[S["xor"] + 1] += ["v_xor_b32 %[rdA1], 0x10000, %[rdA1]", "v_xor_b32 %[rdB1], 0x10000, %[rdB1]"]
         # tile t + 1 has landed (only pieces of tile t + 2 are in flight) and every wave knows it
         inflight = sum(1 for p in S["A"] + S["B"] if p < S["bar3"])
         before[S["bar3"]] += [f"s_waitcnt vmcnt({inflight})" if d else "s_waitcnt vmcnt(0)", "s_barrier"]
         for y in range(8):
             after[S["y0"][y]].append(rd_y(0, y))
         for x in range(8):
-            after[S["x0"][x]].append(rd_x(0, x))
+            after[S["x0"][x]] += rd_x(0, x)
     out = []
     i = 0
     for h in range(2):
@@ -213,46 +240,61 @@ def loop(instrs):
     return [".p2align 6", "1:"] + b + ["s_cbranch_scc0 1b"], pads
 
 
+def emit_family(pfx):
+    l, pads = loop(body("dma"))
+    print(f"// {'NN' if NN else 'NT'}: schedule '{SCHED}'; steady-state loop: {sum(size(i) for i in l)} bytes, {pads} alignment pads")
+    emit_macro(f"{pfx}_LOOP", l)
+    if not NN:
+        for name, drop in (("KND", {"dma"}), ("KNR", {"read"}), ("KMF", {"dma", "read"}), ("KMO", {"dma", "read", "sync"}),
+                           ("KNV", {"vm"}), ("KNB", {"bar"})):
+            emit_macro(f"{pfx}_LOOP_{name}", loop(body("dma", drop))[0])
+    emit_macro(f"{pfx}_NODMA", [".p2align 3"] + aligned(body("nodma"))[0])
+    emit_macro(f"{pfx}_LAST", [".p2align 3"] + aligned(body("last"))[0])
+    # a whole tile's 16 pieces back to back (prologue), sources advanced, DMA destination flipped
+    pro = []
+    for op in "AB":
+        for c in range(8):
+            pro += [m0_for(op, c), "s_nop 0", dma(op, c)]
+    pro += advance() + ["s_xor_b32 %[m0bA], %[m0bA], 0x10000", "s_xor_b32 %[m0bB], %[m0bB], 0x10000"]
+    emit_macro(f"{pfx}_ISSUE_TILE", pro)
+    rd = [rd_y(0, y) for y in range(8)]
+    for x in range(8):
+        rd += rd_x(0, x)
+    emit_macro(f"{pfx}_READ0", rd + ["s_waitcnt lgkmcnt(0)"])
+    # operand lists
+    fr = ", ".join(f'[{n}{h}_{i}] "+v"({n}f[{h}][{i}])' for n in ("y" if NN else "yx") for h in range(2) for i in range(8))
+    rdp = ", ".join(f'[rdA{h}] "+v"(rdA[{h}])' for h in range(2)) + ", " + \
+        (", ".join(f'[rdBn{x}] "+v"(rdBn[{x}])' for x in range(8)) if NN else ", ".join(f'[rdB{h}] "+v"(rdB[{h}])' for h in range(2)))
+    print(f"#define {pfx}_OUT_FRAGS " + fr)
+    print(f"#define {pfx}_OUT_RD " + rdp)
+    xclob = (", " + ", ".join(f'"v{r}"' for r in range(XREG0, XREG0 + 64))) if NN else ""
+    print(f'#define {pfx}_CLOBBER "memory", "m0", "scc", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"' + xclob)
+    print(f'#define {pfx}_CLOBBER_C "memory"' + xclob)
+    print()
+
+
 def main():
+    global NN
     print("// GENERATED by tools/gen/gen_gemm256s.py -- do not edit (the schedule is documented there).")
     print("// clang-format off")
-    l, pads = loop(body("dma"))
-    print(f"// schedule '{SCHED}'; steady-state loop: {sum(size(i) for i in l)} bytes, {pads} alignment pads")
-    emit_macro("G256S_LOOP", l)
-    for name, drop in (("KND", {"dma"}), ("KNR", {"read"}), ("KMF", {"dma", "read"}), ("KMO", {"dma", "read", "sync"}),
-                       ("KNV", {"vm"}), ("KNB", {"bar"})):
-        emit_macro(f"G256S_LOOP_{name}", loop(body("dma", drop))[0])
-    emit_macro("G256S_NODMA", [".p2align 3"] + aligned(body("nodma"))[0])
-    emit_macro("G256S_LAST", [".p2align 3"] + aligned(body("last"))[0])
-    # the sources of the DMA: buffer descriptors (raw, no range clamp) over the tile origins of both operands
+    NN = False
+    emit_family("G256S")
+    NN = True
+    emit_family("G256SN")
+    # shared: the sources of the DMA -- buffer descriptors (raw, no range clamp) over the tile origins of both operands
     src = []
     for op in "AB":
         lo, hi = SRD_LO[op]
         w2, w3 = ("s86", "s87") if op == "A" else ("s90", "s91")
         src += [f"s_mov_b64 s[{lo[1:]}:{hi[1:]}], %[base{op}]", f"s_mov_b32 {w2}, -1", f"s_mov_b32 {w3}, 0x20000"]
     emit_macro("G256S_SETSRC", src)
-    # a whole tile's 16 pieces back to back (prologue), sources advanced, DMA destination flipped
-    pro = []
-    for op in "AB":
-        for c in range(8):
-            pro += [m0_for(op, c), "s_nop 0", dma(op, c)]
-    pro += advance() + ["s_xor_b32 %[m0b], %[m0b], 0x10000"]
-    emit_macro("G256S_ISSUE_TILE", pro)
-    rd = [rd_y(0, y) for y in range(8)] + [rd_x(0, x) for x in range(8)] + ["s_waitcnt lgkmcnt(0)"]
-    emit_macro("G256S_READ0", rd)
-    # operand lists
     acc = ", ".join(f'[acc{q}] "+a"(acc[{q}])' for q in range(64))
-    fr = ", ".join(f'[{n}{h}_{i}] "+v"({n}f[{h}][{i}])' for n in "yx" for h in range(2) for i in range(8))
-    rdp = ", ".join(f'[rd{o}{h}] "+v"(rd{o}[{h}])' for o in "AB" for h in range(2))
     so = ", ".join(f'[so{o}{c}] "s"(so{o}[{c}])' for o in "AB" for c in range(8))
     print("#define G256S_OUT_ACC " + acc)
-    print("#define G256S_OUT_FRAGS " + fr)
-    print("#define G256S_OUT_RD " + rdp)
-    print('#define G256S_OUT_M0 [m0b] "+s"(m0b)')
+    print('#define G256S_OUT_M0 [m0bA] "+s"(m0bA), [m0bB] "+s"(m0bB)')
     print("#define G256S_IN_SO " + so)
     print('#define G256S_IN_DMA [voffA] "v"(voffA), [voffB] "v"(voffB), [baseA] "s"(baseA), [baseB] "s"(baseB), '
           '[stepA] "s"(stepA), [stepB] "s"(stepB)')
-    print('#define G256S_CLOBBER "memory", "m0", "scc", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"')
     print("// clang-format on")
 
 

@@ -770,7 +770,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 // VAR: 0 = the kernel; 2..5 = knock-out timing builds (-DUAMD_G256S_KNOCKOUTS: no DMA / no fragment reads / neither / MFMAs
 // only -- results are garbage, tools/gemm_s4_knock.py uses them for nothing but a clock).
-template <typename T, int VAR>
+template <typename T, bool BNN, int VAR>
 __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -807,16 +807,24 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     f32x4_t acc[64];                   // acc[x * 8 + y]: n-tile x, m-tile y of the wave's 128 x 128
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    frag_t yf[2][8], xf[2][8];         // [k-half][tile]: A-operand (m) and B-operand (n) fragments
+    frag_t yf[2][8];                   // [k-half][tile]: A-operand (m) fragments
+    frag_t xf[BNN ? 1 : 2][BNN ? 1 : 8];   // B-operand (n) fragments (BNN: in the pinned v[192:255], not operands)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { yf[h][i] = frag_t{}; xf[h][i] = frag_t{}; }
+        for (int i = 0; i < 8; ++i) {
+            yf[h][i] = frag_t{};
+            if constexpr (!BNN) xf[h][i] = frag_t{};
+        }
+    (void)xf;
 
-    // ---- DMA sources. Piece c (0..7) of operand A issued by wave w fills sub-tile c*4 + w = rows (c*4 + w)*8 .. +7 of
-    //      the tile, [8 rows x 64 k] = 8 full lines; lane -> (row = lane >> 3, swizzled 16-byte slot) as everywhere in
-    //      this file. The per-lane part (row inside the first piece, slot) is ONE 32-bit offset per operand; the piece
-    //      (c * 32 rows) and the K tile ride in the eight scalar offsets so[c], advanced by `step` after every use.
+    // ---- DMA sources. A-operand (and the NT B-operand): piece c (0..7) issued by wave w fills sub-tile c*4 + w = rows
+    //      (c*4 + w)*8 .. +7 of the tile, [8 rows x 64 k] = 8 full lines; lane -> (row = lane >> 3, swizzled 16-byte slot) as
+    //      everywhere in this file. The per-lane part (row inside the first piece, slot) is ONE 32-bit offset per operand; the
+    //      piece (c * 32 rows) rides in the eight scalar offsets so[c], the K tile in the descriptor's base.
+    //      NN B-operand ([K, N], a [64 k][256 n] LDS image): piece = two k-rows x 512 B, sub-tile order chosen so that the bank
+    //      swizzle does not depend on c (gen_gemm256s.py PIECE_LDS_NN): k-row of (w, c, h = lane >> 5) = 2 (w & 1) + 8 (w >> 1)
+    //      + h + 4 (c & 1) + 16 (c >> 1), f = h | (w & 1) << 1 | (w >> 1) << 2.
     const int sub_row = lane >> 3;
     const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
     auto u32 = [](int64_t v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v); };
@@ -825,28 +833,45 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         return ((uint64_t)hi << 32) | lo;
     };
+    const int nn_h = lane >> 5;
+    const int nn_krow0 = 2 * (wave & 1) + 8 * (wave >> 1) + nn_h;
+    auto nn_voff = [&](int ld, int ln) {                      // per-lane byte offset of the NN B-operand's piece 0
+        const int f = (ln >> 5) | ((wave & 1) << 1) | ((wave >> 1) << 2);
+        return (unsigned)((nn_krow0 * ld + (((ln & 31) ^ (f << 1)) << 3)) * (int)sizeof(T));
+    };
     const int lda = __builtin_amdgcn_readfirstlane((int)p.lda), ldb = __builtin_amdgcn_readfirstlane((int)g.ldb);
-    // buffer descriptors (built inside the asm, in the pinned s[84:87] / s[88:91]) start at the TILE's first row
+    // buffer descriptors (built inside the asm, in the pinned s[84:87] / s[88:91]) start at the TILE's first row / column
     uint64_t baseA = sgpr64(p.A, (int64_t)m0 * lda * (int64_t)sizeof(T));
-    uint64_t baseB = sgpr64(g.B, (int64_t)n0 * ldb * (int64_t)sizeof(T));
+    uint64_t baseB = BNN ? sgpr64(g.B, (int64_t)n0 * (int64_t)sizeof(T)) : sgpr64(g.B, (int64_t)n0 * ldb * (int64_t)sizeof(T));
     unsigned voffA = (unsigned)(((wave * 8 + sub_row) * lda + sub_slot * 8) * (int)sizeof(T));
-    unsigned voffB = (unsigned)(((wave * 8 + sub_row) * ldb + sub_slot * 8) * (int)sizeof(T));
+    unsigned voffB = BNN ? nn_voff(ldb, lane) : (unsigned)(((wave * 8 + sub_row) * ldb + sub_slot * 8) * (int)sizeof(T));
     unsigned soA[8], soB[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         soA[c] = u32((int64_t)c * 32 * lda * (int64_t)sizeof(T));
-        soB[c] = u32((int64_t)c * 32 * ldb * (int64_t)sizeof(T));
+        soB[c] = BNN ? u32((int64_t)(4 * (c & 1) + 16 * (c >> 1)) * ldb * (int64_t)sizeof(T)) : u32((int64_t)c * 32 * ldb * (int64_t)sizeof(T));
     }
-    unsigned stepA = TK * sizeof(T), stepB = TK * sizeof(T);
+    unsigned stepA = TK * sizeof(T), stepB = BNN ? u32((int64_t)TK * ldb * (int64_t)sizeof(T)) : (unsigned)(TK * sizeof(T));
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;      // 0: no static LDS in this kernel (stage bit = 0x10000)
-    unsigned m0b = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024 + 64);     // + 64: gen_gemm256s.py M0_BIAS
+    // DMA destinations of the wave's first piece of each operand, + 64 (gen_gemm256s.py M0_BIAS)
+    unsigned m0bA = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024 + 64);
+    unsigned m0bB = __builtin_amdgcn_readfirstlane(lds_base + 32 * 1024 + (BNN ? (wave & 1) * 1024 + (wave >> 1) * 4096 : wave * 1024) + 64);
     const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
-    unsigned rdA[2], rdB[2];
+    unsigned rdA[2], rdB[2], rdBn[8];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         rdA[h] = lds_base + (wm * 8) * 2048 + (frag_off0 ^ (h * 64));
         rdB[h] = lds_base + 32 * 1024 + (wn * 8) * 2048 + (frag_off0 ^ (h * 64));
     }
+    {
+        // transposing reads: k-row l4*8 + (l15 >> 2) (+4 for the second read, + 32 for the second k-half), logical 32-byte
+        // granule (16-column tile) wn*8 + x, swizzled by the k-row's f
+        const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
+        const int nn_lane = 32 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) rdBn[x] = lds_base + nn_lane + (((wn * 8 + x) ^ nn_f) << 5);
+    }
+    (void)rdB; (void)rdBn;
     const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);       // host: >= 3
     const int nk_rank = __builtin_amdgcn_readfirstlane(g.lora_xk != nullptr ? g.Rk / TK : 0);
     unsigned cnt = 0;
@@ -854,60 +879,75 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
 #define G256S_ASM(BODY)                                                                              \
     asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt)   \
                  : G256S_IN_SO, G256S_IN_DMA : G256S_CLOBBER)
-#define G256S_RUN(MACRO)                                                    \
-    do {                                                                    \
-        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(MACRO("bf16")); \
-        else G256S_ASM(MACRO("f16"));                                       \
-    } while (0)
+#define G256SN_ASM(BODY)                                                                             \
+    asm volatile(BODY : G256S_OUT_ACC, G256SN_OUT_FRAGS, G256SN_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt) \
+                 : G256S_IN_SO, G256S_IN_DMA : G256SN_CLOBBER)
 // bodies without DMA take no DMA operands: the values the rank-block branch below rewrites are then dead at its join
 // (as live-out "s" operands they become PHIs, which hipcc refuses to keep in SGPRs: "illegal VGPR to SGPR copy")
-#define G256S_ASM_C(BODY) asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD : : "memory")
-#define G256S_RUN_C(MACRO)                                                  \
-    do {                                                                    \
-        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM_C(MACRO("bf16")); \
-        else G256S_ASM_C(MACRO("f16"));                                     \
+#define G256S_ASM_C(BODY) asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD : : G256S_CLOBBER_C)
+#define G256SN_ASM_C(BODY) asm volatile(BODY : G256S_OUT_ACC, G256SN_OUT_FRAGS, G256SN_OUT_RD : : G256SN_CLOBBER_C)
+// NAME: the part of the macro name behind G256S_ / G256SN_; K: ASM (DMA operands) or ASM_C
+#define G256S_RUN2(NAME, K)                                                                 \
+    do {                                                                                    \
+        if constexpr (BNN) {                                                                \
+            if constexpr (std::is_same<T, bf16_t>::value) G256SN_##K(G256SN_##NAME("bf16")); \
+            else G256SN_##K(G256SN_##NAME("f16"));                                          \
+        } else {                                                                            \
+            if constexpr (std::is_same<T, bf16_t>::value) G256S_##K(G256S_##NAME("bf16"));  \
+            else G256S_##K(G256S_##NAME("f16"));                                            \
+        }                                                                                   \
     } while (0)
+#define G256S_RUN(NAME) G256S_RUN2(NAME, ASM)
+#define G256S_RUN_C(NAME) G256S_RUN2(NAME, ASM_C)
 
     // ---- prologue: K tiles 0 and 1 in flight, tile 0 landed and published, its k-half-0 fragments in registers
-    G256S_RUN(G256S_SETSRC);
-    G256S_RUN(G256S_ISSUE_TILE);
-    G256S_RUN(G256S_ISSUE_TILE);
+    if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(G256S_SETSRC("bf16")); else G256S_ASM(G256S_SETSRC("f16"));
+    G256S_RUN(ISSUE_TILE);
+    G256S_RUN(ISSUE_TILE);
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    G256S_RUN_C(G256S_READ0);
+    G256S_RUN_C(READ0);
     // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper (the loop runs cnt + 1 trips)
     //      -- unconditional (host: K >= 192): a branch around an asm statement with "+s" operands makes them PHIs
     cnt = (unsigned)(nk_main - 3);
-    if constexpr (VAR == 2) G256S_RUN(G256S_LOOP_KND);
-    else if constexpr (VAR == 3) G256S_RUN(G256S_LOOP_KNR);
-    else if constexpr (VAR == 4) G256S_RUN(G256S_LOOP_KMF);
-    else if constexpr (VAR == 5) G256S_RUN(G256S_LOOP_KMO);
-    else if constexpr (VAR == 6) G256S_RUN(G256S_LOOP_KNV);
-    else if constexpr (VAR == 7) G256S_RUN(G256S_LOOP_KNB);
-    else G256S_RUN(G256S_LOOP);
-    // ---- the rank block's tiles are fetched from XK [M, Rk] / BK [N, Rk] by the same body: only the sources change
+    if constexpr (BNN || VAR == 0) {
+        G256S_RUN(LOOP);
+    } else {
+        if constexpr (VAR == 2) G256S_ASM(G256S_LOOP_KND("bf16"));
+        else if constexpr (VAR == 3) G256S_ASM(G256S_LOOP_KNR("bf16"));
+        else if constexpr (VAR == 4) G256S_ASM(G256S_LOOP_KMF("bf16"));
+        else if constexpr (VAR == 5) G256S_ASM(G256S_LOOP_KMO("bf16"));
+        else if constexpr (VAR == 6) G256S_ASM(G256S_LOOP_KNV("bf16"));
+        else G256S_ASM(G256S_LOOP_KNB("bf16"));
+    }
+    // ---- the rank block's tiles are fetched from XK [M, Rk] / BK ([N, Rk]; NN: [Rk, N]) by the same body: only the sources change
     if (nk_rank) {
         const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
         baseA = sgpr64(g.lora_xk, (int64_t)m0 * ld_xk * (int64_t)sizeof(T));
-        baseB = sgpr64(g.lora_bk, (int64_t)n0 * ld_bk * (int64_t)sizeof(T));
+        baseB = BNN ? sgpr64(g.lora_bk, (int64_t)n0 * (int64_t)sizeof(T)) : sgpr64(g.lora_bk, (int64_t)n0 * ld_bk * (int64_t)sizeof(T));
         int ln = lane;
         asm volatile("" : "+v"(ln));             // rebuilt here, not held across the main loop
         const int sr = ln >> 3, ss = (ln & 7) ^ (((wave & 1) << 2) | (sr >> 1));
         voffA = (unsigned)(((wave * 8 + sr) * ld_xk + ss * 8) * (int)sizeof(T));
-        voffB = (unsigned)(((wave * 8 + sr) * ld_bk + ss * 8) * (int)sizeof(T));
+        voffB = BNN ? nn_voff(ld_bk, ln) : (unsigned)(((wave * 8 + sr) * ld_bk + ss * 8) * (int)sizeof(T));
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             soA[c] = u32((int64_t)c * 32 * ld_xk * (int64_t)sizeof(T));
-            soB[c] = u32((int64_t)c * 32 * ld_bk * (int64_t)sizeof(T));
+            soB[c] = BNN ? u32((int64_t)(4 * (c & 1) + 16 * (c >> 1)) * ld_bk * (int64_t)sizeof(T))
+                         : u32((int64_t)c * 32 * ld_bk * (int64_t)sizeof(T));
         }
-        G256S_RUN(G256S_SETSRC);
+        if constexpr (BNN) stepB = u32((int64_t)TK * ld_bk * (int64_t)sizeof(T));
+        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(G256S_SETSRC("bf16")); else G256S_ASM(G256S_SETSRC("f16"));
         cnt = (unsigned)(nk_rank - 1);
-        G256S_RUN(G256S_LOOP);
+        G256S_RUN(LOOP);
     }
-    G256S_RUN_C(G256S_NODMA);
-    G256S_RUN_C(G256S_LAST);
+    G256S_RUN_C(NODMA);
+    G256S_RUN_C(LAST);
 #undef G256S_RUN_C
-#undef G256S_ASM_C
 #undef G256S_RUN
+#undef G256S_RUN2
+#undef G256SN_ASM_C
+#undef G256S_ASM_C
+#undef G256SN_ASM
 #undef G256S_ASM
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // last MFMA's write -> the epilogue's v_accvgpr_read (asm MFMAs)
 
@@ -1178,36 +1218,35 @@ int launch256h(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
-template <typename T, int VAR>
+template <typename T, bool BNN, int VAR>
 int launch256s_(const G256Args& a, hipStream_t st) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T, VAR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T, BNN, VAR>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_nt256s_kernel<T, VAR>), dim3((unsigned)a.total_tiles), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt256s_kernel<T, BNN, VAR>), dim3((unsigned)a.total_tiles), dim3(256), LDS_BYTES, st, a);
     return uamd_launch_status();
 }
 
-template <typename T>
+template <typename T, bool BNN>
 int launch256s(const G256Args& a, hipStream_t st) {
-    const int v = uamd_tuning_get(UAMD_TUNE_GEMM_S);
 #ifdef UAMD_G256S_KNOCKOUTS
-    if (std::is_same<T, bf16_t>::value) {
-        if (v == 3) return launch256s_<T, 2>(a, st);
-        if (v == 4) return launch256s_<T, 3>(a, st);
-        if (v == 5) return launch256s_<T, 4>(a, st);
-        if (v == 6) return launch256s_<T, 5>(a, st);
-        if (v == 7) return launch256s_<T, 6>(a, st);
-        if (v == 8) return launch256s_<T, 7>(a, st);
+    const int v = uamd_tuning_get(UAMD_TUNE_GEMM_S);
+    if constexpr (std::is_same<T, bf16_t>::value && !BNN) {
+        if (v == 3) return launch256s_<T, false, 2>(a, st);
+        if (v == 4) return launch256s_<T, false, 3>(a, st);
+        if (v == 5) return launch256s_<T, false, 4>(a, st);
+        if (v == 6) return launch256s_<T, false, 5>(a, st);
+        if (v == 7) return launch256s_<T, false, 6>(a, st);
+        if (v == 8) return launch256s_<T, false, 7>(a, st);
     }
 #endif
-    (void)v;
-    return launch256s_<T, 0>(a, st);
+    return launch256s_<T, BNN, 0>(a, st);
 }
 
 template <typename T, bool BNN, bool ATN = false>
@@ -1342,13 +1381,13 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
         if (dtype == UAMD_F16) return bnn ? launch256h<f16_t, true>(a, st) : launch256h<f16_t, false>(a, st);
         return UAMD_ERR_DTYPE;
     }
-    // whole-tile NT launches: the one-wave-per-SIMD kernel (UAMD_TUNE_GEMM_S)
-    if (!bnn && K >= 3 * TK && (M & (TM - 1)) == 0 && uamd_tuning_get(UAMD_TUNE_GEMM_S) != 0) {
+    // whole-tile NT / NN launches: the one-wave-per-SIMD kernel (UAMD_TUNE_GEMM_S)
+    if (K >= 3 * TK && (M & (TM - 1)) == 0 && uamd_tuning_get(UAMD_TUNE_GEMM_S) != 0) {
         bool whole = true;
         for (int i = 0; i < n_groups; ++i) whole = whole && (groups[i].N & (TN - 1)) == 0;
         if (whole) {
-            if (dtype == UAMD_BF16) return launch256s<bf16_t>(a, st);
-            if (dtype == UAMD_F16) return launch256s<f16_t>(a, st);
+            if (dtype == UAMD_BF16) return bnn ? launch256s<bf16_t, true>(a, st) : launch256s<bf16_t, false>(a, st);
+            if (dtype == UAMD_F16) return bnn ? launch256s<f16_t, true>(a, st) : launch256s<f16_t, false>(a, st);
             return UAMD_ERR_DTYPE;
         }
     }
