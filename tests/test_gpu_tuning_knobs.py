@@ -100,4 +100,4 @@ def test_gemm256_raster_group_height_is_bitwise_neutral(lib, group_m):
 
 
 def test_set_tuning_refuses_what_it_does_not_know(lib):
-    assert lib.uamd_set_tuning(-1, 0) != 0 and lib.uamd_set_tuning(11, 0) != 0 and lib.uamd_set_tuning(0, -1) != 0
+    assert lib.uamd_set_tuning(-1, 0) != 0 and lib.uamd_set_tuning(12, 0) != 0 and lib.uamd_set_tuning(0, -1) != 0
