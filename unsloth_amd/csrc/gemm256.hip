@@ -951,22 +951,58 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
 #undef G256S_ASM
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // last MFMA's write -> the epilogue's v_accvgpr_read (asm MFMAs)
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = ..+4*l4 (B-operand is MFMA source A)
+    // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = x*16 + 4*l4 (B-operand is MFMA source A) for each of its 64
+    //      accumulator quads. Stored as 8-byte pieces that is 64 store instructions per lane, each touching 16 rows with 32 bytes
+    //      -- and with one workgroup per CU the tile's store tail hides behind nothing (round 3's knock-out: half the store
+    //      instructions = +7.5 % on o_proj). The lane pairs (l4, l4 ^ 1) -- lanes l and l ^ 16, the 16-lane ROWS that
+    //      v_permlane16_swap exchanges -- hold adjacent column quads of the SAME row: one swap per packed dword of a tile pair
+    //      (x even, x + 1) hands the even row both quads of tile x and the odd row both of tile x + 1: 32 stores of 16 bytes,
+    //      64 contiguous bytes per row and instruction, same bytes at the same addresses (host contract: whole tiles, so no
+    //      edge tests; ldc % 8 == 0 and a 16-byte aligned C checked there too).
     T* Cg = (T*)g.C;
-    const bool vec_ok = ((g.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(Cg) & 7) == 0);
     const T* bias = (const T*)g.bias;
+    const int odd = l4 & 1;
     auto epi = [&](auto acc_c, auto bias_c) {
+        constexpr bool ACC = decltype(acc_c)::value, BIAS = decltype(bias_c)::value;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
             const int m = m0 + wm * 128 + y * 16 + l15;
-            if (m >= M) continue;
+            T* crow = Cg + (int64_t)m * g.ldc + n0 + wn * 128;
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const int n = n0 + wn * 128 + x * 16 + l4 * 4;
-                if (n >= N) continue;
-                const f32x4_t v = acc[x * 8 + y];
-                store_c4<T, decltype(acc_c)::value, decltype(bias_c)::value>(Cg + (int64_t)m * g.ldc + n, v[0], v[1], v[2], v[3],
-                                                                             n, N, vec_ok, bias);
+            for (int xp = 0; xp < 4; ++xp) {
+                uint32_t w[2][2];                       // [tile of the pair][dword]: this lane's quads, packed
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int x = 2 * xp + t;
+                    f32x4_t v = acc[x * 8 + y];
+                    const int nq = x * 16 + l4 * 4;     // column of the quad inside the wave's 128
+                    if (BIAS) {
+                        union { uint2 raw; T e[4]; } bv;
+                        bv.raw = *reinterpret_cast<const uint2*>(bias + n0 + wn * 128 + nq);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32(bv.e[r]);
+                    }
+                    if (ACC) {
+                        union { uint2 raw; T e[4]; } cv;
+                        cv.raw = *reinterpret_cast<const uint2*>(crow + nq);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += to_f32(cv.e[r]);
+                    }
+                    union { T e[4]; uint32_t u[2]; } o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
+                    w[t][0] = o.u[0];
+                    w[t][1] = o.u[1];
+                }
+                // odd rows of the first operand <-> even rows of the second: even lanes keep their tile-x quad and receive the
+                // partner's, odd lanes keep their tile-(x+1) quad and receive the partner's
+                const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+                uint4 out;
+                out.x = s0[0]; out.y = s1[0]; out.z = s0[1]; out.w = s1[1];
+                // even lane: [own tile-x quad | partner's tile-x quad] at tile x, column 4 l4; odd lane: [partner's tile-(x+1) quad
+                // | own] at tile x + 1, column 4 (l4 - 1)
+                *reinterpret_cast<uint4*>(crow + (2 * xp + odd) * 16 + (l4 & 2) * 4) = out;
             }
         }
     };
@@ -1383,8 +1419,10 @@ static int gemm256_entry(const void* A, int64_t lda, int M, int K, const uamd_ge
     }
     // whole-tile NT / NN launches: the one-wave-per-SIMD kernel (UAMD_TUNE_GEMM_S)
     if (K >= 3 * TK && (M & (TM - 1)) == 0 && uamd_tuning_get(UAMD_TUNE_GEMM_S) != 0) {
-        bool whole = true;
-        for (int i = 0; i < n_groups; ++i) whole = whole && (groups[i].N & (TN - 1)) == 0;
+        bool whole = true;                      // ... and C rows that take 16-byte stores
+        for (int i = 0; i < n_groups; ++i)
+            whole = whole && (groups[i].N & (TN - 1)) == 0 && (groups[i].ldc & 7) == 0 && aligned16(groups[i].C) &&
+                    (groups[i].bias == nullptr || (reinterpret_cast<uintptr_t>(groups[i].bias) & 7) == 0);
         if (whole) {
             if (dtype == UAMD_BF16) return bnn ? launch256s<bf16_t, true>(a, st) : launch256s<bf16_t, false>(a, st);
             if (dtype == UAMD_F16) return bnn ? launch256s<f16_t, true>(a, st) : launch256s<f16_t, false>(a, st);
