@@ -316,9 +316,10 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * vector per thread; 2 = 8 waves and every tile requested two steps ahead; 3 (default) = 2 with the
                                  * columns of a row group split over adjacent workgroups (uamd_glu_{fwd,bwd}_xa_ws; without a
                                  * workspace: 2) where that measured faster -- rows of whole 4 KB pages, or at most 2048 rows --; 8 = always */
-#define UAMD_TUNE_GEMM_S 11     /* (UAMD_GEMM_S) uamd_gemm_nt_256 on whole 256 x 256 tiles (M % 256 == 0, every N_g % 256 == 0): 1 = the
-                                 * one-wave-per-SIMD kernel with the hand-ordered K loop (gemm_nt256s_kernel, default), 0 = the 8-wave
-                                 * ping-pong kernels */
+#define UAMD_TUNE_GEMM_S 11     /* (UAMD_GEMM_S) uamd_gemm_n{t,n}_256 on whole 256 x 256 tiles (M % 256 == 0, every N_g % 256 == 0, K >= 192):
+                                 * 1 = the one-wave-per-SIMD kernel with the hand-ordered K loop (gemm_nt256s_kernel; default), as a
+                                 * persistent walk when every CU gets at least four output tiles; 2 = the same, one workgroup per tile
+                                 * always; 9 = the walk from two tiles per CU on; 0 = the 8-wave ping-pong kernels */
 #define UAMD_TUNE_COUNT 12
 int uamd_set_tuning(int knob, int value);
 int uamd_gemm_nt_nf4(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,

@@ -445,13 +445,18 @@ def test_gemm256_persistent_walk_is_bit_identical(nn, dtype, M, Ns, K, rank):
                                          (512, (512,), 192, True),                     # one loop trip + one rank tile
                                          (2048, (2560,), 1024, True),
                                          (1024, (1024,), 4096, False),                 # a long K loop
-                                         (256, (768, 256), 320, True)])                # odd K-tile count
+                                         (256, (768, 256), 320, True),                 # odd K-tile count
+                                         (4096, (8192,), 320, True),                   # 512 tiles: the persistent walk, 2 per CU, odd count
+                                         (2048, (16384 + 256, 256), 192, True),        # 528 tiles over 256 CUs: uneven walk, 2 groups
+                                         (8192, (4096,), 256, False)])                 # 512 tiles, even K-tile count (no stage flip)
 def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(nn, dtype, M, Ns, K, rank):
     """gemm_nt256s_kernel (4 waves x 128 x 128, hand-ordered K loop, `buffer_load ... lds` pieces with SGPR offsets; knob 11,
     default for whole-tile NT and NN launches) against the 8-wave gemm_nt256_kernel: same LDS image, same per-accumulator k
     order (main tiles in order, then the rank block's), so BIT-IDENTICAL -- multi-group launches with per-group rank blocks,
     accumulate, bias-free, padded row strides, both operand forms (NN: B and BK as [K, N], transposing fragment reads into
-    pinned registers); and run-to-run deterministic."""
+    pinned registers); knob 11 = 9 takes the PERSISTENT walk from two output tiles per CU on (the next tile's first K tiles
+    fetched during the current one's last, stage parity carried across tiles; the default, 1, from four on), 2 = one workgroup
+    per tile always; and run-to-run deterministic."""
     from unsloth_amd import _lib
     from unsloth_amd.kernels.utils import _group, _launch_gemm
     from unsloth_amd.kernels import utils as U
@@ -494,11 +499,13 @@ def test_gemm256s_one_wave_per_simd_kernel_is_bit_identical(nn, dtype, M, Ns, K,
         L.uamd_set_tuning(7, 0)
         for accumulate in (False, True):
             ref = run(0, accumulate)
-            got = run(1, accumulate)
-            again = run(1, accumulate)
-            for r, o, o2 in zip(ref, got, again):
+            got = run(9, accumulate)                 # the persistent walk from two tiles per CU on
+            again = run(9, accumulate)
+            single = run(2, accumulate)              # one workgroup per tile
+            for r, o, o2, o3 in zip(ref, got, again, single):
                 assert torch.equal(o, o2), "run-to-run"
                 assert torch.equal(r, o), float((r.float() - o.float()).abs().max())
+                assert torch.equal(r, o3), float((r.float() - o3.float()).abs().max())
         y = run(1, False)[0]
         want = Xs.float().cpu() @ (Bs[0].float().cpu() if nn else Bs[0].float().cpu().t())
         if rank:

@@ -42,8 +42,11 @@ M0_BIAS = 64          # %[m0bA] / %[m0bB] = LDS address of the wave's first piec
 # bank swizzle f(k-row) = (krow & 3) | ((krow >> 3) & 1) << 2 does not depend on c and ONE per-lane offset serves all pieces.
 PIECE_LDS_ROWS = [c * 4096 for c in range(8)]
 PIECE_LDS_NN = [(c & 1) * 2048 + (c >> 1) * 8192 for c in range(8)]
-XREG0 = 192           # NN: the B-operand fragments live in PINNED v[192:255] (a 64-bit transposing read fills HALF a fragment, and an
-                      # asm operand cannot name half of a register tuple): fragment (h, x) = v[192 + 32 h + 4 x : +3]
+XREG0 = 192           # the B-operand fragments live in PINNED v[192:255]: fragment (h, x) = v[192 + 32 h + 4 x : +3]. NN needs it (a
+                      # 64-bit transposing read fills HALF a fragment, and an asm operand cannot name half of a register tuple);
+                      # NT takes the same registers so that the allocator sees 64 fragment registers instead of 128 (with all of
+                      # them as operands the persistent walk spilled twelve around every output tile's source switch -- a scratch
+                      # reload is a VMEM load with a vmcnt(0) behind it, i.e. a drain of the DMA ring)
 
 
 def xreg(h, x, half=None):
@@ -53,10 +56,16 @@ def xreg(h, x, half=None):
     return f"v[{r + 2 * half}:{r + 2 * half + 1}]"
 
 
+def areg(q):
+    """accumulator quad q = x * 8 + y: PINNED a[4q : 4q + 3] (all 256 AGPRs, named by the asm and clobbered by every statement:
+    as operands the allocator permuted them between statements on the persistent walk and repaired that through scratch)"""
+    return f"a[{4 * q}:{4 * q + 3}]"
+
+
 def mfma(h, x, y):
     q = x * 8 + y
-    xs = xreg(h, x) if NN else f"%[x{h}_{x}]"
-    return f"v_mfma_f32_16x16x32_\" TS \" %[acc{q}], {xs}, %[y{h}_{y}], %[acc{q}]"
+    xs = xreg(h, x)
+    return f"v_mfma_f32_16x16x32_\" TS \" {areg(q)}, {xs}, %[y{h}_{y}], {areg(q)}"
 
 
 def rd_y(h, y):
@@ -69,7 +78,7 @@ def rd_x(h, x):
     if NN:
         return [f"ds_read_b64_tr_b16 {xreg(h, x, 0)}, %[rdBn{x}] offset:{h * 16384}",
                 f"ds_read_b64_tr_b16 {xreg(h, x, 1)}, %[rdBn{x}] offset:{h * 16384 + 2048}"]
-    return [f"ds_read_b128 %[x{h}_{x}], %[rdB{h}] offset:{x * 2048}"]
+    return [f"ds_read_b128 {xreg(h, x)}, %[rdB{h}] offset:{x * 2048}"]
 
 
 def dma(op, c):
@@ -262,14 +271,15 @@ def emit_family(pfx):
         rd += rd_x(0, x)
     emit_macro(f"{pfx}_READ0", rd + ["s_waitcnt lgkmcnt(0)"])
     # operand lists
-    fr = ", ".join(f'[{n}{h}_{i}] "+v"({n}f[{h}][{i}])' for n in ("y" if NN else "yx") for h in range(2) for i in range(8))
+    fr = ", ".join(f'[y{h}_{i}] "+v"(yf[{h}][{i}])' for h in range(2) for i in range(8))
     rdp = ", ".join(f'[rdA{h}] "+v"(rdA[{h}])' for h in range(2)) + ", " + \
         (", ".join(f'[rdBn{x}] "+v"(rdBn[{x}])' for x in range(8)) if NN else ", ".join(f'[rdB{h}] "+v"(rdB[{h}])' for h in range(2)))
     print(f"#define {pfx}_OUT_FRAGS " + fr)
+    print(f"#define {pfx}_OUTW_FRAGS " + fr.replace('"+v"', '"=v"'))          # write-only: the old fragments are dead (READ0 after an epilogue)
     print(f"#define {pfx}_OUT_RD " + rdp)
-    xclob = (", " + ", ".join(f'"v{r}"' for r in range(XREG0, XREG0 + 64))) if NN else ""
-    print(f'#define {pfx}_CLOBBER "memory", "m0", "scc", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91"' + xclob)
-    print(f'#define {pfx}_CLOBBER_C "memory"' + xclob)
+    xclob = ", " + ", ".join(f'"v{r}"' for r in range(XREG0, XREG0 + 64))
+    print(f'#define {pfx}_CLOBBER "memory", "m0", "scc", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", G256S_ACC_CLOBBER' + xclob)
+    print(f'#define {pfx}_CLOBBER_C "memory", G256S_ACC_CLOBBER' + xclob)
     print()
 
 
@@ -288,9 +298,24 @@ def main():
         w2, w3 = ("s86", "s87") if op == "A" else ("s90", "s91")
         src += [f"s_mov_b64 s[{lo[1:]}:{hi[1:]}], %[base{op}]", f"s_mov_b32 {w2}, -1", f"s_mov_b32 {w3}, 0x20000"]
     emit_macro("G256S_SETSRC", src)
-    acc = ", ".join(f'[acc{q}] "+a"(acc[{q}])' for q in range(64))
+    print("#define G256S_ACC_CLOBBER " + ", ".join(f'"a{i}"' for i in range(256)))
+    print("// all accumulators = 0 (the trailing s_nop: v_accvgpr_write -> MFMA reading it as SrcC)")
+    print("__device__ __forceinline__ void g256s_acc_zero() {")
+    print('    asm volatile("' + "\\n\\t".join(f"v_accvgpr_write_b32 a{i}, 0" for i in range(256)) + '\\n\\ts_nop 3" ::: G256S_ACC_CLOBBER);')
+    print("}")
+    print("// the two accumulator quads (n-tiles 2 XP, 2 XP + 1) of m-tile Y -> 8 floats")
+    print("template <int Y, int XP>")
+    print("__device__ __forceinline__ void g256s_acc_read(float (&f)[8]) {")
+    for y in range(8):
+        for xp in range(4):
+            kw = "if" if (y, xp) == (0, 0) else "else if"
+            regs = [4 * ((2 * xp + t) * 8 + y) + r for t in range(2) for r in range(4)]
+            body = "\\n\\t".join(f"v_accvgpr_read_b32 %{j}, a{r}" for j, r in enumerate(regs))
+            outs = ", ".join(f'"=v"(f[{j}])' for j in range(8))
+            print(f"    {kw} constexpr (Y == {y} && XP == {xp})")
+            print(f'        asm volatile("{body}" : {outs} :: G256S_ACC_CLOBBER);')
+    print("}")
     so = ", ".join(f'[so{o}{c}] "s"(so{o}[{c}])' for o in "AB" for c in range(8))
-    print("#define G256S_OUT_ACC " + acc)
     print('#define G256S_OUT_M0 [m0bA] "+s"(m0bA), [m0bB] "+s"(m0bB)')
     print("#define G256S_IN_SO " + so)
     print('#define G256S_IN_DMA [voffA] "v"(voffA), [voffB] "v"(voffB), [baseA] "s"(baseA), [baseB] "s"(baseB), '

@@ -766,11 +766,26 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256p_kernel(G256Args p) {
 // N_g % 256 == 0 (no edge tiles: the piece offsets ride in SGPRs, rows cannot be clamped per lane), K >= 192.
 #include "gemm256s_loop.inc"
 
+template <int N, typename F, int... Is>
+__device__ __forceinline__ void g256s_static_for_(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void g256s_static_for(F&& f) {
+    g256s_static_for_<N>(f, std::make_integer_sequence<int, N>{});
+}
+
 typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
-// VAR: 0 = the kernel; 2..5 = knock-out timing builds (-DUAMD_G256S_KNOCKOUTS: no DMA / no fragment reads / neither / MFMAs
-// only -- results are garbage, tools/gemm_s4_knock.py uses them for nothing but a clock).
-template <typename T, bool BNN, int VAR>
+// VAR: 0 = the kernel; 2..7 = knock-out timing builds (-DUAMD_G256S_KNOCKOUTS: no DMA / no fragment reads / neither / MFMAs
+// only / no vmcnt / no barriers -- results are garbage, tools/gemm_s4_knock.py uses them for nothing but a clock).
+// PERSIST: one workgroup per CU walks the virtual block ids v = blockIdx.x, + gridDim.x, ... (same XCD-aware raster) and treats
+// the K tiles of consecutive OUTPUT tiles as one stream: the last two K tiles of an output tile are multiplied by the
+// steady-state body with its DMA pointed at K tiles 0 and 1 of the NEXT output tile, so a new tile starts with its operands in
+// LDS (no cold 64-KiB prologue with every CU bursting at once) and the epilogue's accumulator reads / stores run while that
+// data lands. With ONE workgroup per CU (128 KiB of LDS, 512 registers per lane) nothing else can hide a tile's prologue and
+// store tail: this is the whole point of the walk.
+template <typename T, bool BNN, int VAR, bool PERSIST>
 __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename Mfma2<T>::frag frag_t;
@@ -778,45 +793,42 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;       // wave owns rows wm*128.., cols wn*128..
     const int l15 = lane & 15, l4 = lane >> 4;
+    const int M = p.M, total = p.total_tiles;
 
-    int tile = blockIdx.x;
-    {
-        const int nt = p.total_tiles, q = nt >> 3, r = nt & 7, x = tile & 7, j = tile >> 3;
-        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
-    }
-    int tm, tn_lin;
-    {
+    // virtual block id -> (first row, first column inside its group, group): see gemm_nt256_kernel
+    auto decode = [&](int v, int& m0, int& n0, int& gi) {
+        int tile;
+        {
+            const int q = total >> 3, r = total & 7, x = v & 7, j = v >> 3;
+            tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+        }
         const int gm = p.group_m, tiles_n = p.tile_start[UAMD_G256_MAX_GROUPS];
         const int per_group = gm * tiles_n;
         const int rg = tile / per_group;
         const int first_m = rg * gm;
         const int gsz = min(gm, p.tiles_m - first_m);
         const int rem = tile - rg * per_group;
-        tn_lin = rem / gsz;
-        tm = first_m + (rem - tn_lin * gsz);
-    }
-    int gi = 0;
+        const int tn_lin = rem / gsz;
+        const int tm = first_m + (rem - tn_lin * gsz);
+        int g_ = 0, start = 0;
 #pragma unroll
-    for (int i = 1; i < UAMD_G256_MAX_GROUPS; ++i)
-        if (i < p.n_groups && tn_lin >= p.tile_start[i]) gi = i;
-    const uamd_gemm_group& g = p.g[gi];
-    const int m0 = __builtin_amdgcn_readfirstlane(tm * TM);
-    const int n0 = __builtin_amdgcn_readfirstlane((tn_lin - p.tile_start[gi]) * TN);
-    const int M = p.M, N = g.N;
+        for (int i = 1; i < UAMD_G256_MAX_GROUPS; ++i)
+            if (i < p.n_groups && tn_lin >= p.tile_start[i]) { g_ = i; start = p.tile_start[i]; }
+        gi = __builtin_amdgcn_readfirstlane(g_);
+        m0 = __builtin_amdgcn_readfirstlane(tm * TM);
+        n0 = __builtin_amdgcn_readfirstlane((tn_lin - start) * TN);
+    };
 
-    f32x4_t acc[64];                   // acc[x * 8 + y]: n-tile x, m-tile y of the wave's 128 x 128
-#pragma unroll
-    for (int i = 0; i < 64; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // the accumulators -- quad x * 8 + y = n-tile x, m-tile y of the wave's 128 x 128 -- are a[0:255], owned by the inline asm
+    // (gemm256s_loop.inc: named in every MFMA, clobbered by every statement, zeroed / read back by asm helpers;
+    // tests/test_attn64_registers.py checks that no compiler-generated instruction touches an AGPR)
+    g256s_acc_zero();
     frag_t yf[2][8];                   // [k-half][tile]: A-operand (m) fragments
-    frag_t xf[BNN ? 1 : 2][BNN ? 1 : 8];   // B-operand (n) fragments (BNN: in the pinned v[192:255], not operands)
+                                       // (the B-operand's live in the pinned v[192:255], gen_gemm256s.py XREG0)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            yf[h][i] = frag_t{};
-            if constexpr (!BNN) xf[h][i] = frag_t{};
-        }
-    (void)xf;
+        for (int i = 0; i < 8; ++i) yf[h][i] = frag_t{};
 
     // ---- DMA sources. A-operand (and the NT B-operand): piece c (0..7) issued by wave w fills sub-tile c*4 + w = rows
     //      (c*4 + w)*8 .. +7 of the tile, [8 rows x 64 k] = 8 full lines; lane -> (row = lane >> 3, swizzled 16-byte slot) as
@@ -825,68 +837,89 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     //      NN B-operand ([K, N], a [64 k][256 n] LDS image): piece = two k-rows x 512 B, sub-tile order chosen so that the bank
     //      swizzle does not depend on c (gen_gemm256s.py PIECE_LDS_NN): k-row of (w, c, h = lane >> 5) = 2 (w & 1) + 8 (w >> 1)
     //      + h + 4 (c & 1) + 16 (c >> 1), f = h | (w & 1) << 1 | (w >> 1) << 2.
-    const int sub_row = lane >> 3;
-    const int sub_slot = (lane & 7) ^ (((wave & 1) << 2) | (sub_row >> 1));
     auto u32 = [](int64_t v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uint64_t)v); };
     auto sgpr64 = [](const void* q, int64_t byte_off) {      // a wave-uniform address as a value the compiler keeps in SGPRs
         const uint64_t u = (uint64_t)(uintptr_t)q + (uint64_t)byte_off;
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         return ((uint64_t)hi << 32) | lo;
     };
-    const int nn_h = lane >> 5;
-    const int nn_krow0 = 2 * (wave & 1) + 8 * (wave >> 1) + nn_h;
-    auto nn_voff = [&](int ld, int ln) {                      // per-lane byte offset of the NN B-operand's piece 0
-        const int f = (ln >> 5) | ((wave & 1) << 1) | ((wave >> 1) << 2);
-        return (unsigned)((nn_krow0 * ld + (((ln & 31) ^ (f << 1)) << 3)) * (int)sizeof(T));
-    };
-    const int lda = __builtin_amdgcn_readfirstlane((int)p.lda), ldb = __builtin_amdgcn_readfirstlane((int)g.ldb);
-    // buffer descriptors (built inside the asm, in the pinned s[84:87] / s[88:91]) start at the TILE's first row / column
-    uint64_t baseA = sgpr64(p.A, (int64_t)m0 * lda * (int64_t)sizeof(T));
-    uint64_t baseB = BNN ? sgpr64(g.B, (int64_t)n0 * (int64_t)sizeof(T)) : sgpr64(g.B, (int64_t)n0 * ldb * (int64_t)sizeof(T));
-    unsigned voffA = (unsigned)(((wave * 8 + sub_row) * lda + sub_slot * 8) * (int)sizeof(T));
-    unsigned voffB = BNN ? nn_voff(ldb, lane) : (unsigned)(((wave * 8 + sub_row) * ldb + sub_slot * 8) * (int)sizeof(T));
-    unsigned soA[8], soB[8];
+    uint64_t baseA = 0, baseB = 0;
+    unsigned voffA = 0, voffB = 0, soA[8], soB[8], stepA = TK * sizeof(T), stepB = TK * sizeof(T);
+    // the lane-only parts are rebuilt at every switch from an opaque copy of the lane id (a few VALU instructions per output
+    // tile) instead of being held -- or spilled -- across the K loop
+    auto set_sources = [&](const void* Ap, int ld_a, const void* Bp, int ld_b, int m0, int n0) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int sr = ln >> 3, ss = (ln & 7) ^ (((wave & 1) << 2) | (sr >> 1));
+        baseA = sgpr64(Ap, (int64_t)m0 * ld_a * (int64_t)sizeof(T));
+        voffA = (unsigned)(((wave * 8 + sr) * ld_a + ss * 8) * (int)sizeof(T));
+        if constexpr (BNN) {
+            const int h = ln >> 5, f = h | ((wave & 1) << 1) | ((wave >> 1) << 2);
+            const int krow0 = 2 * (wave & 1) + 8 * (wave >> 1) + h;
+            baseB = sgpr64(Bp, (int64_t)n0 * (int64_t)sizeof(T));
+            voffB = (unsigned)((krow0 * ld_b + (((ln & 31) ^ (f << 1)) << 3)) * (int)sizeof(T));
+            stepB = u32((int64_t)TK * ld_b * (int64_t)sizeof(T));
+        } else {
+            baseB = sgpr64(Bp, (int64_t)n0 * ld_b * (int64_t)sizeof(T));
+            voffB = (unsigned)(((wave * 8 + sr) * ld_b + ss * 8) * (int)sizeof(T));
+        }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        soA[c] = u32((int64_t)c * 32 * lda * (int64_t)sizeof(T));
-        soB[c] = BNN ? u32((int64_t)(4 * (c & 1) + 16 * (c >> 1)) * ldb * (int64_t)sizeof(T)) : u32((int64_t)c * 32 * ldb * (int64_t)sizeof(T));
-    }
-    unsigned stepA = TK * sizeof(T), stepB = BNN ? u32((int64_t)TK * ldb * (int64_t)sizeof(T)) : (unsigned)(TK * sizeof(T));
+        for (int c = 0; c < 8; ++c) {
+            soA[c] = u32((int64_t)c * 32 * ld_a * (int64_t)sizeof(T));
+            soB[c] = BNN ? u32((int64_t)(4 * (c & 1) + 16 * (c >> 1)) * ld_b * (int64_t)sizeof(T)) : u32((int64_t)c * 32 * ld_b * (int64_t)sizeof(T));
+        }
+    };
+    auto set_main = [&](int m0, int n0, int gi) {
+        const uamd_gemm_group& g = p.g[gi];
+        set_sources(p.A, __builtin_amdgcn_readfirstlane((int)p.lda), g.B, __builtin_amdgcn_readfirstlane((int)g.ldb), m0, n0);
+    };
+    auto set_rank = [&](int m0, int n0, int gi) {
+        const uamd_gemm_group& g = p.g[gi];
+        set_sources(g.lora_xk, __builtin_amdgcn_readfirstlane((int)g.ld_xk), g.lora_bk, __builtin_amdgcn_readfirstlane((int)g.ld_bk), m0, n0);
+    };
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;      // 0: no static LDS in this kernel (stage bit = 0x10000)
     // DMA destinations of the wave's first piece of each operand, + 64 (gen_gemm256s.py M0_BIAS)
     unsigned m0bA = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024 + 64);
     unsigned m0bB = __builtin_amdgcn_readfirstlane(lds_base + 32 * 1024 + (BNN ? (wave & 1) * 1024 + (wave >> 1) * 4096 : wave * 1024) + 64);
-    const int frag_off0 = l15 * 128 + ((l4 ^ ((l15 >> 1) & 7)) << 4);
+    // fragment read pointers of the stage that holds K tile 0 of the current output tile (`par`), rebuilt per output tile from an
+    // opaque copy of the lane id: held across the epilogue (which wants every VGPR for the accumulators) they were spilled
     unsigned rdA[2], rdB[2], rdBn[8];
+    auto make_rd = [&](int par) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int a15 = ln & 15, a4 = ln >> 4;
+        const unsigned st = lds_base + ((unsigned)par << 16);
+        const int frag_off0 = a15 * 128 + ((a4 ^ ((a15 >> 1) & 7)) << 4);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        rdA[h] = lds_base + (wm * 8) * 2048 + (frag_off0 ^ (h * 64));
-        rdB[h] = lds_base + 32 * 1024 + (wn * 8) * 2048 + (frag_off0 ^ (h * 64));
-    }
-    {
+        for (int h = 0; h < 2; ++h) {
+            rdA[h] = st + (wm * 8) * 2048 + (frag_off0 ^ (h * 64));
+            rdB[h] = st + 32 * 1024 + (wn * 8) * 2048 + (frag_off0 ^ (h * 64));
+        }
         // transposing reads: k-row l4*8 + (l15 >> 2) (+4 for the second read, + 32 for the second k-half), logical 32-byte
         // granule (16-column tile) wn*8 + x, swizzled by the k-row's f
-        const int nn_f = (l15 >> 2) | ((l4 & 1) << 2);
-        const int nn_lane = 32 * 1024 + (l4 * 8 + (l15 >> 2)) * 512 + (l15 & 3) * 8;
+        const int nn_f = (a15 >> 2) | ((a4 & 1) << 2);
+        const int nn_lane = 32 * 1024 + (a4 * 8 + (a15 >> 2)) * 512 + (a15 & 3) * 8;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) rdBn[x] = lds_base + nn_lane + (((wn * 8 + x) ^ nn_f) << 5);
-    }
-    (void)rdB; (void)rdBn;
+        for (int x = 0; x < 8; ++x) rdBn[x] = st + nn_lane + (((wn * 8 + x) ^ nn_f) << 5);
+    };
     const int nk_main = __builtin_amdgcn_readfirstlane(p.K / TK);       // host: >= 3
-    const int nk_rank = __builtin_amdgcn_readfirstlane(g.lora_xk != nullptr ? g.Rk / TK : 0);
     unsigned cnt = 0;
 
 #define G256S_ASM(BODY)                                                                              \
-    asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt)   \
+    asm volatile(BODY : G256S_OUT_FRAGS, G256S_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt)   \
                  : G256S_IN_SO, G256S_IN_DMA : G256S_CLOBBER)
 #define G256SN_ASM(BODY)                                                                             \
-    asm volatile(BODY : G256S_OUT_ACC, G256SN_OUT_FRAGS, G256SN_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt) \
+    asm volatile(BODY : G256SN_OUT_FRAGS, G256SN_OUT_RD, G256S_OUT_M0, [cnt] "+s"(cnt) \
                  : G256S_IN_SO, G256S_IN_DMA : G256SN_CLOBBER)
 // bodies without DMA take no DMA operands: the values the rank-block branch below rewrites are then dead at its join
 // (as live-out "s" operands they become PHIs, which hipcc refuses to keep in SGPRs: "illegal VGPR to SGPR copy")
-#define G256S_ASM_C(BODY) asm volatile(BODY : G256S_OUT_ACC, G256S_OUT_FRAGS, G256S_OUT_RD : : G256S_CLOBBER_C)
-#define G256SN_ASM_C(BODY) asm volatile(BODY : G256S_OUT_ACC, G256SN_OUT_FRAGS, G256SN_OUT_RD : : G256SN_CLOBBER_C)
-// NAME: the part of the macro name behind G256S_ / G256SN_; K: ASM (DMA operands) or ASM_C
+#define G256S_ASM_C(BODY) asm volatile(BODY : G256S_OUT_FRAGS, G256S_OUT_RD : : G256S_CLOBBER_C)
+#define G256SN_ASM_C(BODY) asm volatile(BODY : G256SN_OUT_FRAGS, G256SN_OUT_RD : : G256SN_CLOBBER_C)
+// the first fragment reads of an output tile: every fragment is WRITE-ONLY here, so nothing of the previous tile's stays live
+// across the epilogue in front of it
+#define G256S_ASM_W(BODY) asm volatile(BODY : G256S_OUTW_FRAGS, G256S_OUT_RD : : G256S_CLOBBER_C)
+#define G256SN_ASM_W(BODY) asm volatile(BODY : G256SN_OUTW_FRAGS, G256SN_OUT_RD : : G256SN_CLOBBER_C)
+// NAME: the part of the macro name behind G256S_ / G256SN_; K: ASM (DMA operands), ASM_C or ASM_W
 #define G256S_RUN2(NAME, K)                                                                 \
     do {                                                                                    \
         if constexpr (BNN) {                                                                \
@@ -899,57 +932,11 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     } while (0)
 #define G256S_RUN(NAME) G256S_RUN2(NAME, ASM)
 #define G256S_RUN_C(NAME) G256S_RUN2(NAME, ASM_C)
-
-    // ---- prologue: K tiles 0 and 1 in flight, tile 0 landed and published, its k-half-0 fragments in registers
-    if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(G256S_SETSRC("bf16")); else G256S_ASM(G256S_SETSRC("f16"));
-    G256S_RUN(ISSUE_TILE);
-    G256S_RUN(ISSUE_TILE);
-    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-    G256S_RUN_C(READ0);
-    // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper (the loop runs cnt + 1 trips)
-    //      -- unconditional (host: K >= 192): a branch around an asm statement with "+s" operands makes them PHIs
-    cnt = (unsigned)(nk_main - 3);
-    if constexpr (BNN || VAR == 0) {
-        G256S_RUN(LOOP);
-    } else {
-        if constexpr (VAR == 2) G256S_ASM(G256S_LOOP_KND("bf16"));
-        else if constexpr (VAR == 3) G256S_ASM(G256S_LOOP_KNR("bf16"));
-        else if constexpr (VAR == 4) G256S_ASM(G256S_LOOP_KMF("bf16"));
-        else if constexpr (VAR == 5) G256S_ASM(G256S_LOOP_KMO("bf16"));
-        else if constexpr (VAR == 6) G256S_ASM(G256S_LOOP_KNV("bf16"));
-        else G256S_ASM(G256S_LOOP_KNB("bf16"));
-    }
-    // ---- the rank block's tiles are fetched from XK [M, Rk] / BK ([N, Rk]; NN: [Rk, N]) by the same body: only the sources change
-    if (nk_rank) {
-        const int ld_xk = __builtin_amdgcn_readfirstlane((int)g.ld_xk), ld_bk = __builtin_amdgcn_readfirstlane((int)g.ld_bk);
-        baseA = sgpr64(g.lora_xk, (int64_t)m0 * ld_xk * (int64_t)sizeof(T));
-        baseB = BNN ? sgpr64(g.lora_bk, (int64_t)n0 * (int64_t)sizeof(T)) : sgpr64(g.lora_bk, (int64_t)n0 * ld_bk * (int64_t)sizeof(T));
-        int ln = lane;
-        asm volatile("" : "+v"(ln));             // rebuilt here, not held across the main loop
-        const int sr = ln >> 3, ss = (ln & 7) ^ (((wave & 1) << 2) | (sr >> 1));
-        voffA = (unsigned)(((wave * 8 + sr) * ld_xk + ss * 8) * (int)sizeof(T));
-        voffB = BNN ? nn_voff(ld_bk, ln) : (unsigned)(((wave * 8 + sr) * ld_bk + ss * 8) * (int)sizeof(T));
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            soA[c] = u32((int64_t)c * 32 * ld_xk * (int64_t)sizeof(T));
-            soB[c] = BNN ? u32((int64_t)(4 * (c & 1) + 16 * (c >> 1)) * ld_bk * (int64_t)sizeof(T))
-                         : u32((int64_t)c * 32 * ld_bk * (int64_t)sizeof(T));
-        }
-        if constexpr (BNN) stepB = u32((int64_t)TK * ld_bk * (int64_t)sizeof(T));
-        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(G256S_SETSRC("bf16")); else G256S_ASM(G256S_SETSRC("f16"));
-        cnt = (unsigned)(nk_rank - 1);
-        G256S_RUN(LOOP);
-    }
-    G256S_RUN_C(NODMA);
-    G256S_RUN_C(LAST);
-#undef G256S_RUN_C
-#undef G256S_RUN
-#undef G256S_RUN2
-#undef G256SN_ASM_C
-#undef G256S_ASM_C
-#undef G256SN_ASM
-#undef G256S_ASM
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // last MFMA's write -> the epilogue's v_accvgpr_read (asm MFMAs)
+#define G256S_RUN_W(NAME) G256S_RUN2(NAME, ASM_W)
+#define G256S_SETSRC_RUN()                                                                                                    \
+    do {                                                                                                                      \
+        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(G256S_SETSRC("bf16")); else G256S_ASM(G256S_SETSRC("f16"));   \
+    } while (0)
 
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = x*16 + 4*l4 (B-operand is MFMA source A) for each of its 64
     //      accumulator quads. Stored as 8-byte pieces that is 64 store instructions per lane, each touching 16 rows with 32 bytes
@@ -959,54 +946,128 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     //      (x even, x + 1) hands the even row both quads of tile x and the odd row both of tile x + 1: 32 stores of 16 bytes,
     //      64 contiguous bytes per row and instruction, same bytes at the same addresses (host contract: whole tiles, so no
     //      edge tests; ldc % 8 == 0 and a 16-byte aligned C checked there too).
-    T* Cg = (T*)g.C;
-    const T* bias = (const T*)g.bias;
-    const int odd = l4 & 1;
-    auto epi = [&](auto acc_c, auto bias_c) {
-        constexpr bool ACC = decltype(acc_c)::value, BIAS = decltype(bias_c)::value;
-#pragma unroll
-        for (int y = 0; y < 8; ++y) {
-            const int m = m0 + wm * 128 + y * 16 + l15;
-            T* crow = Cg + (int64_t)m * g.ldc + n0 + wn * 128;
-#pragma unroll
-            for (int xp = 0; xp < 4; ++xp) {
-                uint32_t w[2][2];                       // [tile of the pair][dword]: this lane's quads, packed
+    auto store_tile = [&](int m0, int n0, int gi) {
+        const uamd_gemm_group& g = p.g[gi];
+        T* Cg = (T*)g.C;
+        const T* bias = (const T*)g.bias;
+        int lno = lane;
+        asm volatile("" : "+v"(lno));            // (rebuilt per tile, see set_sources)
+        const int l4o = lno >> 4, l15o = lno & 15, odd = l4o & 1;
+        auto epi = [&](auto acc_c, auto bias_c) {
+            constexpr bool ACC = decltype(acc_c)::value, BIAS = decltype(bias_c)::value;
+            g256s_static_for<32>([&](auto idx) {
+                constexpr int y = decltype(idx)::value >> 2, xp = decltype(idx)::value & 3;
+                const int m = m0 + wm * 128 + y * 16 + l15o;
+                T* crow = Cg + (int64_t)m * g.ldc + n0 + wn * 128;
+                float f[8];                                 // [tile of the pair][column of the quad]
+                g256s_acc_read<y, xp>(f);
+                uint32_t w[2][2];                           // [tile of the pair][dword]: this lane's quads, packed
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int x = 2 * xp + t;
-                    f32x4_t v = acc[x * 8 + y];
-                    const int nq = x * 16 + l4 * 4;     // column of the quad inside the wave's 128
+                    const int nq = x * 16 + l4o * 4;        // column of the quad inside the wave's 128
                     if (BIAS) {
                         union { uint2 raw; T e[4]; } bv;
                         bv.raw = *reinterpret_cast<const uint2*>(bias + n0 + wn * 128 + nq);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += to_f32(bv.e[r]);
+                        for (int r = 0; r < 4; ++r) f[4 * t + r] += to_f32(bv.e[r]);
                     }
                     if (ACC) {
                         union { uint2 raw; T e[4]; } cv;
                         cv.raw = *reinterpret_cast<const uint2*>(crow + nq);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += to_f32(cv.e[r]);
+                        for (int r = 0; r < 4; ++r) f[4 * t + r] += to_f32(cv.e[r]);
                     }
                     union { T e[4]; uint32_t u[2]; } o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(v[r]);
+                    for (int r = 0; r < 4; ++r) o.e[r] = from_f32<T>(f[4 * t + r]);
                     w[t][0] = o.u[0];
                     w[t][1] = o.u[1];
                 }
-                // odd rows of the first operand <-> even rows of the second: even lanes keep their tile-x quad and receive the
-                // partner's, odd lanes keep their tile-(x+1) quad and receive the partner's
+                // odd rows of the first operand <-> even rows of the second: even lanes keep their tile-x quad and receive
+                // the partner's, odd lanes keep their tile-(x+1) quad and receive the partner's
                 const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
                 uint4 out;
                 out.x = s0[0]; out.y = s1[0]; out.z = s0[1]; out.w = s1[1];
-                // even lane: [own tile-x quad | partner's tile-x quad] at tile x, column 4 l4; odd lane: [partner's tile-(x+1) quad
-                // | own] at tile x + 1, column 4 (l4 - 1)
-                *reinterpret_cast<uint4*>(crow + (2 * xp + odd) * 16 + (l4 & 2) * 4) = out;
-            }
-        }
+                // even lane: [own tile-x quad | partner's tile-x quad] at tile x, column 4 l4; odd lane: [partner's
+                // tile-(x+1) quad | own] at tile x + 1, column 4 (l4 - 1)
+                *reinterpret_cast<uint4*>(crow + (2 * xp + odd) * 16 + (l4o & 2) * 4) = out;
+            });
+        };
+        UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
     };
-    UAMD_EPILOGUE_DISPATCH(epi, p.accumulate, bias);
+
+    int v = blockIdx.x;
+    int c_m0, c_n0, c_gi;
+    int par = 0;                       // LDS stage of the current output tile's K tile 0
+    decode(v, c_m0, c_n0, c_gi);
+    set_main(c_m0, c_n0, c_gi);
+    make_rd(0);
+    // ---- prologue (first output tile of this workgroup only): K tiles 0 and 1 in flight, tile 0 landed and published
+    G256S_SETSRC_RUN();
+    G256S_RUN(ISSUE_TILE);
+    G256S_RUN(ISSUE_TILE);
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    for (;;) {
+        // (the per-lane source offsets and read pointers of THIS tile, rebuilt here: nothing per-lane lives across the epilogue)
+        set_main(c_m0, c_n0, c_gi);
+        make_rd(par);
+        G256S_RUN_W(READ0);            // k-half-0 fragments of this output tile's K tile 0
+        // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper (the loop runs cnt + 1 trips)
+        //      -- unconditional (host: K >= 192): a branch around an asm statement with "+s" operands makes them PHIs
+        cnt = (unsigned)(nk_main - 3);
+        if constexpr (BNN || VAR == 0) {
+            G256S_RUN(LOOP);
+        } else {
+            if constexpr (VAR == 2) G256S_ASM(G256S_LOOP_KND("bf16"));
+            else if constexpr (VAR == 3) G256S_ASM(G256S_LOOP_KNR("bf16"));
+            else if constexpr (VAR == 4) G256S_ASM(G256S_LOOP_KMF("bf16"));
+            else if constexpr (VAR == 5) G256S_ASM(G256S_LOOP_KMO("bf16"));
+            else if constexpr (VAR == 6) G256S_ASM(G256S_LOOP_KNV("bf16"));
+            else G256S_ASM(G256S_LOOP_KNB("bf16"));
+        }
+        // ---- the rank block's tiles are fetched from XK [M, Rk] / BK ([N, Rk]; NN: [Rk, N]) by the same body: only the sources change
+        const int nk_rank = __builtin_amdgcn_readfirstlane(p.g[c_gi].lora_xk != nullptr ? p.g[c_gi].Rk / TK : 0);
+        if (nk_rank) {
+            set_rank(c_m0, c_n0, c_gi);
+            G256S_SETSRC_RUN();
+            cnt = (unsigned)(nk_rank - 1);
+            G256S_RUN(LOOP);
+        }
+        const int vn = PERSIST ? v + (int)gridDim.x : total;
+        const bool has_next = PERSIST && vn < total;
+        int n_m0 = 0, n_n0 = 0, n_gi = 0;
+        if (has_next) {
+            // ---- the last two K tiles of this output tile, multiplied while K tiles 0 and 1 of the NEXT one are fetched
+            decode(vn, n_m0, n_n0, n_gi);
+            set_main(n_m0, n_n0, n_gi);
+            G256S_SETSRC_RUN();
+            cnt = 1;
+            G256S_RUN(LOOP);
+        } else {
+            G256S_RUN_C(NODMA);
+            G256S_RUN_C(LAST);
+        }
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // last MFMA's write -> the epilogue's v_accvgpr_read (asm MFMAs)
+        store_tile(c_m0, c_n0, c_gi);
+        if (!has_next) break;
+        g256s_acc_zero();
+        par ^= (nk_main + nk_rank) & 1;       // every K tile flipped the stages once
+        c_m0 = n_m0; c_n0 = n_n0; c_gi = n_gi;
+        v = vn;
+    }
+#undef G256S_SETSRC_RUN
+#undef G256S_RUN_W
+#undef G256S_RUN_C
+#undef G256S_RUN
+#undef G256S_RUN2
+#undef G256SN_ASM_W
+#undef G256S_ASM_W
+#undef G256SN_ASM_C
+#undef G256S_ASM_C
+#undef G256SN_ASM
+#undef G256S_ASM
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1254,35 +1315,44 @@ int launch256h(const G256Args& a, hipStream_t st) {
     return uamd_launch_status();
 }
 
-template <typename T, bool BNN, int VAR>
-int launch256s_(const G256Args& a, hipStream_t st) {
+template <typename T, bool BNN, int VAR, bool PERSIST>
+int launch256s_(const G256Args& a, hipStream_t st, int grid) {
     static bool attr_set[64] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (!attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T, BNN, VAR>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt256s_kernel<T, BNN, VAR, PERSIST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL((gemm_nt256s_kernel<T, BNN, VAR>), dim3((unsigned)a.total_tiles), dim3(256), LDS_BYTES, st, a);
+    hipLaunchKernelGGL((gemm_nt256s_kernel<T, BNN, VAR, PERSIST>), dim3((unsigned)grid), dim3(256), LDS_BYTES, st, a);
     return uamd_launch_status();
 }
 
+int cu_count();
+
+// UAMD_TUNE_GEMM_S: 1 = by tile count (the persistent walk when every CU gets at least FOUR output tiles, one workgroup per tile
+// otherwise), 2 = one workgroup per tile always, 9 = the walk from two tiles per CU on (tests), 0 = the 8-wave kernels
+// (gemm256_entry); 3..8 = knock-out builds. Measured (profiles/r06l_gemm_persistent_ab.jsonl, same box, interleaved with
+// hipBLASLt): gate|up (14 tiles per CU) +1.3 %, down-dX (7) +1.1 %, 2-3 tiles per CU -1.1 .. 0 % -- the dispatcher's balancing is
+// worth more than the hidden prologue there.
 template <typename T, bool BNN>
 int launch256s(const G256Args& a, hipStream_t st) {
-#ifdef UAMD_G256S_KNOCKOUTS
     const int v = uamd_tuning_get(UAMD_TUNE_GEMM_S);
+#ifdef UAMD_G256S_KNOCKOUTS
     if constexpr (std::is_same<T, bf16_t>::value && !BNN) {
-        if (v == 3) return launch256s_<T, false, 2>(a, st);
-        if (v == 4) return launch256s_<T, false, 3>(a, st);
-        if (v == 5) return launch256s_<T, false, 4>(a, st);
-        if (v == 6) return launch256s_<T, false, 5>(a, st);
-        if (v == 7) return launch256s_<T, false, 6>(a, st);
-        if (v == 8) return launch256s_<T, false, 7>(a, st);
+        if (v == 3) return launch256s_<T, false, 2, false>(a, st, a.total_tiles);
+        if (v == 4) return launch256s_<T, false, 3, false>(a, st, a.total_tiles);
+        if (v == 5) return launch256s_<T, false, 4, false>(a, st, a.total_tiles);
+        if (v == 6) return launch256s_<T, false, 5, false>(a, st, a.total_tiles);
+        if (v == 7) return launch256s_<T, false, 6, false>(a, st, a.total_tiles);
+        if (v == 8) return launch256s_<T, false, 7, false>(a, st, a.total_tiles);
     }
 #endif
-    return launch256s_<T, BNN, 0>(a, st);
+    const int n_cu = cu_count();
+    if (v != 2 && (n_cu & 7) == 0 && a.total_tiles >= (v == 9 ? 2 : 4) * n_cu) return launch256s_<T, BNN, 0, true>(a, st, n_cu);
+    return launch256s_<T, BNN, 0, false>(a, st, a.total_tiles);
 }
 
 template <typename T, bool BNN, bool ATN = false>
