@@ -17,9 +17,11 @@ the data-parallel gradient arena. Each block also exists as a pair of plain func
 (`mlp_forward` / `mlp_backward`, ...) for the whole-layer Function with selective recompute
 (models/fast_layer.py).
 """
+import os
+
 import torch
 
-from .utils import glu_bwd_terms, glu_fwd_xa
+from .utils import _same_rows, alloc_rows, glu_bwd_terms, glu_fwd_xa
 from .utils import (
     GRAD_SINKS,
     grad_sink,
@@ -95,17 +97,38 @@ _ACT_NAMES = {swiglu_fg_kernel: "swiglu", swiglu_DWf_DW_dfg_kernel: "swiglu",
               geglu_approx_forward_kernel: "geglu_approx", geglu_approx_backward_kernel: "geglu_approx"}
 
 
+MERGE_GATE_UP = os.environ.get("UNSLOTH_AMD_MERGE_GATE_UP", "1") != "0"
+
+
+def _gate_up(X, gate, up, return_xa=False):
+    """(e, g) = X @ W_gate^T, X @ W_up^T (+ LoRA) as the two column halves of ONE row-padded buffer (utils.alloc_rows): the
+    in-place activation backward then leaves df | de side by side, so dX = [df | de] @ [W_up; W_gate] is ONE GEMM over the
+    concatenated 2 I features (utils._lora_linear_dx_merged -- no read-modify-write of dX, one launch), and every GEMM that
+    reads an intermediate as its A operand (down_proj forward: h; that dX: df | de) sees rows that are not a whole number of
+    4 KiB pages."""
+    outs = None
+    widths = [(q.shape[0] if q is not None else W.shape[0]) for (W, q, *_rest) in (gate, up)]
+    if (MERGE_GATE_UP and X.is_cuda and X.dtype in (torch.bfloat16, torch.float16) and widths[0] == widths[1]
+            and widths[0] % 64 == 0 and all(len(p) <= 5 or p[5] is None for p in (gate, up))):
+        M = X.numel() // X.shape[-1]
+        eg = alloc_rows(M, 2 * widths[0], X.dtype, X.device)
+        outs = [eg[:, :widths[0]], eg[:, widths[0]:]]
+    return lora_linear_forward(X, [gate, up], outs=outs, return_xa=return_xa)
+
+
 def mlp_forward(X, gate, up, down, act_fwd):
     """gate/up/down = (W, W_quant, A, B, s). Returns (out, e, g, (xa_gate, xa_up, xa_down)); fast_lora.py:93-96.
     The activation kernel also produces h @ A_down^T while h is in its registers (utils.glu_fwd_xa) when it can."""
-    (e, g), xa_gu = lora_linear_forward(X, [gate, up], return_xa=True)
+    (e, g), xa_gu = _gate_up(X, gate, up, return_xa=True)
     act = _ACT_NAMES.get(act_fwd)
-    fused = glu_fwd_xa(act, e.view(-1, e.shape[-1]), g.view(-1, g.shape[-1]), down) if (
-        act is not None and e.is_contiguous() and g.is_contiguous()) else None
+    e2, g2 = e.view(-1, e.shape[-1]), g.view(-1, g.shape[-1])
+    fused = glu_fwd_xa(act, e2, g2, down) if (act is not None and _same_rows([e2, g2])) else None
     if fused is not None:
         h, pre = fused
         (out,), xa_d = lora_linear_forward(h.view(e.shape), [down], return_xa=True, pre_xa=pre)
     else:
+        if not e.is_contiguous():                  # (the plain activation kernels take flat buffers)
+            e, g = e.contiguous(), g.contiguous()
         h = act_fwd(e, g)
         (out,), xa_d = lora_linear_forward(h, [down], return_xa=True)
     return out, e, g, (xa_gu[0], xa_gu[1], xa_d[0])
@@ -113,7 +136,7 @@ def mlp_forward(X, gate, up, down, act_fwd):
 
 def mlp_gate_up_forward(X, gate, up):
     """The recomputable half of mlp_forward: (e, g) only (the backward rebuilds h = act(e) * g itself)."""
-    return lora_linear_forward(X, [gate, up])
+    return _gate_up(X, gate, up)
 
 
 def mlp_backward(dY, X, e, g, xas, gate, up, down, act_bwd, inplace=True):
@@ -128,12 +151,17 @@ def mlp_backward(dY, X, e, g, xas, gate, up, down, act_bwd, inplace=True):
     dtype = X2.dtype
     # DW = dY @ W_down (+ LoRA)                                     fast_lora.py:156
     (p_d,) = lora_dx_terms([dY], [down])
-    DW = lora_linear_dx([dY], [down], terms=[p_d])
+    # (DW shares e's row stride: the activation backward takes ONE `ld` for DW, e and g)
+    padded = e.stride(0) != e.shape[1] and _same_rows([e, g])
+    DW = lora_linear_dx([dY], [down], terms=[p_d],
+                        out=alloc_rows(e.shape[0], e.shape[1], e.dtype, e.device, ld=e.stride(0)) if padded else None)
     act = _ACT_NAMES.get(act_bwd)
     fused = glu_bwd_terms(act, DW, e, g, up, gate) if (act is not None and DW.dim() == 2) else None
     if fused is not None:                                          # activation backward + df @ B_up, de @ B_gate in one pass
         h, df, de, (p_u, p_g) = fused
     else:
+        if padded:                                                 # (the plain in-place kernels take flat buffers)
+            DW, e, g = DW.contiguous(), e.contiguous(), g.contiguous()
         DW, e, g = act_bwd(DW, e, g)                               # in place (:157)
         h, df, de = DW, e, g
         p_u, p_g = lora_dx_terms([df, de], [up, gate])

@@ -907,14 +907,37 @@ GLU_FUSED_MIN_ROWS = 2048
 _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 
 
+# Rows of a whole number of 4 KiB pages (14336 or 28672 bf16 columns: the gated-MLP intermediates) read as the A operand of a
+# GEMM -- 256 rows x 128 bytes per K tile -- put every line of a tile on the same few memory channels: the same GEMM with 128
+# bytes of row padding measured +4.3 % (NT, K = 14336), +2.7 % (NN), tools/gemm_pad_probe.py / profiles/r06_gemm_row_padding.jsonl.
+# alloc_rows gives such buffers a row stride of N + ROW_PAD elements (UNSLOTH_AMD_ROW_PAD=0: plain).
+ROW_PAD = int(os.environ.get("UNSLOTH_AMD_ROW_PAD", "64"))
+
+
+def alloc_rows(M, N, dtype, device, ld=None):
+    """A [M, N] row-major buffer; `ld` = forced row stride (elements), default N (+ ROW_PAD for page-multiple rows >= 16 KiB)."""
+    if ld is None:
+        item = torch.empty((), dtype=dtype).element_size()
+        ld = N + ROW_PAD if (ROW_PAD and N * item >= 16384 and (N * item) % 4096 == 0) else N
+    buf = torch.empty((M, ld), dtype=dtype, device=device)
+    return buf if ld == N else buf[:, :N]
+
+
+def _same_rows(ts):
+    """2-D row-major views with ONE row stride (a multiple of 8 elements) and 16-byte aligned starts: what the gated-activation
+    kernels take through their single `ld`"""
+    t0 = ts[0]
+    return all(t.dim() == 2 and t.stride(1) == 1 and t.stride(0) == t0.stride(0) and t.stride(0) % 8 == 0
+               and t.data_ptr() % 16 == 0 and t.shape == t0.shape for t in ts)
+
+
 def _glu_fusable(dtype, tensors, ranks, backward):
     K = tensors[0].shape[-1]
     mode = GLU_FUSED if GLU_FUSED is not True else "all"
     if not mode or (mode == "bwd" and not backward) or (mode in ("bwd", "both") and tensors[0].shape[0] < GLU_FUSED_MIN_ROWS):
         return False
     return (LORA_XA_V2 and dtype in (torch.bfloat16, torch.float16) and K % 8 == 0
-            and all(t.is_cuda and t.dim() == 2 and t.is_contiguous() and t.dtype == dtype and t.shape == tensors[0].shape
-                    for t in tensors)
+            and all(t.is_cuda and t.dtype == dtype for t in tensors) and _same_rows(tensors)
             and all(r is not None and r % 8 == 0 and 0 < r <= 64 for r in ranks))
 
 
@@ -954,7 +977,7 @@ def glu_fwd_xa(act, e, g, down, n_out_cols_hint=None):
     fused_nf4 = q is not None and FUSED_NF4 and M < FUSED_NF4_MAX_M and q.blocksize == 64 and K % 64 == 0
     want_k = (not fused_nf4) and _use_gemm256(M, K, [N])
     Ac = _cached_cast(A, "rowmajor", dtype, lambda: A.to(dtype).contiguous())
-    h = torch.empty_like(e)
+    h = alloc_rows(M, K, dtype, e.device, ld=e.stride(0))          # (one `ld` for e, g and h)
     xa = torch.empty((M, r), dtype=torch.float32, device=e.device)
     xk = torch.empty((M, _rank_width(r)), dtype=dtype, device=e.device) if want_k else None
     with _lib.device_ctx(e):
