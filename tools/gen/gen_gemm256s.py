@@ -19,8 +19,9 @@ What round 6's measurements changed against the vendor's placement (profiles/r06
   * every DMA piece is issued as EARLY as its half of the stage allows (A: MFMAs 21..35, B: 46..60; the vendor spreads B's
     pieces up to MFMA 124): on K = 14336 the loop is latency-exposed -- a fifth of the pieces miss the XCD's L2 every tile
     -- and the last piece had 96 MFMAs (0.7 us) to land, now 160;
-  * the K advance is two 64-bit scalar adds on the buffer descriptors' bases (PINNED s[84:87] / s[88:91]: an asm operand
-    cannot name half of a register tuple) instead of sixteen adds on the piece offsets;
+  * the K advance is two 64-bit scalar adds on the buffer descriptors' bases instead of sixteen adds on the piece offsets; the
+    descriptors sit in s[84:87] / s[88:91] (an asm operand cannot name half of a register tuple) for the duration of ONE
+    statement: built at its entry from the 64-bit `cur` operands, the advanced bases handed back at its exit;
   * the loop head is 64-byte aligned and every 4-byte instruction sits next to another one, so that all 8-byte
     instructions (MFMA, ds_read, buffer_load, literal SALU) stay 8-byte aligned: +2.5 % measured, and a 4-byte shift of
     the same stream costs that much again (MI355X_MICROARCH "code-placement sensitivity").
@@ -244,9 +245,29 @@ def emit_macro(name, instrs):
     print()
 
 
+def srd_in():
+    """the buffer descriptors live in s[84:91] only INSIDE a statement: built at its entry from the `cur` operands (32-bit halves: a 64-bit "+s" operand assigned under a branch is a PHI hipcc cannot keep in SGPRs), the
+    advanced bases handed back at its exit (held across statements they were fair game for the compiler, whose scalar register
+    use of this kernel reaches s91)"""
+    out = []
+    for op in "AB":
+        lo, hi = SRD_LO[op]
+        w2, w3 = ("s86", "s87") if op == "A" else ("s90", "s91")
+        out += [f"s_mov_b32 {lo}, %[cur{op}lo]", f"s_mov_b32 {hi}, %[cur{op}hi]", f"s_mov_b32 {w2}, -1", f"s_mov_b32 {w3}, 0x20000"]
+    return out
+
+
+def srd_out():
+    out = []
+    for op in "AB":
+        lo, hi = SRD_LO[op]
+        out += [f"s_mov_b32 %[cur{op}lo], {lo}", f"s_mov_b32 %[cur{op}hi], {hi}"]
+    return out
+
+
 def loop(instrs):
     b, pads = aligned(instrs)
-    return [".p2align 6", "1:"] + b + ["s_cbranch_scc0 1b"], pads
+    return srd_in() + [".p2align 6", "1:"] + b + ["s_cbranch_scc0 1b"] + srd_out(), pads
 
 
 def emit_family(pfx):
@@ -265,7 +286,7 @@ def emit_family(pfx):
         for c in range(8):
             pro += [m0_for(op, c), "s_nop 0", dma(op, c)]
     pro += advance() + ["s_xor_b32 %[m0bA], %[m0bA], 0x10000", "s_xor_b32 %[m0bB], %[m0bB], 0x10000"]
-    emit_macro(f"{pfx}_ISSUE_TILE", pro)
+    emit_macro(f"{pfx}_ISSUE_TILE", srd_in() + pro + srd_out())
     rd = [rd_y(0, y) for y in range(8)]
     for x in range(8):
         rd += rd_x(0, x)
@@ -291,13 +312,6 @@ def main():
     emit_family("G256S")
     NN = True
     emit_family("G256SN")
-    # shared: the sources of the DMA -- buffer descriptors (raw, no range clamp) over the tile origins of both operands
-    src = []
-    for op in "AB":
-        lo, hi = SRD_LO[op]
-        w2, w3 = ("s86", "s87") if op == "A" else ("s90", "s91")
-        src += [f"s_mov_b64 s[{lo[1:]}:{hi[1:]}], %[base{op}]", f"s_mov_b32 {w2}, -1", f"s_mov_b32 {w3}, 0x20000"]
-    emit_macro("G256S_SETSRC", src)
     print("#define G256S_ACC_CLOBBER " + ", ".join(f'"a{i}"' for i in range(256)))
     print("// all accumulators = 0 (the trailing s_nop: v_accvgpr_write -> MFMA reading it as SrcC)")
     print("__device__ __forceinline__ void g256s_acc_zero() {")
@@ -316,10 +330,9 @@ def main():
             print(f'        asm volatile("{body}" : {outs} :: G256S_ACC_CLOBBER);')
     print("}")
     so = ", ".join(f'[so{o}{c}] "s"(so{o}[{c}])' for o in "AB" for c in range(8))
-    print('#define G256S_OUT_M0 [m0bA] "+s"(m0bA), [m0bB] "+s"(m0bB)')
+    print('#define G256S_OUT_M0 [m0bA] "+s"(m0bA), [m0bB] "+s"(m0bB), [curAlo] "+s"(curAlo), [curAhi] "+s"(curAhi), [curBlo] "+s"(curBlo), [curBhi] "+s"(curBhi)')
     print("#define G256S_IN_SO " + so)
-    print('#define G256S_IN_DMA [voffA] "v"(voffA), [voffB] "v"(voffB), [baseA] "s"(baseA), [baseB] "s"(baseB), '
-          '[stepA] "s"(stepA), [stepB] "s"(stepB)')
+    print('#define G256S_IN_DMA [voffA] "v"(voffA), [voffB] "v"(voffB), [stepA] "s"(stepA), [stepB] "s"(stepB)')
     print("// clang-format on")
 
 

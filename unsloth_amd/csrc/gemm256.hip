@@ -843,24 +843,31 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
         return ((uint64_t)hi << 32) | lo;
     };
-    uint64_t baseA = 0, baseB = 0;
+    // bases of the two buffer descriptors (tile origin + the K tiles fetched so far), as 32-bit halves
+    unsigned curAlo = 0, curAhi = 0, curBlo = 0, curBhi = 0;
     unsigned voffA = 0, voffB = 0, soA[8], soB[8], stepA = TK * sizeof(T), stepB = TK * sizeof(T);
     // the lane-only parts are rebuilt at every switch from an opaque copy of the lane id (a few VALU instructions per output
     // tile) instead of being held -- or spilled -- across the K loop
-    auto set_sources = [&](const void* Ap, int ld_a, const void* Bp, int ld_b, int m0, int n0) {
+    // `ahead`: the descriptors are pointed at K tile `ahead` of these matrices (2 at the top of an output tile: its K tiles 0 and
+    // 1 were fetched by the prologue / during the previous tile's last two K tiles -- recomputed, not carried over: a value that
+    // is written by asm AND lives across the tile loop's back edge is a PHI hipcc handles through VGPRs, and the first build
+    // that carried the bases that way read garbage for every second output tile)
+    auto set_sources = [&](const void* Ap, int ld_a, const void* Bp, int ld_b, int m0, int n0, int ahead) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int sr = ln >> 3, ss = (ln & 7) ^ (((wave & 1) << 2) | (sr >> 1));
-        baseA = sgpr64(Ap, (int64_t)m0 * ld_a * (int64_t)sizeof(T));
+        uint64_t baseA = (uint64_t)(uintptr_t)Ap + (uint64_t)((int64_t)m0 * ld_a * (int64_t)sizeof(T)) +
+                         (uint64_t)ahead * (TK * sizeof(T));
+        uint64_t baseB;
         voffA = (unsigned)(((wave * 8 + sr) * ld_a + ss * 8) * (int)sizeof(T));
         if constexpr (BNN) {
             const int h = ln >> 5, f = h | ((wave & 1) << 1) | ((wave >> 1) << 2);
             const int krow0 = 2 * (wave & 1) + 8 * (wave >> 1) + h;
-            baseB = sgpr64(Bp, (int64_t)n0 * (int64_t)sizeof(T));
+            baseB = (uint64_t)(uintptr_t)Bp + (uint64_t)((int64_t)n0 * (int64_t)sizeof(T));
             voffB = (unsigned)((krow0 * ld_b + (((ln & 31) ^ (f << 1)) << 3)) * (int)sizeof(T));
             stepB = u32((int64_t)TK * ld_b * (int64_t)sizeof(T));
         } else {
-            baseB = sgpr64(Bp, (int64_t)n0 * ld_b * (int64_t)sizeof(T));
+            baseB = (uint64_t)(uintptr_t)Bp + (uint64_t)((int64_t)n0 * ld_b * (int64_t)sizeof(T));
             voffB = (unsigned)(((wave * 8 + sr) * ld_b + ss * 8) * (int)sizeof(T));
         }
 #pragma unroll
@@ -868,19 +875,32 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
             soA[c] = u32((int64_t)c * 32 * ld_a * (int64_t)sizeof(T));
             soB[c] = BNN ? u32((int64_t)(4 * (c & 1) + 16 * (c >> 1)) * ld_b * (int64_t)sizeof(T)) : u32((int64_t)c * 32 * ld_b * (int64_t)sizeof(T));
         }
+        baseB += (uint64_t)ahead * stepB;
+        {
+            curAlo = __builtin_amdgcn_readfirstlane((unsigned)baseA);
+            curAhi = __builtin_amdgcn_readfirstlane((unsigned)(baseA >> 32)) & 0xffffu;     // (descriptor word 1: stride 0)
+            curBlo = __builtin_amdgcn_readfirstlane((unsigned)baseB);
+            curBhi = __builtin_amdgcn_readfirstlane((unsigned)(baseB >> 32)) & 0xffffu;
+        }
     };
-    auto set_main = [&](int m0, int n0, int gi) {
+    auto set_main = [&](int m0, int n0, int gi, int ahead) {
         const uamd_gemm_group& g = p.g[gi];
-        set_sources(p.A, __builtin_amdgcn_readfirstlane((int)p.lda), g.B, __builtin_amdgcn_readfirstlane((int)g.ldb), m0, n0);
+        set_sources(p.A, __builtin_amdgcn_readfirstlane((int)p.lda), g.B, __builtin_amdgcn_readfirstlane((int)g.ldb), m0, n0, ahead);
     };
     auto set_rank = [&](int m0, int n0, int gi) {
         const uamd_gemm_group& g = p.g[gi];
-        set_sources(g.lora_xk, __builtin_amdgcn_readfirstlane((int)g.ld_xk), g.lora_bk, __builtin_amdgcn_readfirstlane((int)g.ld_bk), m0, n0);
+        set_sources(g.lora_xk, __builtin_amdgcn_readfirstlane((int)g.ld_xk), g.lora_bk, __builtin_amdgcn_readfirstlane((int)g.ld_bk), m0, n0, 0);
     };
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;      // 0: no static LDS in this kernel (stage bit = 0x10000)
-    // DMA destinations of the wave's first piece of each operand, + 64 (gen_gemm256s.py M0_BIAS)
-    unsigned m0bA = __builtin_amdgcn_readfirstlane(lds_base + wave * 1024 + 64);
-    unsigned m0bB = __builtin_amdgcn_readfirstlane(lds_base + 32 * 1024 + (BNN ? (wave & 1) * 1024 + (wave >> 1) * 4096 : wave * 1024) + 64);
+    // DMA destinations of the wave's first piece of each operand in stage `par`, + 64 (gen_gemm256s.py M0_BIAS). Like the
+    // descriptor bases they are rebuilt at the top of every output tile (K tile 2 goes where K tile 0 sits), not carried over
+    unsigned m0bA = 0, m0bB = 0;
+    auto make_m0 = [&](int par) {
+        const unsigned st = lds_base + ((unsigned)par << 16) + 64;
+        m0bA = __builtin_amdgcn_readfirstlane(st + wave * 1024);
+        m0bB = __builtin_amdgcn_readfirstlane(st + 32 * 1024 + (BNN ? (wave & 1) * 1024 + (wave >> 1) * 4096 : wave * 1024));
+    };
+    make_m0(0);
     // fragment read pointers of the stage that holds K tile 0 of the current output tile (`par`), rebuilt per output tile from an
     // opaque copy of the lane id: held across the epilogue (which wants every VGPR for the accumulators) they were spilled
     unsigned rdA[2], rdB[2], rdBn[8];
@@ -930,13 +950,16 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
             else G256S_##K(G256S_##NAME("f16"));                                            \
         }                                                                                   \
     } while (0)
-#define G256S_RUN(NAME) G256S_RUN2(NAME, ASM)
+// (the descriptor bases are assigned under wave-uniform branches AND written by asm: hipcc treats an asm output as divergent, the
+// PHI at the join becomes a VGPR -- readfirstlane hands the next statement a scalar again)
+#define G256S_RUN(NAME)                                                                                     \
+    do {                                                                                                    \
+        curAlo = __builtin_amdgcn_readfirstlane(curAlo); curAhi = __builtin_amdgcn_readfirstlane(curAhi);   \
+        curBlo = __builtin_amdgcn_readfirstlane(curBlo); curBhi = __builtin_amdgcn_readfirstlane(curBhi);   \
+        G256S_RUN2(NAME, ASM);                                                                              \
+    } while (0)
 #define G256S_RUN_C(NAME) G256S_RUN2(NAME, ASM_C)
 #define G256S_RUN_W(NAME) G256S_RUN2(NAME, ASM_W)
-#define G256S_SETSRC_RUN()                                                                                                    \
-    do {                                                                                                                      \
-        if constexpr (std::is_same<T, bf16_t>::value) G256S_ASM(G256S_SETSRC("bf16")); else G256S_ASM(G256S_SETSRC("f16"));   \
-    } while (0)
 
     // ---- epilogue: lane holds C[m][n..n+3], m = ..+l15, n = x*16 + 4*l4 (B-operand is MFMA source A) for each of its 64
     //      accumulator quads. Stored as 8-byte pieces that is 64 store instructions per lane, each touching 16 rows with 32 bytes
@@ -1002,17 +1025,17 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
     int c_m0, c_n0, c_gi;
     int par = 0;                       // LDS stage of the current output tile's K tile 0
     decode(v, c_m0, c_n0, c_gi);
-    set_main(c_m0, c_n0, c_gi);
+    set_main(c_m0, c_n0, c_gi, 0);
     make_rd(0);
     // ---- prologue (first output tile of this workgroup only): K tiles 0 and 1 in flight, tile 0 landed and published
-    G256S_SETSRC_RUN();
     G256S_RUN(ISSUE_TILE);
     G256S_RUN(ISSUE_TILE);
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
     for (;;) {
         // (the per-lane source offsets and read pointers of THIS tile, rebuilt here: nothing per-lane lives across the epilogue)
-        set_main(c_m0, c_n0, c_gi);
+        set_main(c_m0, c_n0, c_gi, 2);
         make_rd(par);
+        make_m0(par);
         G256S_RUN_W(READ0);            // k-half-0 fragments of this output tile's K tile 0
         // ---- tiles 0 .. nk_main - 3 fetch tiles 2 .. nk_main - 1 of the operands proper (the loop runs cnt + 1 trips)
         //      -- unconditional (host: K >= 192): a branch around an asm statement with "+s" operands makes them PHIs
@@ -1031,7 +1054,6 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
         const int nk_rank = __builtin_amdgcn_readfirstlane(p.g[c_gi].lora_xk != nullptr ? p.g[c_gi].Rk / TK : 0);
         if (nk_rank) {
             set_rank(c_m0, c_n0, c_gi);
-            G256S_SETSRC_RUN();
             cnt = (unsigned)(nk_rank - 1);
             G256S_RUN(LOOP);
         }
@@ -1041,8 +1063,7 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
         if (has_next) {
             // ---- the last two K tiles of this output tile, multiplied while K tiles 0 and 1 of the NEXT one are fetched
             decode(vn, n_m0, n_n0, n_gi);
-            set_main(n_m0, n_n0, n_gi);
-            G256S_SETSRC_RUN();
+            set_main(n_m0, n_n0, n_gi, 0);
             cnt = 1;
             G256S_RUN(LOOP);
         } else {
@@ -1057,7 +1078,6 @@ __global__ void __launch_bounds__(256) gemm_nt256s_kernel(G256Args p) {
         c_m0 = n_m0; c_n0 = n_n0; c_gi = n_gi;
         v = vn;
     }
-#undef G256S_SETSRC_RUN
 #undef G256S_RUN_W
 #undef G256S_RUN_C
 #undef G256S_RUN
