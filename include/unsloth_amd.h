@@ -286,13 +286,15 @@ int uamd_gemm_nn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
  * M % 8 == 0, N_g % 8 == 0, K % 64 == 0, lda % 8 == 0, ldb % 8 == 0; no LoRA fields. */
 int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_group* groups,
                      int n_groups, int accumulate, int dtype, void* stream);
-/* process-wide tuning knobs (each also has an environment variable; defaults are the measured-fastest values):
- *   UAMD_TUNE_GROUP_M     (UAMD_GEMM_GROUP_M) row panels per raster group of the 256x256 kernel (L2 reuse) */
-#define UAMD_TUNE_GLU_VAR 0     /* (UAMD_GLU_VAR) gated-MLP activation kernels: 0 = 2048-block grid-stride, 1 = uncapped grid,
+/* process-wide kernel-variant hooks (`uamd_set_tuning(knob, value)`; defaults are the measured-fastest values). Three of them can
+ * also be set from the environment -- UAMD_ATTN_VAR, UAMD_GLU_XA, UAMD_GEMM_S: the ones whose best value depends on the workload --;
+ * the A/Bs of the others are settled and they remain here for the parity tests only (every listed value is exercised by one).
+ *   UAMD_TUNE_GROUP_M     row panels per raster group of the 256x256 kernel (L2 reuse) */
+#define UAMD_TUNE_GLU_VAR 0     /* gated-MLP activation kernels: 0 = 2048-block grid-stride, 1 = uncapped grid,
                                  * one 16-byte vector per thread, 2 = uncapped grid, two vectors per thread */
 #define UAMD_TUNE_GROUP_M 1
-#define UAMD_TUNE_STREAM_NT 2   /* (UAMD_STREAM_NT) streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
-#define UAMD_TUNE_DEQUANT_T 3   /* (UAMD_DEQUANT_T) transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64, 2 = 64x256 with
+#define UAMD_TUNE_STREAM_NT 2   /* streaming kernels: bit0 non-temporal loads, bit1 n.t. stores */
+#define UAMD_TUNE_DEQUANT_T 3   /* transposing NF4 dequant: 1 = 64x256 tile kernel, 0 = 64x64, 2 = 64x256 with
                                  * the row tile as the fastest grid index (adjacent output segments written together) */
 #define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention forward: 0 = by shape (plain causal batches with >= 2 work items per CU take
                                  * attn_fwd_ps_kernel -- one persistent workgroup per CU, ping-pong wave groups -- everything else
@@ -300,16 +302,16 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
                                  * always. (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
                                  * round-1 dK/dV kernel, a 4-wave dQ kernel -- all measured at parity or slower: removed in round 4,
                                  * git 4501bb3:tools/experiments/attention_removed_r04.hip) */
-#define UAMD_TUNE_RMS_VAR 5     /* (UAMD_RMS_VAR) RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
+#define UAMD_TUNE_RMS_VAR 5     /* RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
                                  * 1 = one 256-thread block per row (one LDS reduction, 8 blocks per CU, several passes) */
-#define UAMD_TUNE_GEMM_HALF 6   /* (UAMD_GEMM_HALF) uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has
+#define UAMD_TUNE_GEMM_HALF 6   /* uamd_gemm_nt_256 tile height: 1 = 128-row tiles when the 256-row tiling has
                                  * fewer than 192 tiles (default), 0 = always 256 rows, 2 = always 128 rows */
-#define UAMD_TUNE_GEMM_PERSIST 7 /* (UAMD_GEMM_PERSIST) uamd_gemm_n{t,n}_256 with 256-row tiles: one persistent block per CU walks the tiles
+#define UAMD_TUNE_GEMM_PERSIST 7 /* uamd_gemm_n{t,n}_256 with 256-row tiles: one persistent block per CU walks the tiles
                                  * and prefetches the next tile's first K tiles during the current one's last: 1 = when every CU gets
                                  * >= 4 tiles (default), 2 = whenever it gets more than one, 0 = never (one block per tile) */
-#define UAMD_TUNE_DEQUANT_X4 8  /* (UAMD_DEQUANT_X4) row-major NF4 dequant to a 16-bit dtype: 1 = four 8-element groups per lane per
+#define UAMD_TUNE_DEQUANT_X4 8  /* row-major NF4 dequant to a 16-bit dtype: 1 = four 8-element groups per lane per
                                  * trip, loads issued ahead, shift instead of the 64-bit division (default), 0 = one group per lane */
-#define UAMD_TUNE_GEMM_PLAIN 9  /* (UAMD_GEMM_PLAIN) persistent 256x256 GEMM without accumulate / bias: 1 = the kernel instance whose
+#define UAMD_TUNE_GEMM_PLAIN 9  /* persistent 256x256 GEMM without accumulate / bias: 1 = the kernel instance whose
                                  * epilogue has no global loads (default: no vmcnt(0) in the K loop), 0 = the run-time-dispatch instance */
 #define UAMD_TUNE_GLU_XA 10     /* (UAMD_GLU_XA) the gated activation fused with the LoRA rank products: 0 = 4 waves per 16-row block, two
                                  * 16-byte vectors per thread per tensor, tiles requested one step ahead (rounds 3-4); 1 = 8 waves, one

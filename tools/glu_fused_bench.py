@@ -3,10 +3,10 @@
 import json
 import sys
 import os
-os.environ.setdefault("UNSLOTH_AMD_GLU_FUSED", "all")      # the direct calls below must not be refused by the size / direction policy
 import torch
 sys.path.insert(0, ".")
 from unsloth_amd.kernels import utils as U
+U.GLU_FUSED = "all"      # the direct calls below must not be refused by the size / direction policy
 from unsloth_amd.kernels.swiglu import swiglu_DWf_DW_dfg_kernel, swiglu_fg_kernel
 
 dev = torch.device("cuda", 0)

@@ -8,12 +8,12 @@ import json
 import os
 import sys
 
-os.environ.setdefault("UNSLOTH_AMD_GLU_FUSED", "all")
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unsloth_amd import _lib  # noqa: E402
 from unsloth_amd.kernels import utils as U  # noqa: E402
+U.GLU_FUSED = "all"
 from unsloth_amd.kernels.swiglu import swiglu_DWf_DW_dfg_kernel, swiglu_fg_kernel  # noqa: E402
 
 dev = torch.device("cuda", 0)

@@ -97,7 +97,7 @@ _ACT_NAMES = {swiglu_fg_kernel: "swiglu", swiglu_DWf_DW_dfg_kernel: "swiglu",
               geglu_approx_forward_kernel: "geglu_approx", geglu_approx_backward_kernel: "geglu_approx"}
 
 
-MERGE_GATE_UP = os.environ.get("UNSLOTH_AMD_MERGE_GATE_UP", "1") != "0"
+MERGE_GATE_UP = True          # module attribute (tests flip it); the environment switch went with its A/B (profiles/r06_gemm_row_padding.jsonl)
 
 
 def _gate_up(X, gate, up, return_xa=False):

@@ -28,17 +28,17 @@ next_power_of_2 = lambda n: 1 << (max(int(n), 1) - 1).bit_length()
 # once per 128-row M tile, so it only pays while the launch is weight-bandwidth-bound (few tokens). From
 # FUSED_NF4_MAX_M tokens on, W is decoded ONCE into a per-device bf16 scratch (2.5 B/param of HBM traffic,
 # ~3 % of the GEMM time at 8192 tokens) and the dense 256x256 LDS-DMA kernel runs at ~2x the fused rate.
-FUSED_NF4 = os.environ.get("UNSLOTH_AMD_FUSED_NF4", "1") == "1"
-FUSED_NF4_MAX_M = int(os.environ.get("UNSLOTH_AMD_FUSED_NF4_MAX_M", "512"))
+FUSED_NF4 = True
+FUSED_NF4_MAX_M = 512
 # dense GEMM kernel selection: "auto" = the 256x256 ping-pong kernel (csrc/gemm256.hip: LDS-DMA, 8 waves in two
 # anti-phase groups) once the launch has enough 256x256 tiles to fill the 256 CUs (GEMM256_MIN_TILES), else the
 # 128x128 register-staged kernel (csrc/gemm.hip); "on"/"off" force it.
-GEMM256_MODE = os.environ.get("UNSLOTH_AMD_GEMM256", "auto")
+GEMM256_MODE = "auto"
 # (160 since round 4: Qwen2-VL's ViT linears with N = 1280 at 4096 patches are 160 half-height tiles -- on the 128 x 128 kernel
 # they ran at 0.18 PFLOP/s, the config-4 step is 2.7 % faster with them on the 256 family: profiles/r04p_config4_min_tiles_ab.txt)
-GEMM256_MIN_TILES = int(os.environ.get("UNSLOTH_AMD_GEMM256_MIN_TILES", "160"))
+GEMM256_MIN_TILES = 160
 # X @ A^T / dY @ B: streaming LDS-DMA kernel (csrc/lora_side.hip) for total rank <= 64, else the first version
-LORA_XA_V2 = os.environ.get("UNSLOTH_AMD_LORA_XA_V2", "1") == "1"
+LORA_XA_V2 = True
 
 
 def calculate_settings(n):
@@ -343,7 +343,7 @@ class _PreparedFactors:
 
 
 _PREPARED = {}
-LORA_PREPARE = os.environ.get("UNSLOTH_AMD_LORA_PREPARE", "1") != "0"
+LORA_PREPARE = True
 
 
 def _cached_cast(P, tag, dtype, build):
@@ -668,10 +668,10 @@ def lora_dx_terms(dYs, projs):
     return terms
 
 
-MERGE_DX = os.environ.get("UNSLOTH_AMD_MERGE_DX", "1") != "0"
+MERGE_DX = True
 # dX = dY @ W through the NN form of the 256-tile GEMM (row-major decode, transposing LDS reads) instead of a
 # transposed decode + the NT form
-NN_DX = os.environ.get("UNSLOTH_AMD_NN_DX", "1") != "0"
+NN_DX = True
 
 
 def _adjacent_columns(ts):
@@ -900,9 +900,9 @@ def lora_tn(problems, targets=None):
 # adjacent workgroups (round 5, csrc/glu.hip launch_xa) the fused kernels win there too -- 38 vs 55 us forward, 79 vs 109 us
 # backward at 2048 tokens, 139 vs 153 / 252 vs 325 us at 8192; batch-1 step -1.7 % (profiles/r05_glu_fused_bench.txt) -- so both
 # directions are fused from 2048 tokens on.
-# UNSLOTH_AMD_GLU_FUSED = "both" (default) | "bwd" (backward only, round 3's first default) | "all" (both, any size) | "0".
-GLU_FUSED = os.environ.get("UNSLOTH_AMD_GLU_FUSED", "both")
-GLU_FUSED = {"1": "all", "0": False, "": "both"}.get(GLU_FUSED, GLU_FUSED)
+# GLU_FUSED (module attribute; tools/glu_*.py set "all"): "both" | "bwd" (backward only, round 3's first default) | "all" (both, any
+# size) | False.
+GLU_FUSED = "both"
 GLU_FUSED_MIN_ROWS = 2048
 _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 
@@ -910,8 +910,8 @@ _GLU_ACTS = {"swiglu": 0, "geglu_exact": 1, "geglu_approx": 2}
 # Rows of a whole number of 4 KiB pages (14336 or 28672 bf16 columns: the gated-MLP intermediates) read as the A operand of a
 # GEMM -- 256 rows x 128 bytes per K tile -- put every line of a tile on the same few memory channels: the same GEMM with 128
 # bytes of row padding measured +4.3 % (NT, K = 14336), +2.7 % (NN), tools/gemm_pad_probe.py / profiles/r06_gemm_row_padding.jsonl.
-# alloc_rows gives such buffers a row stride of N + ROW_PAD elements (UNSLOTH_AMD_ROW_PAD=0: plain).
-ROW_PAD = int(os.environ.get("UNSLOTH_AMD_ROW_PAD", "64"))
+# alloc_rows gives such buffers a row stride of N + ROW_PAD elements (ROW_PAD = 0: plain).
+ROW_PAD = 64
 
 
 def alloc_rows(M, N, dtype, device, ld=None):

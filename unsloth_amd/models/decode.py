@@ -40,7 +40,7 @@ def _base(model):
 # measured slower than the 14, 4.97 vs 4.13 ms per token, profiles/r03r_decode_fused_ab.jsonl; t is now computed once per
 # launch and handed over through a device workspace, RoPE / append / combine ride in the attention launch and SwiGLU in the
 # gate|up epilogue.)
-FUSED_STEP = os.environ.get("UNSLOTH_AMD_DECODE_FUSED", "1") == "1"
+FUSED_STEP = True
 
 
 class DecodeEngine:

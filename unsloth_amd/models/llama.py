@@ -49,8 +49,9 @@ from .. import nf4 as _nf4
 from ..kernels import attention as _flash
 from . import fast_layer as _fast_layer
 
-_USE_FLASH = os.environ.get("UNSLOTH_AMD_FLASH_ATTENTION", "1") == "1"
-_FUSED_RESIDUAL = os.environ.get("UNSLOTH_AMD_FUSED_RESIDUAL", "1") == "1"
+_USE_FLASH = True
+_FUSED_RESIDUAL = True
+CHECK_POSITIONS = False        # True: assert on the host that packed position_ids restart where the documents do (a sync per step)
 
 __version__ = "0.1.0"
 
@@ -186,20 +187,20 @@ def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
         if _flash.native(q, k, v) or (_flash.supported(q, k, v) and (need_band or D == 128 or B * T >= 4096)):
             band = _attention_band(seq_info, B, T, window, Q.device) if need_band else None
             return _flash.flash_attention(q, k, v, None, band).reshape(B, T, Hq * D)
-    if seq_info is None and attention_mask is None and window is None:
-        A = F.scaled_dot_product_attention(Q, K, V, is_causal=True, enable_gqa=True)
-        return A.transpose(1, 2).reshape(B, T, Hq * D)
-    # dense additive mask from the same (lo, hi) band the flash kernels take: one [T, T] block per batch row
-    pos = torch.arange(T, device=Q.device)
-    allowed = (pos[:, None] >= pos[None, :])[None]                              # causal, [1, T(q), T(key)]
-    if seq_info is not None or window is not None:
-        lo, _ = _attention_band(seq_info, B, T, window, Q.device)
-        allowed = allowed & (pos[None, None, :] >= lo[:, :, None])
-    allowed = allowed[:, None]
-    if attention_mask is not None:
-        allowed = allowed & attention_mask.to(torch.bool)[:, None, None, :]
-    mask = torch.zeros(allowed.shape, dtype=Q.dtype, device=Q.device).masked_fill_(~allowed, float("-inf"))
-    A = F.scaled_dot_product_attention(Q, K, V, attn_mask=mask, enable_gqa=True)
+    # ---- the library kernel (ONE call site): plain causal without a mask tensor, everything else with a dense additive mask
+    #      built from the same (lo, hi) band the flash kernels take -- one [T, T] block per batch row
+    mask = None
+    if not (seq_info is None and attention_mask is None and window is None):
+        pos = torch.arange(T, device=Q.device)
+        allowed = (pos[:, None] >= pos[None, :])[None]                          # causal, [1, T(q), T(key)]
+        if seq_info is not None or window is not None:
+            lo, _ = _attention_band(seq_info, B, T, window, Q.device)
+            allowed = allowed & (pos[None, None, :] >= lo[:, :, None])
+        allowed = allowed[:, None]
+        if attention_mask is not None:
+            allowed = allowed & attention_mask.to(torch.bool)[:, None, None, :]
+        mask = torch.zeros(allowed.shape, dtype=Q.dtype, device=Q.device).masked_fill_(~allowed, float("-inf"))
+    A = F.scaled_dot_product_attention(Q, K, V, attn_mask=mask, is_causal=mask is None, enable_gqa=True)
     return A.transpose(1, 2).reshape(B, T, Hq * D)
 
 
@@ -292,7 +293,7 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
         rope_position_ids = rope_position_ids.reshape(-1)
     tables = _rope_tables(self)
     cos, sin = tables.get(max(q_len, 1), hidden_states.device, dtype)
-    if rope_position_ids is not None and os.environ.get("UNSLOTH_AMD_CHECK_POSITIONS", "0") == "1":
+    if rope_position_ids is not None and CHECK_POSITIONS:
         assert int(rope_position_ids.max()) < cos.shape[0]
     gc = bool(getattr(self, "gradient_checkpointing", False)) and self.training and torch.is_grad_enabled()
     policy = getattr(self, "_unsloth_amd_layer_policy", None)

@@ -118,6 +118,9 @@ def _patch_trl_trainer():
     return done
 
 
+FLAT_ADAMW = True              # one-launch AdamW over flat arenas (optim.FlatAdamW); False = torch's fused AdamW
+
+
 def make_optimizer(model, lr=None, weight_decay=0.01, betas=(0.9, 0.999), arena=None, flat=None):
     """AdamW on the trainable (LoRA) parameters. On the GPU with fp32 parameters: optim.FlatAdamW -- parameters,
     gradients and moments in flat arenas, ONE launch per step (`arena`: the dp.LoRAGradArena of a data-parallel run, else
@@ -132,7 +135,7 @@ def make_optimizer(model, lr=None, weight_decay=0.01, betas=(0.9, 0.999), arena=
         return ShardedAdamW(arena if isinstance(arena, FullGradBuckets) else model, lr=lr, betas=betas,
                             weight_decay=weight_decay)
     if flat is None:
-        flat = os.environ.get("UNSLOTH_AMD_FLAT_ADAMW", "1") != "0"
+        flat = FLAT_ADAMW
     if flat and params and all(p.is_cuda and p.dtype == torch.float32 for p in params):
         from .optim import FlatAdamW
         return FlatAdamW(model, lr=lr, betas=betas, weight_decay=weight_decay, arena=arena)
