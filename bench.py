@@ -799,12 +799,17 @@ def main():
                     farena._force = True
                     model.for_training(use_gradient_checkpointing=GC_MODE[a.gc])
                     c0 = farena.collectives
+                    farena.timing = True
+                    farena.exposed_ms()
                     ddt, dpeak, _, dgs = timed_steps(lambda i: training_step(model, batches[i % 2], opt, farena, n_items),
                                                      a.alt_steps, 3, True)
+                    exposed = farena.exposed_ms() / (a.alt_steps + 3)
+                    farena.timing = False
                     farena._force = False
                     return point(B * T, ddt, a.alt_steps, dpeak, dgs, batch=B, timing="median step x steps",
                                  buckets=len(farena.buckets), bucket_mb=[round((e - s) * 4 / 2**20, 1) for s, e, _ in farena.buckets],
-                                 collectives_issued_per_step=(farena.collectives - c0) / (a.alt_steps + 3), rccl_group_size=1)
+                                 collectives_issued_per_step=(farena.collectives - c0) / (a.alt_steps + 3), rccl_group_size=1,
+                                 dp_exposed_ms=round(exposed, 3))
                 finally:
                     os.environ["UNSLOTH_AMD_DP_FORCE"] = "0"
             guarded(alt, "dp_path_forced_on_one_rank (UNSLOTH_AMD_DP_FORCE=1: hooks + bucketed RCCL all-reduce inside backward)", dp_force)
