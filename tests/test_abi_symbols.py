@@ -122,3 +122,18 @@ def test_no_cxx_mangled_or_undeclared_exports():
     assert not mangled, mangled
     stray = [n for n in names if (n.startswith("uamd_") or n.startswith("cdequantize_")) and n not in declared]
     assert not stray, f"exported but not declared in the header: {stray}"
+
+
+def test_generated_gemm_loop_is_in_sync_with_its_generator():
+    """unsloth_amd/csrc/gemm256s_loop.inc is the committed output of tools/gen/gen_gemm256s.py (schedule 'vendor'): the K loop of
+    gemm_nt256s_kernel is edited in the generator, never in the include."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("G256S_SCHED", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_gemm256s.py")], capture_output=True, text=True,
+                         check=True, env=env).stdout
+    with open(os.path.join(root, "unsloth_amd", "csrc", "gemm256s_loop.inc")) as f:
+        assert f.read() == out
