@@ -25,41 +25,58 @@ def _device_asm(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_dkdv4_accumulators_are_asm_owned_and_step_bodies_do_not_spill(tmp_path):
-    """attn_bwd_dkdv4_kernel: ALL 256 AGPRs are the dK^T / dV^T accumulators, owned by inline asm (attn_acc256.inc). No
-    compiler-generated instruction may name an AGPR, and the four step bodies (the basic blocks that carry the 64 MFMAs
-    of a step) must not touch scratch memory."""
+def test_dkdv4_accumulators_are_asm_owned_and_step_loops_are_whole(tmp_path):
+    """attn_bwd_dkdv4_kernel: ALL 256 AGPRs are the dK^T / dV^T accumulators, owned by inline asm (attn_acc256.inc and the
+    generated step loops, attn_kd4_loop.inc). No compiler-generated instruction may name an AGPR. The steps over whole tiles run
+    in two generated loops per instance (plain and masked): each is ONE asm statement with both ring stages' bodies (2 x 64
+    MFMAs), a backward branch, counted waits only and no scratch access; the C++ body of the ragged tiles stays (64 MFMAs per
+    stage)."""
     lines = _device_asm(tmp_path)
     kernels = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*attn_bwd_dkdv4_kernel.*:", l)]
     assert len(kernels) == 2                                    # bf16 and fp16
     for start in kernels:
         end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
-        in_asm = False
-        blocks, cur = [], {"mfma": 0, "scratch": 0}
+        in_asm, block, loops, cxx_mfma = False, [], [], 0
         for l in lines[start:end + 1]:
             t = l.strip()
-            if re.match(r"^\.LBB\d+_\d+:", t):
-                blocks.append(cur)
-                cur = {"mfma": 0, "scratch": 0}
-                continue
             if t.startswith(";;#ASMSTART"):
-                in_asm = True
+                in_asm, block = True, []
                 continue
             if t.startswith(";;#ASMEND"):
                 in_asm = False
+                if sum(b.startswith("v_mfma") for b in block) == 128:
+                    loops.append(block)
+                else:
+                    cxx_mfma += sum(b.startswith("v_mfma") for b in block)
                 continue
             if t.startswith(";") or not t:
                 continue
-            if t.startswith("v_mfma"):
-                cur["mfma"] += 1
-            if t.startswith("scratch_"):
-                cur["scratch"] += 1
-            if not in_asm:
+            if in_asm:
+                block.append(t)
+            else:
                 assert not re.search(r"\ba\d+\b|\ba\[\d+:\d+\]|v_accvgpr", t), f"compiler-generated AGPR use: {t}"
-        blocks.append(cur)
-        bodies = [b for b in blocks if b["mfma"] >= 64]
-        assert len(bodies) == 4, [b for b in blocks if b["mfma"]]     # {plain, masked} x {stage 0, stage 1}
-        assert all(b["mfma"] == 64 and b["scratch"] == 0 for b in bodies), bodies
+        assert len(loops) == 2, len(loops)                      # plain, masked
+        assert cxx_mfma == 128, cxx_mfma                        # the C++ body: 64 MFMAs x 2 stages, one asm statement each
+        for block in loops:
+            assert any(re.match(r"s_cbranch_scc0\s+1b", b) for b in block)
+            assert not any(b.startswith("scratch_") for b in block)
+            assert sum(b.startswith("global_load_lds") for b in block) == 34          # 17 pieces per stage
+            waits = [b for b in block if b.startswith("s_waitcnt")]
+            assert all(re.fullmatch(r"s_waitcnt (lgkmcnt|vmcnt)\(\d+\)", w) for w in waits), waits
+            off = 0                                             # 8-byte instructions on 8-byte boundaries inside the bodies
+            body = block[block.index("1:"):]
+            for b in body:
+                op = b.split()[0]
+                if op.endswith(":"):
+                    continue
+                if op == ".p2align":
+                    off = 0
+                    continue
+                lit = [x for x in b.replace(",", " ").split()[1:] if re.fullmatch(r"-?\d+|0x[0-9a-fA-F]+", x)]
+                wide = op.startswith(("v_mfma", "ds_read", "global_load", "v_fma", "v_cvt_pk", "v_med3", "v_bfi", "v_bfe")) or \
+                    op.endswith("_e64") or (op == "s_add_u32" and lit and not -16 <= int(lit[0], 0) <= 64)
+                assert not (wide and off % 8), f"misaligned 8-byte instruction in a step body: {b}"
+                off += 8 if wide else 4
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")

@@ -66,7 +66,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "unsloth_amd.h"), os.path.join(CSRC, "attn_acc256.inc"),
-               os.path.join(CSRC, "gemm256s_loop.inc")]
+               os.path.join(CSRC, "gemm256s_loop.inc"), os.path.join(CSRC, "attn_kd4_loop.inc")]
     objs, jobs = [], []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

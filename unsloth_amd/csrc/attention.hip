@@ -823,6 +823,7 @@ struct AttnBwdArgs {
     float scale, scale_log2;
     int noncausal;                       // 1: bidirectional inside documents -- query q and key k attend iff lo[q] <= k <= hi[q]
                                          // (documents are intervals, so equivalently lo[k] <= q <= hi[k]); needs lo AND hi
+    int no_asm;                          // attn_bwd_dkdv4_kernel: 1 = no step takes the generated loop (UAMD_TUNE_ATTN_VAR bit 2)
 };
 
 __device__ __forceinline__ int swz_c(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -868,8 +869,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
     const float lse2 = p.LSE[stat_idx] * 1.4426950408889634f;
     if (lh == 0 && q_pos < T_) {
-        p.Delta[stat_idx] = delta;
-        p.Delta[(int64_t)p.B * p.Hq * p.lse_st + stat_idx] = lse2;        // plane 1: LSE log2(e), for attn_bwd_dkdv4_kernel
+        p.Delta[stat_idx] = -delta;                                       // plane 0: -Delta, the C operand of attn_bwd_dkdv4_kernel's dP MFMAs
+        p.Delta[(int64_t)p.B * p.Hq * p.lse_st + stat_idx] = lse2;        // plane 1: LSE log2(e)
     }
     const float delta_s = delta * p.scale;
     const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
@@ -1085,6 +1086,7 @@ __device__ __forceinline__ void vmfma(f32x16_t& s, typename MfmaA<T>::frag a, ty
 }
 
 #include "attn_acc256.inc"
+#include "attn_kd4_loop.inc"
 // tuple I of the accumulator file -> this wave's slab of the reduction buffer: red[unit][(I & 7) * 16 + r][lane]
 template <int I>
 __device__ __forceinline__ void acc256_to_lds(float* red, int unit, int lane) {
@@ -1190,16 +1192,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         ct2[dt] = ring_u + (unsigned)((t_lane ^ (dt << 6)) ^ 32) + 8 * 256;
         asm volatile("" : "+v"(ct[dt]), "+v"(ct2[dt]));
     }
-    unsigned cs = lds_base + KD4_STATS_OFF + unit * 256 + lh * 16;   // stats line: + stage * 1024 + quad * 32 + (pair in quad) * 8 (+ 128: Delta)
+    unsigned cs = lds_base + KD4_STATS_OFF + unit * 256 + lh * 16;   // stats line: + stage * 1024 + quad * 32 + (pair in quad) * 8 (+ 128: -Delta)
     asm volatile("" : "+v"(cs));
+    // the stats line's DMA source of the generated loop: lanes 0-31 LSE2 (plane 1), lanes 32-63 -Delta (plane 0), relative to the
+    // -Delta row (host: one plane < 2^31 bytes)
+    const unsigned vstat = (lh ? 0u : (unsigned)(p.B * p.Hq * p.lse_st) * 4u) + (unsigned)l31 * 4u;
+    const bool no_asm = p.no_asm != 0;                 // (A/B and parity tests: every step through the C++ body)
+    // the masked loop's band edges per key half, relative to the lane half's first row: key k attends rows qlo .. qhi
+    int mqlo[2], mqhi[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        mqlo[kh] = qlo_k[kh] - 4 * lh;
+        mqhi[kh] = min(hi_k[kh], T_ - 1) - 4 * lh;
+    }
 
-    // accumulators: a[0:127] = dV^T tuples (kh * 4 + dt), a[128:255] = dK^T tuples (8 + kh * 4 + dt); asm-owned
-    acc256_zero();
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // the V tile is in LDS for every wave
-    asm volatile("" ::: "memory");
-
+    // (the accumulators are zeroed and the V tile awaited inside the first pass, BEHIND the issue of its first Q / dO tile: one
+    // DMA round trip per workgroup less on the critical path)
     const float* lse2_all = p.Delta + (int64_t)p.B * p.Hq * p.lse_st;            // plane 1 of the scratch: LSE * log2(e)
     for (int pass = 0; pass < npass; ++pass) {
         const int head = kvh * G + pass * hpp + hin;
@@ -1259,8 +1267,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         // fp expression would otherwise float up to right behind the MFMA chain that produces its operand -- and results
         // are consumed by an empty asm BEFORE the next chunk's MFMAs, so a packed operand is never written right in front
         // of the (asm) MFMA that reads it.
-        auto body = [&](auto masked, auto stage_c, int q0, int qn) {
-            constexpr bool MASK = decltype(masked)::value;
+        auto body = [&](auto stage_c, int q0, int qn) {
+            constexpr bool MASK = true;        // (the unmasked steps of a pass run in the generated loop, KD4_LOOP)
             constexpr int STAGE = decltype(stage_c)::value;
             constexpr int SO = STAGE * 16384;
             f32x16_t sc[2], dp[2];
@@ -1302,8 +1310,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     if constexpr (k == 0) vmfma_first<T>(sc[kh], o[0], kf[kh][0]);
                     else vmfma<T>(sc[kh], o[0], kf[kh][k]);
                 } else if constexpr (k < 16) {
-                    if constexpr (k == 8) vmfma_first<T>(dp[kh], o[0], o[1 + kh]);
-                    else vmfma<T>(dp[kh], o[0], o[1 + kh]);
+                    vmfma<T>(dp[kh], o[0], o[1 + kh]);             // (dp starts at -Delta, below)
                 } else if constexpr (k < 24) {
                     constexpr int c = (k - 16) >> 2, dt = (k - 16) & 3;
                     acc256_mfma<T, 4 * kh + dt>(o[0], pb[kh].f[c]);
@@ -1337,10 +1344,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 pb[kh].w[j] = pack_pair2<T>(x[0], x[1]);
                 return pb[kh].w[j];
             };
-            auto ds_pair = [&](auto pic, float2 dl) {            // masked entries have P = 0, hence dS' = 0
+            auto ds_pair = [&](auto pic) {                       // masked entries have P = 0, hence dS' = 0
                 constexpr int pi = decltype(pic)::value, kh = pi & 1, j = pi >> 1;
-                const float x0 = sc[kh][2 * j] * (dp[kh][2 * j] - dl.x);
-                const float x1 = sc[kh][2 * j + 1] * (dp[kh][2 * j + 1] - dl.y);
+                const float x0 = sc[kh][2 * j] * dp[kh][2 * j];
+                const float x1 = sc[kh][2 * j + 1] * dp[kh][2 * j + 1];
                 sb[kh].w[j] = pack_pair2<T>(x0, x1);
                 return sb[kh].w[j];
             };
@@ -1366,28 +1373,36 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     constexpr int slot = k - 17, first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2), count = slot < 2 ? 3 : 2;
                     if constexpr (FIRST) {
                         asm volatile("" : "+v"(dp[0]), "+v"(dp[1]));
-                        const uint32_t w0 = ds_pair(std::integral_constant<int, first>{}, st2[k & 1][0]);
+                        const uint32_t w0 = ds_pair(std::integral_constant<int, first>{});
                         asm volatile("" :: "v"(w0));
                     } else {
-                        const uint32_t w1 = ds_pair(std::integral_constant<int, first + 1>{}, st2[k & 1][1]);
+                        const uint32_t w1 = ds_pair(std::integral_constant<int, first + 1>{});
                         uint32_t w2 = w1;
-                        if constexpr (count == 3) w2 = ds_pair(std::integral_constant<int, first + 2>{}, st2[k & 1][2]);
+                        if constexpr (count == 3) w2 = ds_pair(std::integral_constant<int, first + 2>{});
                         asm volatile("" :: "v"(w1), "v"(w2));
                     }
                 }
                 if constexpr (!FIRST) {
-                    // stats of the pairs chunk k + 1 will process (P: chunks 9-15, dS': 17-23)
-                    if constexpr ((k >= 8 && k < 15) || (k >= 16 && k < 23)) {
-                        constexpr int slot = (k >= 16 ? k - 16 : k - 8), first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2);
-                        constexpr int count = slot < 2 ? 3 : 2, dl = k >= 16 ? 128 : 0;
-                        st2[(k + 1) & 1][0] = stat_pair(std::integral_constant<int, first>{}, dl);
-                        st2[(k + 1) & 1][1] = stat_pair(std::integral_constant<int, first + 1>{}, dl);
-                        if constexpr (count == 3) st2[(k + 1) & 1][2] = stat_pair(std::integral_constant<int, first + 2>{}, dl);
+                    // LSE2 of the pairs chunk k + 1 will process (P: chunks 9-15)
+                    if constexpr (k >= 8 && k < 15) {
+                        constexpr int slot = k - 8, first = slot < 2 ? 3 * slot : 6 + 2 * (slot - 2);
+                        constexpr int count = slot < 2 ? 3 : 2;
+                        st2[(k + 1) & 1][0] = stat_pair(std::integral_constant<int, first>{}, 0);
+                        st2[(k + 1) & 1][1] = stat_pair(std::integral_constant<int, first + 1>{}, 0);
+                        if constexpr (count == 3) st2[(k + 1) & 1][2] = stat_pair(std::integral_constant<int, first + 2>{}, 0);
                     }
                     if constexpr (k >= UAMD_KD4_DMA_CHUNK && k < UAMD_KD4_DMA_CHUNK + 5)
-                        issue(qn, STAGE ^ 1, k - UAMD_KD4_DMA_CHUNK, std::integral_constant<bool, !MASK>{});
+                        issue(qn, STAGE ^ 1, k - UAMD_KD4_DMA_CHUNK, std::false_type{});
                 }
             };
+            // dP starts at -Delta[q] (plane 0 of the scratch holds the negated row sums): dP' = dO V^T - Delta comes out of the
+            // MFMA chain, the same arithmetic as the generated loop's
+#pragma unroll
+            for (int g_ = 0; g_ < 4; ++g_) {
+                const u32x4a_t v = *(const lds_u32x4a*)(uintptr_t)(cs + (STAGE * 1024 + 128 + g_ * 32));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[0][4 * g_ + e] = dp[1][4 * g_ + e] = __uint_as_float(v[e]);
+            }
             static_for<PF>([&](auto kc) { reads(kc, ob[decltype(kc)::value]); });
             static_for<32>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
@@ -1412,15 +1427,76 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 issue(qn, STAGE ^ 1, -1, std::false_type{});
                 return;
             }
-            // slow body: some element of the tile is masked (diagonal / ragged / band edge) or the tile to fetch is ragged
-            const bool slow = (q0 < qlo_w1) || (q0 + 32 > T_) || (k0 + KT > T_) || (q0 + 31 > hi_w0) || (qn + 32 > T_);
-            if (slow) body(std::true_type{}, stage_c, q0, qn); else body(std::false_type{}, stage_c, q0, qn);
+            body(stage_c, q0, qn);
+        };
+        // Steps over WHOLE tiles (32 query rows and 64 keys inside the sequence, and a whole tile to prefetch) run in the generated
+        // loops (attn_kd4_loop.inc, tools/gen/gen_attn_kd4.py): consecutive steps of one class are ONE asm statement that alternates
+        // the ring stages itself, prefetches step s + 1's tile during step s and advances its sources by a constant. Class 1: no
+        // element masked. Class 2: diagonal / band-edge tiles -- the valid rows of a key are an interval, turned into a bit mask
+        // per step and ANDed into P (dS' = P dP' follows). Class 0 (ragged tiles, idle slices): the C++ body above. The last step
+        // of a pass prefetches its own tile once more (a spare, like the C++ path), so it is a run of its own.
+        auto cls = [&](int s_) {
+            const int q0 = q0_of(s_);
+            if (q0 + 32 > T_ || k0 + KT > T_ || q0 > hi_blk) return 0;
+            const int qn = s_ + 1 < nsteps ? q0_of(s_ + 1) : q0;
+            if (qn + 32 > T_) return 0;
+            return (q0 < qlo_w1 || q0 + 31 > hi_w0) ? 2 : 1;
+        };
+        auto asm_run = [&](bool masked, int step, int n) {
+            const int qn = step + 1 < nsteps ? q0_of(step + 1) : q0_of(step);
+            auto lo32 = [](uint64_t x) { return __builtin_amdgcn_readfirstlane((unsigned)x); };
+            auto hi32 = [](uint64_t x) { return __builtin_amdgcn_readfirstlane((unsigned)(x >> 32)); };
+            const uint64_t q0p = (uint64_t)(uintptr_t)(qbase + (int64_t)qn * p.q_st), q1p = q0p + (uint64_t)(32 * p.q_st);
+            const uint64_t d0p = (uint64_t)(uintptr_t)(dobase + (int64_t)qn * p.do_st), d1p = d0p + (uint64_t)(32 * p.do_st);
+            const uint64_t stp = (uint64_t)(uintptr_t)(del_row + qn);
+            const uint64_t advq = (uint64_t)(nslice * 64 * p.q_st), advd = (uint64_t)(nslice * 64 * p.do_st);    // 32 rows x 2 bytes
+            const unsigned advs = (unsigned)(nslice * 32 * 4);
+            const unsigned ringu = ring_u, statu = lds_base + KD4_STATS_OFF + unit * 256;
+            unsigned cnt = (unsigned)(n - 1);
+            const unsigned stage = (unsigned)(step & 1);
+#define KD4_SGPR_IN                                                                                                              \
+            [q0lo] "s"(lo32(q0p)), [q0hi] "s"(hi32(q0p)), [q1lo] "s"(lo32(q1p)), [q1hi] "s"(hi32(q1p)), [d0lo] "s"(lo32(d0p)),  \
+            [d0hi] "s"(hi32(d0p)), [d1lo] "s"(lo32(d1p)), [d1hi] "s"(hi32(d1p)), [stlo] "s"(lo32(stp)), [sthi] "s"(hi32(stp)),   \
+            [advqlo] "s"(lo32(advq)), [advqhi] "s"(hi32(advq)), [advdlo] "s"(lo32(advd)), [advdhi] "s"(hi32(advd)),             \
+            [advs] "s"(advs), [ringu] "s"(ringu), [statu] "s"(statu), [sl2] "s"(p.scale_log2), [stage] "s"(stage)
+            if (!masked) {
+                if constexpr (std::is_same<T, bf16_t>::value)
+                    asm volatile(KD4_LOOP("bf16") : [cnt] "+s"(cnt) : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_SGPR_IN : KD4_CLOBBER);
+                else
+                    asm volatile(KD4_LOOP("f16") : [cnt] "+s"(cnt) : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_SGPR_IN : KD4_CLOBBER);
+            } else {
+                const unsigned q0s = (unsigned)q0_of(step), rowadv = (unsigned)(nslice * 32);
+                if constexpr (std::is_same<T, bf16_t>::value)
+                    asm volatile(KD4_LOOP_M("bf16") : [cnt] "+s"(cnt)
+                                 : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_IN_MASK, KD4_SGPR_IN, [q0s] "s"(q0s), [rowadv] "s"(rowadv) : KD4_CLOBBER);
+                else
+                    asm volatile(KD4_LOOP_M("f16") : [cnt] "+s"(cnt)
+                                 : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_IN_MASK, KD4_SGPR_IN, [q0s] "s"(q0s), [rowadv] "s"(rowadv) : KD4_CLOBBER);
+            }
+#undef KD4_SGPR_IN
         };
 
         if (nsteps > 0) issue(fetch_q0(0), 0, -1, std::false_type{});
-        for (int step = 0; step < nsteps; step += 2) {
-            run(std::integral_constant<int, 0>{}, step);
-            if (step + 1 < nsteps) run(std::integral_constant<int, 1>{}, step + 1);
+        if (pass == 0) {
+            // accumulators: a[0:127] = dV^T tuples (kh * 4 + dt), a[128:255] = dK^T tuples (8 + kh * 4 + dt); asm-owned
+            acc256_zero();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                  // the V tile is in LDS for every wave
+            asm volatile("" ::: "memory");
+        }
+        for (int step = 0; step < nsteps;) {
+            const int c = no_asm ? 0 : cls(step);
+            if (c == 0) {
+                if (step & 1) run(std::integral_constant<int, 1>{}, step);
+                else run(std::integral_constant<int, 0>{}, step);
+                ++step;
+                continue;
+            }
+            int n = 1;
+            while (step + n + 1 < nsteps && cls(step + n) == c) ++n;      // (the pass's last step never joins a run)
+            if (step + 1 >= nsteps) n = 1;
+            asm_run(c == 2, step, n);
+            step += n;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last step's spare DMA has landed
     }
@@ -1521,6 +1597,8 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     a.noncausal = causal ? 0 : 1;
+    a.no_asm = (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 4) ? 1 : 0;
+    if ((int64_t)B * Hq * lse_stride * 4 >= (1ll << 31)) return UAMD_ERR_ARG;      // 32-bit lane offset between the two stat planes
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
     dim3 grid_q((unsigned)(a.nqt * Hk * B));
