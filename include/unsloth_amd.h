@@ -220,6 +220,14 @@ int uamd_nf4_dequantize(const uint8_t* packed, const float* absmax_f32, const ui
                         const float* code2, const float* absmax2, float offset, int blocksize2,
                         const float* nf4_lut, void* out, int64_t rows, int64_t cols, int blocksize,
                         int out_dtype, int transpose_out, int64_t ld_out, void* stream);
+/* The row-major decode of up to FOUR weights in one launch: the members of one grouped GEMM (q | k | v, gate | up), whose
+ * single decodes are latency-bound ([1024, 4096]: 1.9 TB/s, [4096, 4096]: 4.4 TB/s against 5.6 for the MLP weights). Every
+ * weight: first-level absmax already in fp32 (uamd_dequantize_absmax), numel a multiple of 8192, 16-bit contiguous output,
+ * its own 16-entry level table (nf4_lut NULL or an entry NULL: the NF4 levels).
+ * Bit-identical to uamd_nf4_dequantize (the reference decodes weight by weight: kernels/utils.py:650-675). */
+int uamd_nf4_dequantize_multi(int nseg, const uint8_t* const* packed, const float* const* absmax_f32,
+                              void* const* out, const int64_t* numel, const float* const* nf4_lut, int blocksize,
+                              int out_dtype, void* stream);
 /* First-level NF4 quantiser (absmax + 4-bit codes); replaces bitsandbytes quantize_4bit for
  * building checkpoints without bitsandbytes. blocksize: power of two in [8,512]. */
 int uamd_nf4_quantize(const void* in, uint8_t* packed, float* absmax, int64_t n, int blocksize,

@@ -94,6 +94,35 @@ def test_nf4_dequantize_four_groups_per_lane_kernel_is_bit_identical(rows, cols,
             assert torch.equal(four.cpu(), R.nf4_dequantize_state(packed, qs))
 
 
+@pytest.mark.parametrize("nested", [False, True])
+@pytest.mark.parametrize("shapes", [[(4096, 4096), (1024, 4096), (1024, 4096)], [(14336, 4096), (14336, 4096)],
+                                    [(64, 128), (192, 128), (64, 128), (128, 128), (64, 128)], [(64, 128), (96, 264)]])
+def test_nf4_dequantize_group_launch_is_bit_identical(shapes, nested):
+    """uamd_nf4_dequantize_multi (nf4.dequantize_nf4_group): the weights of one grouped GEMM decoded by one launch per four
+    -- q | k | v and gate | up at the step's sizes, five small weights (two launches), trips that straddle segment boundaries
+    inside a block -- against the single launches; a member the grouped launch does not take (numel not a multiple of 8192)
+    sends the whole group through the single launches."""
+    from unsloth_amd.nf4 import quantize_nf4, dequantize_nf4, dequantize_nf4_group
+    for dtype in (torch.bfloat16, torch.float16):
+        pks, qss, want = [], [], []
+        for i, (r, c) in enumerate(shapes):
+            W = (torch.randn(r, c, generator=g(r + c + i)) * 0.02).to(dtype)
+            pk, qs = quantize_nf4(W.to(DEV), compress_statistics=nested)
+            pks.append(pk)
+            qss.append(qs)
+            want.append(dequantize_nf4(pk, qs).clone())
+        # members of equal width as row blocks of one buffer (how the stacked decode of the dX product uses it), others alone
+        same = len({c for _, c in shapes}) == 1
+        buf = torch.full((sum(r for r, _ in shapes), shapes[0][1]), 7.0, dtype=dtype, device=DEV) if same else None
+        outs, row = [], 0
+        for (r, c) in shapes:
+            outs.append(buf[row:row + r] if same else torch.empty((r, c), dtype=dtype, device=DEV))
+            row += r
+        got = dequantize_nf4_group(pks, qss, outs)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("rows,cols", [(1024, 4096), (200, 264), (64, 256), (136, 1032)])
 @pytest.mark.parametrize("knob", [0, 1])
 def test_nf4_dequantize_transposed_kernels_bit_exact(rows, cols, knob):

@@ -108,6 +108,8 @@ SIGNATURES = {
     "uamd_nf4_dequantize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int,
                                     c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int64,
                                     c_void_p]),
+    "uamd_nf4_dequantize_multi": (c_int, [c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p),
+                                          ctypes.POINTER(c_int64), ctypes.POINTER(c_void_p), c_int, c_int, c_void_p]),
     "uamd_nf4_quantize": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "uamd_gemm_nt": (c_int, [c_void_p, c_int64, c_int, c_int, ctypes.POINTER(GemmGroup), c_int, c_int,
                              c_int, c_void_p]),

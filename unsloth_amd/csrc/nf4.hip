@@ -162,6 +162,58 @@ nf4_dequant_x4_kernel(const uint8_t* __restrict__ packed, AbsmaxSrc am, const fl
     }
 }
 
+// Up to FOUR weights in ONE launch (q | k | v, gate | up: the weights of one grouped GEMM, decoded back to back). Alone, a
+// [1024, 4096] weight is 512 trips -- a quarter of the chip's resident blocks, 5.5 us at 1.9 TB/s -- and a [4096, 4096] one
+// is a single round of one-trip blocks (9.5 us, 4.4 TB/s): latency, not bandwidth. The trips of the segments are dealt
+// to the blocks as one sequence (a block's trips are consecutive and may straddle a segment boundary); arithmetic and
+// stores are those of nf4_dequant_x4_kernel, so the output is bit-identical to the single launches.
+struct DqMulti {
+    const uint8_t* packed[4];
+    const float* absmax[4];
+    const float* lut[4];     // per weight (NULL: the NF4 levels)
+    void* out[4];
+    int64_t trip_end[4];     // running total of whole trips (numel / 8192) up to and including segment i
+    int nseg;
+};
+template <typename T>
+__global__ void __launch_bounds__(256)
+nf4_dequant_x4_multi_kernel(DqMulti m, int shift, int64_t per_block) {
+    __shared__ float luts[4][16];
+    if (threadIdx.x < 64) {
+        const float* lg = m.lut[threadIdx.x >> 4];
+        luts[threadIdx.x >> 4][threadIdx.x & 15] = lg ? lg[threadIdx.x & 15] : kNF4[threadIdx.x & 15];
+    }
+    __syncthreads();
+    const int64_t total = m.trip_end[m.nseg - 1];
+    const int64_t t0 = (int64_t)blockIdx.x * per_block, t1 = min(t0 + per_block, total);
+    for (int64_t t = t0; t < t1; ++t) {
+        int seg = 0;
+        while (t >= m.trip_end[seg]) ++seg;
+        const int64_t g0 = (t - (seg ? m.trip_end[seg - 1] : 0)) * 1024 + threadIdx.x;
+        const uint32_t* __restrict__ words = reinterpret_cast<const uint32_t*>(m.packed[seg]);
+        const float* __restrict__ am = m.absmax[seg];
+        const float* lut = luts[seg];
+        T* __restrict__ out = (T*)m.out[seg];
+        uint32_t w[4];
+        float a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = words[g0 + j * 256];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = am[(g0 + j * 256) >> shift];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            Vec16<T> o;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t byte = (w[j] >> (8 * b)) & 0xff;
+                o.e[2 * b] = from_f32<T>(lut[byte >> 4] * a[j]);
+                o.e[2 * b + 1] = from_f32<T>(lut[byte & 15] * a[j]);
+            }
+            st16(out + (g0 + j * 256) * 8, o);
+        }
+    }
+}
+
 // Transposed output: W is logically [rows, cols] (cols contiguous, packed); writes
 // out[c * ld_out + r].  Used to hand the backward GEMM (dX = dY @ W) a K-contiguous operand.
 // 64x64 tile through LDS; both the packed read and the transposed write are 16B/128B coalesced.
@@ -466,6 +518,42 @@ extern "C" int uamd_nf4_dequantize(const uint8_t* packed, const float* absmax_f3
 
 // Blockwise NF4 quantiser (first-level only; the 8-bit nested quantisation of absmax is host
 // logic, see unsloth_amd/nf4.py). blocksize: power of two in [8, 512].
+// Row-major NF4 decode of up to four weights in one launch (see nf4_dequant_x4_multi_kernel). Every weight: fp32 absmax
+// (first level, already dequantised), numel a multiple of 8192, 16-bit output, contiguous. Bit-identical to uamd_nf4_dequantize.
+extern "C" int uamd_nf4_dequantize_multi(int nseg, const uint8_t* const* packed, const float* const* absmax_f32,
+                                         void* const* out, const int64_t* numel, const float* const* nf4_lut, int blocksize,
+                                         int out_dtype, void* stream) {
+    if (nseg < 1 || nseg > 4 || !packed || !absmax_f32 || !out || !numel) return UAMD_ERR_ARG;
+    if (blocksize < 8 || blocksize > 8192 || (blocksize & (blocksize - 1))) return UAMD_ERR_ARG;
+    if (out_dtype != UAMD_BF16 && out_dtype != UAMD_F16) return UAMD_ERR_DTYPE;
+    DqMulti m;
+    int64_t total = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (i < nseg) {
+            if (!packed[i] || !absmax_f32[i] || !out[i] || numel[i] <= 0 || (numel[i] & 8191)) return UAMD_ERR_ARG;
+            if (!aligned16(packed[i]) || !aligned16(out[i])) return UAMD_ERR_ALIGN;
+            total += numel[i] / 8192;
+        }
+        m.packed[i] = i < nseg ? packed[i] : nullptr;
+        m.absmax[i] = i < nseg ? absmax_f32[i] : nullptr;
+        m.lut[i] = (i < nseg && nf4_lut) ? nf4_lut[i] : nullptr;
+        m.out[i] = i < nseg ? out[i] : nullptr;
+        m.trip_end[i] = total;
+    }
+    m.nseg = nseg;
+    int shift = 0;
+    while ((8 << shift) < blocksize) ++shift;
+    // whole trips spread evenly over at most 8 blocks per CU, as the single launch does
+    const int64_t per_block = (total + 2047) / 2048;
+    const unsigned grid = (unsigned)((total + per_block - 1) / per_block);
+    hipStream_t st = (hipStream_t)stream;
+    if (out_dtype == UAMD_BF16)
+        hipLaunchKernelGGL((nf4_dequant_x4_multi_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, m, shift, per_block);
+    else
+        hipLaunchKernelGGL((nf4_dequant_x4_multi_kernel<f16_t>), dim3(grid), dim3(256), 0, st, m, shift, per_block);
+    return uamd_launch_status();
+}
+
 extern "C" int uamd_nf4_quantize(const void* in, uint8_t* packed, float* absmax, int64_t n,
                                  int blocksize, int in_dtype, void* stream) {
     if (n < 0 || blocksize < 8 || blocksize > 512 || (blocksize & (blocksize - 1))) return UAMD_ERR_ARG;

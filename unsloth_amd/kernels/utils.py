@@ -553,6 +553,16 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False, pre_xa=None):
     resident = None
     if len(projs) > 1 and all(q is not None and _nf4.mirror_wanted(q) for (_, q, _, _, _) in projs) and not any(fused_nf4):
         _, resident = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
+    # the members that are decoded for this launch: ONE decode launch for all of them (nf4.dequantize_nf4_group), each into the
+    # scratch slot of its own that the grouped GEMM reads
+    decoded = {}
+    if resident is None:
+        todo = [gi for gi, (W, q, _, _, _) in enumerate(projs) if q is not None and not fused_nf4[gi]]
+        if len(todo) > 1 and all(projs[gi][1].dtype == dtype and projs[gi][1].quant_type == "nf4" for gi in todo):
+            slots = [_nf4.scratch(X.device, projs[gi][1].shape[0] * projs[gi][1].shape[1], dtype, slot=8 + gi).view(
+                tuple(projs[gi][1].shape)) for gi in todo]
+            _nf4.dequantize_nf4_group([projs[gi][0] for gi in todo], [projs[gi][1] for gi in todo], slots)
+            decoded = dict(zip(todo, slots))
     li = 0
     for gi, (W, W_quant, A, B, s) in enumerate(projs):
         if W_quant is not None:
@@ -584,6 +594,8 @@ def lora_linear_forward(X, projs, outs=None, return_xa=False, pre_xa=None):
             Wd = W
             if resident is not None:
                 Wd = resident[gi]
+            elif gi in decoded:
+                Wd = decoded[gi]
             elif W_quant is not None:
                 # one scratch slot per group member: the grouped launch reads all of them
                 Wd = _nf4.dequantize_nf4(W, W_quant, use_global_buffer=True, slot=8 + gi)
@@ -720,11 +732,11 @@ def _lora_linear_dx_merged(dYs, projs, out, terms):
             Wcat, _ = _nf4.resident_group([p_[0] for p_ in projs], [p_[1] for p_ in projs])
         else:
             Wcat = _nf4.scratch(dYcat.device, Ntot * Kin, dtype, slot=2).view(Ntot, Kin)
-            row = 0
+            row, rows_of = 0, []
             for (W, q, _, _, _) in projs:
-                n = q.shape[0]
-                _nf4.dequantize_nf4(W, q, out=Wcat[row:row + n])
-                row += n
+                rows_of.append(Wcat[row:row + q.shape[0]])
+                row += q.shape[0]
+            _nf4.dequantize_nf4_group([p_[0] for p_ in projs], [p_[1] for p_ in projs], rows_of)
         xk = xks[0][0]
         bk = rank_block_bk([(A, x[1], s) for (_, _, A, _, s), x in zip(projs, xks)], xk.shape[1], Kin, False, dtype,
                            by_rows=True)                      # [s_q A_q; s_k A_k; s_v A_v; 0] : [Rk, Kin]

@@ -285,12 +285,14 @@ def resident_group(packed_list, qs_list):
         cols = first.shape[1]
         rows = sum(q.shape[0] for q in qs_list)
         buf = torch.empty((rows, cols), dtype=first.dtype, device=packed_list[0].device)
-        r = 0
-        for pk, q in zip(packed_list, qs_list):
-            dequantize_nf4(pk, q, out=buf[r:r + q.shape[0]])
-            q._resident = buf[r:r + q.shape[0]]
-            _MIRRORED.add(q)
+        r, rows_of = 0, []
+        for q in qs_list:
+            rows_of.append(buf[r:r + q.shape[0]])
             r += q.shape[0]
+        dequantize_nf4_group(packed_list, qs_list, rows_of)
+        for q, view in zip(qs_list, rows_of):
+            q._resident = view
+            _MIRRORED.add(q)
         first._resident_group = ([_weakref.ref(q) for q in qs_list], buf)
         ent = first._resident_group
     buf = ent[1]
@@ -364,6 +366,39 @@ def dequantize_nf4(packed, quant_state, out=None, transpose=False, use_global_bu
         qs._resident = out
         _MIRRORED.add(qs)
     return out
+
+
+def dequantize_nf4_group(packed_list, qs_list, outs):
+    """Row-major decode of the weights of ONE grouped GEMM (q | k | v, gate | up) into `outs` with one launch per four weights
+    (uamd_nf4_dequantize_multi: the single decodes of the small ones are latency-bound). Bit-identical to dequantize_nf4 per
+    weight, and falls back to it for anything the grouped launch does not take (nested absmax not cached yet on a
+    non-default path, ragged sizes, 32-bit outputs). The reference decodes weight by weight (kernels/utils.py:650-675)."""
+    first = qs_list[0]
+    ok = len(qs_list) > 1 and all(
+        q.quant_type == "nf4" and q.blocksize == first.blocksize and q.dtype == first.dtype and
+        q.dtype in (torch.bfloat16, torch.float16) and (q.shape[0] * q.shape[1]) % 8192 == 0 and
+        o.is_contiguous() and tuple(o.shape) == tuple(q.shape) and o.dtype == q.dtype
+        for q, o in zip(qs_list, outs))
+    if not ok:
+        for pk, q, o in zip(packed_list, qs_list, outs):
+            dequantize_nf4(pk, q, out=o)
+        return outs
+    _lib.require_gpu(packed_list[0])
+    L = _lib.lib()
+    with _lib.device_ctx(packed_list[0]):
+        for i in range(0, len(qs_list), 4):
+            pk, qs, os_ = packed_list[i:i + 4], qs_list[i:i + 4], outs[i:i + 4]
+            n = len(qs)
+            vp = _lib.ctypes.c_void_p
+            a_pk = (vp * n)(*[_lib.ptr(x) for x in pk])
+            a_am = (vp * n)(*[_lib.ptr(absmax_f32(q)) for q in qs])
+            a_out = (vp * n)(*[_lib.ptr(o) for o in os_])
+            a_n = (_lib.ctypes.c_int64 * n)(*[q.shape[0] * q.shape[1] for q in qs])
+            a_lut = (vp * n)(*[_lib.ptr(q.code) for q in qs])
+            rc = L.uamd_nf4_dequantize_multi(n, a_pk, a_am, a_out, a_n, a_lut, first.blocksize,
+                                             _lib.dtype_code(first.dtype), _lib.stream_of(pk[0]))
+            _lib.check(rc, "uamd_nf4_dequantize_multi")
+    return outs
 
 
 class Params4bit(torch.nn.Parameter):
