@@ -786,6 +786,19 @@ def main():
             _nf4.set_resident(False, model=base_)
             base_._uamd_auto_policy = None
             torch.cuda.empty_cache()
+        if os.environ.get("BENCH_STEP_DECODE_ALT", "1") == "1":
+            # the step decode (opt-in UNSLOTH_AMD_STEP_DECODE=auto | 1): every NF4 weight decoded ONCE per step, in the forward,
+            # and kept until its layer's backward (one decoded copy of the projections at the turning point, nothing kept
+            # across steps) -- half the decode launches for +12 GB of peak VRAM
+            from unsloth_amd import nf4 as _nf4
+            _nf4.STEP_DECODE_MODE = "1"
+            base_._uamd_auto_policy = None
+            alt_point("gc_unsloth_with_step_decode (opt-in UNSLOTH_AMD_STEP_DECODE=auto | 1: NF4 weights decoded once per step, "
+                      "kept from a layer's forward to its backward)", "unsloth", B)
+            _nf4.STEP_DECODE_MODE = "0"
+            base_._uamd_auto_policy = None
+            base_._uamd_step_decode = False
+            torch.cuda.empty_cache()
         if os.environ.get("BENCH_DP_FORCE_ALT", "1") == "1" and world == 1 and arena is None:
             # the data-parallel path on ONE rank: gradient arena owned by dp.LoRAGradArena, the post-accumulate hooks, the 11
             # bucketed RCCL all-reduces issued from inside the backward (a 1-rank group: the collective is a device copy, its

@@ -236,6 +236,56 @@ def test_resident_decoded_weights_are_bitwise_neutral():
         assert torch.equal(res[0][1][k], res[1][1][k]), k
 
 
+def test_step_decode_halves_the_decodes_and_is_bitwise_neutral():
+    """nf4.STEP_DECODE_MODE (default "auto", part of the fit-to-memory decision of the bare "unsloth" spelling): under the
+    keep-everything policy a layer's decoded NF4 weights live from its forward to its backward of the same step -- the
+    backward decodes nothing, loss and gradients are bit-identical, and nothing outlives the step."""
+    from unsloth_amd import nf4
+    from unsloth_amd.kernels import utils as U
+    ids, labels, pos = _batch(seed=11)
+    batch = dict(input_ids=ids.to(DEV), labels=labels.to(DEV), position_ids=pos.to(DEV))
+    res = []
+    calls = []
+    real_one, real_grp = nf4.dequantize_nf4, nf4.dequantize_nf4_group
+    fused, U.FUSED_NF4 = U.FUSED_NF4, False         # 192 tokens would take the in-kernel NF4 decode: nothing to keep
+    g256, U.GEMM256_MODE = U.GEMM256_MODE, "on"     # ... and the small-launch dX products a TRANSPOSED decode: the step's kernels
+    mode0 = nf4.STEP_DECODE_MODE
+    try:
+        for mode in ("0", "1", "auto"):
+            nf4.STEP_DECODE_MODE = mode
+            model = _tiny(gc="unsloth", head_dim=128)
+            base = model.get_base_model().model
+            for step in range(2):
+                for p_ in model.parameters():
+                    p_.grad = None
+                calls.clear()
+                # (a call that finds the kept copy launches nothing)
+                nf4.dequantize_nf4 = lambda *a, **k: (calls.append(1) if getattr(a[1], "_resident", None) is None or k.get("transpose")
+                                                      or k.get("out") is not None else None, real_one(*a, **k))[1]
+                nf4.dequantize_nf4_group = lambda pk, qs, outs: (calls.append(-len(qs)), real_grp(pk, qs, outs))[1]
+                try:
+                    out = model(**batch)
+                    fwd_calls = list(calls)
+                    calls.clear()
+                    out.loss.backward()
+                finally:
+                    nf4.dequantize_nf4, nf4.dequantize_nf4_group = real_one, real_grp
+                decoded_bwd = sum(1 if c > 0 else -c for c in calls)
+            assert nf4.resident_count(base) == 0 and not nf4.mirrors_on(base)        # given back
+            res.append((out.loss.detach().clone(), _grads(model), decoded_bwd, bool(getattr(base, "_uamd_step_decode", False))))
+            del model, out
+    finally:
+        U.FUSED_NF4 = fused
+        U.GEMM256_MODE = g256
+        nf4.STEP_DECODE_MODE = mode0
+    assert not res[0][3] and res[1][3] and res[2][3]                  # "auto": a tiny model on an empty GPU keeps them
+    assert res[0][2] == 2 * 7 and res[1][2] == 0 and res[2][2] == 0, [r[2] for r in res]       # weights decoded in the backward
+    for r in res[1:]:
+        assert torch.equal(res[0][0], r[0])
+        for k in res[0][1]:
+            assert torch.equal(res[0][1][k], r[1][k]), k
+
+
 def test_return_logits_branch_and_n_items():
     from oracle.ref_model import hf_reference_loss_and_lora_grads
     model = _tiny()

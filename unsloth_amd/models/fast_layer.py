@@ -28,6 +28,7 @@ norm2 + gate/up), "all" = everything (no recompute; equals use_gradient_checkpoi
 """
 import torch
 
+from .. import nf4 as _nf4
 from ..kernels import attention as _flash
 from ..kernels.fast_lora import (
     get_lora_parameters, mlp_backward, mlp_forward, mlp_gate_up_forward, qkv_backward, qkv_forward, w_backward,
@@ -129,6 +130,12 @@ def auto_policy(model, hidden_states):
         elif not want and auto_on:                    # (mirrors a caller switched on with nf4.set_resident(True) are the caller's)
             _nf4.set_resident(False, model=model)
             torch.cuda.empty_cache()
+    # the step decode (nf4.STEP_DECODE_MODE): decoded weights kept from a layer's forward to its backward when nothing is
+    # recomputed and one decoded copy of the projections fits beside everything else
+    if _nf4.STEP_DECODE_MODE == "auto":
+        model._uamd_step_decode = pol == POLICIES["all"] and not _nf4.mirrors_on(model) and mirrors_fit(*args, vocab=vocab)
+    else:
+        model._uamd_step_decode = _nf4.STEP_DECODE_MODE == "1" and pol == POLICIES["all"]
     model._uamd_auto_policy = (key, pol)
     return pol
 
@@ -192,7 +199,7 @@ def _eps(norm):
 class _Static:
     """Non-tensor context of one layer call (weights, norm parameters, rope tables, band, shapes)."""
     __slots__ = ("projs", "biases", "w1", "w2", "eps1", "eps2", "cos", "sin", "idx", "band", "n_heads", "n_kv", "head_dim",
-                 "scale", "keep", "shape")
+                 "scale", "keep", "shape", "step_decode")
 
 
 def _rope(st, q4, k4, backward):
@@ -223,6 +230,8 @@ class DecoderLayerFunction(torch.autograd.Function):
         shape = residual.shape
         st.shape = shape
         projs = st.projs
+        if st.step_decode:
+            _nf4.step_keep([p_[1] for p_ in projs])
         # ---- attention block
         if delta is None:
             h0 = residual.reshape(-1, shape[-1])
@@ -325,14 +334,17 @@ class DecoderLayerFunction(torch.autograd.Function):
             # ---- norm1 backward + the residual path: d h0 = rms'(dx1) + d h1
             need_in = ctx.needs_input_grad[1] or (not ctx.first and ctx.needs_input_grad[2])
             dh0 = rms_bwd_(dx1, h0, st.w1, r1, dh1).view(shape) if need_in else None
+            if st.step_decode:
+                _nf4.step_release([p_[1] for p_ in st.projs])
         grads = [g_qkv[0], g_qkv[1], g_qkv[2], g_qkv[3], g_qkv[4], g_qkv[5], g_o[0], g_o[1],
                  g_mlp[0], g_mlp[1], g_mlp[2], g_mlp[3], g_mlp[4], g_mlp[5]]
         grads = [gr if m else None for gr, m in zip(grads, ctx.lora_mask)]
         return (None, dh0, None if ctx.first else dh0, *grads)
 
 
-def decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids, band, keep):
-    """(residual', delta') through DecoderLayerFunction. `keep`: a resolved policy (frozenset)."""
+def decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids, band, keep, step_decode=False):
+    """(residual', delta') through DecoderLayerFunction. `keep`: a resolved policy (frozenset). `step_decode`: the layer's
+    decoded NF4 weights live until its backward (nf4.STEP_DECODE_MODE; only with the keep-everything policy)."""
     attn = layer.self_attn
     cfg = attn.config
     st = _Static()
@@ -353,6 +365,7 @@ def decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids, b
     st.n_heads, st.n_kv, st.head_dim = cfg.num_attention_heads, cfg.num_key_value_heads, attn.head_dim
     st.scale = None
     st.keep = keep
+    st.step_decode = bool(step_decode) and keep == POLICIES["all"]
     lora = []
     for (_, _, A, B, _) in st.projs:
         lora += [A, B]

@@ -308,11 +308,13 @@ def LlamaModel_fast_forward(self, input_ids=None, attention_mask=None, position_
         band = None if (seq_info is None and window is None) else \
             _attention_band(seq_info, bsz, q_len, window, hidden_states.device)
         residual, delta = hidden_states, None
+        step_decode = False
         if policy == _fast_layer.AUTO:
             policy = _fast_layer.auto_policy(self, hidden_states)
+            step_decode = bool(getattr(self, "_uamd_step_decode", False))
         for li, layer in enumerate(self.layers):
             residual, delta = _fast_layer.decoder_layer_forward(layer, residual, delta, cos, sin, rope_position_ids,
-                                                                band, _fast_layer.policy_for_layer(policy, li))
+                                                                band, _fast_layer.policy_for_layer(policy, li), step_decode)
         return fast_add_rms_layernorm(self.norm, delta, residual)[1]
     if gc and not hidden_states.requires_grad:
         hidden_states.requires_grad_(True)      # reentrant checkpoint needs an input that requires grad
