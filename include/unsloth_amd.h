@@ -307,7 +307,8 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention forward: 0 = by shape (plain causal batches with >= 2 work items per CU take
                                  * attn_fwd_ps_kernel -- one persistent workgroup per CU, ping-pong wave groups -- everything else
                                  * attn_fwd_kernel, one block per work item); bit 0 = attn_fwd_kernel always; bit 1 = attn_fwd_ps_kernel
-                                 * always. (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
+                                 * always; bit 2 = every step of attn_bwd_dkdv4_kernel through its C++ body instead of the
+                                 * generated asm loops (bit-identical; A/B and parity tests). (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
                                  * round-1 dK/dV kernel, a 4-wave dQ kernel -- all measured at parity or slower: removed in round 4,
                                  * git 4501bb3:tools/experiments/attention_removed_r04.hip) */
 #define UAMD_TUNE_RMS_VAR 5     /* RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),
@@ -367,7 +368,8 @@ int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* w
  * T rounded up to a multiple of 32, pad zero-filled by the caller). Hq/Hk in {1,2,4,8}.
  * uamd_attn_bwd: two launches (dQ + Delta = rowsum(dO*O), then dK/dV), deterministic, no atomics. `strides` has
  * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [2,B,Hq,lse_stride] fp32 scratch (plane 0:
- * rowsum(dO*O), plane 1: LSE*log2(e); both written by the first launch, read by the second).
+ * -rowsum(dO*O), the C operand of the second launch's dP MFMAs; plane 1: LSE*log2(e); both written by the first launch, read
+ * by the second; one plane < 2^31 bytes).
  * Band (packed documents / sliding window; block-diagonal causal mask of utils/packing.py:650-693, window rule
  * `q - key < W`): query q attends keys lo[q] <= key <= q, equivalently key is seen by queries key <= q <= hi[key].
  * lo, hi: int32 [B, T], non-decreasing along T, lo[q] <= q <= hi[q]; NULL (both) = plain causal. Tiles outside

@@ -301,3 +301,41 @@ def test_document_band_is_the_cu_seqlens_window():
     assert lo.tolist() == [[0, 0, 0, 3, 3, 3, 3, 3, 8, 8]] and hi.tolist() == [[2, 2, 2, 7, 7, 7, 7, 7, 9, 9]]
     lo, hi = document_band(4, batch=2)
     assert lo.tolist() == [[0] * 4] * 2 and hi.tolist() == [[3] * 4] * 2
+
+
+KD4_CASES = [  # (B, T, Hq, Hk, dtype, document lengths or None, causal)
+    (1, 1024, 32, 8, torch.bfloat16, None, True), (1, 1024, 32, 8, torch.float16, None, True),
+    (2, 2048, 32, 8, torch.bfloat16, None, True), (1, 1000, 32, 8, torch.bfloat16, None, True),
+    (2, 777, 8, 8, torch.bfloat16, None, True), (1, 2048, 16, 8, torch.bfloat16, None, True),
+    (1, 1024, 64, 8, torch.bfloat16, None, True), (1, 4096, 32, 8, torch.bfloat16, [700, 1348, 64, 33, 1951], True),
+    (1, 2048, 16, 16, torch.float16, [1024, 1000, 24], False),
+]
+
+
+@pytest.mark.parametrize("B,T,Hq,Hk,dtype,lengths,causal", KD4_CASES)
+def test_dkdv_generated_step_loops_are_bit_identical_to_the_cxx_body(B, T, Hq, Hk, dtype, lengths, causal):
+    """attn_bwd_dkdv4_kernel: the steps over whole tiles run in the generated asm loops (csrc/attn_kd4_loop.inc, plain and
+    masked); UAMD_TUNE_ATTN_VAR bit 2 sends EVERY step through the C++ body of the ragged tiles. Same arithmetic in the same
+    order (Delta rides in the dP MFMAs' C operand in both): dQ, dK, dV bit-identical -- plain causal at G = 1, 2, 4, 8, ragged T,
+    packed documents (band edges inside tiles), non-causal windows, both dtypes."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels import attention as A
+    L = _lib.lib()
+    qkv = (torch.randn(B, T, (Hq + 2 * Hk) * 128, generator=g(T + Hq)) * 0.7).to(dtype).to(DEV)
+    q = qkv[..., :Hq * 128].view(B, T, Hq, 128)
+    k = qkv[..., Hq * 128:(Hq + Hk) * 128].view(B, T, Hk, 128)
+    v = qkv[..., (Hq + Hk) * 128:].view(B, T, Hk, 128)
+    band = None
+    if lengths is not None:
+        band = (A.attention_band if causal else A.document_band)(T, batch=B, seq_lengths=lengths, device=DEV)
+    o, lse = A.attn_forward(q, k, v, None, band, causal)
+    do = torch.randn(o.shape, generator=g(5)).to(dtype).to(DEV)
+    try:
+        got = [t.clone() for t in A.attn_backward(do, q, k, v, o, lse, None, band, causal)]
+        assert L.uamd_set_tuning(4, 4) == 0
+        want = [t.clone() for t in A.attn_backward(do, q, k, v, o, lse, None, band, causal)]
+    finally:
+        L.uamd_set_tuning(4, 0)
+    for name, a, b in zip(("dq", "dk", "dv"), got, want):
+        assert not torch.isnan(a.float()).any(), name
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))

@@ -271,7 +271,7 @@ def _backward_native(do, q, k, v, o, lse, scale, band, causal=True):
     dq = dqkv[..., :Hq * D].view(B, T, Hq, D)
     dk = dqkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
     dv = dqkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
-    # scratch of the two launches: plane 0 = Delta = rowsum(dO * O), plane 1 = LSE * log2(e) (written by the dQ kernel,
+    # scratch of the two launches: plane 0 = -Delta = -rowsum(dO * O), plane 1 = LSE * log2(e) (written by the dQ kernel,
     # read by the dK/dV kernel's LDS-DMA)
     delta = (torch.empty if Tp == T else torch.zeros)((2, B, Hq, Tp), dtype=torch.float32, device=q.device)
     if not causal and band is None:
