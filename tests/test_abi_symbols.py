@@ -137,3 +137,18 @@ def test_generated_gemm_loop_is_in_sync_with_its_generator():
                          check=True, env=env).stdout
     with open(os.path.join(root, "unsloth_amd", "csrc", "gemm256s_loop.inc")) as f:
         assert f.read() == out
+
+
+def test_generated_attention_step_loop_is_in_sync_with_its_generator():
+    """unsloth_amd/csrc/attn_kd4_loop.inc is the committed output of tools/gen/gen_attn_kd4.py at its default settings: the step
+    loops of attn_bwd_dkdv4_kernel are edited in the generator (which also checks the hazards no assembler checks for inline
+    asm), never in the include."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("KD4_")}
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_attn_kd4.py")], capture_output=True, text=True,
+                         check=True, env=env).stdout
+    with open(os.path.join(root, "unsloth_amd", "csrc", "attn_kd4_loop.inc")) as f:
+        assert f.read() == out
