@@ -253,7 +253,7 @@ def build_items(stage, mask=False):
         it = Item(f"adv{n}", [Ins(f"s_add_u32 s{lo}, s{lo}, %[{st}lo]", "salu", size=4), Ins(f"s_addc_u32 s{hi}, s{hi}, %[{st}hi]", "salu", size=4)],
                   0, 50, preds=[prev])
         items.append(it)
-    items.append(Item("advs", [Ins("s_add_u32 s92, s92, %[advs]", "salu", size=4), Ins("s_addc_u32 s93, s93, 0", "salu", size=4)], 0, 50, preds=[prev]))
+    items.append(Item("advs", [Ins("s_add_u32 s92, s92, %[advs]", "salu", size=4), Ins("s_addc_u32 s93, s93, %[advshi]", "salu", size=4)], 0, 50, preds=[prev]))
     # ---- the next step: its tile has landed (issued 40+ MFMAs ago), its first three Q fragments into ring slots 0..2
     vm = Item("vmcnt", [Ins("s_waitcnt vmcnt(0)", "wait", size=4)], VMGAP, max(56, VMGAP + 2), preds=[prev])    # (behind the last piece)
     items.append(vm)

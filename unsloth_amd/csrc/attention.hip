@@ -1215,7 +1215,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const T* dobase = (const T*)p.dO + b * p.do_sb + (int64_t)head * p.do_sh;
         const float* lse_row = lse2_all + ((int64_t)b * p.Hq + head) * p.lse_st;
         const float* del_row = p.Delta + ((int64_t)b * p.Hq + head) * p.lse_st;
+        // the steps of a pass sweep the query tiles DOWNWARDS, from the band's upper end to the diagonal: whatever their key
+        // tile, the workgroups that run side by side on an XCD (the heaviest-first order starts them together) then stream the
+        // SAME Q / dO rows at the same time -- one L2 fill serves them all. Upwards from each block's own diagonal, a row was
+        // re-read two steps after its first use, with the XCD's whole traffic of two steps (4 MB = its L2) in between.
+#ifdef UAMD_KD4_UPWARD
         auto q0_of = [&](int step) { return (q32_first + step * nslice + slice) * 32; };
+        constexpr int SWEEP = 1;
+#else
+        auto q0_of = [&](int step) { return (q32_first + (nsteps - 1 - step) * nslice + slice) * 32; };
+        constexpr int SWEEP = -1;
+#endif
         // tile a step's DMA fetches: its own q tile, or (idle slice at the end of the sequence) the last valid one
         auto fetch_q0 = [&](int step) {
             const int q0 = q0_of(step);
@@ -1449,8 +1459,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const uint64_t q0p = (uint64_t)(uintptr_t)(qbase + (int64_t)qn * p.q_st), q1p = q0p + (uint64_t)(32 * p.q_st);
             const uint64_t d0p = (uint64_t)(uintptr_t)(dobase + (int64_t)qn * p.do_st), d1p = d0p + (uint64_t)(32 * p.do_st);
             const uint64_t stp = (uint64_t)(uintptr_t)(del_row + qn);
-            const uint64_t advq = (uint64_t)(nslice * 64 * p.q_st), advd = (uint64_t)(nslice * 64 * p.do_st);    // 32 rows x 2 bytes
-            const unsigned advs = (unsigned)(nslice * 32 * 4);
+            const uint64_t advq = (uint64_t)((int64_t)SWEEP * nslice * 64 * p.q_st);          // 32 rows x 2 bytes, signed
+            const uint64_t advd = (uint64_t)((int64_t)SWEEP * nslice * 64 * p.do_st);
+            const uint64_t advs = (uint64_t)((int64_t)SWEEP * nslice * 32 * 4);
             const unsigned ringu = ring_u, statu = lds_base + KD4_STATS_OFF + unit * 256;
             unsigned cnt = (unsigned)(n - 1);
             const unsigned stage = (unsigned)(step & 1);
@@ -1458,14 +1469,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             [q0lo] "s"(lo32(q0p)), [q0hi] "s"(hi32(q0p)), [q1lo] "s"(lo32(q1p)), [q1hi] "s"(hi32(q1p)), [d0lo] "s"(lo32(d0p)),  \
             [d0hi] "s"(hi32(d0p)), [d1lo] "s"(lo32(d1p)), [d1hi] "s"(hi32(d1p)), [stlo] "s"(lo32(stp)), [sthi] "s"(hi32(stp)),   \
             [advqlo] "s"(lo32(advq)), [advqhi] "s"(hi32(advq)), [advdlo] "s"(lo32(advd)), [advdhi] "s"(hi32(advd)),             \
-            [advs] "s"(advs), [ringu] "s"(ringu), [statu] "s"(statu), [sl2] "s"(p.scale_log2), [stage] "s"(stage)
+            [advs] "s"(lo32(advs)), [advshi] "s"(hi32(advs)), [ringu] "s"(ringu), [statu] "s"(statu), [sl2] "s"(p.scale_log2), [stage] "s"(stage)
             if (!masked) {
                 if constexpr (std::is_same<T, bf16_t>::value)
                     asm volatile(KD4_LOOP("bf16") : [cnt] "+s"(cnt) : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_SGPR_IN : KD4_CLOBBER);
                 else
                     asm volatile(KD4_LOOP("f16") : [cnt] "+s"(cnt) : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_SGPR_IN : KD4_CLOBBER);
             } else {
-                const unsigned q0s = (unsigned)q0_of(step), rowadv = (unsigned)(nslice * 32);
+                const unsigned q0s = (unsigned)q0_of(step), rowadv = (unsigned)(SWEEP * nslice * 32);
                 if constexpr (std::is_same<T, bf16_t>::value)
                     asm volatile(KD4_LOOP_M("bf16") : [cnt] "+s"(cnt)
                                  : KD4_IN_KF, KD4_IN_ADDR, KD4_IN_DMA, KD4_IN_MASK, KD4_SGPR_IN, [q0s] "s"(q0s), [rowadv] "s"(rowadv) : KD4_CLOBBER);
