@@ -873,6 +873,13 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         p.Delta[(int64_t)p.B * p.Hq * p.lse_st + stat_idx] = lse2;        // plane 1: LSE log2(e)
     }
     const float delta_s = delta * p.scale;
+    // Plain-causal build (which has the registers): -Delta rides as the C operand of the dP chain's first MFMA (16 registers
+    // holding the lane's value) and the softmax scale is applied to dQ once, at the store -- dS = P dP' is one multiply per
+    // element instead of a fused multiply-add plus a multiply (MFMA time and VALU time add up on this chip).
+    constexpr bool CFOLD = !BAND;
+    f32x16_t ndelta;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ndelta[r] = -delta;
     const int lo_q = BAND ? p.lo[(int64_t)b * T_ + q_ld] : 0;
     const int lo_w0 = BAND ? __builtin_amdgcn_readfirstlane(lo_q) : 0, lo_w1 = BAND ? __builtin_amdgcn_readlane(lo_q, 31) : 0;
     const int t_first = BAND ? p.lo[(int64_t)b * T_ + min(qtile * QT, T_ - 1)] / KT : 0;
@@ -948,6 +955,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
             f32x16_t st, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
+            if constexpr (CFOLD) dp = ndelta;
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 union { uint4 r; frag_t f; } u, w;
@@ -964,7 +972,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                     const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (key > lim_q || key >= T_ || key < lo_q) pv = 0.f;
                 }
-                st[r] = pv * __builtin_fmaf(dp[r], p.scale, -delta_s);        // (dP - Delta) * scale in one fma
+                if constexpr (CFOLD) st[r] = pv * dp[r];
+                else st[r] = pv * __builtin_fmaf(dp[r], p.scale, -delta_s);   // (dP - Delta) * scale in one fma
             }
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
@@ -1004,7 +1013,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         int qr = q_ld;                       // (the row address formed HERE: hoisted, the pointer pair is spilled around the loop)
         asm volatile("" : "+v"(qr));
         T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)qr * p.dq_st + (int64_t)head * p.dq_sh;
-        store_rows_x4<T>(op, dq_acc, 1.0f, lh, q_pos < T_);
+        store_rows_x4<T>(op, dq_acc, CFOLD ? p.scale : 1.0f, lh, q_pos < T_);
     }
 }
 
