@@ -365,7 +365,8 @@ int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* w
  * unsloth/models/llama.py:757). Q [B,T,Hq,D], K/V [B,T,Hk,D], O [B,T,Hq,D] given by element strides
  * `strides` = {q_b,q_t,q_h, k_b,k_t,k_h, v_b,v_t,v_h, o_b,o_t,o_h} (d contiguous, multiples of 8);
  * LSE [B,Hq,lse_stride] fp32 (natural log-sum-exp of the scaled scores, saved for the backward; lse_stride =
- * T rounded up to a multiple of 32, pad zero-filled by the caller). Hq/Hk in {1,2,4,8}.
+ * T rounded up to a multiple of 32, pad zero-filled by the caller). Hq/Hk in 1 .. 8 (3, 5, 6, 7: a KV head's query heads run in
+ * groups of 4 / 2 / 1 over the same K / V head -- no padded copies).
  * uamd_attn_bwd: two launches (dQ + Delta = rowsum(dO*O), then dK/dV), deterministic, no atomics. `strides` has
  * 24 entries: the 12 above, then dO, dQ, dK, dV (b, t, h each). Delta is a [2,B,Hq,lse_stride] fp32 scratch (plane 0:
  * -rowsum(dO*O), the C operand of the second launch's dP MFMAs; plane 1: LSE*log2(e); both written by the first launch, read

@@ -203,7 +203,7 @@ def test_attn_forward_rescale_heavy_inputs(fwd_variant):
 
 
 PADDED_CASES = [  # B, T, Hq, Hk, D, packed lengths, window
-    (1, 200, 7, 1, 128, None, None),                  # G = 7 -> padded to 8
+    (1, 200, 7, 1, 128, None, None),                  # G = 7 (native: passes of 4 + 2 + 1 heads)
     (2, 333, 28, 4, 128, None, None),                 # Qwen2.5-7B / Qwen2-VL-7B head layout
     (1, 256, 6, 2, 128, [100, 156], None),            # G = 3 -> 4, packed
     (1, 192, 5, 1, 128, None, 48),                    # G = 5 -> 8, sliding window
@@ -216,9 +216,9 @@ PADDED_CASES = [  # B, T, Hq, Hk, D, packed lengths, window
 
 @pytest.mark.parametrize("B,T,Hq,Hk,D,lengths,window", PADDED_CASES)
 def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
-    """Head dims below 128 and group sizes 3 / 5 / 6 / 7 run on the native kernels zero-padded (kernels/attention.py
-    _pad_qkv): outputs, LSE and all three gradients against the fp32 oracle on the UNPADDED problem, and the gradient
-    buffers keep the dQ | dK | dV column-block layout."""
+    """Head dims below 128 run on the native kernels zero-padded (kernels/attention.py _pad_qkv), group sizes 3 / 5 / 6 / 7 are
+    native (round 6; zero-padded to 4 / 8 before): outputs, LSE and all three gradients against the fp32 oracle on the UNPADDED
+    problem, and the gradient buffers keep the dQ | dK | dV column-block layout."""
     from unsloth_amd.kernels.attention import attention_band, attn_backward, attn_forward, native, supported
     dtype = torch.bfloat16
     qkv = torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(31)).to(dtype)
@@ -239,7 +239,7 @@ def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
     q = qd[..., :Hq * D].view(B, T, Hq, D)
     k = qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
     v = qd[..., (Hq + Hk) * D:].view(B, T, Hk, D)
-    assert supported(q, k, v) and not native(q, k, v)
+    assert supported(q, k, v) and native(q, k, v) == (D == 128)
     o, lse = attn_forward(q, k, v, None, band)                      # default scale = 1 / sqrt(D) of the REAL head dim
     assert o.shape == (B, T, Hq, D) and lse.shape == (B, Hq, T)
     torch.testing.assert_close(lse.cpu(), lse_ref.detach(), rtol=1e-4, atol=2e-3)
@@ -251,6 +251,71 @@ def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
         e = (got.float().cpu() - want).abs().max().item()
         ref = want.abs().max().item()
         assert e <= 3e-2 * max(ref, 1.0), (name, e, ref)
+
+
+ODD_GROUP_CASES = [  # B, T, Hq, Hk, packed lengths, window, causal, dtype
+    (2, 777, 14, 2, None, None, True, torch.bfloat16),             # G = 7: dK/dV passes of 4 + 2 + 1 heads
+    (1, 2048, 28, 4, None, None, True, torch.bfloat16),            # Qwen2.5-7B / Qwen2-VL-7B text tower, plain causal (persistent forward)
+    (1, 1024, 6, 2, [300, 200, 524], None, True, torch.bfloat16),  # G = 3 (2 + 1), packed documents
+    (2, 640, 5, 1, None, 200, True, torch.float16),                # G = 5 (4 + 1), sliding window, fp16
+    (1, 896, 12, 2, None, None, True, torch.bfloat16),             # G = 6 (4 + 2)
+    (1, 900, 7, 1, [400, 500], None, False, torch.bfloat16),       # G = 7, non-causal inside documents
+]
+
+
+@pytest.mark.parametrize("B,T,Hq,Hk,lengths,window,causal,dtype", ODD_GROUP_CASES)
+def test_group_sizes_3_5_6_7_native_equal_the_zero_padded_run(B, T, Hq, Hk, lengths, window, causal, dtype):
+    """Round 6: group sizes 3 / 5 / 6 / 7 without copies -- the forward and dQ kernels run a KV head's query heads as virtual KV
+    heads of 4 / 2 / 1 heads over the same K / V head, the dK / dV kernel in passes of 4, 2 and 1 heads. Against the SAME kernels
+    on the zero-padded problem (all-zero dummy query heads up to 8 per KV head: rounds 2-5's path): a query row meets the same
+    key tiles in the same order either way, so O, LSE and dQ are BIT-IDENTICAL; dK / dV sum the heads in a different order
+    (norm-wise 2e-3). And against the fp32 oracle like every other shape."""
+    from unsloth_amd.kernels import attention as A
+    D, G = 128, Hq // Hk
+    qkv = (torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(41)) * 0.7).to(dtype).to(DEV)
+    do = torch.randn(B, T, Hq, D, generator=g(42)).to(dtype).to(DEV)
+    q = qkv[..., :Hq * D].view(B, T, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    band = None
+    if not causal:
+        band = A.document_band(T, batch=B, seq_lengths=(lengths + [T - sum(lengths)]) * B if lengths else None, device=DEV)
+    elif lengths or window:
+        band = A.attention_band(T, batch=B, seq_lengths=(lengths + [T - sum(lengths)]) * B if lengths else None,
+                                sliding_window=window, device=DEV)
+    assert A.native(q, k, v)
+    scale = 1.0 / math.sqrt(D)
+    extra = () if causal else (False,)
+    o, lse = A._forward_native(q, k, v, scale, band, *extra)
+    dq, dk, dv = A._backward_native(do, q, k, v, o, lse, scale, band, *extra)
+    # the zero-padded problem on the same kernels
+    qp = A._pad_heads(q, G, 8, D)
+    op_, lsep = A._forward_native(qp, k, v, scale, band, *extra)
+    o_cut = op_.view(B, T, Hk, 8, D)[:, :, :, :G].reshape(B, T, Hq, D)
+    lse_cut = lsep.reshape(B, Hk, 8, T)[:, :, :G].reshape(B, Hq, T)
+    assert torch.equal(o, o_cut) and torch.equal(lse, lse_cut)
+    dop = A._pad_heads(do, G, 8, D)
+    Tp = (T + 31) // 32 * 32
+    lse_store = torch.as_strided(lsep, (B, Hk * 8, Tp), (Hk * 8 * Tp, Tp, 1))
+    dqp, dkp, dvp = A._backward_native(dop, qp, k, v, op_, lse_store[:, :, :T], scale, band, *extra)
+    assert torch.equal(dq, dqp.view(B, T, Hk, 8, D)[:, :, :, :G].reshape(B, T, Hq, D))
+    for name, got, want in (("dk", dk, dkp), ("dv", dv, dvp)):
+        err = (got.float() - want.float()).norm().item() / max(want.float().norm().item(), 1e-6)
+        assert err <= 2e-3, (name, err)
+    # and the oracle (fp32 softmax on the host) at a size it finishes in seconds
+    if T <= 1024:
+        if not causal:
+            allowed = _doc_mask(T, lengths or [T])
+        else:
+            allowed = packed_mask(T, lengths or [T], window) if (lengths or window) else None
+        qr, kr, vr = (t.float().cpu().requires_grad_(True) for t in (q, k, v))
+        o_ref, lse_ref = ref_attention(qr, kr, vr, scale, allowed)
+        o_ref.backward(do.float().cpu())
+        torch.testing.assert_close(lse.cpu(), lse_ref.detach(), rtol=1e-4, atol=2e-3)
+        assert (o.float().cpu() - o_ref.detach()).abs().max().item() <= 2e-2
+        for name, got, want in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+            e = (got.float().cpu() - want).abs().max().item()
+            assert e <= 3e-2 * max(want.abs().max().item(), 1.0), (name, e)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

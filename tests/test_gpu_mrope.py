@@ -115,7 +115,7 @@ def test_fastmodel_language_tower_matches_hf_qwen2_vl_text_model(hidden, heads, 
         out = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=pos3.cuda())
     finally:
         flash._forward_native = real
-    assert calls and all(g_ in (1, 2, 4, 8) for g_ in calls)            # the hand kernels ran (7 query heads: padded to 8)
+    assert calls and all(1 <= g_ <= 8 for g_ in calls)                  # the hand kernels ran (7 query heads on a KV head: native)
     out_t = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=torch.arange(T).expand(B, T).cuda())
     out_3 = model(input_ids=ids.cuda(), labels=labels.cuda(), position_ids=torch.arange(T).expand(3, B, T).contiguous().cuda())
     assert abs(float(out_t.loss) - float(out_3.loss)) < 1e-6

@@ -69,7 +69,9 @@ struct AttnArgs {
     const int* hi;                       // [B, T] LAST key each query may attend, >= t, non-decreasing (NULL: t itself = causal).
                                          // Non-causal (bidirectional) attention inside documents: lo = document start, hi = its end
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh;
-    int B, T, Hq, Hk, G, nsub;          // G = Hq / Hk, nsub = 8 / G q-subtiles of 32 rows per block
+    int B, T, Hq, Hk, G, nsub;          // G = query heads per block (1, 2, 4, 8), nsub = 8 / G q-subtiles of 32 rows per block
+    int kvm;                             // Hk counts VIRTUAL KV heads: virtual head v reads K / V head v / kvm and serves query heads
+                                         // v G .. v G + G - 1 (group sizes 3, 5, 6, 7 = kvm x the largest of 1, 2, 4, 8 dividing them)
     int nqt;                             // number of q tiles
     int lse_st;                          // row stride of LSE [B, Hq, lse_st] (T rounded up to 32)
     float scale_log2;                    // softmax scale * log2(e)
@@ -219,6 +221,17 @@ __device__ __forceinline__ void store_rows_x4(T* row, const f32x16_t (&acc)[4], 
 // BAND = false: plain causal attention, the band bookkeeping folds away at compile time (it costs ~50 VGPRs).
 // (A 2-stage ring = 64 KiB = two blocks per CU was tried in round 4: the kernel needs ~240 registers per lane -- O 64, S 32, Q^T 32,
 // operand fragments -- so the 128-register cap of 4 waves per SIMD spills 126-256 registers. Not built.)
+// lgkmcnt(0) as the BUILTIN (an S_WAITCNT hipcc's own wait insertion sees and accounts for) behind a compiler-level memory
+// barrier: behind an inline-asm wait the compiler still counts the reads as pending and puts a (satisfied) counted wait in
+// front of every MFMA that takes one -- 21 instructions per tile step of the persistent forward.
+__device__ __forceinline__ void wait_lgkm0() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }     // one v_max3_f32
+
 template <typename T, bool BAND>
 __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -278,8 +291,9 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         koff[i] = (unsigned)((int64_t)row * p.k_st * 2 + dks[i]);
         voff[i] = (unsigned)((int64_t)row * p.v_st * 2 + dvs[i]);
     }
-    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
-    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh;
+    const int kvr = p.kvm == 1 ? kvh : kvh / p.kvm;                                     // the K / V head behind a virtual one
+    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvr * p.k_sh;
+    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvr * p.v_sh;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
     const unsigned dst_w = lds_base + wave * 2048;
     auto issue = [&](int t, int stage) {
@@ -538,12 +552,13 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
     const int nitems = p.nqt * npairs, nwg = (int)gridDim.x, wg = (int)blockIdx.x;
     // item k of this workgroup: snake over the heaviest-first list
     auto item_index = [&](int k) { return k * nwg + ((k & 1) ? nwg - 1 - wg : wg); };
-    struct Item { int qtile, kvh, b, t_first, nt; };
+    struct Item { int qtile, kvh, kvr, b, t_first, nt; };            // kvr: the K / V head behind the (virtual) head kvh
     auto decode = [&](int idx) {
         Item it;
         it.qtile = p.nqt - 1 - idx / npairs;
         const int pair_ = idx % npairs;
         it.kvh = pair_ % p.Hk;
+        it.kvr = p.kvm == 1 ? it.kvh : it.kvh / p.kvm;
         it.b = pair_ / p.Hk;
         it.t_first = BAND ? p.lo[(int64_t)it.b * T_ + min(it.qtile * QT, T_ - 1)] / KT : 0;
         it.nt = min((it.qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT) - it.t_first;
@@ -559,8 +574,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
     // opaque copy of the lane id (a dozen VALU instructions per tile): kept in registers across the tile loop they are the first
     // thing hipcc spills, and a scratch reload in front of the DMA drains vmcnt (= the ring)
     auto issue_tile = [&](const Item& it, int t, int stage) {
-        const T* kbase = (const T*)p.K + it.b * p.k_sb + (int64_t)it.kvh * p.k_sh;
-        const T* vbase = (const T*)p.V + it.b * p.v_sb + (int64_t)it.kvh * p.v_sh;
+        const T* kbase = (const T*)p.K + it.b * p.k_sb + (int64_t)it.kvr * p.k_sh;
+        const T* vbase = (const T*)p.V + it.b * p.v_sb + (int64_t)it.kvr * p.v_sh;
         const int k0 = t * KT;
         const unsigned d = dst_w + stage * STAGE_B;
         int ln = lane;
@@ -611,7 +626,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             u.r = *reinterpret_cast<const uint4*>(smem + QSTAGE_OFF + wave * 8192 + (k_lane ^ (ks * 32)));
             qf[ks] = u.f;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        wait_lgkm0();
     };
 
     if (item_index(0) >= nitems) return;                 // (whole workgroup: no barrier was executed yet)
@@ -683,7 +698,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
                         u.r = *reinterpret_cast<const uint4*>(sk + kt * 32 * 256 + (k_lane ^ (ks * 32)));
                         kv[kt * 8 + ks] = u.f;
                     }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_lgkm0();
             }
             bar();
             // ---------------- P2 (matrix): S^T = K Q^T; in its shadow the DMA of stream tile sx + 2 (this item's tile ti + 2, or
@@ -746,10 +761,26 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
                         kv[u * 4 + dt] = va.f;
                     }
                     const int kt = u >> 1, c = u & 1;
+#ifdef UAMD_ATTN_MAX_TREE2
                     m8[2 * u] = fmaxf(fmaxf(st[kt][8 * c], st[kt][8 * c + 1]), fmaxf(st[kt][8 * c + 2], st[kt][8 * c + 3]));
                     m8[2 * u + 1] = fmaxf(fmaxf(st[kt][8 * c + 4], st[kt][8 * c + 5]), fmaxf(st[kt][8 * c + 6], st[kt][8 * c + 7]));
+#else
+                    // four independent chains of v_max3_f32 (a chain link takes in TWO new scores): 18 instructions for the 32
+                    // scores of a lane instead of the pairwise tree's 31 -- the kernel is bound by instruction count
+#define SP_(i) st[kt][8 * c + (i)]
+                    if (u == 0) { m8[0] = max3f(SP_(0), SP_(1), SP_(2)); m8[1] = max3f(SP_(3), SP_(4), SP_(5)); m8[2] = SP_(6); m8[3] = SP_(7); }
+                    else if (u == 1) { m8[2] = max3f(m8[2], SP_(0), SP_(1)); m8[3] = max3f(m8[3], SP_(2), SP_(3));
+                                       m8[0] = max3f(m8[0], SP_(4), SP_(5)); m8[1] = max3f(m8[1], SP_(6), SP_(7)); }
+                    else { m8[0] = max3f(m8[0], SP_(0), SP_(1)); m8[1] = max3f(m8[1], SP_(2), SP_(3));
+                           m8[2] = max3f(m8[2], SP_(4), SP_(5)); m8[3] = max3f(m8[3], SP_(6), SP_(7)); }
+#undef SP_
+#endif
                 }
+#ifdef UAMD_ATTN_MAX_TREE2
                 float mt = fmaxf(fmaxf(fmaxf(m8[0], m8[1]), fmaxf(m8[2], m8[3])), fmaxf(fmaxf(m8[4], m8[5]), fmaxf(m8[6], m8[7])));
+#else
+                float mt = fmaxf(max3f(m8[0], m8[1], m8[2]), m8[3]);
+#endif
                 mt = max_across_halves(mt) * p.scale_log2;
                 if (__builtin_amdgcn_ballot_w64(mt > m_run) != 0) {
                     const float m_new = fmaxf(m_run, mt);
@@ -762,7 +793,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
                 m_ref = m_run == -INFINITY ? 0.f : m_run;
                 softmax_piece(0, m_ref, ls0, ls1);
                 __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_lgkm0();
             }
             // stream tile sx + 1 has landed (this wave's pieces) one barrier before anybody reads it. It was issued one tile ago --
             // or in THIS tile's P2 when the item has a single tile (then everything is waited for)
@@ -820,6 +851,8 @@ struct AttnBwdArgs {
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh;
     int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
     int B, T, Hq, Hk, G, nsub, lse_st, nqt;
+    int kvm;                             // attn_bwd_dq_kernel: Hk counts virtual KV heads (AttnArgs::kvm); the dK / dV kernel takes the
+                                         // real heads with G = Hq / Hk of any size 1 .. 8 (passes of 4, 2 and 1 query heads)
     float scale, scale_log2;
     int noncausal;                       // 1: bidirectional inside documents -- query q and key k attend iff lo[q] <= k <= hi[q]
                                          // (documents are intervals, so equivalently lo[k] <= q <= hi[k]); needs lo AND hi
@@ -890,8 +923,9 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     const int lim_blk = full ? p.hi[(int64_t)b * T_ + min(qtile * QT + QT - 1, T_ - 1)] : qtile * QT + QT - 1;
 
     const int nkv_blk = min(lim_blk / KT + 1, (T_ + KT - 1) / KT);
-    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvh * p.k_sh;
-    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvh * p.v_sh;
+    const int kvr = p.kvm == 1 ? kvh : kvh / p.kvm;                                     // the K / V head behind a virtual one
+    const T* kbase = (const T*)p.K + b * p.k_sb + (int64_t)kvr * p.k_sh;
+    const T* vbase = (const T*)p.V + b * p.v_sb + (int64_t)kvr * p.v_sh;
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
     const unsigned dst_w = lds_base + wave * 2048;
     // the four per-lane DMA source offsets are RECOMPUTED at every issue from an opaque copy of the lane id (see
@@ -1113,9 +1147,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int unit = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
     const int G = p.G, T_ = p.T;
-    const int hpp = G < 4 ? G : 4;                    // heads per pass
-    const int npass = G / hpp, nslice = 4 / hpp;
-    const int hin = unit % hpp, slice = unit / hpp;
+    // The G query heads of the KV head go through the four waves in PASSES of 4, 2 or 1 heads -- G = 4 a + 2 b + c: a passes of
+    // a head per wave, then (b) two heads x two q-slices, then (c) one head x four q-slices (q-slice: every nslice-th 32-row
+    // step of the head's queries) -- so no wave idles whatever the group size (3, 5, 6, 7: Llama-3.2-3B, Qwen2.5-14B / 32B,
+    // Qwen2.5-7B / Qwen2-VL-7B = BASELINE config 4; rounds 2-5 ran them zero-padded to 4 / 8 heads through copies of Q, O, dO).
+    const int npass = (G >> 2) + ((G >> 1) & 1) + (G & 1);
+    int hpp, nslice, hin, slice, head0;               // of the current pass (set at its top)
     const int npairs = p.Hk * p.B;
     int jt, pair_;                                    // key tile 0 sees every q tile (causal): heaviest first
     block_to_work((int)blockIdx.x, npairs, jt, pair_);
@@ -1179,7 +1216,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     const int nq32 = (T_ + 31) / 32;
     const int q32_first = qlo_blk / 32;
-    const int nsteps = (min(nq32, hi_blk / 32 + 1) - q32_first + nslice - 1) / nslice;
+    int nsteps;                                        // steps of the current pass: the band's 32-row q tiles / nslice
 
     // ---- per-lane ABSOLUTE LDS byte addresses (swizzle C; the dynamic region's base included), made opaque once:
     //      stage / operand / k-step / c are immediates on them
@@ -1219,7 +1256,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // DMA round trip per workgroup less on the critical path)
     const float* lse2_all = p.Delta + (int64_t)p.B * p.Hq * p.lse_st;            // plane 1 of the scratch: LSE * log2(e)
     for (int pass = 0; pass < npass; ++pass) {
-        const int head = kvh * G + pass * hpp + hin;
+        if (pass < (G >> 2)) { hpp = 4; head0 = 4 * pass; }
+        else if ((G & 2) && pass == (G >> 2)) { hpp = 2; head0 = G & ~3; }
+        else { hpp = 1; head0 = G - 1; }
+        const int hsh = hpp == 4 ? 2 : hpp - 1;          // log2(hpp)
+        nslice = 4 >> hsh;
+        hin = unit & (hpp - 1);
+        slice = unit >> hsh;
+        nsteps = (min(nq32, hi_blk / 32 + 1) - q32_first + nslice - 1) >> (2 - hsh);
+        const int head = kvh * G + head0 + hin;
         const T* qbase = (const T*)p.Q + b * p.q_sb + (int64_t)head * p.q_sh;
         const T* dobase = (const T*)p.dO + b * p.do_sb + (int64_t)head * p.do_sh;
         const float* lse_row = lse2_all + ((int64_t)b * p.Hq + head) * p.lse_st;
@@ -1595,7 +1640,10 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     if (D != AD || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
     if (!causal && !(lo && hi)) return UAMD_ERR_ARG;          // non-causal: the (lo, hi) band of the documents is required
     const int G = Hq / Hk;
-    if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
+    if (G > 8) return UAMD_ERR_ARG;
+    // dQ kernel: 8 waves = Gq query heads x 8 / Gq q-subtiles, Gq the largest of 1, 2, 4, 8 dividing G; the other G / Gq - 1 head
+    // groups of a KV head are blocks of their own that read the same K / V head (virtual KV heads, AttnArgs::kvm)
+    const int Gq = (G & 7) == 0 ? 8 : (G & 3) == 0 ? 4 : (G & 1) == 0 ? 2 : 1, kvm = G / Gq;
     for (int i = 0; i < 24; ++i)
         if (strides[i] & 7) return UAMD_ERR_ALIGN;
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O) || !aligned16(dO) || !aligned16(dQ) ||
@@ -1614,15 +1662,17 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     a.dq_sb = strides[15]; a.dq_st = strides[16]; a.dq_sh = strides[17];
     a.dk_sb = strides[18]; a.dk_st = strides[19]; a.dk_sh = strides[20];
     a.dv_sb = strides[21]; a.dv_st = strides[22]; a.dv_sh = strides[23];
-    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
+    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk * kvm; a.G = Gq; a.nsub = 8 / Gq; a.kvm = kvm; a.lse_st = lse_stride;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     a.noncausal = causal ? 0 : 1;
     a.no_asm = (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 4) ? 1 : 0;
     if ((int64_t)B * Hq * lse_stride * 4 >= (1ll << 31)) return UAMD_ERR_ARG;      // 32-bit lane offset between the two stat planes
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
-    dim3 grid_q((unsigned)(a.nqt * Hk * B));
+    dim3 grid_q((unsigned)(a.nqt * a.Hk * B));
     dim3 grid_k((unsigned)(((T + KT - 1) / KT) * Hk * B));
+    AttnBwdArgs ak = a;                                       // dK / dV: the real KV heads, all G query heads of each
+    ak.Hk = Hk; ak.G = G; ak.kvm = 1;
     hipStream_t st = (hipStream_t)stream;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -1642,7 +1692,7 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
         }
         if ((rc_ = uamd_launch_status())) return rc_;
         if ((rc_ = set_lds_attr(&attn_bwd_dkdv4_kernel<T>, KD4_LDS, &done_kd[ti][dev]))) return rc_;
-        hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<T>), grid_k, dim3(256), KD4_LDS, st, a);
+        hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<T>), grid_k, dim3(256), KD4_LDS, st, ak);
         return 0;
     };
     if (dtype == UAMD_BF16) rc = run(bf16_t{});
@@ -1661,8 +1711,11 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
     if (D != AD || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
     if (!causal && !(lo && hi)) return UAMD_ERR_ARG;          // non-causal: the (lo, hi) band of the documents is required
     if (causal) hi = nullptr;
-    const int G = Hq / Hk;
-    if (G != 1 && G != 2 && G != 4 && G != 8) return UAMD_ERR_ARG;
+    const int Gr = Hq / Hk;
+    if (Gr > 8) return UAMD_ERR_ARG;
+    // 8 waves = G query heads x 8 / G q-subtiles, G the largest of 1, 2, 4, 8 dividing the group size; a KV head's other head
+    // groups are work items of their own over the same K / V head (virtual KV heads, AttnArgs::kvm): group sizes 3, 5, 6, 7
+    const int G = (Gr & 7) == 0 ? 8 : (Gr & 3) == 0 ? 4 : (Gr & 1) == 0 ? 2 : 1, kvm = Gr / G;
     for (int i = 0; i < 12; ++i)
         if (strides[i] & 7) return UAMD_ERR_ALIGN;
     if (!aligned16(Q) || !aligned16(K) || !aligned16(V) || !aligned16(O)) return UAMD_ERR_ALIGN;
@@ -1674,11 +1727,11 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
     a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
     a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];
     a.o_sb = strides[9]; a.o_st = strides[10]; a.o_sh = strides[11];
-    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk; a.G = G; a.nsub = 8 / G; a.lse_st = lse_stride;
+    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk * kvm; a.G = G; a.nsub = 8 / G; a.kvm = kvm; a.lse_st = lse_stride;
     a.scale_log2 = scale * 1.4426950408889634f;
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
-    dim3 grid((unsigned)(a.nqt * Hk * B));
+    dim3 grid((unsigned)(a.nqt * a.Hk * B));
     hipStream_t st = (hipStream_t)stream;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;

@@ -17,18 +17,20 @@ _I64x12 = ctypes.c_int64 * 12
 _I64x24 = ctypes.c_int64 * 24
 
 
-_GROUPS = (1, 2, 4, 8)          # query heads per KV head the kernels are built for (8 waves per block)
+_GROUPS = (1, 2, 3, 4, 5, 6, 7, 8)   # query heads per KV head the kernels take (csrc/attention.hip: the forward and dQ kernels run a
+                                     # KV head's heads in groups of 8, 4, 2 or 1 over virtual KV heads, the dK / dV kernel in passes of
+                                     # 4, 2 and 1 heads -- rounds 2-5 zero-padded 3 / 5 / 6 / 7 to 4 / 8 through copies of Q, O and dO)
 
 
 def native(q, k, v):
-    """Shapes the kernels take as they are: head_dim 128, G = Hq / Hk in {1, 2, 4, 8}."""
+    """Shapes the kernels take as they are: head_dim 128, G = Hq / Hk in 1 .. 8."""
     return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 128
             and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) in _GROUPS)
 
 
 def supported(q, k, v):
     """Native shapes, plus the ones that run on the same kernels after zero-padding (`_pad_qkv`): head dims below 128
-    (TinyLlama / Llama-3.2-1B: 64) and group sizes 3, 5, 6, 7 (Qwen2.5-7B / Qwen2-VL-7B: 28 query heads on 4 KV heads)."""
+    (TinyLlama / Llama-3.2-1B: 64, Qwen2-VL's vision tower: 80)."""
     return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and 0 < q.shape[-1] <= 128
             and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) <= 8)
 
@@ -66,7 +68,8 @@ def _pad_heads(x, G, Gp, D):
 
 def _pad_qkv(q, k, v):
     """Zero-padding onto a native shape. Head dim D < 128: extra zero columns change neither Q K^T nor the real columns
-    of P V. Group size G not in {1,2,4,8}: every KV group gets Gp - G extra query heads that are all zero -- their
+    of P V. (Every group size 1 .. 8 is native since round 6, so Gp == G; the head padding below is what a group size outside
+    `_GROUPS` would take.) Group size G not in _GROUPS: every KV group gets Gp - G extra query heads that are all zero -- their
     scores are 0, their dO is 0 (the caller never sees their output), so they add exactly nothing to dK / dV
     (dV += P^T dO = 0; dP = dO V^T = 0 and Delta = 0 give dS = 0). Returns (qp [B,T,Hk*Gp,128], kp, vp, G, Gp)."""
     B, T, Hq, D = q.shape
@@ -199,7 +202,7 @@ def attn_forward(q, k, v, scale=None, band=None, causal=True, keep_padded=None):
 
 
 def _forward_native(q, k, v, scale, band, causal=True):
-    """The launch itself: head_dim 128, G in {1, 2, 4, 8}."""
+    """The launch itself: head_dim 128, G in 1 .. 8."""
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
     o = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)
@@ -294,7 +297,7 @@ class FlashAttention(torch.autograd.Function):
         # (causal only when it is not the default: tests and tools swap attn_forward / attn_backward for five-argument stand-ins)
         ctx.scale, ctx.band, ctx.causal = scale, band, causal
         if q.is_cuda and not native(q, k, v) and supported(q, k, v):
-            # a shape that runs zero-padded (the ViT's head_dim 80, group sizes 3 / 5 / 6 / 7): keep the PADDED operands for the
+            # a shape that runs zero-padded (the ViT's head_dim 80, TinyLlama's 64): keep the PADDED operands for the
             # backward instead of padding q, k, v, o and the LSE a second time there (288 GB: the copies are cheaper kept than redone)
             kept = []
             o, _ = attn_forward(q, k, v, scale, band, causal, keep_padded=kept)

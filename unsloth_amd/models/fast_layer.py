@@ -188,7 +188,7 @@ def layer_supported(layer, hidden, attention_mask):
             return False
     cfg = getattr(attn, "config", None)
     groups = (cfg.num_attention_heads // cfg.num_key_value_heads) if cfg is not None else 1
-    # (group sizes 3 / 5 / 6 / 7 run zero-padded inside kernels/attention.attn_forward / attn_backward)
+    # (every group size 1 .. 8 is native to csrc/attention.hip)
     return attn.head_dim == 128 and groups <= 8 and getattr(layer.input_layernorm, "weight", None) is not None
 
 

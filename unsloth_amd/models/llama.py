@@ -177,8 +177,8 @@ def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
     if attention_mask is None and _USE_FLASH:
         q, k, v = Q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2)          # [B,T,H,D] views
         need_band = seq_info is not None or window is not None
-        # shapes the kernels take as they are; group sizes 3/5/6/7 at head_dim 128 (Qwen2.5-7B, Qwen2-VL-7B: 28 query
-        # heads on 4 KV heads) and smaller heads with a packed / windowed / padded batch run on the same kernels
+        # shapes the kernels take as they are (head_dim 128, 1 .. 8 query heads per KV head: Qwen2.5-7B / Qwen2-VL-7B's 28 on 4
+        # included); smaller heads with a packed / windowed / padded batch run on the same kernels
         # zero-padded (kernels/attention._pad_qkv) -- nothing builds a dense [T, T] mask. Plain causal batches of
         # small-head models (TinyLlama / Llama-3.2-1B: 64) too once the batch is large enough to amortise the padding
         # copies (profiles/r02u_attention_d64_vs_sdpa.jsonl: forward + backward 1.28 ms against SDPA's 1.36 ms at
