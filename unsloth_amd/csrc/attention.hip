@@ -609,6 +609,24 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
         dma16x4g(qbase, qo[0], qo[1], qo[2], qo[3], qdst_w);
         dma16x4g(qbase, qo[4], qo[5], qo[6], qo[7], qdst_w + 4096);
     };
+    // The common case -- tile ti + 2 of the CURRENT item, all 64 keys inside the sequence -- takes a short issue: the four
+    // per-lane source offsets are kernel constants (no row clamp), the tile's K / V addresses are running pointers advanced by a
+    // constant, the ring stage a counter. The general issue above costs ~26 VALU + ~40 SALU instructions per tile step (64-bit
+    // base products, a division by 3 through mul_hi, the clamp), this one ~12; the kernel is bound by its instruction count
+    // (DESIGN 5b), and at 237 VGPRs the four offsets no longer spill.
+    unsigned kof[2], vof[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 4 + (lane >> 4);
+        kof[i] = (unsigned)(row * (int)p.k_st * 2 + ((lane & 15) ^ (row & 15)) * 16);
+        vof[i] = (unsigned)(row * (int)p.v_st * 2 + ((lane & 15) ^ ((row & 3) << 2)) * 16);
+    }
+    const int64_t kstep = (int64_t)KT * p.k_st, vstep = (int64_t)KT * p.v_st;       // elements per tile
+    auto issue_fast = [&](const T* kq, const T* vq, int stage) {
+        const unsigned d = dst_w + stage * STAGE_B;
+        dma16x2(kq, kof[0], kof[1], d, d + 1024);
+        dma16x2(vq, vof[0], vof[1], d + TILE_B, d + TILE_B + 1024);
+    };
     const int kx = l31 & 15;
     const int k_lane = l31 * 256 + (((kx & 14) | (lh ^ (kx & 1))) << 4);
     const int sg = lane & 15, gh = (lane >> 4) & 1;
@@ -639,6 +657,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
     bar();
     if (wave >= 4) bar();                // the trailing group drops one phase behind
     int s_ = 0;                          // stream index of the current item's first tile (ring stage = stream index % 3)
+    int stg = 0;                         // ring stage of the CURRENT tile = (s_ + ti) % 3, counted instead of divided
     int kitem = 0;
     int pre = 2;                         // leading tiles of the current item that are already fetched (the prologue: both)
     frag_t kv[16];
@@ -663,6 +682,9 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
         const int t_diag = (qs + 1) / KT, t_rag = (T_ % KT) ? T_ / KT : nkv_blk;
         const int t_suf = max(t_pre_end, min(min(t_diag, t_rag), nkv_blk));
         const int nt = cur.nt;
+        // K / V rows of tile ti + 2 (running: + one tile per step)
+        const T* kq = (const T*)p.K + cur.b * p.k_sb + (int64_t)cur.kvr * p.k_sh + (int64_t)(cur.t_first + 2) * kstep;
+        const T* vq = (const T*)p.V + cur.b * p.v_sb + (int64_t)cur.kvr * p.v_sh + (int64_t)(cur.t_first + 2) * vstep;
         read_q();
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -686,8 +708,9 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             const int t = cur.t_first + ti;
             const int sx = s_ + ti;                                              // stream index
             const bool live = !(t > last_tile_wave || t < first_tile_wave);     // wave-uniform
-            const unsigned char* sk = smem + (sx % NST) * STAGE_B;
+            const unsigned char* sk = smem + stg * STAGE_B;
             const unsigned char* sv = sk + TILE_B;
+            const int stg2 = stg == 0 ? 2 : stg - 1;                            // (sx + 2) % 3
             // ---------------- P1 (load): K rows -> 64 registers
             if (live) {
 #pragma unroll
@@ -705,7 +728,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             //                  the NEXT item's tile ti + 2 - nt) and, once per item, the next item's Q rows
             if (live) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { st[0][r] = 0.f; st[1][r] = 0.f; }
+                for (int r = 0; r < 16; ++r) st[0][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) st[0] = MfmaA<T>::run(kv[ks], qf[ks], st[0]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -716,7 +739,10 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             if (ti == 0 && has_next) issue_q(nxt);                 // (this item's read_q is long done)
             if (ti == 0 && pre == 1 && nt > 1) issue_tile(cur, t + 1, (sx + 1) % NST);      // predecessor had a single tile
             if (ti + 2 < nt) {
-                issue_tile(cur, t + 2, (sx + 2) % NST);
+                if ((t + 3) * KT <= T_) issue_fast(kq, vq, stg2);
+                else issue_tile(cur, t + 2, stg2);                    // ragged last tile of the sequence: rows clamped
+                kq += kstep;
+                vq += vstep;
                 issued = true;
             } else if (has_next) {
                 // the next item's tile j = stream tile s_ + nt + j. A single-tile item has only this one slot: it fetches the
@@ -731,6 +757,10 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ks = 4; ks < 8; ++ks) st[0] = MfmaA<T>::run(kv[ks], qf[ks], st[0]);
+                // (zeroed HERE, in the block of its first MFMA: the C operand becomes the inline constant 0 -- set in the block
+                // above, across the DMA code, hipcc built the 16 zeros through 16 s_mov + 8 v_mov_b64 per tile step)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[1][r] = 0.f;
 #pragma unroll
                 for (int ks = 0; ks < 8; ++ks) st[1] = MfmaA<T>::run(kv[8 + ks], qf[ks], st[1]);
             }
@@ -816,6 +846,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
                 l_run += ls0 + ls1;
             }
             bar();
+            stg = stg == NST - 1 ? 0 : stg + 1;
         }
         // ---- epilogue of the item: O = O^T / l, LSE
         {
@@ -951,6 +982,23 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         dma16x2(vbase + (int64_t)k0 * p.v_st, vo[0], vo[1], d + TILE_B, d + TILE_B + 1024);
     };
 
+    // Plain-causal build (which has the registers): whole tiles take a short issue -- constant per-lane offsets, running K / V
+    // pointers, a counted ring stage (see attn_fwd_ps_kernel: ~85 -> ~30 instructions per tile step)
+    unsigned kof[2] = {0, 0}, vof[2] = {0, 0};
+    if constexpr (!BAND) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 4 + (lane >> 4);
+            const int sw = ((lane & 15) ^ swz_c(row)) * 16;
+            kof[i] = (unsigned)(row * (int)p.k_st * 2 + sw);
+            vof[i] = (unsigned)(row * (int)p.v_st * 2 + sw);
+        }
+    }
+    const int64_t kstep = (int64_t)KT * p.k_st, vstep = (int64_t)KT * p.v_st;
+    const T* kq = kbase + (int64_t)(t_first + 2) * kstep;          // K / V rows of tile ti + 2 (running)
+    const T* vq = vbase + (int64_t)(t_first + 2) * vstep;
+    int stg = 0;                                                    // ring stage of the current tile = ti % 3, counted
+
     // row reads (K for S^T, V for dP^T): lane -> row l31 (+32 kt), 16 B at logical slot 2 ks + lh
     const int r_lane = l31 * 256 + ((swz_c(l31 & 15) ^ lh) << 4);
     // transposing reads of K (A operand of dQ^T), swizzle C: second 4-row block = (addr ^ 32) + 8 rows
@@ -979,9 +1027,21 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ti + 2 < nt) issue(t + 2, (ti + 2) % NST);
+        const int stg_cur = stg, stg2 = stg == 0 ? 2 : stg - 1;        // ti % 3, (ti + 2) % 3
+        stg = stg == NST - 1 ? 0 : stg + 1;
+        if (ti + 2 < nt) {
+            if (!BAND && (t + 3) * KT <= T_) {
+                const unsigned d = dst_w + stg2 * STAGE_B;
+                dma16x2(kq, kof[0], kof[1], d, d + 1024);
+                dma16x2(vq, vof[0], vof[1], d + TILE_B, d + TILE_B + 1024);
+            } else {
+                issue(t + 2, stg2);
+            }
+            kq += kstep;
+            vq += vstep;
+        }
         if (t > last_tile_wave || t < first_tile_wave) return;
-        const unsigned char* sk = smem + (ti % NST) * STAGE_B;
+        const unsigned char* sk = smem + stg_cur * STAGE_B;
         const unsigned char* sv = sk + TILE_B;
         const int k0 = t * KT;
 #pragma unroll
