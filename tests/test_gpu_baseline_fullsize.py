@@ -349,7 +349,7 @@ def test_config4_qwen2_vl_7b_tower_nf4_lora_r32_seq4096_mrope():
     finally:
         flash._forward_native = real_native
         L._fast_layer.decoder_layer_forward = real_layer
-    assert calls["attn"] and all(g_ == 8 for g_ in calls["attn"])        # 7 query heads per KV head: padded onto the G = 8 kernels
+    assert calls["attn"] and all(g_ == 7 for g_ in calls["attn"])        # 7 query heads per KV head: native since round 6 (no padded copies)
     assert calls["layer_fn"] == 2, "multimodal positions must go through the whole-layer Function under 'unsloth'"
 
 
