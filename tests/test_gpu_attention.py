@@ -211,14 +211,15 @@ PADDED_CASES = [  # B, T, Hq, Hk, D, packed lengths, window
     (1, 300, 4, 4, 64, [64, 36, 200], None),
     (1, 128, 14, 2, 64, None, None),                  # Qwen2.5-0.5B: G = 7 AND head_dim 64
     (1, 96, 4, 2, 96, None, None),
+    (1, 80, 4, 2, 36, None, None),                    # not a multiple of 8: the one shape class that still runs zero-padded
 ]
 
 
 @pytest.mark.parametrize("B,T,Hq,Hk,D,lengths,window", PADDED_CASES)
 def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
-    """Head dims below 128 run on the native kernels zero-padded (kernels/attention.py _pad_qkv), group sizes 3 / 5 / 6 / 7 are
-    native (round 6; zero-padded to 4 / 8 before): outputs, LSE and all three gradients against the fp32 oracle on the UNPADDED
-    problem, and the gradient buffers keep the dQ | dK | dV column-block layout."""
+    """Head dims below 128 and group sizes 3 / 5 / 6 / 7 are native since round 6 (zero-padded through copies before; a head dim
+    that is not a multiple of 8 still is, kernels/attention.py _pad_qkv): outputs, LSE and all three gradients against the fp32
+    oracle on the UNPADDED problem, and the gradient buffers keep the dQ | dK | dV column-block layout."""
     from unsloth_amd.kernels.attention import attention_band, attn_backward, attn_forward, native, supported
     dtype = torch.bfloat16
     qkv = torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(31)).to(dtype)
@@ -239,7 +240,7 @@ def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
     q = qd[..., :Hq * D].view(B, T, Hq, D)
     k = qd[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
     v = qd[..., (Hq + Hk) * D:].view(B, T, Hk, D)
-    assert supported(q, k, v) and native(q, k, v) == (D == 128)
+    assert supported(q, k, v) and native(q, k, v) == (D % 8 == 0)
     o, lse = attn_forward(q, k, v, None, band)                      # default scale = 1 / sqrt(D) of the REAL head dim
     assert o.shape == (B, T, Hq, D) and lse.shape == (B, Hq, T)
     torch.testing.assert_close(lse.cpu(), lse_ref.detach(), rtol=1e-4, atol=2e-3)
@@ -251,6 +252,60 @@ def test_zero_padded_shapes_forward_backward(B, T, Hq, Hk, D, lengths, window):
         e = (got.float().cpu() - want).abs().max().item()
         ref = want.abs().max().item()
         assert e <= 3e-2 * max(ref, 1.0), (name, e, ref)
+
+
+SMALL_HEAD_CASES = [  # B, T, Hq, Hk, D, packed lengths, window, causal, dtype
+    (1, 700, 32, 4, 64, None, None, True, torch.bfloat16),             # TinyLlama-1.1B (BASELINE config 1) head layout
+    (2, 333, 8, 2, 64, None, None, True, torch.float16),
+    (1, 1000, 16, 16, 80, [300, 700], None, False, torch.bfloat16),    # Qwen2-VL's vision tower: non-causal windows, head_dim 80
+    (1, 640, 4, 2, 96, [100, 250, 290], None, True, torch.bfloat16),   # packed documents
+    (1, 512, 14, 2, 64, None, 100, True, torch.bfloat16),              # Qwen2.5-0.5B: G = 7 AND head_dim 64, sliding window
+    (1, 200, 2, 1, 16, None, None, True, torch.bfloat16), (1, 300, 4, 4, 112, None, None, True, torch.bfloat16),
+]
+
+
+@pytest.mark.parametrize("B,T,Hq,Hk,D,lengths,window,causal,dtype", SMALL_HEAD_CASES)
+def test_head_dims_below_128_native_equal_the_zero_padded_run(B, T, Hq, Hk, D, lengths, window, causal, dtype):
+    """Round 6: head dims below 128 (multiples of 8) without copies -- the kernels keep their 256-byte-row tiling but read nothing
+    past a head's D elements as data: LDS-DMA lanes past D re-read slot 0 of their row, one side of every product holds zero
+    registers (or zeroed LDS) there, rows past D of O^T / dQ^T / dK^T / dV^T are not stored. Against the SAME kernels on the
+    zero-padded copies (rounds 2-5's path): the real columns go through the same arithmetic in the same order, so O, LSE, dQ,
+    dK and dV are BIT-IDENTICAL. Inputs sit in one fused buffer so that a read past a head lands in its NEIGHBOUR's data (not
+    zeros), and the buffers are poisoned behind their last element."""
+    from unsloth_amd.kernels import attention as A
+    G = Hq // Hk
+    W = (Hq + 2 * Hk) * D
+    pool = torch.full((B * T * W + 4096,), float("nan"), dtype=dtype, device=DEV)          # NaN behind the last row
+    qkv = pool[:B * T * W].view(B, T, W)
+    qkv.copy_((torch.randn(B, T, W, generator=g(51)) * 0.7).to(dtype))
+    dpool = torch.full((B * T * Hq * D + 4096,), float("nan"), dtype=dtype, device=DEV)
+    do = dpool[:B * T * Hq * D].view(B, T, Hq, D)
+    do.copy_(torch.randn(B, T, Hq, D, generator=g(52)).to(dtype))
+    q = qkv[..., :Hq * D].view(B, T, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    band = None
+    if not causal:
+        band = A.document_band(T, batch=B, seq_lengths=(lengths + [T - sum(lengths)]) * B if lengths else None, device=DEV)
+    elif lengths or window:
+        band = A.attention_band(T, batch=B, seq_lengths=(lengths + [T - sum(lengths)]) * B if lengths else None,
+                                sliding_window=window, device=DEV)
+    assert A.native(q, k, v)
+    scale = 1.0 / math.sqrt(D)
+    extra = () if causal else (False,)
+    o, lse = A._forward_native(q, k, v, scale, band, *extra)
+    assert o.shape == (B, T, Hq, D) and torch.isfinite(o.float()).all()
+    dq, dk, dv = A._backward_native(do, q, k, v, o, lse, scale, band, *extra)
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+    qp, kp, vp = (A._pad_heads(t, 1, 1, D) for t in (q, k, v))
+    op_, lsep = A._forward_native(qp, kp, vp, scale, band, *extra)
+    assert torch.equal(o, op_[..., :D]) and torch.equal(lse, lsep)
+    Tp = (T + 31) // 32 * 32
+    lse_store = torch.as_strided(lsep, (B, Hq, Tp), (Hq * Tp, Tp, 1))
+    dqp, dkp, dvp = A._backward_native(A._pad_heads(do, 1, 1, D), qp, kp, vp, op_, lse_store[:, :, :T], scale, band, *extra)
+    assert torch.equal(dq, dqp[..., :D]) and torch.equal(dk, dkp[..., :D]) and torch.equal(dv, dvp[..., :D])
+    # (the oracle: test_zero_padded_shapes_forward_backward and the non-causal document tests run the same shapes against fp32)
 
 
 ODD_GROUP_CASES = [  # B, T, Hq, Hk, packed lengths, window, causal, dtype

@@ -1,7 +1,7 @@
 """-m gpu: the BASELINE.json configurations as parity cases AT THEIR REAL WIDTHS (few layers, synthetic weights): the
 whole drop-in surface (from_pretrained -> get_peft_model -> forward / backward) on the HIP path against the
 implementation-independent oracle (stock HF model on the CPU in fp32 over oracle-dequantised weights + merged LoRA).
-  config 1  TinyLlama-1.1B widths, LoRA r=8 on a 16-bit base, seq 512, batch 1 (head_dim 64: library flash through SDPA)
+  config 1  TinyLlama-1.1B widths, LoRA r=8 on a 16-bit base, seq 512, batch 1 (head_dim 64: native to csrc/attention.hip since round 6)
   config 2  Llama-3-8B widths, QLoRA NF4 r=16 (the benchmark's model, one layer, 512 tokens)
   config 5  Mistral-7B widths, LoRA r=16, sliding window (band kernels) -- the fused linear-CE path of the DPO/GRPO runs
   config 4  (Qwen2-VL-7B text tower, mrope, 28:4 heads) lives in tests/test_gpu_mrope.py at its real widths

@@ -73,6 +73,10 @@ struct AttnArgs {
     int kvm;                             // Hk counts VIRTUAL KV heads: virtual head v reads K / V head v / kvm and serves query heads
                                          // v G .. v G + G - 1 (group sizes 3, 5, 6, 7 = kvm x the largest of 1, 2, 4, 8 dividing them)
     int nqt;                             // number of q tiles
+    int D;                               // head dim, a multiple of 8, <= 128. Below 128 (attn_fwd_kernel only) the kernel still works
+                                         // on 256-byte rows: LDS-DMA lanes whose 16-byte slot lies past D re-read slot 0 of their row
+                                         // (in bounds, finite), the Q fragments past D are zero registers -- so Q K^T sees only the real
+                                         // columns -- and the rows of O^T past D are never stored. No padded copies of Q / K / V.
     int lse_st;                          // row stride of LSE [B, Hq, lse_st] (T rounded up to 32)
     float scale_log2;                    // softmax scale * log2(e)
 };
@@ -196,7 +200,7 @@ __device__ unsigned* g_attn_trace = nullptr;
 // v_permlane32_swap per dword of a group pair (g, g + 1) hands the lower half 16 contiguous bytes of group g and the upper
 // half 16 of group g + 1: 8 x dwordx4 per lane, same bytes, same addresses.
 template <typename T>
-__device__ __forceinline__ void store_rows_x4(T* row, const f32x16_t (&acc)[4], float mul, int lh, bool live) {
+__device__ __forceinline__ void store_rows_x4(T* row, const f32x16_t (&acc)[4], float mul, int lh, bool live, int D = 128) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -213,7 +217,7 @@ __device__ __forceinline__ void store_rows_x4(T* row, const f32x16_t (&acc)[4], 
 #else
             const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-            if (live) *reinterpret_cast<uint4*>(row + dt * 32 + qd * 8 + lh * 8) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            if (live && dt * 32 + qd * 8 + lh * 8 < D) *reinterpret_cast<uint4*>(row + dt * 32 + qd * 8 + lh * 8) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
 #endif
         }
 }
@@ -229,6 +233,9 @@ __device__ __forceinline__ void wait_lgkm0() {
     __builtin_amdgcn_s_waitcnt(0xc07f);
     asm volatile("" ::: "memory");
 }
+
+// 16-byte slot `s` (8 elements) of a 256-byte row when the head has only D elements: slots past D re-read slot 0
+__device__ __forceinline__ int slot_in(int s, int D) { return s * 8 < D ? s : 0; }
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }     // one v_max3_f32
 
@@ -271,7 +278,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             union { uint4 r; frag_t f; } u;
-            u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
+            u.r = make_uint4(0, 0, 0, 0);
+            if (ks * 16 + lh * 8 < p.D) u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
             qf[ks] = u.f;
         }
     }
@@ -286,8 +294,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 4 + (lane >> 4);
         drow[i] = row;
-        dks[i] = ((lane & 15) ^ (row & 15)) * 16;
-        dvs[i] = ((lane & 15) ^ ((row & 3) << 2)) * 16;
+        dks[i] = slot_in((lane & 15) ^ (row & 15), p.D) * 16;
+        dvs[i] = slot_in((lane & 15) ^ ((row & 3) << 2), p.D) * 16;
         koff[i] = (unsigned)((int64_t)row * p.k_st * 2 + dks[i]);
         voff[i] = (unsigned)((int64_t)row * p.v_st * 2 + dvs[i]);
     }
@@ -493,7 +501,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const float inv = 1.0f / l_tot;
     {
         T* op = (T*)p.O + b * p.o_sb + (int64_t)q_ld * p.o_st + (int64_t)head * p.o_sh;
-        store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_);
+        store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_, p.D);
         if (lh == 0 && q_pos < T_) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
@@ -882,6 +890,9 @@ struct AttnBwdArgs {
     int64_t q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh;
     int64_t dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh;
     int B, T, Hq, Hk, G, nsub, lse_st, nqt;
+    int D;                               // head dim (multiple of 8, <= 128; AttnArgs::D): operands past D are zero REGISTERS on one side
+                                         // of every product (Q, dO in the dQ kernel; K in the dK / dV kernel, whose V tile is zeroed
+                                         // past D in LDS), rows past D of dQ^T / dK^T / dV^T are never stored
     int kvm;                             // attn_bwd_dq_kernel: Hk counts virtual KV heads (AttnArgs::kvm); the dK / dV kernel takes the
                                          // real heads with G = Hq / Hk of any size 1 .. 8 (passes of 4, 2 and 1 query heads)
     float scale, scale_log2;
@@ -920,9 +931,12 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             union { uint4 r; frag_t f; T e[8]; } u, d, o;
-            u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
-            d.r = *reinterpret_cast<const uint4*>(dp_ + ks * 16);
-            o.r = *reinterpret_cast<const uint4*>(op + ks * 16);
+            u.r = d.r = o.r = make_uint4(0, 0, 0, 0);
+            if (ks * 16 + lh * 8 < p.D) {                                 // (head dims below 128: zero registers past D)
+                u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
+                d.r = *reinterpret_cast<const uint4*>(dp_ + ks * 16);
+                o.r = *reinterpret_cast<const uint4*>(op + ks * 16);
+            }
             qf[ks] = u.f;
             dof[ks] = d.f;
 #pragma unroll
@@ -974,7 +988,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 4 + (ln >> 4);
             const int r = min(row, rmax);
-            const int sw = ((ln & 15) ^ swz_c(row)) * 16;
+            const int sw = slot_in((ln & 15) ^ swz_c(row), p.D) * 16;
             ko[i] = (unsigned)(r * (int)p.k_st * 2 + sw);
             vo[i] = (unsigned)(r * (int)p.v_st * 2 + sw);
         }
@@ -989,7 +1003,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = (wave * 2 + i) * 4 + (lane >> 4);
-            const int sw = ((lane & 15) ^ swz_c(row)) * 16;
+            const int sw = slot_in((lane & 15) ^ swz_c(row), p.D) * 16;
             kof[i] = (unsigned)(row * (int)p.k_st * 2 + sw);
             vof[i] = (unsigned)(row * (int)p.v_st * 2 + sw);
         }
@@ -1107,7 +1121,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         int qr = q_ld;                       // (the row address formed HERE: hoisted, the pointer pair is spilled around the loop)
         asm volatile("" : "+v"(qr));
         T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)qr * p.dq_st + (int64_t)head * p.dq_sh;
-        store_rows_x4<T>(op, dq_acc, CFOLD ? p.scale : 1.0f, lh, q_pos < T_);
+        store_rows_x4<T>(op, dq_acc, CFOLD ? p.scale : 1.0f, lh, q_pos < T_, p.D);
     }
 }
 
@@ -1248,7 +1262,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int i = 0; i < 4; ++i) {
             const int row = (unit * 4 + i) * 4 + (lane >> 4);
             const int r = min(row, T_ - 1 - k0);
-            dma16x1(vbase + (int64_t)r * p.v_st + ((lane & 15) ^ swz_c(row)) * 8, lds_base + (unit * 4 + i) * 1024);
+            dma16x1(vbase + (int64_t)r * p.v_st + slot_in((lane & 15) ^ swz_c(row), p.D) * 8, lds_base + (unit * 4 + i) * 1024);
         }
     }
     // ---- K^T operand (B of S = Q K^T: lane -> key, 8 d at 16 ks + 8 lh), both key halves, resident
@@ -1260,19 +1274,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             union { uint4 r; frag_t f; } u;
-            u.r = *reinterpret_cast<const uint4*>(kp + ks * 16);
+            u.r = make_uint4(0, 0, 0, 0);
+            if (ks * 16 + lh * 8 < p.D) u.r = *reinterpret_cast<const uint4*>(kp + ks * 16);     // (head dims below 128: zero past D)
             kf[kh][ks] = u.f;
         }
     }
 
     // DMA source offsets of the wave's Q and dO tiles: piece i (rows 4 i + (lane >> 4)) = base(+16 rows for i >= 4)
     // + row * stride * 2 + (dsw0 ^ ((i & 3) << 4))   (swz_c(row) = ((lane >> 4) << 2) | (i & 3) for these rows)
-    const int dsw0 = ((lane & 15) ^ ((lane >> 4) << 2)) << 4;
+    // (head dims below 128: a lane whose slot lies past D re-reads slot 0 of its row -- the Q / dO columns past D meet zero K / V)
+    const int dsl0 = (lane & 15) ^ ((lane >> 4) << 2);
+    unsigned dsw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dsw[i] = (unsigned)(slot_in(dsl0 ^ i, p.D) << 4);
     unsigned qo[4], doo[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        qo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.q_st * 2) + (unsigned)(dsw0 ^ (i << 4));
-        doo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.do_st * 2) + (unsigned)(dsw0 ^ (i << 4));
+        qo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.q_st * 2) + dsw[i];
+        doo[i] = (unsigned)((int64_t)(i * 4 + (lane >> 4)) * p.do_st * 2) + dsw[i];
     }
     const int nq32 = (T_ + 31) / 32;
     const int q32_first = qlo_blk / 32;
@@ -1363,7 +1382,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int r = min(((h & 1) * 4 + i) * 4 + (lane >> 4), T_ - 1 - q0);
-                        o[i] = (unsigned)((int64_t)r * st_ * 2) + (unsigned)(dsw0 ^ (i << 4));
+                        o[i] = (unsigned)((int64_t)r * st_ * 2) + dsw[i];
                     }
                     dma16x4g(base + (int64_t)q0 * st_, o[0], o[1], o[2], o[3], d + h * 4096);
                 }
@@ -1606,6 +1625,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             // accumulators: a[0:127] = dV^T tuples (kh * 4 + dt), a[128:255] = dK^T tuples (8 + kh * 4 + dt); asm-owned
             acc256_zero();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (p.D < AD) {
+                // head dims below 128: the V slots past D (this wave's own pieces have landed) become zeros -- dP = dO V^T must not
+                // see what the Q / dO ring holds there
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (unit * 4 + i) * 4 + (lane >> 4);
+                    if (((lane & 15) ^ swz_c(row)) * 8 >= p.D)
+                        *(lds_u32x4a*)(uintptr_t)(lds_base + (unit * 4 + i) * 1024 + lane * 16) = u32x4a_t{0u, 0u, 0u, 0u};
+                }
+                wait_lgkm0();
+            }
             __builtin_amdgcn_s_barrier();                  // the V tile is in LDS for every wave
             asm volatile("" ::: "memory");
         }
@@ -1663,7 +1693,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     uint2 o;
                     o.x = pack_pair2<T>(v[4 * qd + 0], v[4 * qd + 1]);
                     o.y = pack_pair2<T>(v[4 * qd + 2], v[4 * qd + 3]);
-                    *reinterpret_cast<uint2*>(op + d) = o;
+                    if (d < p.D) *reinterpret_cast<uint2*>(op + d) = o;
                 }
             }
         }
@@ -1697,7 +1727,7 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;                     // empty batch: nothing to read (pointers may be null)
     if (!Q || !K || !V || !O || !dO || !LSE || !dQ || !dK || !dV || !Delta || !strides) return UAMD_ERR_ARG;
-    if (D != AD || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
+    if (D < 8 || D > AD || (D & 7) || Hq % Hk || lse_stride < T || (lse_stride & 31)) return UAMD_ERR_ARG;
     if (!causal && !(lo && hi)) return UAMD_ERR_ARG;          // non-causal: the (lo, hi) band of the documents is required
     const int G = Hq / Hk;
     if (G > 8) return UAMD_ERR_ARG;
@@ -1722,7 +1752,7 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     a.dq_sb = strides[15]; a.dq_st = strides[16]; a.dq_sh = strides[17];
     a.dk_sb = strides[18]; a.dk_st = strides[19]; a.dk_sh = strides[20];
     a.dv_sb = strides[21]; a.dv_st = strides[22]; a.dv_sh = strides[23];
-    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk * kvm; a.G = Gq; a.nsub = 8 / Gq; a.kvm = kvm; a.lse_st = lse_stride;
+    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk * kvm; a.G = Gq; a.nsub = 8 / Gq; a.kvm = kvm; a.lse_st = lse_stride; a.D = D;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;
     a.noncausal = causal ? 0 : 1;
     a.no_asm = (uamd_tuning_get(UAMD_TUNE_ATTN_VAR) & 4) ? 1 : 0;
@@ -1768,7 +1798,7 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
     if (B < 0 || T < 0 || Hq <= 0 || Hk <= 0) return UAMD_ERR_ARG;
     if (B == 0 || T == 0) return UAMD_OK;                     // empty batch: nothing to read (pointers may be null)
     if (!Q || !K || !V || !O || !LSE || !strides) return UAMD_ERR_ARG;
-    if (D != AD || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
+    if (D < 8 || D > AD || (D & 7) || Hq % Hk || lse_stride < T) return UAMD_ERR_ARG;
     if (!causal && !(lo && hi)) return UAMD_ERR_ARG;          // non-causal: the (lo, hi) band of the documents is required
     if (causal) hi = nullptr;
     const int Gr = Hq / Hk;
@@ -1787,7 +1817,7 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
     a.k_sb = strides[3]; a.k_st = strides[4]; a.k_sh = strides[5];
     a.v_sb = strides[6]; a.v_st = strides[7]; a.v_sh = strides[8];
     a.o_sb = strides[9]; a.o_st = strides[10]; a.o_sh = strides[11];
-    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk * kvm; a.G = G; a.nsub = 8 / G; a.kvm = kvm; a.lse_st = lse_stride;
+    a.B = B; a.T = T; a.Hq = Hq; a.Hk = Hk * kvm; a.G = G; a.nsub = 8 / G; a.kvm = kvm; a.lse_st = lse_stride; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
     const int QT = 32 * a.nsub;
     a.nqt = (T + QT - 1) / QT;
@@ -1806,7 +1836,7 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
     // items differ in length in ways the static deal does not see -- and small grids take one block per item.
     // UAMD_TUNE_ATTN_VAR bit 0 = never persistent, bit 1 = always (A/B). 32-bit Q row offsets: T * q_st < 2^31.
     const int var = uamd_tuning_get(UAMD_TUNE_ATTN_VAR);
-    const bool persistent = !(var & 1) && (int64_t)T * strides[1] < (1ll << 31) &&
+    const bool persistent = !(var & 1) && D == AD && (int64_t)T * strides[1] < (1ll << 31) &&
                             ((var & 2) || (!lo && (int)grid.x >= 2 * ncu[dev]));
     auto run = [&](auto tag) -> int {
         typedef decltype(tag) T;

@@ -23,14 +23,16 @@ _GROUPS = (1, 2, 3, 4, 5, 6, 7, 8)   # query heads per KV head the kernels take 
 
 
 def native(q, k, v):
-    """Shapes the kernels take as they are: head_dim 128, G = Hq / Hk in 1 .. 8."""
-    return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 128
+    """Shapes the kernels take as they are: G = Hq / Hk in 1 .. 8 and a head_dim that is a multiple of 8 up to 128. Below 128
+    (TinyLlama / Llama-3.2-1B: 64, Qwen2-VL's vision tower: 80) the kernels still work on 256-byte rows but read nothing past a
+    head's D elements as data (csrc/attention.hip AttnArgs::D): no padded copies of q, k, v, o, do."""
+    return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and 8 <= q.shape[-1] <= 128 and q.shape[-1] % 8 == 0
             and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) in _GROUPS)
 
 
 def supported(q, k, v):
-    """Native shapes, plus the ones that run on the same kernels after zero-padding (`_pad_qkv`): head dims below 128
-    (TinyLlama / Llama-3.2-1B: 64, Qwen2-VL's vision tower: 80)."""
+    """Native shapes, plus the ones that run on the same kernels after zero-padding (`_pad_qkv`): head dims below 128 that are
+    not a multiple of 8."""
     return (q.is_cuda and q.dtype in (torch.bfloat16, torch.float16) and 0 < q.shape[-1] <= 128
             and k.shape[2] > 0 and q.shape[2] % k.shape[2] == 0 and (q.shape[2] // k.shape[2]) <= 8)
 
@@ -202,7 +204,7 @@ def attn_forward(q, k, v, scale=None, band=None, causal=True, keep_padded=None):
 
 
 def _forward_native(q, k, v, scale, band, causal=True):
-    """The launch itself: head_dim 128, G in 1 .. 8."""
+    """The launch itself: head_dim a multiple of 8 up to 128, G in 1 .. 8."""
     B, T, Hq, D = q.shape
     Hk = k.shape[2]
     o = torch.empty((B, T, Hq, D), dtype=q.dtype, device=q.device)

@@ -173,7 +173,7 @@ def policy_for_layer(policy, index):
 
 def layer_supported(layer, hidden, attention_mask):
     """The whole-layer Function covers what the fused hooks cover: LoRA (or plain frozen) projections without bias /
-    dropout / DoRA, SwiGLU MLP, head_dim 128 flash attention, no key-padding mask, 16-bit activations."""
+    dropout / DoRA, SwiGLU MLP, flash attention at a head_dim that is a multiple of 8 up to 128, no key-padding mask, 16-bit activations."""
     from ..kernels.fast_lora import apply_lora_mlp_swiglu, apply_lora_o, apply_lora_qkv
     attn, mlp = layer.self_attn, layer.mlp
     if attention_mask is not None or hidden.dtype not in (torch.bfloat16, torch.float16):
@@ -189,7 +189,9 @@ def layer_supported(layer, hidden, attention_mask):
     cfg = getattr(attn, "config", None)
     groups = (cfg.num_attention_heads // cfg.num_key_value_heads) if cfg is not None else 1
     # (every group size 1 .. 8 is native to csrc/attention.hip)
-    return attn.head_dim == 128 and groups <= 8 and getattr(layer.input_layernorm, "weight", None) is not None
+    # (head dims below 128 -- TinyLlama / Llama-3.2-1B: 64 -- are native to the attention kernels since round 6)
+    return (attn.head_dim <= 128 and attn.head_dim % 8 == 0 and groups <= 8
+            and getattr(layer.input_layernorm, "weight", None) is not None)
 
 
 def _eps(norm):

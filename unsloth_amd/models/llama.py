@@ -170,21 +170,19 @@ def _attention(Q, K, V, seq_info, attention_mask, sliding_window=None):
     here as documents too, see LlamaModel_fast_forward) or sliding-window -- take the hand-written CDNA4 kernels
     (kernels/attention.py), which read the [B,T,H,D] memory directly and write the o_proj input layout: no
     transposes, no copies, no dense mask. What is left for torch SDPA (run_attention's SDPA branch,
-    attention_dispatch.py:560-617): plain causal batches below 4096 tokens of models with heads below 128 (the
-    library's flash kernel), key-padding masks with holes, more than 8 query heads per KV head."""
+    attention_dispatch.py:560-617): key-padding masks with holes, more than 8 query heads per KV head, head dims above 128
+    or not a multiple of 8."""
     B, Hq, T, D = Q.shape
     window = sliding_window if (sliding_window is not None and 0 < sliding_window < T) else None   # mistral.py:116-120
     if attention_mask is None and _USE_FLASH:
         q, k, v = Q.transpose(1, 2), K.transpose(1, 2), V.transpose(1, 2)          # [B,T,H,D] views
         need_band = seq_info is not None or window is not None
-        # shapes the kernels take as they are (head_dim 128, 1 .. 8 query heads per KV head: Qwen2.5-7B / Qwen2-VL-7B's 28 on 4
-        # included); smaller heads with a packed / windowed / padded batch run on the same kernels
-        # zero-padded (kernels/attention._pad_qkv) -- nothing builds a dense [T, T] mask. Plain causal batches of
-        # small-head models (TinyLlama / Llama-3.2-1B: 64) too once the batch is large enough to amortise the padding
-        # copies (profiles/r02u_attention_d64_vs_sdpa.jsonl: forward + backward 1.28 ms against SDPA's 1.36 ms at
-        # 4 x 2048 tokens despite 2x the flops, 0.75 vs 0.69 ms at 1 x 2048, 0.56 vs 0.26 ms at 4 x 512); below that
-        # the library's flash kernel through SDPA.
-        if _flash.native(q, k, v) or (_flash.supported(q, k, v) and (need_band or D == 128 or B * T >= 4096)):
+        # shapes the kernels take as they are: head_dim a multiple of 8 up to 128 (TinyLlama / Llama-3.2-1B: 64 -- no padded copies
+        # since round 6: forward + backward 0.78 ms against SDPA's 1.35 ms at 4 x 2048 tokens, 0.35 vs 0.68 at 1 x 2048, 0.26 vs
+        # 0.25 at 4 x 512, profiles/r06zf_attention_d64_vs_sdpa.jsonl), 1 .. 8 query heads per KV head (Qwen2.5-7B / Qwen2-VL-7B's
+        # 28 on 4 included). Head dims that are not a multiple of 8 run on the same kernels zero-padded when the batch is packed /
+        # windowed / padded or large enough to amortise the copies -- nothing builds a dense [T, T] mask.
+        if _flash.native(q, k, v) or (_flash.supported(q, k, v) and (need_band or B * T >= 4096)):
             band = _attention_band(seq_info, B, T, window, Q.device) if need_band else None
             return _flash.flash_attention(q, k, v, None, band).reshape(B, T, Hq * D)
     # ---- the library kernel (ONE call site): plain causal without a mask tensor, everything else with a dense additive mask
