@@ -360,7 +360,8 @@ int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int M, float* w
                  int64_t workspace_floats, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Causal GQA flash attention, head_dim 128 (csrc/attention.hip). The step between RoPE and o_proj that the
+ * Causal GQA flash attention, head_dim D = a multiple of 8 up to 128 (csrc/attention.hip; below 128 the kernels keep their
+ * 256-byte-row tiling and read nothing past a head's D elements as data). The step between RoPE and o_proj that the
  * reference delegates to flash-attn / xformers / SDPA (unsloth/utils/attention_dispatch.py:298-617, called from
  * unsloth/models/llama.py:757). Q [B,T,Hq,D], K/V [B,T,Hk,D], O [B,T,Hq,D] given by element strides
  * `strides` = {q_b,q_t,q_h, k_b,k_t,k_h, v_b,v_t,v_h, o_b,o_t,o_h} (d contiguous, multiples of 8);

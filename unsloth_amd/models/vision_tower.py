@@ -8,7 +8,7 @@ their forwards are replaced per instance (the way the language tower's attention
   * attention: q | k | v stay where the qkv GEMM wrote them ([S, 3, H, D] -> three strided [1, S, H, D] views), the rotary
     embedding (fp32 tables of the 2-D patch positions, row = patch) rotates q and k IN PLACE through csrc/rope_embedding.hip,
     and csrc/attention.hip runs the bidirectional attention inside the `cu_seqlens` windows (kernels/attention.document_band;
-    head_dim 80 and 16 : 16 heads go through the zero-padding of kernels/attention._pad_qkv) -- in round 3 this was torch SDPA:
+    head_dim 80 is native to the kernels since round 6: no padded copies of q, k, v, o, dO) -- in round 3 this was torch SDPA:
     aotriton's flash kernels at 14 % (forward) and 6 % (backward) of the MFMA peak, 20 % of the config-4 step
     (profiles/r04m_config4_kernel_stats.csv: bwd_kernel_dk_dv 1.07 ms, bwd_kernel_dq 0.38 ms, attn_fwd 0.24 ms per block);
   * patch embedding: the Conv3d with kernel == stride as ONE GEMM over the flattened patches (no MIOpen convolution);
