@@ -74,6 +74,19 @@ def patch_embed_fast_forward(self, hidden_states):
     return Dense_W.apply(x, W.view(W.shape[0], -1), None).view(-1, self.embed_dim)
 
 
+def merger_fast_forward(self, x):
+    """PatchMerger.forward (LayerNorm -> Linear -> GELU -> Linear over 2 x 2 merged patches): the two frozen linears on the MFMA
+    GEMM (kernels/fast_dense.Dense_W: Y = X W^T + b forward, dX = dY W backward) instead of F.linear -- these were the last
+    hipBLASLt launches of the config-4 step (profiles/r06zh_config4_kernel_stats.csv: three per step)."""
+    l0, l1 = self.mlp[0], self.mlp[2]
+    if (not x.is_cuda) or x.dtype not in (torch.bfloat16, torch.float16) or l0.weight.dtype != x.dtype or l1.weight.dtype != x.dtype:
+        return self._uamd_hf_forward(x)
+    from ..kernels.fast_dense import Dense_W
+    h = self.ln_q(x).view(-1, self.hidden_size)
+    h = self.mlp[1](Dense_W.apply(h, l0.weight, l0.bias))
+    return Dense_W.apply(h, l1.weight, l1.bias)
+
+
 def patch_vision_tower(visual):
     """Install the fast forwards on every block of a Qwen2VisionTransformerPretrainedModel. Returns the number of blocks patched."""
     n = 0
@@ -82,6 +95,14 @@ def patch_vision_tower(visual):
             and tuple(pe.proj.kernel_size) == tuple(pe.proj.stride) and tuple(pe.proj.padding) == (0, 0, 0):
         pe._uamd_hf_forward = pe.forward
         pe.forward = MethodType(patch_embed_fast_forward, pe)
+    mg = getattr(visual, "merger", None)
+    seq = getattr(mg, "mlp", None)
+    if (mg is not None and isinstance(seq, torch.nn.Sequential) and len(seq) == 3 and type(seq[0]) is torch.nn.Linear
+            and type(seq[2]) is torch.nn.Linear and hasattr(mg, "ln_q") and hasattr(mg, "hidden_size")
+            and seq[0].in_features % 8 == 0 and seq[0].out_features % 8 == 0 and seq[2].out_features % 8 == 0
+            and not hasattr(mg, "_uamd_hf_forward")):
+        mg._uamd_hf_forward = mg.forward
+        mg.forward = MethodType(merger_fast_forward, mg)
     for blk in getattr(visual, "blocks", []):
         attn, mlp = getattr(blk, "attn", None), getattr(blk, "mlp", None)
         if attn is not None and hasattr(attn, "qkv") and hasattr(attn, "proj") and not hasattr(attn, "_uamd_hf_forward"):
