@@ -239,7 +239,7 @@ __device__ __forceinline__ int slot_in(int s, int D) { return s * 8 < D ? s : 0;
 
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }     // one v_max3_f32
 
-template <typename T, bool BAND>
+template <typename T, bool BAND, int DC>
 __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename MfmaA<T>::frag frag_t;
@@ -353,8 +353,11 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const int last_tile_wave = lim_w1 / KT;                          // tiles beyond are fully masked for this wave
     const int first_tile_wave = lo_w0 / KT;                          // ... and tiles before
     // One tile step; MASKED is compile-time and the tile range is split by hand (see attn_bwd_dq_kernel).
+    // DC (template) = head-dim class, 64 / 96 / 128 columns: the k-steps of S^T and the d-tiles of O^T past it are not computed (the
+    // Q fragments there are zero and the rows are never stored anyway: same results, half the MFMAs and LDS reads at head_dim 64)
     auto step = [&](int ti, auto mode_c, bool rt_mask) {       // mode 0: no mask, 1: mask, 2: mask iff rt_mask
         constexpr int MODE = decltype(mode_c)::value;
+        constexpr int NKS = DC / 16, NDT = DC / 32;
         const int t = t_first + ti;
         ASTAMP(ti, 0);
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -376,7 +379,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[kt][r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 union { uint4 r; frag_t f; } u;
                 u.r = *reinterpret_cast<const uint4*>(sk + kt * 32 * 256 + (k_lane ^ (ks * 32)));
                 st[kt] = MfmaA<T>::run(u.f, qf[ks], st[kt]);
@@ -392,7 +395,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
         constexpr bool PREFETCH = !BAND;
         auto load_v = [&](int u, frag_t* dst) {                       // u = 2 kt + c: keys 16 u .. 16 u + 15
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
+            for (int dt = 0; dt < NDT; ++dt) {
                 const int a0 = (u * 16) * 256 + (v_lane ^ (dt << 6));
                 union { s16x4_t h[2]; frag_t f; } va;
                 va.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sv + a0));
@@ -430,7 +433,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o_acc[i] *= alpha;
+            for (int i = 0; i < NDT; ++i) o_acc[i] *= alpha;
         }
         const float m_ref = m_run == -INFINITY ? 0.f : m_run;
         float ls = 0.f;
@@ -453,7 +456,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) pb.w[j] = pack_pair2<T>(st[kt][8 * c + 2 * j], st[kt][8 * c + 2 * j + 1]);
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o_acc[dt] = MfmaA<T>::run(vsrc[dt], pb.f, o_acc[dt]);
+            for (int dt = 0; dt < NDT; ++dt) o_acc[dt] = MfmaA<T>::run(vsrc[dt], pb.f, o_acc[dt]);
         };
         if (PREFETCH) {                                               // operand fetch two steps ahead, 3 buffers
             load_v(2, va2);
@@ -903,7 +906,7 @@ struct AttnBwdArgs {
 
 __device__ __forceinline__ int swz_c(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-template <typename T, bool BAND>
+template <typename T, bool BAND, int DC>
 __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename MfmaA<T>::frag frag_t;
@@ -1034,8 +1037,10 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
     // One tile step. MASKED is a compile-time flag and the tile range is split by hand into
     // [band-edge tiles | interior tiles | diagonal / ragged tiles]: with a run-time `need_mask` that depends on
     // the band the compiler keeps both paths' registers alive in one loop body (+50 VGPRs, spills).
+    // (DC: the head-dim class, see attn_fwd_kernel -- k-steps of S^T / dP^T and d-tiles of dQ^T past it are not computed)
     auto step = [&](int ti, auto mode_c, bool rt_mask) {       // mode 0: no mask, 1: mask, 2: mask iff rt_mask
         constexpr int MODE = decltype(mode_c)::value;
+        constexpr int NKS = DC / 16, NDT = DC / 32;
         const int t = t_first + ti;
         if (ti + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1065,7 +1070,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
             for (int r = 0; r < 16; ++r) { st[r] = 0.f; dp[r] = 0.f; }
             if constexpr (CFOLD) dp = ndelta;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < NKS; ++ks) {
                 union { uint4 r; frag_t f; } u, w;
                 u.r = *reinterpret_cast<const uint4*>(sk + kt * 32 * 256 + (r_lane ^ (ks * 32)));
                 w.r = *reinterpret_cast<const uint4*>(sv + kt * 32 * 256 + (r_lane ^ (ks * 32)));
@@ -1090,7 +1095,7 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
                 for (int j = 0; j < 4; ++j) sb.w[j] = BAND ? pack_pair<T>(st[8 * c + 2 * j], st[8 * c + 2 * j + 1])   // (the packed form spills in the band build)
                                        : pack_pair2<T>(st[8 * c + 2 * j], st[8 * c + 2 * j + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < NDT; ++dt) {
                     const int a0 = (kt * 32 + c * 16) * 256 + (t_lane ^ (dt << 6));
                     union { s16x4_t h[2]; frag_t f; } ka;
                     ka.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sk + a0));
@@ -1771,15 +1776,23 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     auto run = [&](auto tag) -> int {
         typedef decltype(tag) T;
         constexpr int ti = std::is_same<T, bf16_t>::value ? 0 : 1;
-        static bool done_dq[2][2][64] = {}, done_kd[2][64] = {};
+        static bool done_dq[2][2][3][64] = {}, done_kd[2][64] = {};
         int rc_;
-        if (lo) {
-            if ((rc_ = set_lds_attr(&attn_bwd_dq_kernel<T, true>, ATTN_LDS, &done_dq[ti][1][dev]))) return rc_;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, true>), grid_q, dim3(512), ATTN_LDS, st, a);
-        } else {
-            if ((rc_ = set_lds_attr(&attn_bwd_dq_kernel<T, false>, ATTN_LDS, &done_dq[ti][0][dev]))) return rc_;
-            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, false>), grid_q, dim3(512), ATTN_LDS, st, a);
-        }
+        // head-dim class of the dQ kernel: 64 / 96 / 128 columns computed (attn_fwd_kernel's DC)
+        auto dq = [&](auto band_c, auto dc_c) -> int {
+            constexpr bool BAND_ = decltype(band_c)::value;
+            constexpr int DC_ = decltype(dc_c)::value;
+            int r_;
+            if ((r_ = set_lds_attr(&attn_bwd_dq_kernel<T, BAND_, DC_>, ATTN_LDS, &done_dq[ti][BAND_][DC_ / 32 - 2][dev]))) return r_;
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<T, BAND_, DC_>), grid_q, dim3(512), ATTN_LDS, st, a);
+            return 0;
+        };
+        auto dq_b = [&](auto band_c) -> int {
+            if (D > 96) return dq(band_c, std::integral_constant<int, 128>{});
+            if (D > 64) return dq(band_c, std::integral_constant<int, 96>{});
+            return dq(band_c, std::integral_constant<int, 64>{});
+        };
+        if ((rc_ = lo ? dq_b(std::true_type{}) : dq_b(std::false_type{}))) return rc_;
         if ((rc_ = uamd_launch_status())) return rc_;
         if ((rc_ = set_lds_attr(&attn_bwd_dkdv4_kernel<T>, KD4_LDS, &done_kd[ti][dev]))) return rc_;
         hipLaunchKernelGGL((attn_bwd_dkdv4_kernel<T>), grid_k, dim3(256), KD4_LDS, st, ak);
@@ -1853,8 +1866,15 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
             return lo ? go(&attn_fwd_ps_kernel<T, true>, nwg, ATTN_PS_LDS, &done[ti][1][1][dev])
                       : go(&attn_fwd_ps_kernel<T, false>, nwg, ATTN_PS_LDS, &done[ti][0][1][dev]);
         }
-        return lo ? go(&attn_fwd_kernel<T, true>, (int)grid.x, ATTN_LDS, &done[ti][1][0][dev])
-                  : go(&attn_fwd_kernel<T, false>, (int)grid.x, ATTN_LDS, &done[ti][0][0][dev]);
+        static bool done_dc[2][2][2][64] = {};          // the head-dim classes 64 / 96 (128: `done` above)
+        if (D > 96)
+            return lo ? go(&attn_fwd_kernel<T, true, 128>, (int)grid.x, ATTN_LDS, &done[ti][1][0][dev])
+                      : go(&attn_fwd_kernel<T, false, 128>, (int)grid.x, ATTN_LDS, &done[ti][0][0][dev]);
+        if (D > 64)
+            return lo ? go(&attn_fwd_kernel<T, true, 96>, (int)grid.x, ATTN_LDS, &done_dc[ti][1][1][dev])
+                      : go(&attn_fwd_kernel<T, false, 96>, (int)grid.x, ATTN_LDS, &done_dc[ti][0][1][dev]);
+        return lo ? go(&attn_fwd_kernel<T, true, 64>, (int)grid.x, ATTN_LDS, &done_dc[ti][1][0][dev])
+                  : go(&attn_fwd_kernel<T, false, 64>, (int)grid.x, ATTN_LDS, &done_dc[ti][0][0][dev]);
     };
     if (dtype == UAMD_BF16) rc = run(bf16_t{});
     else if (dtype == UAMD_F16) rc = run(f16_t{});
