@@ -42,7 +42,7 @@ GC_MODE = {"on": True, "off": False, "unsloth": "unsloth", "unsloth:min": "unslo
            "unsloth:auto": "unsloth:auto", "unsloth:attn": "unsloth:attn"}
 MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, MI355X_MICROARCH.md (never the 2:1-sparse figure)
 HBM_PEAK_GBPS = 8000.0
-ONLY_POINTS = ("primary", "packed", "config4", "config5_ce", "config5_logprob", "dp_force", "batch1", "fullft")
+ONLY_POINTS = ("primary", "packed", "config1", "config4", "config5_ce", "config5_logprob", "dp_force", "batch1", "fullft")
 
 
 def llama3_8b_config(n_layers=32, vocab=128256):
@@ -52,6 +52,15 @@ def llama3_8b_config(n_layers=32, vocab=128256):
         num_key_value_heads=8, head_dim=128, vocab_size=vocab, rms_norm_eps=1e-5, max_position_embeddings=8192,
         rope_parameters={"rope_type": "default", "rope_theta": 500000.0}, tie_word_embeddings=False,
         attention_bias=False, mlp_bias=False)
+
+
+def tinyllama_1b_config(n_layers=22):
+    """BASELINE config 1: TinyLlama-1.1B widths (32 query heads on 4 KV heads, head_dim 64)."""
+    from transformers import LlamaConfig
+    return LlamaConfig(hidden_size=2048, intermediate_size=5632, num_hidden_layers=n_layers, num_attention_heads=32,
+                       num_key_value_heads=4, head_dim=64, vocab_size=32000, rms_norm_eps=1e-5, max_position_embeddings=2048,
+                       rope_parameters={"rope_type": "default", "rope_theta": 1e4}, tie_word_embeddings=False,
+                       attention_bias=False, mlp_bias=False)
 
 
 def mistral_7b_config(n_layers=32):
@@ -536,6 +545,35 @@ def main():
 
     # ------------------------------------------------------------------------------------------------------------
     # operating points that build their own model (BASELINE configs 3, 4, 5)
+    def run_config1(rows, steps, warmup, per_step):
+        """BASELINE config 1 ON THE GPU (the configuration itself is the reference's CPU plumbing case; its CPU timing is
+        cpu_baseline.config1_tinyllama_direct): TinyLlama-1.1B widths, 16-bit base, LoRA r=8 on the 7 projections, seq 512,
+        `rows` rows per step (1 = the configuration as stated: launch-bound; 16 = 8192 tokens, the headline's step size).
+        head_dim 64 on the hand attention kernels without padded copies (round 6)."""
+        tcfg = tinyllama_1b_config(22 if a.layers == 32 else a.layers)
+        m, _ = FastLanguageModel.from_pretrained(config=tcfg, max_seq_length=2048, dtype=torch.bfloat16, load_in_4bit=False,
+                                                 device=dev, random_state=3407, use_gradient_checkpointing=GC_MODE[a.gc])
+        m = FastLanguageModel.get_peft_model(m, r=8, lora_alpha=8, use_gradient_checkpointing=GC_MODE[a.gc], random_state=3407)
+        randomize_lora_b(m)
+        o = make_optimizer(m, lr=2e-4)
+        m.for_training(use_gradient_checkpointing=GC_MODE[a.gc])
+        S = 512
+        try:
+            bt = []
+            for _ in range(2):
+                ids = torch.randint(0, 32000, (rows, S), generator=gi).to(dev)
+                pos = torch.arange(S, dtype=torch.int32, device=dev).unsqueeze(0).expand(rows, S).contiguous()
+                bt.append(dict(input_ids=ids, labels=ids.clone(), position_ids=pos))
+            ni = torch.tensor((S - 1) * rows, device=dev)
+            dt, peak, losses, gs = timed_steps(lambda i: training_step(m, bt[i % 2], o, None, ni), steps, warmup, per_step)
+            return point(rows * S, dt, steps, peak, gs, rows=rows, seq_len=S, lora_rank=8, base="bf16 (no NF4)", head_dim=64,
+                         loss_first_last=[round(losses[0], 4), round(losses[-1], 4)])
+        finally:
+            if hasattr(o, "close"):
+                o.close()
+            del m, o
+            torch.cuda.empty_cache()
+
     def run_config5(leg, steps, warmup, per_step):
         """BASELINE config 5: Mistral-7B widths, NF4 + LoRA r=16, seq 4096, 2 rows per GPU. `ce`: the SFT / DPO-style CE step;
         `logprob`: one GRPO policy step -- [left-padded prompt | right-padded completion] rows packed into one varlen forward
@@ -663,6 +701,7 @@ def main():
 
     PACKED_TAG = "packed_padding_free_1x8192 (the reference's default SFT batch: mixed-length documents in one row)"
     C4_TAG = "config4_qwen2_vl_7b_nf4_r32_seq4096_one_image"
+    C1_TAG = "config1_tinyllama_1.1b_lora_r8_seq512_on_the_gpu"
     C5CE_TAG = "config5_mistral_7b_nf4_r16_seq4096_ce_leg"
     C5LP_TAG = "config5_mistral_7b_nf4_r16_seq4096_grpo_logprob_leg"
 
@@ -682,6 +721,8 @@ def main():
                         collectives_issued_per_step=(arena.collectives / (a.steps + a.warmup)) if arena is not None else None)
         elif a.only == "config4":
             rec = run_config4(a.steps, a.warmup, False)
+        elif a.only == "config1":
+            rec = run_config1(int(os.environ.get("BENCH_CONFIG1_ROWS", 16)), a.steps, a.warmup, False)
         elif a.only == "fullft":
             rec = run_fullft(a.steps, a.warmup)
         else:
@@ -860,6 +901,8 @@ def main():
             guarded(alt, C5CE_TAG, lambda: run_config5("ce", a.alt_steps, 3, True))
             guarded(alt, C5LP_TAG, lambda: run_config5("logprob", a.alt_steps, 3, True))
             guarded(alt, C4_TAG, lambda: run_config4(a.alt_steps, 3, True))
+            guarded(alt, C1_TAG + "_bs1", lambda: run_config1(1, a.alt_steps, 3, True))
+            guarded(alt, C1_TAG + "_bs16", lambda: run_config1(16, a.alt_steps, 3, True))
         if os.environ.get("BENCH_FULLFT_ALT", "1") == "1" and world == 1:
             guarded(alt, "config3_full_finetune_bf16_1gpu (every parameter trains, fp32-master AdamW)",
                     lambda: run_fullft(a.alt_steps, 2))
