@@ -275,13 +275,26 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     frag_t qf[8];
     {
         const T* qp = (const T*)p.Q + b * p.q_sb + (int64_t)q_ld * p.q_st + (int64_t)head * p.q_sh + lh * 8;
+        // MASKED = head dims below 128: fragments past D are zero. The load stays UNCONDITIONAL -- a lane past D re-reads the row's
+        // first 16 bytes -- and the zeroing is an AND with a lane mask, not an `if`: behind per-lane branches hipcc waits for each
+        // load before it issues the next (the dQ kernel's 24 prologue loads one by one: +9 % on the whole kernel at head_dim 128,
+        // profiles/r06zm_attn_bisect.txt). head_dim 128 (a wave-uniform test) keeps the plain loads.
+        auto load_q = [&](auto masked_c) __attribute__((always_inline)) {
+            constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            union { uint4 r; frag_t f; } u;
-            u.r = make_uint4(0, 0, 0, 0);
-            if (ks * 16 + lh * 8 < p.D) u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
-            qf[ks] = u.f;
-        }
+            for (int ks = 0; ks < 8; ++ks) {
+                const bool in = !MASKED || ks * 16 + lh * 8 < p.D;
+                union { uint4 r; frag_t f; } u;
+                u.r = *reinterpret_cast<const uint4*>(in ? qp + ks * 16 : qp - lh * 8);
+                if constexpr (MASKED) {
+                    const unsigned keep = in ? 0xffffffffu : 0u;
+                    u.r.x &= keep; u.r.y &= keep; u.r.z &= keep; u.r.w &= keep;
+                }
+                qf[ks] = u.f;
+            }
+        };
+        if (DC == AD && p.D == AD) load_q(std::false_type{});
+        else load_q(std::true_type{});
     }
 
     // ---- DMA plan: a stage = K tile (64 rows x 256 B) then V tile. One DMA instruction = 4 rows. Wave w issues
@@ -504,7 +517,8 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
     const float inv = 1.0f / l_tot;
     {
         T* op = (T*)p.O + b * p.o_sb + (int64_t)q_ld * p.o_st + (int64_t)head * p.o_sh;
-        store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_, p.D);
+        if (p.D == AD) store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_);
+        else store_rows_x4<T>(op, o_acc, inv, lh, q_pos < T_, p.D);
         if (lh == 0 && q_pos < T_) p.LSE[((int64_t)b * p.Hq + head) * p.lse_st + q_pos] = (m_run + log2f(l_tot)) * 0.6931471805599453f;
     }
 }
@@ -931,20 +945,31 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         const T* qp = (const T*)p.Q + b * p.q_sb + (int64_t)q_ld * p.q_st + (int64_t)head * p.q_sh + lh * 8;
         const T* dp_ = (const T*)p.dO + b * p.do_sb + (int64_t)q_ld * p.do_st + (int64_t)head * p.do_sh + lh * 8;
         const T* op = (const T*)p.O + b * p.o_sb + (int64_t)q_ld * p.o_st + (int64_t)head * p.o_sh + lh * 8;
+        // MASKED = head dims below 128: zero registers past D. The loads stay unconditional (a lane past D re-reads the row's
+        // first 16 bytes) and the zeroing is an AND, see attn_fwd_kernel; head_dim 128 (a wave-uniform test) keeps the plain loads.
+        auto load_rows = [&](auto masked_c) __attribute__((always_inline)) {
+            constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            union { uint4 r; frag_t f; T e[8]; } u, d, o;
-            u.r = d.r = o.r = make_uint4(0, 0, 0, 0);
-            if (ks * 16 + lh * 8 < p.D) {                                 // (head dims below 128: zero registers past D)
-                u.r = *reinterpret_cast<const uint4*>(qp + ks * 16);
-                d.r = *reinterpret_cast<const uint4*>(dp_ + ks * 16);
-                o.r = *reinterpret_cast<const uint4*>(op + ks * 16);
+            for (int ks = 0; ks < 8; ++ks) {
+                union { uint4 r; frag_t f; T e[8]; } u, d, o;
+                const bool in = !MASKED || ks * 16 + lh * 8 < p.D;
+                const int co = in ? ks * 16 : -lh * 8;
+                u.r = *reinterpret_cast<const uint4*>(qp + co);
+                d.r = *reinterpret_cast<const uint4*>(dp_ + co);
+                o.r = *reinterpret_cast<const uint4*>(op + co);
+                if constexpr (MASKED) {
+                    const unsigned keep = in ? 0xffffffffu : 0u;
+                    u.r.x &= keep; u.r.y &= keep; u.r.z &= keep; u.r.w &= keep;
+                    d.r.x &= keep; d.r.y &= keep; d.r.z &= keep; d.r.w &= keep;
+                }
+                qf[ks] = u.f;
+                dof[ks] = d.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) delta += to_f32(d.e[j]) * to_f32(o.e[j]);
             }
-            qf[ks] = u.f;
-            dof[ks] = d.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) delta += to_f32(d.e[j]) * to_f32(o.e[j]);
-        }
+        };
+        if (DC == AD && p.D == AD) load_rows(std::false_type{});
+        else load_rows(std::true_type{});
     }
     delta += __shfl_xor(delta, 32, 64);
     const int64_t stat_idx = ((int64_t)b * p.Hq + head) * p.lse_st + q_ld;
@@ -1126,7 +1151,8 @@ __global__ void __launch_bounds__(512, 2) attn_bwd_dq_kernel(AttnBwdArgs p) {
         int qr = q_ld;                       // (the row address formed HERE: hoisted, the pointer pair is spilled around the loop)
         asm volatile("" : "+v"(qr));
         T* op = (T*)p.dQ + b * p.dq_sb + (int64_t)qr * p.dq_st + (int64_t)head * p.dq_sh;
-        store_rows_x4<T>(op, dq_acc, CFOLD ? p.scale : 1.0f, lh, q_pos < T_, p.D);
+        if (p.D == AD) store_rows_x4<T>(op, dq_acc, CFOLD ? p.scale : 1.0f, lh, q_pos < T_);
+        else store_rows_x4<T>(op, dq_acc, CFOLD ? p.scale : 1.0f, lh, q_pos < T_, p.D);
     }
 }
 
@@ -1278,9 +1304,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const T* kp = (const T*)p.K + b * p.k_sb + (int64_t)key_ld * p.k_st + (int64_t)kvh * p.k_sh + lh * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
+            const bool in = ks * 16 + lh * 8 < p.D;                    // (head dims below 128: zero past D; unconditional loads)
             union { uint4 r; frag_t f; } u;
-            u.r = make_uint4(0, 0, 0, 0);
-            if (ks * 16 + lh * 8 < p.D) u.r = *reinterpret_cast<const uint4*>(kp + ks * 16);     // (head dims below 128: zero past D)
+            const unsigned keep = in ? 0xffffffffu : 0u;
+            u.r = *reinterpret_cast<const uint4*>(in ? kp + ks * 16 : kp - lh * 8);
+            u.r.x &= keep; u.r.y &= keep; u.r.z &= keep; u.r.w &= keep;
             kf[kh][ks] = u.f;
         }
     }
