@@ -307,8 +307,10 @@ int uamd_gemm_tn_256(const void* A, int64_t lda, int M, int K, const uamd_gemm_g
 #define UAMD_TUNE_ATTN_VAR 4    /* (UAMD_ATTN_VAR) attention forward: 0 = by shape (plain causal batches with >= 2 work items per CU take
                                  * attn_fwd_ps_kernel -- one persistent workgroup per CU, ping-pong wave groups -- everything else
                                  * attn_fwd_kernel, one block per work item); bit 0 = attn_fwd_kernel always; bit 1 = attn_fwd_ps_kernel
-                                 * always; bit 2 = every step of attn_bwd_dkdv4_kernel through its C++ body instead of the
-                                 * generated asm loops (bit-identical; A/B and parity tests). (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
+                                 * always (packed / windowed batches: its work items claimed from a counter); bit 2 = every step of
+                                 * attn_bwd_dkdv4_kernel through its C++ body instead of the generated asm loops (bit-identical; A/B
+                                 * and parity tests); bit 3 = with bit 1, packed / windowed batches keep the static deal of the items
+                                 * (bit-identical to the claimed deal; measured: profiles/r06zv_attn_packed_ab.jsonl). (Rounds 2-3 kept three more opt-in kernels behind this knob -- a 4-wave x 64-row forward, the
                                  * round-1 dK/dV kernel, a 4-wave dQ kernel -- all measured at parity or slower: removed in round 4,
                                  * git 4501bb3:tools/experiments/attention_removed_r04.hip) */
 #define UAMD_TUNE_RMS_VAR 5     /* RMSNorm kernels: 0 = one wave per row (row in registers, shuffle reduction),

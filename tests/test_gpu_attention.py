@@ -459,3 +459,80 @@ def test_dkdv_generated_step_loops_are_bit_identical_to_the_cxx_body(B, T, Hq, H
     for name, a, b in zip(("dq", "dk", "dv"), got, want):
         assert not torch.isnan(a.float()).any(), name
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+
+
+DYN_CASES = [  # (B, T, Hq, Hk, dtype, document lengths, sliding window)
+    (1, 8192, 32, 8, torch.bfloat16, [1500, 64, 3, 700, 2048, 129, 511, 33, 1024, 900, 257, 64, 64, 600], None),   # 4 items per CU
+    (2, 4096, 32, 8, torch.bfloat16, [4096, 100, 3000, 996], None),                   # a row that is one document + a ragged row
+    (1, 8192, 28, 4, torch.bfloat16, [2000, 6000, 192], None),                        # G = 7: virtual KV heads of 4 / 2 / 1 heads
+    (1, 4096, 32, 8, torch.float16, None, 512),                                       # sliding window only
+    (1, 1000, 8, 2, torch.bfloat16, [64, 1, 63, 300, 572], None),                     # small grid (forced), single-tile items
+    (1, 192, 4, 1, torch.bfloat16, [70, 122], None),                                  # fewer items than CUs (forced): every first claim fails
+]
+
+
+@pytest.mark.parametrize("B,T,Hq,Hk,dtype,lengths,window", DYN_CASES)
+def test_persistent_forward_claims_items_bit_identical_to_the_static_deal(B, T, Hq, Hk, dtype, lengths, window):
+    """attn_fwd_ps_kernel<BAND, DYN> (opt-in, UAMD_TUNE_ATTN_VAR bit 1): packed / windowed batches on the persistent kernel with items
+    CLAIMED from a counter (every workgroup holds one claimed item ahead; the hand-off rides in a free ring stage). Which
+    workgroup computes an item does not change its arithmetic: O and LSE bit-identical to the persistent kernel with the static
+    deal (UAMD_TUNE_ATTN_VAR bit 3), run after run; against attn_fwd_kernel (one block per item: different phase order) within
+    rounding; against the fp32 oracle on a slice."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels import attention as A
+    L = _lib.lib()
+    D = 128
+    qkv = (torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(T + Hq)) * 0.8).to(dtype).to(DEV)
+    q = qkv[..., :Hq * D].view(B, T, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    band = A.attention_band(T, batch=B, seq_lengths=lengths, sliding_window=window, device=DEV)
+    try:
+        L.uamd_set_tuning(4, 2)                                   # persistent, claimed items
+        runs = [tuple(t.clone() for t in A.attn_forward(q, k, v, None, band)) for _ in range(3)]
+        L.uamd_set_tuning(4, 10)                                  # persistent, static deal
+        o_s, lse_s = A.attn_forward(q, k, v, None, band)
+        L.uamd_set_tuning(4, 1)                                   # one block per item
+        o_1, lse_1 = A.attn_forward(q, k, v, None, band)
+        L.uamd_set_tuning(4, 0)                                   # by shape
+        o_d, lse_d = A.attn_forward(q, k, v, None, band)
+    finally:
+        L.uamd_set_tuning(4, 0)
+    for o, lse in runs:
+        assert not torch.isnan(o.float()).any()
+        assert torch.equal(o, o_s) and torch.equal(lse, lse_s)
+    assert torch.equal(o_d, o_1) and torch.equal(lse_d, lse_1)    # the default for packed / windowed batches: one block per item
+    assert (o_1.float() - o_s.float()).abs().max().item() <= 2e-2
+    torch.testing.assert_close(lse_1, lse_s, rtol=1e-4, atol=2e-3)
+    # fp32 oracle on (row 0, KV head 0), first 1024 positions
+    Tn, G = min(T, 1024), Hq // Hk
+    allowed = packed_mask(T, ([n for n in lengths] if lengths else [T]), window)[:Tn, :Tn] if B == 1 else None
+    if allowed is not None:
+        o_ref, _ = ref_attention(q[:1, :Tn, :G].float().cpu(), k[:1, :Tn, :1].float().cpu(), v[:1, :Tn, :1].float().cpu(),
+                                 1.0 / math.sqrt(D), allowed)
+        assert (o_s[:1, :Tn, :G].float().cpu() - o_ref).abs().max().item() <= (2e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
+def test_persistent_forward_counter_pairs_are_left_zeroed():
+    """The claim counters come from a pool of 512 pairs handed out round-robin; a launch leaves its pair zeroed (the last
+    workgroup to finish resets it). 1,200 launches walk the pool more than twice: every output equals the first."""
+    from unsloth_amd import _lib
+    from unsloth_amd.kernels import attention as A
+    L = _lib.lib()
+    B, T, Hq, Hk, D = 1, 640, 8, 2, 128
+    qkv = torch.randn(B, T, (Hq + 2 * Hk) * D, generator=g(77)).to(torch.bfloat16).to(DEV)
+    q = qkv[..., :Hq * D].view(B, T, Hq, D)
+    k = qkv[..., Hq * D:(Hq + Hk) * D].view(B, T, Hk, D)
+    v = qkv[..., (Hq + Hk) * D:].view(B, T, Hk, D)
+    band = A.attention_band(T, batch=B, seq_lengths=[100, 300, 240], device=DEV)
+    try:
+        L.uamd_set_tuning(4, 2)
+        o0, lse0 = A.attn_forward(q, k, v, None, band)
+        bad = 0
+        for i in range(1200):
+            o, lse = A.attn_forward(q, k, v, None, band)
+            if i % 100 == 99 or i > 1150:
+                bad += int(not (torch.equal(o, o0) and torch.equal(lse, lse0)))
+    finally:
+        L.uamd_set_tuning(4, 0)
+    assert bad == 0

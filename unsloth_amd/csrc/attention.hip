@@ -23,6 +23,7 @@
 //   * Bank conflicts: K rows are read 16 bytes per lane down a column -> 16-byte slot ^= row & 15; V rows are
 //     read by the transposing 8-byte reads, 4 rows x 64 B per 32 lanes -> slot ^= (row & 3) << 2. Both swizzles
 //     are applied on the per-lane DMA SOURCE address (the DMA destination is lane-linear).
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -79,6 +80,8 @@ struct AttnArgs {
                                          // columns -- and the rows of O^T past D are never stored. No padded copies of Q / K / V.
     int lse_st;                          // row stride of LSE [B, Hq, lse_st] (T rounded up to 32)
     float scale_log2;                    // softmax scale * log2(e)
+    int* ctr;                            // attn_fwd_ps_kernel<.., DYN = true>: {claim counter, finished workgroups}, both zero at launch
+                                         // and zeroed again by the last workgroup to finish (attn_ctr_slot)
 };
 
 // Block index -> (rank of the tile in heaviest-first order, (batch, KV head) pair): tile-major, pair-minor. With 8 KV heads the
@@ -564,7 +567,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_kernel(AttnArgs p) {
 constexpr int QSTAGE_OFF = NST * STAGE_B;                 // 96 KiB
 constexpr int ATTN_PS_LDS = QSTAGE_OFF + 8 * 8192;        // 160 KiB
 
-template <typename T, bool BAND>
+template <typename T, bool BAND, bool DYN>
 __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename MfmaA<T>::frag frag_t;
@@ -578,17 +581,24 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
     // item k of this workgroup: snake over the heaviest-first list
     auto item_index = [&](int k) { return k * nwg + ((k & 1) ? nwg - 1 - wg : wg); };
     struct Item { int qtile, kvh, kvr, b, t_first, nt; };            // kvr: the K / V head behind the (virtual) head kvh
-    auto decode = [&](int idx) {
+    // first key tile of item idx (band: the lower edge of the item's first query)
+    auto first_tile = [&](int idx) {
+        if (!BAND) return 0;
+        const int qtile = p.nqt - 1 - idx / npairs;
+        return p.lo[(int64_t)((idx % npairs) / p.Hk) * T_ + min(qtile * QT, T_ - 1)] / KT;
+    };
+    auto decode_at = [&](int idx, int t_first) {
         Item it;
         it.qtile = p.nqt - 1 - idx / npairs;
         const int pair_ = idx % npairs;
         it.kvh = pair_ % p.Hk;
         it.kvr = p.kvm == 1 ? it.kvh : it.kvh / p.kvm;
         it.b = pair_ / p.Hk;
-        it.t_first = BAND ? p.lo[(int64_t)it.b * T_ + min(it.qtile * QT, T_ - 1)] / KT : 0;
+        it.t_first = t_first;
         it.nt = min((it.qtile * QT + QT + KT - 1) / KT, (T_ + KT - 1) / KT) - it.t_first;
         return it;
     };
+    auto decode = [&](int idx) { return decode_at(idx, first_tile(idx)); };
     const unsigned lds_base = (unsigned)(uintptr_t)(lds_u8*)smem;
     const unsigned dst_w = lds_base + wave * 2048;
     const unsigned qdst_w = lds_base + QSTAGE_OFF + wave * 8192;
@@ -672,13 +682,39 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
         wait_lgkm0();
     };
 
-    if (item_index(0) >= nitems) return;                 // (whole workgroup: no barrier was executed yet)
+    // DYN (packed / windowed batches: items of one q tile differ in length by what the band cuts off, the static deal is off by
+    // up to 2x): item 0 of a workgroup is its index, every further item is CLAIMED from a counter in heaviest-first order
+    // (later q tiles cannot be long: a late claim is a short item). The ring and the Q staging need the next item while the
+    // current one runs, so a workgroup always holds one claimed item ahead of the one it works on:
+    //   * wave 0 claims (relaxed agent-scope fetch-add; LLVM's atomic optimizer makes it one lane's add + a v_readfirstlane, so
+    //     the wait for the result sits right behind the atomic: ~ one L2 round trip, in one wave, once per item) at the START
+    //     OF AN ITEM'S EPILOGUE -- two phases behind the last LDS-DMA issue, one before the next: the compiler's vmcnt for the
+    //     result counts only the memory operations it knows of, and between P3 and the next P2 there is none it does not --,
+    //     reads the claimed item's band edge behind the epilogue's stores, and
+    //   * publishes (item, first key tile) in P1 of the next item's first tile through 8 bytes of the ring stage that tile
+    //     step's DMA will fill: free since the trailing group's P3 of the previous tile, written by wave 7 only in ITS P2 --
+    //     the leading waves read it at the top of their P2, the trailing waves (one phase behind) in their P1, all between the
+    //     same two barriers. All 160 KiB of LDS are taken; the hand-off borrows.
+    // Exactly one claim per workgroup fails (>= nitems), then it claims no more. The last workgroup to finish zeroes the pair.
+    auto mailbox = [&](int stage) { return smem + stage * STAGE_B + 7 * 2048; };
+    int pend_v = 0;                                      // wave 0, lane 0: the fetch-add's result, not yet waited for
+    int pend = 0x7fffffff, pend_tf = 0;                  // wave 0: the claimed item and its first key tile, to be published
+    auto claim = [&]() {
+        if (lane == 0) pend_v = __hip_atomic_fetch_add(p.ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto claimed = [&]() {
+        pend = nwg + __builtin_amdgcn_readfirstlane(pend_v);
+        pend_tf = pend < nitems ? first_tile(pend) : 0;
+    };
+    if (DYN && wave == 0) claim();
+    if (item_index(0) >= nitems) return;                 // (whole workgroup: no barrier was executed yet; never under DYN: nwg <= nitems)
     Item cur = decode(item_index(0));
     // ---- prologue of the first item: Q rows, tiles 0 and 1
     issue_q(cur);
     issue_tile(cur, cur.t_first, 0);
     if (cur.nt > 1) issue_tile(cur, cur.t_first + 1, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DYN && wave == 0) claimed();     // (the fetch-add was issued ahead of the prologue's DMA: it has returned)
     bar();
     if (wave >= 4) bar();                // the trailing group drops one phase behind
     int s_ = 0;                          // stream index of the current item's first tile (ring stage = stream index % 3)
@@ -690,10 +726,17 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
     frag_t pb[4];
     f32x16_t o_acc[4];
     for (;;) {
-        const int nxt_idx = item_index(kitem + 1);
-        const bool has_next = nxt_idx < nitems;
+        // the item after this one: by the static deal, or (DYN) taken from the mailbox in this item's first tile
+        int nxt_idx = DYN ? 0x7fffffff : item_index(kitem + 1);
+        bool has_next = nxt_idx < nitems;
         Item nxt = cur;
-        if (has_next) nxt = decode(nxt_idx);
+        if (!DYN && has_next) nxt = decode(nxt_idx);
+        auto take_next = [&](int stage) {
+            const unsigned long long m = *reinterpret_cast<const volatile unsigned long long*>(mailbox(stage));
+            nxt_idx = __builtin_amdgcn_readfirstlane((int)(unsigned)m);
+            has_next = nxt_idx < nitems;
+            if (has_next) nxt = decode_at(nxt_idx, __builtin_amdgcn_readfirstlane((int)(unsigned)(m >> 32)));
+        };
         const int head = cur.kvh * G + (wave % G);
         const int qs = cur.qtile * QT + (wave / G) * 32;
         const int q_pos = qs + l31;
@@ -737,6 +780,16 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             const unsigned char* sv = sk + TILE_B;
             const int stg2 = stg == 0 ? 2 : stg - 1;                            // (sx + 2) % 3
             // ---------------- P1 (load): K rows -> 64 registers
+            if (DYN && ti == 0) {
+                if (wave == 0) {
+                    if (lane == 0)
+                        *reinterpret_cast<volatile unsigned long long*>(mailbox(stg2)) =
+                            (unsigned long long)(unsigned)pend | ((unsigned long long)(unsigned)pend_tf << 32);
+                    wait_lgkm0();
+                } else if (wave >= 4) {
+                    take_next(stg2);                                            // (published one barrier ago)
+                }
+            }
             if (live) {
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
@@ -760,6 +813,7 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             }
             // DMA order inside this slot: next item's Q rows, then a catch-up tile, then the tile two ahead -- the wait at the end
             // of P3 keeps only the LAST group in flight
+            if (DYN && ti == 0 && wave < 4) take_next(stg2);
             bool issued = false;
             if (ti == 0 && has_next) issue_q(nxt);                 // (this item's read_q is long done)
             if (ti == 0 && pre == 1 && nt > 1) issue_tile(cur, t + 1, (sx + 1) % NST);      // predecessor had a single tile
@@ -874,6 +928,10 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
             stg = stg == NST - 1 ? 0 : stg + 1;
         }
         // ---- epilogue of the item: O = O^T / l, LSE
+        if (DYN && wave == 0) {
+            if (has_next) { claim(); claimed(); }                               // the item after the next one (its band edge arrives
+            else pend = 0x7fffffff;                                             // behind the stores below)
+        }
         {
             const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
             const float inv = 1.0f / l_tot;
@@ -890,6 +948,13 @@ __global__ void __launch_bounds__(512, 2) attn_fwd_ps_kernel(AttnArgs p) {
         ++kitem;
     }
     if (wave < 4) bar();                 // the leading group's extra barrier = the trailing group's last phase
+    if (DYN && wave == 0 && lane == 0) {
+        // every workgroup's claims precede its arrival here (same wave, results consumed): the last one in resets the pair
+        if (__hip_atomic_fetch_add(p.ctr + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+            __hip_atomic_store(p.ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.ctr + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1833,6 +1898,30 @@ extern "C" int uamd_attn_bwd(const void* Q, const void* K, const void* V, const 
     return uamd_launch_status();
 }
 
+// {claim counter, finished workgroups} pairs of the persistent forward's dynamic deal: a pool per device, handed out round-robin
+// -- launches on one stream run one after the other, and a launch leaves its pair zeroed (the last workgroup resets it), so a
+// pair is shared only by launches ATTN_CTR_SLOTS apart. Allocated on first use; never inside a stream capture (nullptr then:
+// the caller takes the one-block-per-item kernel).
+constexpr int ATTN_CTR_SLOTS = 512;
+static int* attn_ctr_slot(int dev, hipStream_t st) {
+    static std::mutex mu;
+    static int* pool[64] = {};
+    static unsigned seq[64] = {};
+    std::lock_guard<std::mutex> g(mu);
+    if (!pool[dev]) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+        int* ptr = nullptr;
+        if (hipMalloc((void**)&ptr, ATTN_CTR_SLOTS * 2 * sizeof(int)) != hipSuccess ||
+            hipMemset(ptr, 0, ATTN_CTR_SLOTS * 2 * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        pool[dev] = ptr;
+    }
+    return pool[dev] + 2 * (seq[dev]++ % ATTN_CTR_SLOTS);
+}
+
 static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, float* LSE,
                          const int64_t* strides, int B, int T, int Hq, int Hk, int D, int lse_stride,
                          float scale, int causal, const int* lo, const int* hi, int dtype, void* stream) {
@@ -1872,17 +1961,25 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
         hipDeviceProp_t pr;
         ncu[dev] = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
-    // Plain causal batches with at least two work items per CU take the PERSISTENT kernel (one workgroup per CU walks the
-    // items: +2-3 % at 4 x 2048 / 2 x 4096 tokens, profiles/r04_attn_ab_persistent.jsonl); packed / windowed batches -- whose
-    // items differ in length in ways the static deal does not see -- and small grids take one block per item.
-    // UAMD_TUNE_ATTN_VAR bit 0 = never persistent, bit 1 = always (A/B). 32-bit Q row offsets: T * q_st < 2^31.
+    // Plain causal batches with at least two work items per CU take the PERSISTENT kernel (one workgroup per CU walks the items,
+    // dealt statically: +2-3 % at 4 x 2048 / 2 x 4096 tokens, profiles/r04_attn_ab_persistent.jsonl); packed / windowed batches,
+    // small grids and non-causal bands take one block per item. For packed / windowed batches the persistent kernel exists in two
+    // forms -- the static deal (items of one q tile differ in length by what the band cuts off: 20-50 % slower than one block per
+    // item) and items CLAIMED from a counter (DYN) -- and both were measured against one block per item on eight packed / windowed
+    // shapes (profiles/r06zv_attn_packed_ab.jsonl): the claimed deal recovers the imbalance (-1 .. -10 % against the static deal
+    // on mixed documents) but stays 0 .. 30 % behind one block per item, because a seam of the persistent kernel costs about what
+    // a block's fixed part does (~ 9 us against ~ 12) and a claim waits for a device-scope atomic (~ 3 us, memory-side). Not
+    // the default; reachable for the parity tests and A/Bs: UAMD_TUNE_ATTN_VAR bit 0 = never persistent, bit 1 = always (band
+    // launches: claimed items), bit 3 = band launches keep the static deal. 32-bit Q row offsets: T * q_st < 2^31.
     const int var = uamd_tuning_get(UAMD_TUNE_ATTN_VAR);
-    const bool persistent = !(var & 1) && D == AD && (int64_t)T * strides[1] < (1ll << 31) &&
-                            ((var & 2) || (!lo && (int)grid.x >= 2 * ncu[dev]));
+    bool persistent = !(var & 1) && D == AD && !hi && (int64_t)T * strides[1] < (1ll << 31) &&
+                      ((var & 2) || (!lo && (int)grid.x >= 2 * ncu[dev]));
+    a.ctr = nullptr;
+    if (persistent && lo && !(var & 8)) a.ctr = attn_ctr_slot(dev, (hipStream_t)stream);    // (nullptr inside a capture: static deal)
     auto run = [&](auto tag) -> int {
         typedef decltype(tag) T;
         constexpr int ti = std::is_same<T, bf16_t>::value ? 0 : 1;
-        static bool done[2][2][2][64] = {};
+        static bool done[2][2][2][64] = {}, done_dyn[2][64] = {};
         auto go = [&](auto kernel, int nblk, int lds, bool* d) -> int {
             int r_;
             if ((r_ = set_lds_attr(kernel, lds, d))) return r_;
@@ -1891,8 +1988,9 @@ static int attn_fwd_impl(const void* Q, const void* K, const void* V, void* O, f
         };
         if (persistent) {
             const int nwg = (int)grid.x < ncu[dev] ? (int)grid.x : ncu[dev];
-            return lo ? go(&attn_fwd_ps_kernel<T, true>, nwg, ATTN_PS_LDS, &done[ti][1][1][dev])
-                      : go(&attn_fwd_ps_kernel<T, false>, nwg, ATTN_PS_LDS, &done[ti][0][1][dev]);
+            if (a.ctr) return go(&attn_fwd_ps_kernel<T, true, true>, nwg, ATTN_PS_LDS, &done_dyn[ti][dev]);
+            return lo ? go(&attn_fwd_ps_kernel<T, true, false>, nwg, ATTN_PS_LDS, &done[ti][1][1][dev])
+                      : go(&attn_fwd_ps_kernel<T, false, false>, nwg, ATTN_PS_LDS, &done[ti][0][1][dev]);
         }
         static bool done_dc[2][2][2][64] = {};          // the head-dim classes 64 / 96 (128: `done` above)
         if (D > 96)
