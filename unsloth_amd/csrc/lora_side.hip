@@ -81,6 +81,12 @@ constexpr int TN_STAGE = TN_ZT + TN_PT;          // 10 KiB
 #ifndef UAMD_TN_STAGES
 #define UAMD_TN_STAGES 2
 #endif
+#ifndef UAMD_TN_RPW_MAX
+#define UAMD_TN_RPW_MAX 512       // most rows of one wave (fewer, longer waves = fewer fp32 partials to write and reduce)
+#endif
+#ifndef UAMD_TN_MIN_WAVES
+#define UAMD_TN_MIN_WAVES 4096    // ... as long as the launch keeps this many waves (4 per SIMD)
+#endif
 constexpr int TN_NST = UAMD_TN_STAGES;
 static_assert(TN_NST >= 2 && TN_NST <= 4, "ring of 2..4 stages (4 x 4 x 10 KiB = the 160 KiB of a CU)");
 constexpr int TN_WAVE_LDS = TN_NST * TN_STAGE;   // 20 KiB per wave, 80 KiB per block
@@ -476,8 +482,8 @@ extern "C" int uamd_lora_tn(const uamd_lora_tn_problem* probs, int n_probs, int 
     {   // rows per wave: as many as keep >= 4096 waves in the launch (4 per SIMD), fewer partials otherwise
         int64_t slabs_all = 0;
         for (int i = 0; i < n_probs; ++i) slabs_all += (probs[i].N + TN_COLS - 1) / TN_COLS;
-        int rpw = 512;
-        while (rpw > 128 && slabs_all * ((M + rpw - 1) / rpw) < 4096) rpw >>= 1;
+        int rpw = UAMD_TN_RPW_MAX;
+        while (rpw > 128 && slabs_all * ((M + rpw - 1) / rpw) < UAMD_TN_MIN_WAVES) rpw >>= 1;
         a.rows_per_wave = rpw;
         a.S = (M + rpw - 1) / rpw;
     }
