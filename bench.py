@@ -33,7 +33,11 @@ import os
 import sys
 import time
 
-import torch
+# before the HIP / HSA runtime is initialised (the first torch.cuda call): the host driver only supports dmabuf IPC, and RCCL's
+# intra-node transport fails with `hipIpcGetMemHandle: invalid argument` without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
