@@ -352,7 +352,7 @@ def main():
                          "get_peft_model): the least-recompute schedule that fits the free HBM (models/fast_layer.py "
                          "auto_schedule); off: no checkpointing; on: torch's reentrant per-layer checkpoint (layer inputs only, "
                          "one extra forward per layer); unsloth:<policy>: a fixed selective-recompute policy")
-    ap.add_argument("--alt-steps", type=int, default=int(os.environ.get("BENCH_ALT_STEPS", 3)),
+    ap.add_argument("--alt-steps", type=int, default=int(os.environ.get("BENCH_ALT_STEPS", 5)),
                     help="also time this many steps at the other operating points (reported under 'alt'); 0 = skip")
     ap.add_argument("--only", choices=ONLY_POINTS, default=os.environ.get("BENCH_ONLY", "primary"),
                     help="time ONE operating point with --steps / --warmup as the whole run (per-point rocprofv3 profiles); "
@@ -440,7 +440,7 @@ def main():
     def timed_steps(step_fn, steps, warmup, per_step=False):
         """W untimed + exactly K timed calls of step_fn(i), barrier + synchronize on both sides, MAX over ranks.
         per_step (the short `alt` points only, never the primary): every step is bracketed on its own and the MEDIAN step
-        time x K is returned -- a 3-step point is otherwise at the mercy of one allocator stall after empty_cache()."""
+        time x K is returned -- a 5-step point (3 until round 6) is otherwise at the mercy of one allocator stall after empty_cache()."""
         losses = []
         for i in range(warmup):
             losses.append(step_fn(i))
